@@ -1,0 +1,246 @@
+"""numpy/scipy restatement of the reference's PyFG ingestion and data-matrix
+assembly -- TEST INFRASTRUCTURE ONLY (checker for the C++ host in
+cora_amd/csrc/host).
+
+Follows (reference file:line):
+  src/pyfg_text_parser.cpp:112-401      record grammar, covariance layout
+  include/CORA/Measurements.h:79-112,151  scalar precisions
+  src/CORA_problem.cpp:24-113           variable / measurement registry, origin pose
+  src/CORA_problem.cpp:115-147          fillRangeSubmatrices
+  src/CORA_problem.cpp:149-295          fillRelPoseSubmatrices
+  src/CORA_problem.cpp:297-377          fillRotConnLaplacian
+  src/CORA_problem.cpp:625-712          fillDataMatrix
+Pinned by tests/golden/*/{Apose,Arange,T,OmegaPose,OmegaRange,RangeDistances,
+RotConLaplacian,DataMatrix}.mm (tests/test_oracle_golden.py).
+"""
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _read_sym(tok, k, dim):
+    """readSymmetric, src/pyfg_text_parser.cpp:385-401: row-wise upper triangle."""
+    cov = np.zeros((dim, dim))
+    for i in range(dim):
+        for j in range(i, dim):
+            cov[i, j] = cov[j, i] = float(tok[k])
+            k += 1
+    return cov, k
+
+
+def _from_quat(qx, qy, qz, qw):
+    """fromQuat, src/pyfg_text_parser.cpp:330-338: Eigen::Quaterniond(w,x,y,z)
+    .toRotationMatrix() -- Eigen does NOT normalise the quaternion."""
+    tx, ty, tz = 2 * qx, 2 * qy, 2 * qz
+    twx, twy, twz = tx * qw, ty * qw, tz * qw
+    txx, txy, txz = tx * qx, ty * qx, tz * qx
+    tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+def _from_angle(th):
+    return np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+
+
+class PyFG:
+    def __init__(self):
+        self.dim = None
+        self.poses = {}       # symbol -> insertion index
+        self.landmarks = {}
+        self.rpms = []        # (a, b, R, t, cov)
+        self.rplms = []       # (a, b, t, cov)
+        self.ranges = []      # (a, b, r, cov)
+        self.pose_priors = []      # (sym, R, t, cov)
+        self.landmark_priors = []  # (sym, p, cov)
+        self.has_priors = False
+
+    def _add_pose(self, s):
+        if s in self.poses:
+            raise ValueError("Pose variable already exists")
+        self.poses[s] = len(self.poses)
+
+    def _origin(self):
+        if not self.has_priors:
+            self.has_priors = True
+            self._add_pose("O0")  # src/CORA_problem.cpp:80-86
+
+
+def parse_pyfg(path):
+    g = PyFG()
+    with open(path) as fh:
+        for ln, line in enumerate(fh):
+            tok = line.split()
+            if not tok:
+                if ln == 0:
+                    raise ValueError("Could not read item type")
+                raise ValueError("Could not read item type from line")
+            kind = tok[0]
+            if ln == 0:
+                g.dim = {"VERTEX_SE2": 2, "VERTEX_SE3:QUAT": 3, "VERTEX_XY": 2,
+                         "VERTEX_XYZ": 3}[kind]
+            d = g.dim
+            if kind in ("VERTEX_SE2", "VERTEX_SE3:QUAT"):
+                g._add_pose(tok[2])
+            elif kind in ("VERTEX_XY", "VERTEX_XYZ"):
+                if tok[1] in g.landmarks:
+                    raise ValueError("Landmark variable already exists")
+                g.landmarks[tok[1]] = len(g.landmarks)
+            elif kind == "EDGE_SE2":
+                t = np.array([float(tok[4]), float(tok[5])])
+                R = _from_angle(float(tok[6]))
+                cov, _ = _read_sym(tok, 7, 3)
+                g.rpms.append((tok[2], tok[3], R, t, cov))
+            elif kind == "EDGE_SE3:QUAT":
+                t = np.array([float(x) for x in tok[4:7]])
+                R = _from_quat(*[float(x) for x in tok[7:11]])
+                cov, _ = _read_sym(tok, 11, 6)
+                g.rpms.append((tok[2], tok[3], R, t, cov))
+            elif kind in ("EDGE_SE2_XY", "EDGE_SE3_XYZ"):
+                t = np.array([float(x) for x in tok[4:4 + d]])
+                cov, _ = _read_sym(tok, 4 + d, d)
+                g.rplms.append((tok[2], tok[3], t, cov))
+            elif kind == "EDGE_RANGE":
+                g.ranges.append((tok[2], tok[3], float(tok[4]), float(tok[5])))
+            elif kind == "VERTEX_SE2:PRIOR":
+                t = np.array([float(tok[3]), float(tok[4])])
+                R = _from_angle(float(tok[5]))
+                cov, _ = _read_sym(tok, 6, 3)
+                g.pose_priors.append((tok[2], R, t, cov))
+                g._origin()
+            elif kind == "VERTEX_SE3:QUAT:PRIOR":
+                t = np.array([float(x) for x in tok[3:6]])
+                R = _from_quat(*[float(x) for x in tok[6:10]])
+                cov, _ = _read_sym(tok, 10, 6)
+                g.pose_priors.append((tok[2], R, t, cov))
+                g._origin()
+            elif kind in ("VERTEX_XY:PRIOR", "VERTEX_XYZ:PRIOR"):
+                p = np.array([float(x) for x in tok[3:3 + d]])
+                cov, _ = _read_sym(tok, 3 + d, d)
+                g.landmark_priors.append((tok[2], p, cov))
+                g._origin()
+            else:
+                raise ValueError("Unknown item type " + kind)
+    return g
+
+
+def _rot_precision(cov):
+    # Measurements.h:79-93
+    if cov.shape[0] == 6:
+        return 1.5 / (cov[3, 3] + cov[4, 4] + cov[5, 5])
+    return 1.0 / cov[2, 2]
+
+
+def _trans_precision(cov, d):
+    # Measurements.h:109-112
+    return d / np.trace(cov[:d, :d])
+
+
+def assemble(g):
+    """Returns dict of submatrices (scipy CSR) + Q + dims (d, n, l, r, N)."""
+    d = g.dim
+    n, l, r = len(g.poses), len(g.landmarks), len(g.ranges)
+    nt = n + l
+    dn = d * n
+
+    def tidx(s):  # translation index relative to the translation block
+        if s in g.poses:
+            return g.poses[s]
+        if s in g.landmarks:
+            return n + g.landmarks[s]
+        raise ValueError("Unknown translation symbol")
+
+    # ---- ranges (src/CORA_problem.cpp:115-147)
+    Ar = sp.lil_matrix((r, nt))
+    Dr = np.zeros(r)
+    Or = np.zeros(r)
+    for k, (a, b, rr, cov) in enumerate(g.ranges):
+        Dr[k] = rr
+        Or[k] = 1.0 / cov
+        Ar[k, tidx(a)] = -1.0
+        Ar[k, tidx(b)] = 1.0
+    Ar = Ar.tocsr()
+
+    # ---- relative-pose block (src/CORA_problem.cpp:149-295); row order:
+    # pose-pose, pose priors, pose-landmark, landmark priors
+    npp, nprior, npl, nlp = len(g.rpms), len(g.pose_priors), len(g.rplms), len(g.landmark_priors)
+    m = npp + nprior + npl + nlp
+    At = sp.lil_matrix((m, nt))
+    T = sp.lil_matrix((m, dn))
+    Ot = np.zeros(m)
+    row = 0
+    for (a, b, R, t, cov) in g.rpms:
+        Ot[row] = _trans_precision(cov, d)
+        i1, i2 = tidx(a), tidx(b)
+        At[row, i1] = -1.0
+        At[row, i2] = 1.0
+        for c in range(d):
+            T[row, i1 * d + c] = -t[c]
+        row += 1
+    for (s, R, t, cov) in g.pose_priors:
+        Ot[row] = _trans_precision(cov, d)
+        i1, i2 = tidx("O0"), tidx(s)
+        At[row, i1] = -1.0
+        At[row, i2] = 1.0
+        for c in range(d):
+            T[row, i1 * d + c] = -t[c]
+        row += 1
+    for (a, b, t, cov) in g.rplms:
+        Ot[row] = _trans_precision(cov, d)
+        i1, i2 = tidx(a), tidx(b)
+        At[row, i1] = -1.0
+        At[row, i2] = 1.0
+        for c in range(d):
+            T[row, i1 * d + c] = -t[c]
+        row += 1
+    for (s, p, cov) in g.landmark_priors:
+        Ot[row] = _trans_precision(cov, d)
+        i1, i2 = tidx("O0"), tidx(s)
+        At[row, i1] = -1.0
+        At[row, i2] = 1.0
+        for c in range(d):
+            T[row, i1 * d + c] = -p[c]
+        row += 1
+    At, T = At.tocsr(), T.tocsr()
+
+    # ---- rotation connection Laplacian (src/CORA_problem.cpp:297-377)
+    ri, ci, vi = [], [], []
+
+    def lap(i, j, kappa, R):
+        for k in range(d):
+            ri.append(d * i + k); ci.append(d * i + k); vi.append(kappa)
+        for k in range(d):
+            ri.append(d * j + k); ci.append(d * j + k); vi.append(kappa)
+        for a in range(d):
+            for c in range(d):
+                ri.append(i * d + a); ci.append(j * d + c); vi.append(-kappa * R[a, c])
+        for a in range(d):
+            for c in range(d):
+                ri.append(j * d + a); ci.append(i * d + c); vi.append(-kappa * R[c, a])
+
+    for (a, b, R, t, cov) in g.rpms:
+        lap(g.poses[a], g.poses[b], _rot_precision(cov), R)
+    for (s, R, t, cov) in g.pose_priors:
+        lap(g.poses["O0"], g.poses[s], _rot_precision(cov), R)
+    L = sp.coo_matrix((vi, (ri, ci)), shape=(dn, dn)).tocsr()
+
+    # ---- data matrix (src/CORA_problem.cpp:625-712)
+    Om_t = sp.diags(Ot) if m else sp.csr_matrix((0, 0))
+    Om_r = sp.diags(Or) if r else sp.csr_matrix((0, 0))
+    D = sp.diags(Dr) if r else sp.csr_matrix((0, 0))
+    Q11 = L + T.T @ Om_t @ T
+    Q13 = T.T @ Om_t @ At
+    Q22 = Om_r @ D @ D
+    Q23 = Om_r @ D @ Ar
+    Q33 = At.T @ Om_t @ At + Ar.T @ Om_r @ Ar
+    Z12 = sp.csr_matrix((dn, r))
+    Q = sp.bmat([[Q11, Z12, Q13], [Z12.T, Q22, Q23], [Q13.T, Q23.T, Q33]],
+                format="csr")
+    Q.sum_duplicates()
+    Q.sort_indices()
+    N = dn + r + nt
+    return dict(d=d, n=n, l=l, r=r, N=N, Arange=Ar, OmegaRange=sp.csr_matrix(Om_r),
+                RangeDistances=sp.csr_matrix(D), Apose=At, T=T,
+                OmegaPose=sp.csr_matrix(Om_t), RotConLaplacian=L, Q=Q)

@@ -1,0 +1,237 @@
+"""ctypes wrapper around oracle/libcora_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module (see the header of cora_oracle.c).  All dense arrays are
+column-major float64 (Fortran order), exactly like the reference's
+Eigen::MatrixXd; Q is CSR with int32 indices.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libcora_oracle.so")
+    src = os.path.join(_HERE, "cora_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcora_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_cost.restype = C.c_double
+        _LIB.orc_inner.restype = C.c_double
+        _LIB.orc_chol_factor.restype = C.c_void_p
+        _LIB.orc_chol_nnz.restype = C.c_longlong
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f(a):
+    """column-major float64 2-D view/copy"""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    return np.asfortranarray(a)
+
+
+class CSR:
+    """Symmetric data matrix Q in CSR (int32 / float64), as Eigen stores it."""
+
+    def __init__(self, rowptr, col, val, N):
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64)
+        self.N = int(N)
+        self.nnz = int(self.rowptr[-1]) if len(self.rowptr) else 0
+
+    @staticmethod
+    def from_scipy(A):
+        A = A.tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        return CSR(A.indptr, A.indices, A.data, A.shape[0])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val, self.col, self.rowptr), shape=(self.N, self.N))
+
+
+class Dims:
+    """(d, n poses, r range measurements, N) -- N = n(d+1) + l + r."""
+
+    def __init__(self, d, n, r, N):
+        self.d, self.n, self.r, self.N = int(d), int(n), int(r), int(N)
+        self.dn = self.d * self.n
+        self.n_trans = self.N - self.dn - self.r
+
+
+def spmm(Q, X, rowwise=False):
+    X = _f(X)
+    out = np.empty((Q.N, X.shape[1]), order="F")
+    fn = lib().orc_spmm_rowwise if rowwise else lib().orc_spmm
+    fn(Q.N, _i(Q.rowptr), _i(Q.col), _d(Q.val), _d(X), X.shape[0], X.shape[1],
+       _d(out), Q.N)
+    return out
+
+
+def cost(Q, Y):
+    Y = _f(Y)
+    work = np.empty((Q.N, Y.shape[1]), order="F")
+    return lib().orc_cost(Q.N, _i(Q.rowptr), _i(Q.col), _d(Q.val), _d(Y),
+                          Y.shape[0], Y.shape[1], _d(work))
+
+
+def inner(A, B):
+    A, B = _f(A), _f(B)
+    return lib().orc_inner(A.shape[0], A.shape[1], _d(A), A.shape[0], _d(B), B.shape[0])
+
+
+def egrad(Q, Y):
+    return spmm(Q, Y)
+
+
+def tangent_proj(dm, Y, V):
+    Y, V = _f(Y), _f(V)
+    out = np.empty_like(V, order="F")
+    lib().orc_tangent_proj(dm.d, dm.n, dm.r, dm.N, Y.shape[1], _d(Y), dm.N,
+                           _d(V), dm.N, _d(out), dm.N)
+    return out
+
+
+def rgrad(Q, dm, Y):
+    return tangent_proj(dm, Y, egrad(Q, Y))
+
+
+def hvp(Q, dm, Y, G, Ydot):
+    Y, G, Ydot = _f(Y), _f(G), _f(Ydot)
+    p = Y.shape[1]
+    out = np.empty((dm.N, p), order="F")
+    work = np.empty((dm.N, p), order="F")
+    lib().orc_hvp(dm.d, dm.n, dm.r, dm.N, p, _i(Q.rowptr), _i(Q.col), _d(Q.val),
+                  _d(Y), dm.N, _d(G), dm.N, _d(Ydot), dm.N, _d(out), dm.N, _d(work))
+    return out
+
+
+def lambda_blocks(Q, dm, Y):
+    Y = _f(Y)
+    QY = spmm(Q, Y)
+    Lst = np.zeros((dm.d, max(dm.dn, 1)), order="F")[:, :dm.dn]
+    Lst = np.asfortranarray(Lst)
+    lob = np.zeros(max(dm.r, 1))[:dm.r].copy()
+    lib().orc_lambda_blocks(dm.d, dm.n, dm.r, Y.shape[1], _d(Y), dm.N, _d(QY),
+                            dm.N, _d(Lst), _d(lob))
+    return Lst, lob
+
+
+def S_apply(Q, dm, Lst, lob, X):
+    X = _f(X)
+    k = X.shape[1]
+    out = np.empty((dm.N, k), order="F")
+    work = np.empty((dm.N, k), order="F")
+    Lst = np.asfortranarray(Lst)
+    lob = np.ascontiguousarray(lob)
+    lib().orc_S_apply(dm.d, dm.n, dm.r, dm.N, _i(Q.rowptr), _i(Q.col), _d(Q.val),
+                      _d(Lst), _d(lob), _d(X), dm.N, k, _d(out), dm.N, _d(work))
+    return out
+
+
+def certificate_matrix_dense(Q, dm, Y):
+    """S = Q - Lambda as a dense matrix (small cases only).
+    Problem::get_certificate_matrix, src/CORA_problem.cpp:1162-1166."""
+    Lst, lob = lambda_blocks(Q, dm, Y)
+    S = Q.to_scipy().toarray()
+    d = dm.d
+    for i in range(dm.n):
+        S[i * d:(i + 1) * d, i * d:(i + 1) * d] -= Lst[:, i * d:(i + 1) * d]
+    for j in range(dm.r):
+        S[dm.dn + j, dm.dn + j] -= lob[j]
+    return S
+
+
+def project_manifold(dm, A):
+    A = _f(A)
+    out = np.empty_like(A, order="F")
+    lib().orc_project_manifold(dm.d, dm.n, dm.r, dm.N, A.shape[1], _d(A), dm.N,
+                               _d(out), dm.N)
+    return out
+
+
+def retract(dm, Y, V):
+    Y, V = _f(Y), _f(V)
+    out = np.empty_like(Y, order="F")
+    lib().orc_retract(dm.d, dm.n, dm.r, dm.N, Y.shape[1], _d(Y), dm.N, _d(V),
+                      dm.N, _d(out), dm.N)
+    return out
+
+
+def diag(Q):
+    out = np.empty(Q.N)
+    lib().orc_diag(Q.N, _i(Q.rowptr), _i(Q.col), _d(Q.val), _d(out))
+    return out
+
+
+def precond_jacobi(Q, dm, Y, V):
+    Y, V = _f(Y), _f(V)
+    dinv = 1.0 / diag(Q)
+    out = np.empty_like(V, order="F")
+    lib().orc_precond_jacobi(dm.d, dm.n, dm.r, dm.N, Y.shape[1], _d(dinv), _d(Y),
+                             dm.N, _d(V), dm.N, _d(out), dm.N)
+    return out
+
+
+class Cholesky:
+    """Sparse LL^T of a symmetric CSR matrix; `ok` False <=> not positive definite
+    (the reference's `MChol.info() == Eigen::Success`, src/CORA_utils.cpp:51)."""
+
+    def __init__(self, A, perm=None):
+        self.n = A.N
+        self._A = A
+        p = None
+        if perm is not None:
+            self._perm = np.ascontiguousarray(perm, dtype=np.int32)
+            p = _i(self._perm)
+        self._h = lib().orc_chol_factor(A.N, _i(A.rowptr), _i(A.col), _d(A.val), p)
+        self.ok = bool(self._h)
+
+    @property
+    def nnz(self):
+        return lib().orc_chol_nnz(C.c_void_p(self._h)) if self.ok else -1
+
+    def solve(self, B):
+        B = _f(B)
+        X = np.empty_like(B, order="F")
+        lib().orc_chol_solve(C.c_void_p(self._h), _d(B), B.shape[0], B.shape[1],
+                             _d(X), X.shape[0])
+        return X
+
+    def precond(self, dm, Y, V):
+        Y, V = _f(Y), _f(V)
+        out = np.zeros_like(V, order="F")
+        lib().orc_precond_chol(C.c_void_p(self._h), dm.d, dm.n, dm.r, dm.N,
+                               Y.shape[1], _d(Y), dm.N, _d(V), dm.N, _d(out), dm.N)
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_chol_free(C.c_void_p(self._h))
+            self._h = None
