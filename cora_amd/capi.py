@@ -1,0 +1,308 @@
+"""ctypes binding of libcora_hip.so (include/cora_hip.h).
+
+Plumbing for tests/ and bench.py only: the product is the shared library and
+the C++ host behind it.  There is no fallback -- if the library is missing or
+no gfx950 device is usable, calls raise CoraError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_LIB = None
+
+STATUS = {0: "CORA_OK", 1: "CORA_ERR_SHAPE", 2: "CORA_ERR_NOT_READY", 3: "CORA_ERR_NAN",
+          4: "CORA_ERR_HIP", 5: "CORA_ERR_ARG", 6: "CORA_ERR_NOMEM"}
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_CHOLESKY, PRECOND_REGULARIZED_CHOLESKY = 0, 1, 2, 3
+
+
+class CoraError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS.get(code, str(code)), msg))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Loads the in-tree shared library (building it first when stale)."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:  # hipcc missing on a box that ships the prebuilt .so
+                if not os.path.exists(path):
+                    raise RuntimeError("libcora_hip.so is missing and cannot be built: %s" % e)
+        _LIB = C.CDLL(path)
+        L = _LIB
+        L.cora_last_error.restype = C.c_char_p
+        L.cora_last_error.argtypes = [C.c_void_p]
+        for name in ("cora_rows", "cora_shard_rows", "cora_shard_begin", "cora_nnz", "cora_dim"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("cora_point_Y_dev", "cora_point_egrad_dev", "cora_point_rgrad_dev"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.cora_ctx_destroy.restype = None
+        L.cora_ctx_destroy.argtypes = [C.c_void_p]
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    return np.asfortranarray(a)
+
+
+class Context:
+    """One device-resident problem (cora_ctx).  Host arrays are column-major
+    N x k float64, as in the reference (Eigen::MatrixXd)."""
+
+    def __init__(self, d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, device=0, rank=0, world=1):
+        self.L = load()
+        self.d, self.n, self.r, self.nt = int(d), int(n_poses), int(n_ranges), int(n_trans)
+        self.N = self.d * self.n + self.r + self.nt
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        if len(rowptr) != self.N + 1:
+            raise CoraError(1, "rowptr must have N+1 entries")
+        h = C.c_void_p()
+        rc = self.L.cora_ctx_create_part(C.c_int(device), self.d, self.n, self.r, self.nt,
+                                         rowptr.ctypes.data_as(_ip), colidx.ctypes.data_as(_ip), _d(vals),
+                                         C.c_int(rank), C.c_int(world), C.byref(h))
+        if rc:
+            raise CoraError(rc, self.L.cora_last_error(None).decode())
+        self.h = h
+        self.p = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cora_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise CoraError(rc, self.L.cora_last_error(self.h).decode())
+
+    # ---- queries
+    def set_rank(self, p):
+        self._chk(self.L.cora_set_rank(self.h, int(p)))
+        self.p = int(p)
+
+    @property
+    def ld(self):
+        return self.L.cora_ld(self.h)
+
+    @property
+    def rows(self):
+        return self.L.cora_rows(self.h)
+
+    @property
+    def shard_rows(self):
+        return self.L.cora_shard_rows(self.h)
+
+    @property
+    def shard_begin(self):
+        return self.L.cora_shard_begin(self.h)
+
+    @property
+    def nnz(self):
+        return self.L.cora_nnz(self.h)
+
+    def row_map(self):
+        m = np.empty(self.N, dtype=np.int32)
+        self._chk(self.L.cora_row_map(self.h, m.ctypes.data_as(_ip)))
+        return m
+
+    def format_stats(self):
+        s = (C.c_int64 * 8)()
+        self._chk(self.L.cora_format_stats(self.h, s))
+        keys = ["slices", "padded_nnz", "long_nnz", "long_rows", "long_chunks", "local_rows", "local_nnz",
+                "max_width"]
+        return dict(zip(keys, [int(x) for x in s]))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.cora_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- host-pointer operator API (mirrors CORA::Problem)
+    def _out(self, k):
+        return np.zeros((self.N, k), order="F")
+
+    def dataMatrixProduct(self, X):
+        X = _f(X)
+        out = self._out(X.shape[1])
+        self._chk(self.L.cora_data_matrix_product(self.h, _d(X), X.shape[0], X.shape[1], _d(out), self.N))
+        return out
+
+    def evaluateObjective(self, Y):
+        Y = _f(Y)
+        f = C.c_double()
+        self._chk(self.L.cora_evaluate_objective(self.h, _d(Y), Y.shape[0], C.byref(f)))
+        return f.value
+
+    def Euclidean_gradient(self, Y):
+        Y = _f(Y)
+        out = self._out(self.p)
+        self._chk(self.L.cora_euclidean_gradient(self.h, _d(Y), Y.shape[0], _d(out), self.N))
+        return out
+
+    def Riemannian_gradient(self, Y):
+        Y = _f(Y)
+        out = self._out(self.p)
+        self._chk(self.L.cora_riemannian_gradient(self.h, _d(Y), Y.shape[0], _d(out), self.N))
+        return out
+
+    def tangent_space_projection(self, Y, V):
+        Y, V = _f(Y), _f(V)
+        out = self._out(self.p)
+        self._chk(self.L.cora_tangent_space_projection(self.h, _d(Y), Y.shape[0], _d(V), V.shape[0], _d(out),
+                                                       self.N))
+        return out
+
+    def Riemannian_Hessian_vector_product(self, Y, G, Ydot):
+        Y, G, Ydot = _f(Y), _f(G), _f(Ydot)
+        out = self._out(self.p)
+        self._chk(self.L.cora_riemannian_hessian_vector_product(
+            self.h, _d(Y), Y.shape[0], _d(G), G.shape[0], _d(Ydot), Ydot.shape[0], _d(out), self.N))
+        return out
+
+    def projectToManifold(self, A):
+        A = _f(A)
+        out = self._out(self.p)
+        self._chk(self.L.cora_project_to_manifold(self.h, _d(A), A.shape[0], _d(out), self.N))
+        return out
+
+    def retract(self, Y, V):
+        Y, V = _f(Y), _f(V)
+        out = self._out(self.p)
+        self._chk(self.L.cora_retract(self.h, _d(Y), Y.shape[0], _d(V), V.shape[0], _d(out), self.N))
+        return out
+
+    def precond_setup(self, kind):
+        self._chk(self.L.cora_precond_setup(self.h, int(kind)))
+
+    def precondition(self, V):
+        V = _f(V)
+        out = self._out(self.p)
+        self._chk(self.L.cora_precondition(self.h, _d(V), V.shape[0], _d(out), self.N))
+        return out
+
+    def compute_Lambda_blocks(self, Y):
+        Y = _f(Y)
+        st = np.zeros((self.d, max(self.d * self.n, 1)), order="F")
+        ob = np.zeros(max(self.r, 1))
+        self._chk(self.L.cora_compute_lambda_blocks(self.h, _d(Y), Y.shape[0], _d(st), _d(ob)))
+        return st[:, :self.d * self.n], ob[:self.r]
+
+    def set_point(self, Y):
+        Y = _f(Y)
+        self._chk(self.L.cora_set_point(self.h, _d(Y), Y.shape[0]))
+
+    def point_cost(self):
+        f = C.c_double()
+        self._chk(self.L.cora_point_cost(self.h, C.byref(f)))
+        return f.value
+
+    def certificate_product(self, X):
+        X = _f(X)
+        out = self._out(X.shape[1])
+        self._chk(self.L.cora_certificate_product(self.h, _d(X), X.shape[0], X.shape[1], _d(out), self.N))
+        return out
+
+    def inner_product(self, A, B):
+        A, B = _f(A), _f(B)
+        v = C.c_double()
+        self._chk(self.L.cora_inner_product(self.h, _d(A), A.shape[0], _d(B), B.shape[0], A.shape[1],
+                                            C.byref(v)))
+        return v.value
+
+    # ---- resident API (raw device pointers as ints)
+    def dev_alloc(self, k):
+        p = _dp()
+        self._chk(self.L.cora_dev_alloc(self.h, int(k), C.byref(p)))
+        return C.cast(p, C.c_void_p).value
+
+    def dev_free(self, ptr):
+        self._chk(self.L.cora_dev_free(self.h, C.c_void_p(ptr)))
+
+    def upload(self, host, ptr):
+        host = _f(host)
+        self._chk(self.L.cora_upload(self.h, _d(host), host.shape[0], host.shape[1], C.c_void_p(ptr)))
+
+    def download(self, ptr, k):
+        out = self._out(k)
+        self._chk(self.L.cora_download(self.h, C.c_void_p(ptr), int(k), _d(out), self.N))
+        return out
+
+    def set_point_dev(self, ptr):
+        self._chk(self.L.cora_set_point_dev(self.h, C.c_void_p(ptr)))
+
+    def spmm_dev(self, x, k, out):
+        self._chk(self.L.cora_spmm_dev(self.h, C.c_void_p(x), int(k), C.c_void_p(out)))
+
+    def hvp_dev(self, x, out):
+        self._chk(self.L.cora_hvp_dev(self.h, C.c_void_p(x), C.c_void_p(out)))
+
+    def certificate_product_dev(self, x, k, out):
+        self._chk(self.L.cora_certificate_product_dev(self.h, C.c_void_p(x), int(k), C.c_void_p(out)))
+
+    def tangent_space_projection_dev(self, v, out):
+        self._chk(self.L.cora_tangent_space_projection_dev(self.h, C.c_void_p(v), C.c_void_p(out)))
+
+    def precondition_projected_dev(self, v, out):
+        self._chk(self.L.cora_precondition_projected_dev(self.h, C.c_void_p(v), C.c_void_p(out)))
+
+    def retract_dev(self, v, alpha, out):
+        self._chk(self.L.cora_retract_dev(self.h, C.c_void_p(v), C.c_double(alpha), C.c_void_p(out)))
+
+    def project_to_manifold_dev(self, a, out):
+        self._chk(self.L.cora_project_to_manifold_dev(self.h, C.c_void_p(a), C.c_void_p(out)))
+
+    def axpby_dev(self, a, x, b, y):
+        self._chk(self.L.cora_axpby_dev(self.h, C.c_double(a), C.c_void_p(x), C.c_double(b), C.c_void_p(y)))
+
+    def dot_dev(self, a, b, k):
+        v = C.c_double()
+        self._chk(self.L.cora_dot_dev(self.h, C.c_void_p(a), C.c_void_p(b), int(k), C.byref(v)))
+        return v.value
+
+    def point_ptrs(self):
+        return (self.L.cora_point_Y_dev(self.h), self.L.cora_point_egrad_dev(self.h),
+                self.L.cora_point_rgrad_dev(self.h))
+
+    def timer_start(self):
+        self._chk(self.L.cora_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._chk(self.L.cora_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        self._chk(self.L.cora_sync(self.h))
+
+    # ---- test hook
+    def debug_format_spmm_host(self, X):
+        X = _f(X)
+        out = self._out(X.shape[1])
+        self._chk(self.L.cora_debug_format_spmm_host(self.h, _d(X), X.shape[0], X.shape[1], _d(out), self.N))
+        return out

@@ -1,0 +1,817 @@
+// C-ABI layer of libcora_hip.so (see include/cora_hip.h).  Owns the handle,
+// device memory and stream; every compute entry point ends in a HIP kernel of
+// kernels.hip -- there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cora_hip.h"
+#include "cora_internal.h"
+#include "kernels.h"
+
+using namespace cora;
+
+namespace {
+thread_local std::string g_create_error;
+constexpr int kScratchSlots = 6;
+}  // namespace
+
+struct cora_ctx {
+  HostFormat F;
+  int device = -1;
+  bool has_device = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int p = 0, ld = 0;
+
+  SliceDesc *d_slices = nullptr;
+  double *d_sval = nullptr;
+  int32_t *d_scol = nullptr;
+  int32_t *d_perm = nullptr;
+  LongChunk *d_chunks = nullptr;
+  double *d_lval = nullptr;
+  int32_t *d_lcol = nullptr;
+  double *d_partials = nullptr;
+  unsigned *d_tickets = nullptr;
+  int32_t *d_api2int = nullptr;
+  double *d_diag_inv = nullptr;  // 1/diag(Q), local rows
+  double *d_lam_st = nullptr, *d_lam_ob = nullptr;
+
+  bool have_point = false;
+  double *d_Y = nullptr, *d_G = nullptr, *d_rgrad = nullptr;
+  double f = 0.0;
+  int precond = CORA_PRECOND_NONE;
+
+  double *scratch[kScratchSlots] = {nullptr};
+  size_t scratch_bytes[kScratchSlots] = {0};
+  double *d_stage = nullptr;
+  size_t stage_bytes = 0;
+  double *d_red = nullptr;      // reduction partials
+  size_t red_doubles = 0;
+  double *d_scalars = nullptr;  // 8 doubles
+  double *h_scalars = nullptr;  // pinned, 8 doubles
+  int *d_flag = nullptr;
+  int *h_flag = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void *> user_allocs;
+  std::string err;
+};
+
+namespace {
+
+int fail(cora_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                              \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess)                                                            \
+      return fail((c), CORA_ERR_HIP,                                                  \
+                  std::string(#expr) + ": " + hipGetErrorString(e__));                \
+  } while (0)
+
+#define NEED_DEVICE(c)                                                                \
+  do {                                                                                \
+    if (!(c)) return CORA_ERR_ARG;                                                    \
+    if (!(c)->has_device)                                                             \
+      return fail((c), CORA_ERR_HIP, "no HIP device bound to this handle (plan-only)"); \
+    HIP_TRY((c), hipSetDevice((c)->device));                                          \
+  } while (0)
+
+#define NEED_RANK(c)                                                                  \
+  do {                                                                                \
+    if ((c)->p <= 0) return fail((c), CORA_ERR_NOT_READY, "cora_set_rank not called"); \
+  } while (0)
+
+template <typename T>
+hipError_t to_device(T **dptr, const std::vector<T> &v) {
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(dptr), bytes);
+  if (e != hipSuccess) return e;
+  if (!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+size_t vec_bytes(const cora_ctx *c, int ld) {
+  return static_cast<size_t>(c->F.L.rows) * ld * sizeof(double);
+}
+
+int get_scratch(cora_ctx *c, int slot, int ld, double **out) {
+  const size_t need = vec_bytes(c, ld);
+  if (c->scratch_bytes[slot] < need) {
+    if (c->scratch[slot]) (void)hipFree(c->scratch[slot]);
+    c->scratch[slot] = nullptr;
+    c->scratch_bytes[slot] = 0;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->scratch[slot]), need));
+    c->scratch_bytes[slot] = need;
+  }
+  *out = c->scratch[slot];
+  return CORA_OK;
+}
+
+RowArgs row_args(const cora_ctx *c) {
+  const Layout &L = c->F.L;
+  RowArgs R;
+  R.d = L.d;
+  R.nl_poses = L.nl_poses;
+  R.nl_ranges = L.nl_ranges;
+  R.nl_trans = L.nl_trans;
+  R.rot_base = static_cast<size_t>(L.rot_base);
+  R.rng_base = static_cast<size_t>(L.rng_base);
+  R.trn_base = static_cast<size_t>(L.trn_base);
+  R.base = static_cast<size_t>(L.base);
+  return R;
+}
+
+SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
+  SpmmArgs A;
+  A.slices = c->d_slices;
+  A.n_slices = static_cast<int>(c->F.slices.size());
+  A.n_chunks = static_cast<int>(c->F.chunks.size());
+  A.sval = c->d_sval;
+  A.scol = c->d_scol;
+  A.perm = c->d_perm;
+  A.chunks = c->d_chunks;
+  A.lval = c->d_lval;
+  A.lcol = c->d_lcol;
+  A.partials = c->d_partials;
+  A.tickets = c->d_tickets;
+  A.X = X;
+  A.out = out;
+  A.Y = c->d_Y;
+  A.lam_st = c->d_lam_st;
+  A.lam_ob = c->d_lam_ob;
+  return A;
+}
+
+int ensure_red(cora_ctx *c, size_t doubles) {
+  if (c->red_doubles < doubles) {
+    if (c->d_red) (void)hipFree(c->d_red);
+    c->d_red = nullptr;
+    c->red_doubles = 0;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_red), doubles * sizeof(double)));
+    c->red_doubles = doubles;
+  }
+  return CORA_OK;
+}
+
+// host col-major (N x k, ld) -> resident vector (rows x ld_for(k)), zero padded
+int upload_impl(cora_ctx *c, const double *host, int ldh, int k, double *dptr) {
+  const int64_t N = c->F.L.N;
+  if (k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_SHAPE, "column count must be in [1, 24]");
+  if (ldh < N) return fail(c, CORA_ERR_SHAPE, "leading dimension smaller than N");
+  if (!host || !dptr) return fail(c, CORA_ERR_ARG, "null pointer");
+  const int ld = ld_for(k);
+  const size_t need = static_cast<size_t>(N) * k * sizeof(double);
+  if (c->stage_bytes < need) {
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), need));
+    c->stage_bytes = need;
+  }
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_stage, N * sizeof(double), host, static_cast<size_t>(ldh) * sizeof(double),
+                              N * sizeof(double), k, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(dptr, 0, vec_bytes(c, ld), c->stream));
+  HIP_TRY(c, launch_upload(N, k, ld, c->d_stage, c->d_api2int, dptr, c->stream));
+  return CORA_OK;
+}
+
+int download_impl(cora_ctx *c, const double *dptr, int k, double *host, int ldh) {
+  const int64_t N = c->F.L.N;
+  if (k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_SHAPE, "column count must be in [1, 24]");
+  if (ldh < N) return fail(c, CORA_ERR_SHAPE, "leading dimension smaller than N");
+  if (!host || !dptr) return fail(c, CORA_ERR_ARG, "null pointer");
+  const int ld = ld_for(k);
+  const size_t need = static_cast<size_t>(N) * k * sizeof(double);
+  if (c->stage_bytes < need) {
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), need));
+    c->stage_bytes = need;
+  }
+  HIP_TRY(c, launch_download(N, k, ld, dptr, c->d_api2int, c->d_stage, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(host, static_cast<size_t>(ldh) * sizeof(double), c->d_stage, N * sizeof(double),
+                              N * sizeof(double), k, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CORA_OK;
+}
+
+// Lambda, grad and f from (Y, G) already resident in d_Y / d_G.
+int point_finish(cora_ctx *c) {
+  const RowArgs R = row_args(c);
+  const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+  const int nb = static_cast<int>((units + 255) / 256);
+  int rc = ensure_red(c, static_cast<size_t>(std::max(nb, 1)) * 4);
+  if (rc) return rc;
+  int nblocks = 0;
+  HIP_TRY(c, launch_point_finish(R, c->ld, c->d_Y, c->d_G, c->d_rgrad, c->d_lam_st, c->d_lam_ob, c->d_red,
+                                 &nblocks, c->stream));
+  if (nblocks > 0) {
+    HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->d_scalars, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->f = c->h_scalars[0];
+  } else {
+    c->f = 0.0;
+  }
+  c->have_point = true;
+  return CORA_OK;
+}
+
+int set_point_dev_impl(cora_ctx *c, const double *dY) {
+  if (dY != c->d_Y)
+    HIP_TRY(c, hipMemcpyAsync(c->d_Y, dY, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
+  const SpmmArgs A = spmm_args(c, c->d_Y, c->d_G);
+  HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_NONE, c->stream));
+  return point_finish(c);
+}
+
+void free_rank_state(cora_ctx *c) {
+  for (double **p : {&c->d_Y, &c->d_G, &c->d_rgrad}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  c->have_point = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cora_last_error(const cora_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int cora_ld_for(int k) { return ld_for(k); }
+
+int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_trans, const int32_t *rowptr,
+                         const int32_t *colidx, const double *vals, int rank, int world, cora_ctx **out) {
+  if (!out) return fail(nullptr, CORA_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!rowptr || !colidx || !vals) return fail(nullptr, CORA_ERR_ARG, "null CSR pointer");
+  cora_ctx *c = new (std::nothrow) cora_ctx();
+  if (!c) return fail(nullptr, CORA_ERR_NOMEM, "out of host memory");
+  try {
+    build_format(d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, rank, world, c->F);
+  } catch (const std::exception &e) {
+    const std::string msg = e.what();
+    delete c;
+    return fail(nullptr, CORA_ERR_SHAPE, msg);
+  }
+  c->device = device;
+  if (device < 0) {  // plan-only handle: format inspection / host tests
+    *out = c;
+    return CORA_OK;
+  }
+#define CREATE_TRY(expr)                                                        \
+  do {                                                                          \
+    hipError_t e__ = (expr);                                                    \
+    if (e__ != hipSuccess) {                                                    \
+      const std::string m = std::string(#expr) + ": " + hipGetErrorString(e__); \
+      cora_ctx_destroy(c);                                                      \
+      return fail(nullptr, CORA_ERR_HIP, m);                                    \
+    }                                                                           \
+  } while (0)
+  CREATE_TRY(hipSetDevice(device));
+  c->has_device = true;
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  const HostFormat &F = c->F;
+  CREATE_TRY(to_device(&c->d_slices, F.slices));
+  CREATE_TRY(to_device(&c->d_sval, F.sval));
+  CREATE_TRY(to_device(&c->d_scol, F.scol));
+  CREATE_TRY(to_device(&c->d_perm, F.perm));
+  CREATE_TRY(to_device(&c->d_chunks, F.chunks));
+  CREATE_TRY(to_device(&c->d_lval, F.lval));
+  CREATE_TRY(to_device(&c->d_lcol, F.lcol));
+  CREATE_TRY(to_device(&c->d_api2int, F.api2int));
+  {
+    std::vector<double> dinv(F.diag.size());
+    for (size_t i = 0; i < dinv.size(); ++i) dinv[i] = 1.0 / F.diag[i];
+    CREATE_TRY(to_device(&c->d_diag_inv, dinv));
+  }
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_partials),
+                       std::max<size_t>(F.chunks.size(), 1) * kMaxLD * sizeof(double)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tickets),
+                       std::max<size_t>(F.n_long_rows, 1) * sizeof(unsigned)));
+  CREATE_TRY(hipMemset(c->d_tickets, 0, std::max<size_t>(F.n_long_rows, 1) * sizeof(unsigned)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_lam_st),
+                       std::max<size_t>(static_cast<size_t>(F.L.nl_poses) * d * d, 1) * sizeof(double)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_lam_ob),
+                       std::max<size_t>(F.L.nl_ranges, 1) * sizeof(double)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_scalars), 8 * sizeof(double)));
+  CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), 8 * sizeof(double)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_flag), sizeof(int)));
+  CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_flag), sizeof(int)));
+  CREATE_TRY(hipEventCreate(&c->ev0));
+  CREATE_TRY(hipEventCreate(&c->ev1));
+#undef CREATE_TRY
+  *out = c;
+  return CORA_OK;
+}
+
+int cora_ctx_create(int device, int d, int n_poses, int n_ranges, int n_trans, const int32_t *rowptr,
+                    const int32_t *colidx, const double *vals, cora_ctx **out) {
+  return cora_ctx_create_part(device, d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, 0, 1, out);
+}
+
+void cora_ctx_destroy(cora_ctx *c) {
+  if (!c) return;
+  if (c->has_device) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_rank_state(c);
+    void *ptrs[] = {c->d_slices, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_lval, c->d_lcol,
+                    c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
+                    c->d_stage, c->d_red, c->d_scalars, c->d_flag};
+    for (void *p : ptrs)
+      if (p) (void)hipFree(p);
+    for (int i = 0; i < kScratchSlots; ++i)
+      if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (void *p : c->user_allocs)
+      if (p) (void)hipFree(p);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+int cora_set_rank(cora_ctx *c, int p) {
+  if (!c) return CORA_ERR_ARG;
+  if (p < c->F.L.d || p > kMaxLD)
+    return fail(c, CORA_ERR_SHAPE, "relaxation rank must satisfy d <= p <= 24");
+  if (p == c->p) return CORA_OK;
+  c->p = p;
+  c->ld = ld_for(p);
+  c->have_point = false;
+  if (c->has_device) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_rank_state(c);
+    for (double **q : {&c->d_Y, &c->d_G, &c->d_rgrad}) {
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(q), vec_bytes(c, c->ld)));
+      HIP_TRY(c, hipMemsetAsync(*q, 0, vec_bytes(c, c->ld), c->stream));
+    }
+  }
+  return CORA_OK;
+}
+
+int cora_get_rank(const cora_ctx *c) { return c ? c->p : 0; }
+
+int cora_set_stream(cora_ctx *c, void *hip_stream) {
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  c->own_stream = false;
+  return CORA_OK;
+}
+
+int cora_ld(const cora_ctx *c) { return c ? c->ld : 0; }
+int64_t cora_rows(const cora_ctx *c) { return c ? c->F.L.rows : 0; }
+int64_t cora_shard_rows(const cora_ctx *c) { return c ? c->F.L.shard_rows : 0; }
+int64_t cora_shard_begin(const cora_ctx *c) { return c ? c->F.L.base : 0; }
+int64_t cora_nnz(const cora_ctx *c) { return c ? c->F.nnz_global : 0; }
+int64_t cora_dim(const cora_ctx *c) { return c ? c->F.L.N : 0; }
+
+int cora_row_map(const cora_ctx *c, int32_t *api_to_internal) {
+  if (!c || !api_to_internal) return CORA_ERR_ARG;
+  std::memcpy(api_to_internal, c->F.api2int.data(), c->F.api2int.size() * sizeof(int32_t));
+  return CORA_OK;
+}
+
+int cora_format_stats(const cora_ctx *c, int64_t s[8]) {
+  if (!c || !s) return CORA_ERR_ARG;
+  s[0] = static_cast<int64_t>(c->F.slices.size());
+  s[1] = c->F.padded_nnz;
+  s[2] = c->F.long_nnz;
+  s[3] = c->F.n_long_rows;
+  s[4] = static_cast<int64_t>(c->F.chunks.size());
+  s[5] = c->F.L.local_rows;
+  s[6] = c->F.nnz_local;
+  s[7] = c->F.max_width;
+  return CORA_OK;
+}
+
+// ------------------------------------------------------------ resident API
+
+int cora_dev_alloc(cora_ctx *c, int k, double **dptr) {
+  NEED_DEVICE(c);
+  if (!dptr || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const size_t bytes = vec_bytes(c, ld_for(k));
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(dptr), bytes));
+  HIP_TRY(c, hipMemsetAsync(*dptr, 0, bytes, c->stream));
+  c->user_allocs.push_back(*dptr);
+  return CORA_OK;
+}
+
+int cora_dev_free(cora_ctx *c, double *dptr) {
+  NEED_DEVICE(c);
+  for (auto &p : c->user_allocs)
+    if (p == dptr) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(dptr);
+      p = nullptr;
+      return CORA_OK;
+    }
+  return fail(c, CORA_ERR_ARG, "pointer was not allocated by cora_dev_alloc");
+}
+
+int cora_upload(cora_ctx *c, const double *host, int ld, int k, double *dptr) {
+  NEED_DEVICE(c);
+  int rc = upload_impl(c, host, ld, k, dptr);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffer may be pageable
+  return CORA_OK;
+}
+
+int cora_download(cora_ctx *c, const double *dptr, int k, double *host, int ld) {
+  NEED_DEVICE(c);
+  return download_impl(c, dptr, k, host, ld);
+}
+
+int cora_set_point_dev(cora_ctx *c, const double *dY) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!dY) return fail(c, CORA_ERR_ARG, "null pointer");
+  return set_point_dev_impl(c, dY);
+}
+
+int cora_set_point(cora_ctx *c, const double *Y, int ldy) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  int rc = upload_impl(c, Y, ldy, c->p, c->d_Y);
+  if (rc) return rc;
+  return set_point_dev_impl(c, c->d_Y);
+}
+
+int cora_point_cost(cora_ctx *c, double *f) {
+  if (!c || !f) return CORA_ERR_ARG;
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  *f = c->f;
+  return CORA_OK;
+}
+
+const double *cora_point_Y_dev(const cora_ctx *c) { return (c && c->have_point) ? c->d_Y : nullptr; }
+const double *cora_point_egrad_dev(const cora_ctx *c) { return (c && c->have_point) ? c->d_G : nullptr; }
+const double *cora_point_rgrad_dev(const cora_ctx *c) { return (c && c->have_point) ? c->d_rgrad : nullptr; }
+
+int cora_spmm_dev(cora_ctx *c, const double *dX, int k, double *dOut) {
+  NEED_DEVICE(c);
+  if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const SpmmArgs A = spmm_args(c, dX, dOut);
+  HIP_TRY(c, launch_spmm(A, ld_for(k), c->F.L.d, EPI_NONE, c->stream));
+  return CORA_OK;
+}
+
+int cora_hvp_dev(cora_ctx *c, const double *dX, double *dOut) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  if (!dX || !dOut) return fail(c, CORA_ERR_ARG, "null pointer");
+  const SpmmArgs A = spmm_args(c, dX, dOut);
+  HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP, c->stream));
+  return CORA_OK;
+}
+
+int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *dOut) {
+  NEED_DEVICE(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const SpmmArgs A = spmm_args(c, dX, dOut);
+  HIP_TRY(c, launch_spmm(A, ld_for(k), c->F.L.d, EPI_S, c->stream));
+  return CORA_OK;
+}
+
+int cora_tangent_space_projection_dev(cora_ctx *c, const double *dV, double *dOut) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, nullptr, dOut, c->stream));
+  return CORA_OK;
+}
+
+int cora_precond_setup(cora_ctx *c, int kind) {
+  if (!c) return CORA_ERR_ARG;
+  if (kind == CORA_PRECOND_NONE || kind == CORA_PRECOND_JACOBI) {
+    if (kind == CORA_PRECOND_JACOBI)
+      for (double v : c->F.diag)
+        if (!(v != 0.0)) return fail(c, CORA_ERR_NAN, "zero on the diagonal of Q: Jacobi preconditioner undefined");
+    c->precond = kind;
+    return CORA_OK;
+  }
+  return fail(c, CORA_ERR_NOT_READY,
+              "Cholesky preconditioners need a factor installed with cora_precond_set_cholesky");
+}
+
+int cora_precond_set_cholesky(cora_ctx *c, int, const int32_t *, const int32_t *, const double *,
+                              const int32_t *) {
+  return fail(c, CORA_ERR_NOT_READY, "device sparse triangular solve not implemented yet");
+}
+
+int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  const double *scale = nullptr;
+  if (c->precond == CORA_PRECOND_JACOBI) scale = c->d_diag_inv;
+  else if (c->precond != CORA_PRECOND_NONE) return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up");
+  HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, scale, dOut, c->stream));
+  return CORA_OK;
+}
+
+int cora_retract_dev(cora_ctx *c, const double *dV, double alpha, double *dOut) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, c->d_Y, dV, alpha, dOut, c->stream));
+  return CORA_OK;
+}
+
+int cora_project_to_manifold_dev(cora_ctx *c, const double *dA, double *dOut) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, dA, nullptr, 0.0, dOut, c->stream));
+  return CORA_OK;
+}
+
+int cora_axpby_dev(cora_ctx *c, double a, const double *dX, double b, double *dY) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
+  HIP_TRY(c, launch_axpby(c->F.L.local_rows * c->ld, a, dX + off, b, dY + off, c->stream));
+  return CORA_OK;
+}
+
+int cora_copy_dev(cora_ctx *c, const double *dX, int k, double *dY) {
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipMemcpyAsync(dY, dX, vec_bytes(c, ld_for(k)), hipMemcpyDeviceToDevice, c->stream));
+  return CORA_OK;
+}
+
+int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double *const *dB, double *out) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (count < 1 || count > 4 || !dA || !dB || !out) return fail(c, CORA_ERR_ARG, "bad arguments");
+  DotArgs D;
+  const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
+  for (int j = 0; j < 4; ++j) {
+    D.a[j] = (j < count) ? dA[j] + off : nullptr;
+    D.b[j] = (j < count) ? dB[j] + off : nullptr;
+  }
+  D.count = count;
+  D.n2 = c->F.L.local_rows * c->ld / 2;
+  int rc = ensure_red(c, 4 * 512);
+  if (rc) return rc;
+  D.partial = c->d_red;
+  int nblocks = 0;
+  HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
+  HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, count, c->d_scalars, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int j = 0; j < count; ++j) out[j] = c->h_scalars[j];
+  return CORA_OK;
+}
+
+int cora_dot_dev(cora_ctx *c, const double *dA, const double *dB, int k, double *out) {
+  NEED_DEVICE(c);
+  if (k <= 0 || k > kMaxLD || !dA || !dB || !out) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const int ld = ld_for(k);
+  DotArgs D;
+  const size_t off = static_cast<size_t>(c->F.L.base) * ld;
+  for (int j = 0; j < 4; ++j) { D.a[j] = nullptr; D.b[j] = nullptr; }
+  D.a[0] = dA + off;
+  D.b[0] = dB + off;
+  D.count = 1;
+  D.n2 = c->F.L.local_rows * ld / 2;
+  int rc = ensure_red(c, 4 * 512);
+  if (rc) return rc;
+  D.partial = c->d_red;
+  int nblocks = 0;
+  HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
+  HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->d_scalars, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *out = c->h_scalars[0];
+  return CORA_OK;
+}
+
+int cora_timer_start(cora_ctx *c) {
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  return CORA_OK;
+}
+
+int cora_timer_stop_ms(cora_ctx *c, float *ms) {
+  NEED_DEVICE(c);
+  if (!ms) return fail(c, CORA_ERR_ARG, "null pointer");
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->ev1));
+  HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return CORA_OK;
+}
+
+int cora_sync(cora_ctx *c) {
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CORA_OK;
+}
+
+// ------------------------------------------------- host-pointer operator API
+
+#define CHECK_LD(c, ld)                                                                  \
+  do {                                                                                   \
+    if ((ld) < (c)->F.L.N) return fail((c), CORA_ERR_SHAPE, "leading dimension smaller than N"); \
+  } while (0)
+
+int cora_data_matrix_product(cora_ctx *c, const double *X, int ldx, int k, double *out, int ldo) {
+  NEED_DEVICE(c);
+  if (k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_SHAPE, "column count must be in [1, 24]");
+  double *dX, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, ld_for(k), &dX))) return rc;
+  if ((rc = get_scratch(c, 1, ld_for(k), &dO))) return rc;
+  if ((rc = upload_impl(c, X, ldx, k, dX))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, ld_for(k)), c->stream));
+  if ((rc = cora_spmm_dev(c, dX, k, dO))) return rc;
+  return download_impl(c, dO, k, out, ldo);
+}
+
+int cora_evaluate_objective(cora_ctx *c, const double *Y, int ldy, double *f) {
+  if (!f) return fail(c, CORA_ERR_ARG, "null pointer");
+  int rc = cora_set_point(c, Y, ldy);
+  if (rc) return rc;
+  *f = c->f;
+  return CORA_OK;
+}
+
+int cora_euclidean_gradient(cora_ctx *c, const double *Y, int ldy, double *out, int ldo) {
+  int rc = cora_set_point(c, Y, ldy);
+  if (rc) return rc;
+  return download_impl(c, c->d_G, c->p, out, ldo);
+}
+
+int cora_riemannian_gradient(cora_ctx *c, const double *Y, int ldy, double *out, int ldo) {
+  int rc = cora_set_point(c, Y, ldy);
+  if (rc) return rc;
+  return download_impl(c, c->d_rgrad, c->p, out, ldo);
+}
+
+int cora_tangent_space_projection(cora_ctx *c, const double *Y, int ldy, const double *V, int ldv,
+                                  double *out, int ldo) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  double *dV, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, c->ld, &dV))) return rc;
+  if ((rc = get_scratch(c, 1, c->ld, &dO))) return rc;
+  if ((rc = upload_impl(c, Y, ldy, c->p, c->d_Y))) return rc;
+  c->have_point = false;  // Y replaced without refreshing the cached gradient
+  if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
+  HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, nullptr, dO, c->stream));
+  return download_impl(c, dO, c->p, out, ldo);
+}
+
+int cora_riemannian_hessian_vector_product(cora_ctx *c, const double *Y, int ldy, const double *G, int ldg,
+                                           const double *dotY, int ldd, double *out, int ldo) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  double *dX, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, c->ld, &dX))) return rc;
+  if ((rc = get_scratch(c, 1, c->ld, &dO))) return rc;
+  // honour the reference signature: Lambda is built from the nablaF_Y passed in
+  if ((rc = upload_impl(c, Y, ldy, c->p, c->d_Y))) return rc;
+  if ((rc = upload_impl(c, G, ldg, c->p, c->d_G))) return rc;
+  if ((rc = point_finish(c))) return rc;
+  if ((rc = upload_impl(c, dotY, ldd, c->p, dX))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
+  if ((rc = cora_hvp_dev(c, dX, dO))) return rc;
+  return download_impl(c, dO, c->p, out, ldo);
+}
+
+int cora_project_to_manifold(cora_ctx *c, const double *A, int lda, double *out, int ldo) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  double *dA, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, c->ld, &dA))) return rc;
+  if ((rc = get_scratch(c, 1, c->ld, &dO))) return rc;
+  if ((rc = upload_impl(c, A, lda, c->p, dA))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
+  HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, dA, nullptr, 0.0, dO, c->stream));
+  return download_impl(c, dO, c->p, out, ldo);
+}
+
+int cora_retract(cora_ctx *c, const double *Y, int ldy, const double *V, int ldv, double *out, int ldo) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  double *dY, *dV, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, c->ld, &dY))) return rc;
+  if ((rc = get_scratch(c, 1, c->ld, &dV))) return rc;
+  if ((rc = get_scratch(c, 2, c->ld, &dO))) return rc;
+  if ((rc = upload_impl(c, Y, ldy, c->p, dY))) return rc;
+  if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
+  HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, dY, dV, 1.0, dO, c->stream));
+  return download_impl(c, dO, c->p, out, ldo);
+}
+
+int cora_precondition(cora_ctx *c, const double *V, int ldv, double *out, int ldo) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (c->precond != CORA_PRECOND_JACOBI)
+    return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up (cora_precond_setup)");
+  double *dV, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, c->ld, &dV))) return rc;
+  if ((rc = get_scratch(c, 1, c->ld, &dO))) return rc;
+  if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
+  const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
+  HIP_TRY(c, launch_scale_rows(c->F.L.local_rows, c->ld, c->d_diag_inv, dV + off, dO + off, c->stream));
+  // NaN guard, src/CORA_problem.cpp:898-901
+  HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+  HIP_TRY(c, launch_has_nan(c->F.L.local_rows * c->ld, dO + off, c->d_flag, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (*c->h_flag) return fail(c, CORA_ERR_NAN, "NaNs in preconditioned vector");
+  return download_impl(c, dO, c->p, out, ldo);
+}
+
+int cora_compute_lambda_blocks(cora_ctx *c, const double *Y, int ldy, double *stiefel, double *oblique) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "host Lambda blocks need a 1-GPU handle");
+  int rc = cora_set_point(c, Y, ldy);
+  if (rc) return rc;
+  const Layout &L = c->F.L;
+  // a symmetric d x d block is the same row- or column-major, so the device
+  // array [pose][d*d] already is the d x (d n) column-major matrix
+  if (L.n > 0 && stiefel)
+    HIP_TRY(c, hipMemcpyAsync(stiefel, c->d_lam_st, static_cast<size_t>(L.n) * L.d * L.d * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+  if (L.r > 0 && oblique)
+    HIP_TRY(c, hipMemcpyAsync(oblique, c->d_lam_ob, static_cast<size_t>(L.r) * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CORA_OK;
+}
+
+int cora_certificate_product(cora_ctx *c, const double *X, int ldx, int k, double *out, int ldo) {
+  NEED_DEVICE(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  double *dX, *dO;
+  int rc;
+  if ((rc = get_scratch(c, 0, ld_for(k), &dX))) return rc;
+  if ((rc = get_scratch(c, 1, ld_for(k), &dO))) return rc;
+  if ((rc = upload_impl(c, X, ldx, k, dX))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, ld_for(k)), c->stream));
+  if ((rc = cora_certificate_product_dev(c, dX, k, dO))) return rc;
+  return download_impl(c, dO, k, out, ldo);
+}
+
+int cora_inner_product(cora_ctx *c, const double *A, int lda, const double *B, int ldb, int k, double *out) {
+  NEED_DEVICE(c);
+  double *dA, *dB;
+  int rc;
+  if ((rc = get_scratch(c, 0, ld_for(k), &dA))) return rc;
+  if ((rc = get_scratch(c, 1, ld_for(k), &dB))) return rc;
+  if ((rc = upload_impl(c, A, lda, k, dA))) return rc;
+  if ((rc = upload_impl(c, B, ldb, k, dB))) return rc;
+  return cora_dot_dev(c, dA, dB, k, out);
+}
+
+int cora_debug_format_spmm_host(const cora_ctx *c, const double *X, int ldx, int k, double *out, int ldo) {
+  if (!c || !X || !out || k <= 0 || k > kMaxLD) return CORA_ERR_ARG;
+  const HostFormat &F = c->F;
+  const int ld = ld_for(k);
+  const int64_t N = F.L.N;
+  std::vector<double> xi(static_cast<size_t>(F.L.rows) * ld, 0.0), oi(static_cast<size_t>(F.L.rows) * ld, 0.0);
+  for (int cc = 0; cc < k; ++cc)
+    for (int64_t i = 0; i < N; ++i)
+      xi[static_cast<size_t>(F.api2int[i]) * ld + cc] = X[static_cast<size_t>(cc) * ldx + i];
+  format_spmm_host(F, xi.data(), ld, oi.data());
+  for (int cc = 0; cc < k; ++cc)
+    for (int64_t i = 0; i < N; ++i)
+      out[static_cast<size_t>(cc) * ldo + i] = oi[static_cast<size_t>(F.api2int[i]) * ld + cc];
+  return CORA_OK;
+}
+
+}  // extern "C"

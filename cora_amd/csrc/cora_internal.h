@@ -1,0 +1,95 @@
+// Internal declarations shared by the format builder (host C++), the kernels
+// (HIP) and the C-ABI layer.  Not installed; the public interface is
+// include/cora_hip.h.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace cora {
+
+constexpr int kWave = 64;         // CDNA4 wavefront
+constexpr int kLongRow = 96;      // translation rows longer than this -> long path
+constexpr int kLongChunk = 2048;  // nnz per long-row workgroup chunk
+constexpr int kSigma = 2048;      // sorting window (rows) for translation slices
+constexpr int kMaxLD = 24;
+
+// Row stride (doubles) used for a k-column resident vector.
+inline int ld_for(int k) {
+  if (k <= 12) return (k + 1) & ~1;
+  return (k + 3) & ~3;
+}
+
+enum SliceType : int32_t {
+  kSliceStiefel = 0,   // rows = whole poses (d consecutive rows each)
+  kSliceOblique = 1,   // unit-sphere rows
+  kSliceEuclid = 2,    // translation rows, identity row order
+  kSliceEuclidPerm = 3 // translation rows, rows given by perm[]
+};
+
+// One wavefront's work: up to 64 rows, `width` nonzero slots per row, stored
+// slot-major ([k][lane]) so that every load is a fully coalesced 512 B / 256 B.
+struct SliceDesc {
+  int32_t row0;    // first internal row (or offset into perm[] for kSliceEuclidPerm)
+  int32_t nrows;   // active lanes
+  int32_t width;   // slots per row
+  int32_t type;    // SliceType
+  int64_t off;     // element offset of slot 0 / lane 0 in sval / scol
+  int32_t aux0;    // Stiefel: first LOCAL pose index; Oblique: first LOCAL range index
+  int32_t aux1;
+};
+static_assert(sizeof(SliceDesc) == 32, "SliceDesc must be 32 bytes");
+
+// A chunk of one long row, processed by one 256-thread workgroup.
+struct LongChunk {
+  int32_t row;       // internal row
+  int32_t k0, k1;    // nonzero range in lval / lcol
+  int32_t nchunks;   // chunks of this row
+  int32_t first;     // index of this row's first chunk (partials slot base)
+  int32_t slot;      // long-row ordinal (ticket counter index)
+  int32_t pad0, pad1;
+};
+static_assert(sizeof(LongChunk) == 32, "LongChunk must be 32 bytes");
+
+// Region of the internal row order owned by this handle.
+struct Layout {
+  int d = 0, n = 0, r = 0, nt = 0;  // global problem dims (nt = n + l)
+  int64_t N = 0;                    // n*d + r + nt
+  int rank = 0, world = 1;
+  int64_t shard_rows = 0;           // padded rows per rank
+  int64_t rows = 0;                 // world * shard_rows
+  // local (owned) counts and internal bases
+  int64_t base = 0;                 // rank * shard_rows
+  int nl_poses = 0, nl_ranges = 0, nl_trans = 0;
+  int64_t rot_base = 0, rng_base = 0, trn_base = 0;  // internal row of first local rot/range/trans row
+  int64_t local_rows = 0;
+};
+
+struct HostFormat {
+  Layout L;
+  std::vector<int32_t> api2int;   // N: internal row of API row
+  std::vector<int32_t> int2api;   // rows: API row of internal row (-1 = padding)
+  std::vector<SliceDesc> slices;
+  std::vector<double> sval;
+  std::vector<int32_t> scol;
+  std::vector<int32_t> perm;      // internal rows for kSliceEuclidPerm slices
+  std::vector<LongChunk> chunks;
+  std::vector<double> lval;
+  std::vector<int32_t> lcol;
+  int n_long_rows = 0;
+  std::vector<double> diag;       // diag(Q) for LOCAL rows, indexed by (internal row - base)
+  int64_t nnz_global = 0, nnz_local = 0, padded_nnz = 0, long_nnz = 0;
+  int max_width = 0;
+};
+
+// Builds the partition + sliced format.  Throws std::runtime_error on invalid input.
+void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
+                  const int32_t *col, const double *val, int rank, int world,
+                  HostFormat &out);
+
+// Host execution of the FORMAT (test hook, see cora_debug_format_spmm_host).
+void format_spmm_host(const HostFormat &F, const double *X_int, int ld,
+                      double *out_int);
+
+}  // namespace cora

@@ -1,0 +1,306 @@
+// Host-side construction of the device format of the data matrix Q:
+//   (1) row partition across ranks (pose-aligned, nnz-balanced),
+//   (2) internal row order (rank-major; per rank: rotations | ranges | translations),
+//   (3) sliced-ELL storage, one 64-row slice per wavefront, slot-major so every
+//       wavefront load is coalesced, plus a separate path for the few very long
+//       (landmark) rows.
+// Input is the reference's `Problem::data_matrix_` (Eigen row-major CSR,
+// src/CORA_problem.cpp:625-712) with the variable layout of
+// include/CORA/CORA_problem.h:151-157.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+
+#include "cora_internal.h"
+
+namespace cora {
+
+namespace {
+
+struct RowRef {
+  int32_t api_row;
+  int32_t int_row;
+  int32_t len;
+};
+
+void emit_slice(HostFormat &F, const std::vector<RowRef> &rows, size_t begin,
+                size_t end, int32_t type, int32_t row0, int32_t aux0,
+                const int32_t *rowptr, const int32_t *col, const double *val) {
+  SliceDesc s{};
+  s.row0 = row0;
+  s.nrows = static_cast<int32_t>(end - begin);
+  s.type = type;
+  s.aux0 = aux0;
+  s.aux1 = 0;
+  int width = 0;
+  for (size_t i = begin; i < end; ++i) width = std::max(width, rows[i].len);
+  s.width = width;
+  s.off = static_cast<int64_t>(F.sval.size());
+  F.max_width = std::max(F.max_width, width);
+  const size_t base = F.sval.size();
+  F.sval.resize(base + static_cast<size_t>(width) * kWave, 0.0);
+  F.scol.resize(base + static_cast<size_t>(width) * kWave, 0);
+  for (int lane = 0; lane < kWave; ++lane) {
+    // padding lanes replicate the last active row's columns with zero values
+    const size_t src = begin + std::min<size_t>(lane, end - begin - 1);
+    const RowRef &rr = rows[src];
+    const bool active = lane < s.nrows;
+    const int32_t p0 = rowptr[rr.api_row];
+    int32_t fill = rr.len > 0 ? F.api2int[col[p0]] : rr.int_row;
+    for (int k = 0; k < width; ++k) {
+      const size_t dst = base + static_cast<size_t>(k) * kWave + lane;
+      if (k < rr.len) {
+        F.scol[dst] = F.api2int[col[p0 + k]];
+        F.sval[dst] = active ? val[p0 + k] : 0.0;
+        fill = F.scol[dst];
+      } else {
+        F.scol[dst] = fill;  // padded slot: re-reads a row already in cache
+        F.sval[dst] = 0.0;
+      }
+    }
+  }
+  F.padded_nnz += static_cast<int64_t>(width) * kWave;
+  F.slices.push_back(s);
+}
+
+}  // namespace
+
+void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
+                  const int32_t *col, const double *val, int rank, int world,
+                  HostFormat &F) {
+  if (d != 2 && d != 3) throw std::runtime_error("cora: dimension d must be 2 or 3");
+  if (n < 0 || r < 0 || nt < n) throw std::runtime_error("cora: invalid problem sizes");
+  if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("cora: invalid rank/world");
+  const int64_t dn = static_cast<int64_t>(d) * n;
+  const int64_t N = dn + r + nt;
+  if (N <= 0) throw std::runtime_error("cora: empty problem");
+  if (N > 2000000000LL) throw std::runtime_error("cora: problem too large for int32 rows");
+  if (rowptr[0] != 0) throw std::runtime_error("cora: rowptr[0] must be 0 (call makeCompressed())");
+  const int l = nt - n;
+  Layout &L = F.L;
+  L.d = d; L.n = n; L.r = r; L.nt = nt; L.N = N; L.rank = rank; L.world = world;
+  F.nnz_global = rowptr[N];
+  for (int64_t i = 0; i < N; ++i) {
+    if (rowptr[i + 1] < rowptr[i]) throw std::runtime_error("cora: rowptr not monotone");
+    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q)
+      if (col[q] < 0 || col[q] >= N) throw std::runtime_error("cora: column index out of range");
+  }
+  auto rowlen = [&](int64_t i) { return rowptr[i + 1] - rowptr[i]; };
+
+  // ---- 1. owner of every pose / range row / landmark -----------------------
+  std::vector<int> pose_owner(n, 0), range_pose(r, -1), range_owner(r, 0), lm_owner(l, 0);
+  if (world > 1) {
+    for (int j = 0; j < l; ++j) lm_owner[j] = j % world;
+    // a range row belongs with the first pose translation it touches
+    const int64_t tb = dn + r;
+    for (int k = 0; k < r; ++k) {
+      const int64_t row = dn + k;
+      int lm = -1;
+      for (int32_t q = rowptr[row]; q < rowptr[row + 1]; ++q) {
+        const int64_t c = col[q];
+        if (c >= tb) {
+          const int64_t t = c - tb;
+          if (t < n) { if (range_pose[k] < 0) range_pose[k] = static_cast<int>(t); }
+          else if (lm < 0) lm = static_cast<int>(t - n);
+        }
+      }
+      if (range_pose[k] < 0) range_owner[k] = lm >= 0 ? lm_owner[lm] : 0;
+    }
+    std::vector<int64_t> w(n, 0), lw(world, 0);
+    for (int i = 0; i < n; ++i) {
+      for (int a = 0; a < d; ++a) w[i] += rowlen(static_cast<int64_t>(i) * d + a);
+      w[i] += rowlen(tb + i);
+    }
+    for (int k = 0; k < r; ++k) {
+      if (range_pose[k] >= 0) w[range_pose[k]] += rowlen(dn + k);
+      else lw[range_owner[k]] += rowlen(dn + k);
+    }
+    for (int j = 0; j < l; ++j) lw[lm_owner[j]] += rowlen(tb + n + j);
+    const int64_t total = std::accumulate(w.begin(), w.end(), int64_t{0}) +
+                          std::accumulate(lw.begin(), lw.end(), int64_t{0});
+    int g = 0;
+    int64_t acc = lw[0];
+    const double target = static_cast<double>(total) / world;
+    for (int i = 0; i < n; ++i) {
+      // move on when this rank is full, keeping enough poses for the ranks left
+      if (g < world - 1 && acc + w[i] / 2 > target) {
+        ++g;
+        acc = lw[g];
+      }
+      pose_owner[i] = g;
+      acc += w[i];
+    }
+    for (int k = 0; k < r; ++k)
+      if (range_pose[k] >= 0) range_owner[k] = pose_owner[range_pose[k]];
+  }
+
+  // ---- 2. internal numbering ------------------------------------------------
+  std::vector<int64_t> np(world, 0), nr(world, 0), nlm(world, 0);
+  for (int i = 0; i < n; ++i) np[pose_owner[i]]++;
+  for (int k = 0; k < r; ++k) nr[range_owner[k]]++;
+  for (int j = 0; j < l; ++j) nlm[lm_owner[j]]++;
+  int64_t shard = 0;
+  for (int g = 0; g < world; ++g)
+    shard = std::max(shard, d * np[g] + nr[g] + np[g] + nlm[g]);
+  if (world > 1) shard = (shard + 7) & ~int64_t{7};
+  L.shard_rows = shard;
+  L.rows = shard * world;
+  if (L.rows > 2000000000LL) throw std::runtime_error("cora: too many internal rows");
+  L.base = shard * rank;
+  L.nl_poses = static_cast<int>(np[rank]);
+  L.nl_ranges = static_cast<int>(nr[rank]);
+  L.nl_trans = static_cast<int>(np[rank] + nlm[rank]);
+  L.rot_base = L.base;
+  L.rng_base = L.rot_base + static_cast<int64_t>(d) * L.nl_poses;
+  L.trn_base = L.rng_base + L.nl_ranges;
+  L.local_rows = static_cast<int64_t>(d) * L.nl_poses + L.nl_ranges + L.nl_trans;
+
+  F.api2int.assign(N, -1);
+  F.int2api.assign(L.rows, -1);
+  {
+    std::vector<int64_t> cp(world, 0), cr(world, 0), ct(world, 0);
+    for (int i = 0; i < n; ++i) {
+      const int g = pose_owner[i];
+      const int64_t b = shard * g;
+      for (int a = 0; a < d; ++a)
+        F.api2int[static_cast<int64_t>(i) * d + a] = static_cast<int32_t>(b + d * cp[g] + a);
+      // pose translation
+      F.api2int[dn + r + i] = static_cast<int32_t>(b + d * np[g] + nr[g] + cp[g]);
+      cp[g]++;
+    }
+    for (int k = 0; k < r; ++k) {
+      const int g = range_owner[k];
+      F.api2int[dn + k] = static_cast<int32_t>(shard * g + d * np[g] + cr[g]++);
+    }
+    for (int j = 0; j < l; ++j) {
+      const int g = lm_owner[j];
+      F.api2int[dn + r + n + j] =
+          static_cast<int32_t>(shard * g + d * np[g] + nr[g] + np[g] + ct[g]++);
+    }
+    for (int64_t i = 0; i < N; ++i) F.int2api[F.api2int[i]] = static_cast<int32_t>(i);
+  }
+
+  // ---- 3. local rows -> slices ---------------------------------------------
+  F.slices.clear(); F.sval.clear(); F.scol.clear(); F.perm.clear();
+  F.chunks.clear(); F.lval.clear(); F.lcol.clear();
+  F.padded_nnz = F.long_nnz = F.nnz_local = 0; F.max_width = 0; F.n_long_rows = 0;
+  F.diag.assign(static_cast<size_t>(std::max<int64_t>(L.local_rows, 1)), 0.0);
+
+  auto local_row = [&](int64_t int_row) {
+    RowRef rr;
+    rr.int_row = static_cast<int32_t>(int_row);
+    rr.api_row = F.int2api[int_row];
+    rr.len = rowlen(rr.api_row);
+    F.nnz_local += rr.len;
+    for (int32_t q = rowptr[rr.api_row]; q < rowptr[rr.api_row + 1]; ++q)
+      if (col[q] == rr.api_row) F.diag[int_row - L.base] += val[q];
+    return rr;
+  };
+
+  // Stiefel slices: whole poses, in order (the tangent-projection epilogue
+  // needs a pose's d rows in adjacent lanes).
+  {
+    std::vector<RowRef> rows;
+    rows.reserve(static_cast<size_t>(d) * L.nl_poses);
+    for (int64_t i = 0; i < static_cast<int64_t>(d) * L.nl_poses; ++i)
+      rows.push_back(local_row(L.rot_base + i));
+    const int ps = kWave / d;  // poses per slice
+    for (int p0 = 0; p0 < L.nl_poses; p0 += ps) {
+      const int cnt = std::min(ps, L.nl_poses - p0);
+      emit_slice(F, rows, static_cast<size_t>(p0) * d, static_cast<size_t>(p0 + cnt) * d,
+                 kSliceStiefel, static_cast<int32_t>(L.rot_base + static_cast<int64_t>(p0) * d),
+                 p0, rowptr, col, val);
+    }
+  }
+  // Oblique slices
+  {
+    std::vector<RowRef> rows;
+    rows.reserve(L.nl_ranges);
+    for (int64_t i = 0; i < L.nl_ranges; ++i) rows.push_back(local_row(L.rng_base + i));
+    for (int64_t k0 = 0; k0 < L.nl_ranges; k0 += kWave) {
+      const int64_t cnt = std::min<int64_t>(kWave, L.nl_ranges - k0);
+      emit_slice(F, rows, k0, k0 + cnt, kSliceOblique,
+                 static_cast<int32_t>(L.rng_base + k0), static_cast<int32_t>(k0),
+                 rowptr, col, val);
+    }
+  }
+  // Translation rows: long rows -> chunked path; the rest sorted by length
+  // inside windows of kSigma rows (keeps column locality) and sliced.
+  {
+    std::vector<RowRef> rows;
+    rows.reserve(L.nl_trans);
+    for (int64_t i = 0; i < L.nl_trans; ++i) {
+      RowRef rr = local_row(L.trn_base + i);
+      if (rr.len > kLongRow) {
+        const int32_t p0 = rowptr[rr.api_row];
+        const int32_t k_begin = static_cast<int32_t>(F.lval.size());
+        for (int k = 0; k < rr.len; ++k) {
+          F.lval.push_back(val[p0 + k]);
+          F.lcol.push_back(F.api2int[col[p0 + k]]);
+        }
+        const int nch = (rr.len + kLongChunk - 1) / kLongChunk;
+        const int32_t first = static_cast<int32_t>(F.chunks.size());
+        for (int c = 0; c < nch; ++c) {
+          LongChunk ch{};
+          ch.row = rr.int_row;
+          ch.k0 = k_begin + c * kLongChunk;
+          ch.k1 = k_begin + std::min(rr.len, (c + 1) * kLongChunk);
+          ch.nchunks = nch;
+          ch.first = first;
+          ch.slot = F.n_long_rows;
+          F.chunks.push_back(ch);
+        }
+        F.n_long_rows++;
+        F.long_nnz += rr.len;
+      } else {
+        rows.push_back(rr);
+      }
+    }
+    for (size_t w0 = 0; w0 < rows.size(); w0 += kSigma) {
+      const size_t w1 = std::min(rows.size(), w0 + kSigma);
+      std::stable_sort(rows.begin() + w0, rows.begin() + w1,
+                       [](const RowRef &a, const RowRef &b) { return a.len > b.len; });
+    }
+    for (size_t k0 = 0; k0 < rows.size(); k0 += kWave) {
+      const size_t cnt = std::min<size_t>(kWave, rows.size() - k0);
+      const int32_t poff = static_cast<int32_t>(F.perm.size());
+      for (int lane = 0; lane < kWave; ++lane)
+        F.perm.push_back(rows[k0 + std::min<size_t>(lane, cnt - 1)].int_row);
+      emit_slice(F, rows, k0, k0 + cnt, kSliceEuclidPerm, poff, 0, rowptr, col, val);
+    }
+  }
+}
+
+void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out) {
+  std::vector<double> acc(ld);
+  for (const SliceDesc &s : F.slices) {
+    for (int lane = 0; lane < s.nrows; ++lane) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int k = 0; k < s.width; ++k) {
+        const size_t e = static_cast<size_t>(s.off) + static_cast<size_t>(k) * kWave + lane;
+        const double v = F.sval[e];
+        const double *xr = X + static_cast<size_t>(F.scol[e]) * ld;
+        for (int c = 0; c < ld; ++c) acc[c] += v * xr[c];
+      }
+      const int64_t row = (s.type == kSliceEuclidPerm) ? F.perm[s.row0 + lane] : s.row0 + lane;
+      for (int c = 0; c < ld; ++c) out[static_cast<size_t>(row) * ld + c] = acc[c];
+    }
+  }
+  size_t ci = 0;
+  while (ci < F.chunks.size()) {
+    const LongChunk &c0 = F.chunks[ci];
+    std::fill(acc.begin(), acc.end(), 0.0);
+    for (int c = 0; c < c0.nchunks; ++c) {
+      const LongChunk &ch = F.chunks[ci + c];
+      for (int32_t k = ch.k0; k < ch.k1; ++k) {
+        const double *xr = X + static_cast<size_t>(F.lcol[k]) * ld;
+        for (int j = 0; j < ld; ++j) acc[j] += F.lval[k] * xr[j];
+      }
+    }
+    for (int j = 0; j < ld; ++j) out[static_cast<size_t>(c0.row) * ld + j] = acc[j];
+    ci += c0.nchunks;
+  }
+}
+
+}  // namespace cora

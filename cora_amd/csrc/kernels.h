@@ -1,0 +1,67 @@
+// Kernel argument blocks and launcher declarations (host-visible).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "cora_internal.h"
+
+namespace cora {
+
+enum Epilogue : int { EPI_NONE = 0, EPI_S = 1, EPI_HVP = 2 };
+
+struct SpmmArgs {
+  const SliceDesc *slices;
+  int n_slices;
+  int n_chunks;
+  const double *sval;
+  const int32_t *scol;
+  const int32_t *perm;
+  const LongChunk *chunks;
+  const double *lval;
+  const int32_t *lcol;
+  double *partials;    // [n_chunks][kMaxLD]
+  unsigned *tickets;   // [n_long_rows], zero between launches
+  const double *X;     // rows x LD
+  double *out;         // rows x LD (only local rows are written)
+  const double *Y;     // current point (epilogues)
+  const double *lam_st;  // [local pose][d*d]
+  const double *lam_ob;  // [local range]
+};
+
+struct RowArgs {
+  int d;
+  int nl_poses, nl_ranges, nl_trans;
+  size_t rot_base, rng_base, trn_base, base;
+};
+
+struct DotArgs {
+  const double *a[4];
+  const double *b[4];
+  int count;
+  int64_t n2;        // number of double2 elements
+  double *partial;   // [count][gridDim.x]
+};
+
+hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+hipError_t launch_point_finish(const RowArgs &R, int ld, const double *Y, const double *G,
+                               double *rgrad, double *lam_st, double *lam_ob, double *partial,
+                               int *nblocks, hipStream_t st);
+hipError_t launch_tangent_project(const RowArgs &R, int ld, const double *Y, const double *V,
+                                  const double *scale, double *out, hipStream_t st);
+hipError_t launch_project_manifold(const RowArgs &R, int ld, const double *A, const double *V,
+                                   double alpha, double *out, hipStream_t st);
+hipError_t launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t st);
+hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const double *x, double *y,
+                             hipStream_t st);
+hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st);
+hipError_t launch_reduce_partials(const double *partial, int nblocks, int count, double *out,
+                                  hipStream_t st);
+hipError_t launch_has_nan(int64_t n, const double *x, int *flag, hipStream_t st);
+hipError_t launch_upload(int64_t N, int k, int ld, const double *src, const int32_t *api2int,
+                         double *dst, hipStream_t st);
+hipError_t launch_download(int64_t N, int k, int ld, const double *src, const int32_t *api2int,
+                           double *dst, hipStream_t st);
+
+}  // namespace cora

@@ -1,0 +1,730 @@
+// HIP kernels for the CORA hot path on gfx950 (CDNA4, wave64).
+//
+// All resident vectors are row-major  rows x LD  doubles (LD even, padding
+// columns zero), so one row is LD*8 contiguous bytes and a d x LD pose block is
+// contiguous as well.  fp64 throughout (the reference's `typedef double Scalar`,
+// include/CORA/CORA_types.h:43).  No MFMA: the path is HBM/L2-bound
+// (0.49 flop/B at p = 5).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cora_internal.h"
+#include "kernels.h"
+
+namespace cora {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+template <int LD>
+__device__ __forceinline__ void load_row(const double *__restrict__ p, double (&x)[LD]) {
+  const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+  for (int j = 0; j < LD / 2; ++j) {
+    const double2 t = q[j];
+    x[2 * j] = t.x;
+    x[2 * j + 1] = t.y;
+  }
+}
+
+template <int LD>
+__device__ __forceinline__ void store_row(double *__restrict__ p, const double (&x)[LD]) {
+  double2 *q = reinterpret_cast<double2 *>(p);
+#pragma unroll
+  for (int j = 0; j < LD / 2; ++j) q[j] = make_double2(x[2 * j], x[2 * j + 1]);
+}
+
+template <int LD>
+__device__ __forceinline__ double dot_row(const double (&a)[LD], const double (&b)[LD]) {
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < LD; ++j) s = fma(a[j], b[j], s);
+  return s;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0. `sm` holds >= 4 doubles.
+__device__ __forceinline__ double block_sum_256(double v, double *sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// Tangent-space projection of one Stiefel row when the d rows of the pose sit
+// in d adjacent lanes (lane `a` of the pose holds row a).
+//   out_a = g_a - sum_b sym(Y G^T)[a][b] Y_b        (StiefelProduct.h:79-81)
+// `m[b]` = <Y_b, g_a> = (Y G^T)[b][a] is computed locally; the transposed
+// entries come from the sibling lanes by wave shuffles.
+template <int LD, int D>
+__device__ __forceinline__ void stiefel_project_lane(const double *__restrict__ Yp,
+                                                     int a, int lane, double (&g)[LD]) {
+  double y[D][LD];
+  double m[D];
+#pragma unroll
+  for (int b = 0; b < D; ++b) {
+    load_row<LD>(Yp + b * LD, y[b]);
+    m[b] = dot_row<LD>(y[b], g);
+  }
+  const int base = lane - a;
+  double s[D];
+#pragma unroll
+  for (int b = 0; b < D; ++b) s[b] = m[b];  // s[a] = m[a] is the diagonal entry
+#pragma unroll
+  for (int st = 1; st < D; ++st) {
+    // I (index a) read from partner b = (a+st)%D the value m_partner[a];
+    // seen from the partner (index a'), that is element (a' - st + D) % D.
+    const int mine = (a + D - st) % D;
+    double pub = m[0];
+#pragma unroll
+    for (int t = 1; t < D; ++t) pub = (mine == t) ? m[t] : pub;
+    const int b = (a + st) % D;
+    const double got = __shfl(pub, base + b, 64);
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+      if (t == b) s[t] = 0.5 * (m[t] + got);
+  }
+#pragma unroll
+  for (int b = 0; b < D; ++b) {
+#pragma unroll
+    for (int c = 0; c < LD; ++c) g[c] = fma(-s[b], y[b][c], g[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sliced SpMM with fused epilogues.
+//   EPI_NONE : out = Q X                       (Problem::dataMatrixProduct, :742-746)
+//   EPI_S    : out = Q X - Lambda X            (certificate operator, :1162-1166)
+//   EPI_HVP  : out = Proj_Y(Q X - Lambda X)    (Riemannian Hvp, :822-867)
+// One wavefront per slice, lane = row, LD accumulators per lane in registers.
+// Blocks [0, n_chunks) handle chunks of the long (landmark) rows instead.
+// ---------------------------------------------------------------------------
+template <int LD>
+__device__ __forceinline__ void long_chunk_block(const SpmmArgs &A, int ci, double *sm,
+                                                 int *sflag) {
+  const LongChunk ch = A.chunks[ci];
+  const int tid = threadIdx.x;
+  double acc[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+  for (int k = ch.k0 + tid; k < ch.k1; k += 256) {
+    const double v = A.lval[k];
+    double x[LD];
+    load_row<LD>(A.X + static_cast<size_t>(A.lcol[k]) * LD, x);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[j] = fma(v, x[j], acc[j]);
+  }
+  // block reduce LD values: wave shuffles, then LDS across the 4 waves
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < LD; ++j) {
+    const double v = wave_sum(acc[j]);
+    if (lane == 0) sm[w * LD + j] = v;
+  }
+  __syncthreads();
+  double tot = 0.0;
+  if (tid < LD) tot = sm[tid] + sm[LD + tid] + sm[2 * LD + tid] + sm[3 * LD + tid];
+  double *orow = A.out + static_cast<size_t>(ch.row) * LD;
+  if (ch.nchunks == 1) {
+    if (tid < LD) orow[tid] = tot;
+    return;
+  }
+  // several chunks: publish the partial, the last arriver sums them in chunk
+  // order (deterministic).  Agent-scope release / acquire per the gfx950
+  // inter-workgroup visibility rules.
+  if (tid < LD) A.partials[static_cast<size_t>(ci) * kMaxLD + tid] = tot;
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(A.tickets + ch.slot, 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (old == static_cast<unsigned>(ch.nchunks - 1));
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(A.tickets + ch.slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *sflag = last;
+  }
+  __syncthreads();
+  if (*sflag && tid < LD) {
+    double s = 0.0;
+    for (int c = 0; c < ch.nchunks; ++c)
+      s += __hip_atomic_load(A.partials + static_cast<size_t>(ch.first + c) * kMaxLD + tid,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    orow[tid] = s;
+  }
+}
+
+template <int LD, int D, int EPI>
+__global__ __launch_bounds__(256) void k_spmm(const SpmmArgs A) {
+  __shared__ double sm[4 * kMaxLD];
+  __shared__ int sflag;
+  if (static_cast<int>(blockIdx.x) < A.n_chunks) {
+    long_chunk_block<LD>(A, blockIdx.x, sm, &sflag);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(
+      (static_cast<int>(blockIdx.x) - A.n_chunks) * 4 + static_cast<int>(threadIdx.x >> 6));
+  if (s >= A.n_slices) return;
+  const SliceDesc sd = A.slices[s];
+  const double *__restrict__ vp = A.sval + sd.off + lane;
+  const int32_t *__restrict__ cp = A.scol + sd.off + lane;
+  const double *__restrict__ X = A.X;
+
+  double acc[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+
+#pragma unroll 4
+  for (int k = 0; k < sd.width; ++k) {
+    const double v = vp[static_cast<size_t>(k) * kWave];
+    const int32_t c = cp[static_cast<size_t>(k) * kWave];
+    double x[LD];
+    load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[j] = fma(v, x[j], acc[j]);
+  }
+
+  const bool active = lane < sd.nrows;
+  if (sd.type == kSliceStiefel) {
+    const int64_t row = static_cast<int64_t>(sd.row0) + lane;
+    if (EPI != EPI_NONE) {
+      // clamp idle lanes onto the last pose so that shuffles / loads stay valid
+      const int lr = active ? lane : sd.nrows - 1;
+      const int q = lr / D, a = lr - q * D;
+      const int lpose = sd.aux0 + q;
+      const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(q) * D;
+      const double *Xp = X + prow * LD;
+      const double *Lp = A.lam_st + static_cast<size_t>(lpose) * (D * D) + a * D;
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        const double lam = Lp[b];
+        double x[LD];
+        load_row<LD>(Xp + b * LD, x);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
+      }
+      if (EPI == EPI_HVP)
+        stiefel_project_lane<LD, D>(A.Y + prow * LD, a, active ? lane : (q * D + a), acc);
+    }
+    if (active) store_row<LD>(A.out + static_cast<size_t>(row) * LD, acc);
+  } else if (sd.type == kSliceOblique) {
+    const int64_t row = static_cast<int64_t>(sd.row0) + lane;
+    if (active) {
+      if (EPI != EPI_NONE) {
+        const double lam = A.lam_ob[sd.aux0 + lane];
+        double x[LD];
+        load_row<LD>(X + static_cast<size_t>(row) * LD, x);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
+        if (EPI == EPI_HVP) {
+          double y[LD];
+          load_row<LD>(A.Y + static_cast<size_t>(row) * LD, y);
+          const double ip = dot_row<LD>(y, acc);
+#pragma unroll
+          for (int j = 0; j < LD; ++j) acc[j] = fma(-ip, y[j], acc[j]);
+        }
+      }
+      store_row<LD>(A.out + static_cast<size_t>(row) * LD, acc);
+    }
+  } else {
+    const int64_t row = (sd.type == kSliceEuclidPerm) ? A.perm[sd.row0 + lane]
+                                                      : static_cast<int64_t>(sd.row0) + lane;
+    if (active) store_row<LD>(A.out + static_cast<size_t>(row) * LD, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row-unit kernels: one thread per pose (d x LD block), per range row or per
+// translation row of the LOCAL shard.
+// ---------------------------------------------------------------------------
+struct Unit {
+  int kind;      // 0 pose, 1 range, 2 translation, -1 none
+  int idx;       // local index within its kind
+  size_t row;    // internal row of the unit's first row
+};
+
+__device__ __forceinline__ Unit unit_of(const RowArgs &R, int64_t u) {
+  Unit x;
+  if (u < R.nl_poses) { x.kind = 0; x.idx = static_cast<int>(u); x.row = R.rot_base + static_cast<size_t>(u) * R.d; }
+  else if (u < R.nl_poses + R.nl_ranges) { x.kind = 1; x.idx = static_cast<int>(u - R.nl_poses); x.row = R.rng_base + x.idx; }
+  else if (u < R.nl_poses + R.nl_ranges + R.nl_trans) { x.kind = 2; x.idx = static_cast<int>(u - R.nl_poses - R.nl_ranges); x.row = R.trn_base + x.idx; }
+  else { x.kind = -1; x.idx = 0; x.row = 0; }
+  return x;
+}
+
+// V_i - sym(Y_i V_i^T) Y_i for one pose held entirely by this thread.
+template <int LD, int D>
+__device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
+                                                       double (&v)[D][LD]) {
+  double m[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) m[a][b] = dot_row<LD>(y[a], v[b]);
+  double s[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) s[a][b] = 0.5 * (m[a][b] + m[b][a]);
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b)
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[a][c] = fma(-s[a][b], y[b][c], v[a][c]);
+}
+
+// After G = Q Y:  Lambda blocks (:1105-1131), grad = Proj_Y(G) (:772-780) and
+// the partial sums of f = 1/2 <Y, G> (:759-762).
+template <int LD, int D>
+__global__ __launch_bounds__(256) void k_point_finish(const RowArgs R, const double *__restrict__ Y,
+                                                      const double *__restrict__ G,
+                                                      double *__restrict__ rgrad,
+                                                      double *__restrict__ lam_st,
+                                                      double *__restrict__ lam_ob,
+                                                      double *__restrict__ partial) {
+  __shared__ double sm[4];
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const Unit un = unit_of(R, u);
+  double f = 0.0;
+  if (un.kind == 0) {
+    double y[D][LD], g[D][LD];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(Y + (un.row + a) * LD, y[a]);
+      load_row<LD>(G + (un.row + a) * LD, g[a]);
+      f += dot_row<LD>(y[a], g[a]);
+    }
+    double m[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) m[a][b] = dot_row<LD>(g[a], y[b]);
+    double *L = lam_st + static_cast<size_t>(un.idx) * (D * D);
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        const double s = 0.5 * (m[a][b] + m[b][a]);
+        L[a * D + b] = s;
+#pragma unroll
+        for (int c = 0; c < LD; ++c) g[a][c] = fma(-s, y[b][c], g[a][c]);
+      }
+    // note: g[a] is updated with y only, so the in-place update above is exact
+#pragma unroll
+    for (int a = 0; a < D; ++a) store_row<LD>(rgrad + (un.row + a) * LD, g[a]);
+  } else if (un.kind == 1) {
+    double y[LD], g[LD];
+    load_row<LD>(Y + un.row * LD, y);
+    load_row<LD>(G + un.row * LD, g);
+    const double lam = dot_row<LD>(y, g);
+    f += lam;
+    lam_ob[un.idx] = lam;
+#pragma unroll
+    for (int c = 0; c < LD; ++c) g[c] = fma(-lam, y[c], g[c]);
+    store_row<LD>(rgrad + un.row * LD, g);
+  } else if (un.kind == 2) {
+    double y[LD], g[LD];
+    load_row<LD>(Y + un.row * LD, y);
+    load_row<LD>(G + un.row * LD, g);
+    f += dot_row<LD>(y, g);
+    store_row<LD>(rgrad + un.row * LD, g);
+  }
+  const double tot = block_sum_256(f, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = 0.5 * tot;
+}
+
+// out = Proj_Y(scale .* V)   (scale == nullptr -> 1): tangent_space_projection
+// (:782-820) and the Jacobi `precon` closure (:888-889 + src/CORA.cpp:86-92).
+template <int LD, int D>
+__global__ __launch_bounds__(256) void k_tangent_project(const RowArgs R, const double *__restrict__ Y,
+                                                         const double *__restrict__ V,
+                                                         const double *__restrict__ scale,
+                                                         double *__restrict__ out) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const Unit un = unit_of(R, u);
+  if (un.kind == 0) {
+    double y[D][LD], v[D][LD];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(Y + (un.row + a) * LD, y[a]);
+      load_row<LD>(V + (un.row + a) * LD, v[a]);
+      if (scale) {
+        const double sc = scale[un.row + a - R.base];
+#pragma unroll
+        for (int c = 0; c < LD; ++c) v[a][c] *= sc;
+      }
+    }
+    stiefel_project_thread<LD, D>(y, v);
+#pragma unroll
+    for (int a = 0; a < D; ++a) store_row<LD>(out + (un.row + a) * LD, v[a]);
+  } else if (un.kind == 1) {
+    double y[LD], v[LD];
+    load_row<LD>(Y + un.row * LD, y);
+    load_row<LD>(V + un.row * LD, v);
+    if (scale) {
+      const double sc = scale[un.row - R.base];
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[c] *= sc;
+    }
+    const double ip = dot_row<LD>(y, v);
+#pragma unroll
+    for (int c = 0; c < LD; ++c) v[c] = fma(-ip, y[c], v[c]);
+    store_row<LD>(out + un.row * LD, v);
+  } else if (un.kind == 2) {
+    double v[LD];
+    load_row<LD>(V + un.row * LD, v);
+    if (scale) {
+      const double sc = scale[un.row - R.base];
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[c] *= sc;
+    }
+    store_row<LD>(out + un.row * LD, v);
+  }
+}
+
+// Polar factor of a d x LD block by one-sided (Hestenes) Jacobi on its rows:
+// rotations J with (J A) having orthogonal rows;  A = J^T Sigma U  =>  polar = J^T U.
+// Works on A directly (no Gram matrix), so it is as accurate as the reference's
+// Eigen::JacobiSVD route (src/StiefelProduct.cpp:8-36: U V^T of the thin SVD).
+template <int LD, int D>
+__device__ __forceinline__ void polar_rows(double (&a)[D][LD]) {
+  double J[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) J[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p)
+#pragma unroll
+      for (int q = p + 1; q < D; ++q) {
+        const double alpha = dot_row<LD>(a[p], a[p]);
+        const double beta = dot_row<LD>(a[q], a[q]);
+        const double gamma = dot_row<LD>(a[p], a[q]);
+        const double denom = sqrt(alpha * beta);
+        if (gamma != 0.0 && denom > 0.0) {
+          off = fmax(off, fabs(gamma) / denom);
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+          for (int c = 0; c < LD; ++c) {
+            const double x = a[p][c], y = a[q][c];
+            a[p][c] = cs * x - sn * y;
+            a[q][c] = sn * x + cs * y;
+          }
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            const double x = J[p][c], y = J[q][c];
+            J[p][c] = cs * x - sn * y;
+            J[q][c] = sn * x + cs * y;
+          }
+        }
+      }
+    if (off < 1e-15) break;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const double nrm = sqrt(dot_row<LD>(a[i], a[i]));
+    const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+#pragma unroll
+    for (int c = 0; c < LD; ++c) a[i][c] *= inv;
+  }
+  double o[D][LD];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int c = 0; c < LD; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fma(J[k][i], a[k][c], s);
+      o[i][c] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int c = 0; c < LD; ++c) a[i][c] = o[i][c];
+}
+
+// out = projectToManifold(A + alpha V)  (V == nullptr -> projectToManifold(A)):
+// Problem::projectToManifold :905-934 and Problem::retract :936-938.
+template <int LD, int D>
+__global__ __launch_bounds__(256) void k_project_manifold(const RowArgs R, const double *__restrict__ A,
+                                                          const double *__restrict__ V, double alpha,
+                                                          double *__restrict__ out) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const Unit un = unit_of(R, u);
+  if (un.kind == 0) {
+    double a[D][LD];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      load_row<LD>(A + (un.row + i) * LD, a[i]);
+      if (V) {
+        double v[LD];
+        load_row<LD>(V + (un.row + i) * LD, v);
+#pragma unroll
+        for (int c = 0; c < LD; ++c) a[i][c] = fma(alpha, v[c], a[i][c]);
+      }
+    }
+    polar_rows<LD, D>(a);
+#pragma unroll
+    for (int i = 0; i < D; ++i) store_row<LD>(out + (un.row + i) * LD, a[i]);
+  } else if (un.kind == 1 || un.kind == 2) {
+    double a[LD];
+    load_row<LD>(A + un.row * LD, a);
+    if (V) {
+      double v[LD];
+      load_row<LD>(V + un.row * LD, v);
+#pragma unroll
+      for (int c = 0; c < LD; ++c) a[c] = fma(alpha, v[c], a[c]);
+    }
+    if (un.kind == 1) {
+      const double nrm = sqrt(dot_row<LD>(a, a));
+      if (nrm > 0.0) {
+        const double inv = 1.0 / nrm;
+#pragma unroll
+        for (int c = 0; c < LD; ++c) a[c] *= inv;
+      }
+    }
+    store_row<LD>(out + un.row * LD, a);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// flat vector kernels over the local shard (contiguous doubles)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_axpby(int64_t n2, double a, const double2 *__restrict__ x,
+                                               double b, double2 *__restrict__ y) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const double2 xv = x[i];
+    double2 yv = make_double2(0.0, 0.0);
+    if (b != 0.0) yv = y[i];
+    y[i] = make_double2(fma(a, xv.x, b * yv.x), fma(a, xv.y, b * yv.y));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const double *__restrict__ scale,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t n = rows * ld;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256)
+    y[i] = scale[i / ld] * x[i];
+}
+
+// up to 4 inner products in one pass; partial[j * gridDim.x + block]
+__global__ __launch_bounds__(256) void k_dots(DotArgs D) {
+  __shared__ double sm[4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < D.count) {
+        const double2 a = reinterpret_cast<const double2 *>(D.a[j])[i];
+        const double2 b = reinterpret_cast<const double2 *>(D.b[j])[i];
+        acc[j] = fma(a.x, b.x, fma(a.y, b.y, acc[j]));
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < D.count) {
+      const double t = block_sum_256(acc[j], sm);
+      if (threadIdx.x == 0) D.partial[static_cast<size_t>(j) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// out[j] = sum_b partial[j * nblocks + b]   (one 256-thread block, fixed order)
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nblocks,
+                                                         int count, double *__restrict__ out) {
+  __shared__ double sm[4];
+  for (int j = 0; j < count; ++j) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[static_cast<size_t>(j) * nblocks + b];
+    const double t = block_sum_256(s, sm);
+    if (threadIdx.x == 0) out[j] = t;
+  }
+}
+
+// NaN guard of Problem::precondition (:898-901): flag != 0 if any NaN.
+__global__ __launch_bounds__(256) void k_has_nan(int64_t n, const double *__restrict__ x, int *flag) {
+  int bad = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256)
+    bad |= (x[i] != x[i]);
+  if (bad) atomicOr(flag, 1);
+}
+
+// host column-major (N x k, leading dimension N) -> resident layout
+__global__ __launch_bounds__(256) void k_upload(int64_t N, int k, int ld, const double *__restrict__ src,
+                                                const int32_t *__restrict__ api2int,
+                                                double *__restrict__ dst) {
+  const int64_t tot = N * k;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < tot;
+       t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t c = t / N, i = t - c * N;
+    dst[static_cast<size_t>(api2int[i]) * ld + c] = src[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_download(int64_t N, int k, int ld, const double *__restrict__ src,
+                                                  const int32_t *__restrict__ api2int,
+                                                  double *__restrict__ dst) {
+  const int64_t tot = N * k;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < tot;
+       t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t c = t / N, i = t - c * N;
+    dst[t] = src[static_cast<size_t>(api2int[i]) * ld + c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+#define CORA_LD_CASES(M) M(2) M(4) M(6) M(8) M(10) M(12) M(16) M(20) M(24)
+
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}
+
+template <int LD, int D>
+static hipError_t launch_spmm_ld(const SpmmArgs &A, int epi, hipStream_t st) {
+  const int grid = A.n_chunks + (A.n_slices + 3) / 4;
+  if (grid == 0) return hipSuccess;
+  switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(256), 0, st, A); break;
+    case EPI_S: hipLaunchKernelGGL((k_spmm<LD, D, EPI_S>), dim3(grid), dim3(256), 0, st, A); break;
+    default: hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP>), dim3(grid), dim3(256), 0, st, A); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st) {
+#define CASE(L)                                                      \
+  if (ld == L)                                                       \
+    return d == 2 ? launch_spmm_ld<L, 2>(A, epi, st) : launch_spmm_ld<L, 3>(A, epi, st);
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_point_finish(const RowArgs &R, int ld, const double *Y, const double *G,
+                               double *rgrad, double *lam_st, double *lam_ob, double *partial,
+                               int *nblocks, hipStream_t st) {
+  const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+  const int grid = static_cast<int>((units + 255) / 256);
+  *nblocks = grid;
+  if (grid == 0) return hipSuccess;
+#define CASE(L)                                                                               \
+  if (ld == L) {                                                                              \
+    if (R.d == 2) hipLaunchKernelGGL((k_point_finish<L, 2>), dim3(grid), dim3(256), 0, st, R, \
+                                     Y, G, rgrad, lam_st, lam_ob, partial);                   \
+    else hipLaunchKernelGGL((k_point_finish<L, 3>), dim3(grid), dim3(256), 0, st, R, Y, G,    \
+                            rgrad, lam_st, lam_ob, partial);                                  \
+    return hipGetLastError();                                                                 \
+  }
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_tangent_project(const RowArgs &R, int ld, const double *Y, const double *V,
+                                  const double *scale, double *out, hipStream_t st) {
+  const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+  const int grid = static_cast<int>((units + 255) / 256);
+  if (grid == 0) return hipSuccess;
+#define CASE(L)                                                                                  \
+  if (ld == L) {                                                                                 \
+    if (R.d == 2) hipLaunchKernelGGL((k_tangent_project<L, 2>), dim3(grid), dim3(256), 0, st, R, \
+                                     Y, V, scale, out);                                          \
+    else hipLaunchKernelGGL((k_tangent_project<L, 3>), dim3(grid), dim3(256), 0, st, R, Y, V,    \
+                            scale, out);                                                         \
+    return hipGetLastError();                                                                    \
+  }
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_project_manifold(const RowArgs &R, int ld, const double *A, const double *V,
+                                   double alpha, double *out, hipStream_t st) {
+  const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+  const int grid = static_cast<int>((units + 255) / 256);
+  if (grid == 0) return hipSuccess;
+#define CASE(L)                                                                                   \
+  if (ld == L) {                                                                                  \
+    if (R.d == 2) hipLaunchKernelGGL((k_project_manifold<L, 2>), dim3(grid), dim3(256), 0, st, R, \
+                                     A, V, alpha, out);                                           \
+    else hipLaunchKernelGGL((k_project_manifold<L, 3>), dim3(grid), dim3(256), 0, st, R, A, V,    \
+                            alpha, out);                                                          \
+    return hipGetLastError();                                                                     \
+  }
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_axpby, dim3(grid_for(n / 2)), dim3(256), 0, st, n / 2, a,
+                     reinterpret_cast<const double2 *>(x), b, reinterpret_cast<double2 *>(y));
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const double *x, double *y,
+                             hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scale_rows, dim3(grid_for(rows * ld)), dim3(256), 0, st, rows, ld, scale, x, y);
+  return hipGetLastError();
+}
+
+hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st) {
+  const int grid = grid_for(D.n2, 256, 512);
+  *nblocks = grid;
+  hipLaunchKernelGGL(k_dots, dim3(grid), dim3(256), 0, st, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const double *partial, int nblocks, int count, double *out,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, nblocks, count, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_has_nan(int64_t n, const double *x, int *flag, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_has_nan, dim3(grid_for(n)), dim3(256), 0, st, n, x, flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_upload(int64_t N, int k, int ld, const double *src, const int32_t *api2int,
+                         double *dst, hipStream_t st) {
+  if (N * k <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_upload, dim3(grid_for(N * k)), dim3(256), 0, st, N, k, ld, src, api2int, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_download(int64_t N, int k, int ld, const double *src, const int32_t *api2int,
+                           double *dst, hipStream_t st) {
+  if (N * k <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_download, dim3(grid_for(N * k)), dim3(256), 0, st, N, k, ld, src, api2int, dst);
+  return hipGetLastError();
+}
+
+}  // namespace cora

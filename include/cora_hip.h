@@ -1,0 +1,247 @@
+/*
+ * cora_hip.h -- C ABI of the MI355X-native CORA solver core (libcora_hip.so).
+ *
+ * The reference (MarineRoboticsGroup/cora) has no FFI seam: its hot path is the
+ * set of `const` methods of `CORA::Problem` that `solveCORA` wraps in
+ * std::function closures for the TNT optimizer (src/CORA.cpp:52-92,119-122)
+ * and for LOBPCG (src/CORA_utils.cpp:83).  Each entry point below replaces one
+ * of those methods; the citation is the reference file:line it stands in for.
+ *
+ * Conventions
+ *   - every call returns a cora_status (0 = ok); no exception crosses the ABI;
+ *     cora_last_error() gives the message (replaces MatrixShapeException /
+ *     std::runtime_error, include/CORA/CORA_types.h:23-39).
+ *   - host matrices are column-major double with an explicit leading dimension
+ *     (zero-copy from Eigen::MatrixXd::data(), include/CORA/CORA_types.h:48);
+ *     Q is row-major CSR with int32 indices (Eigen::SparseMatrix<double,
+ *     RowMajor,int> outerIndexPtr/innerIndexPtr/valuePtr after makeCompressed(),
+ *     include/CORA/CORA_types.h:70).
+ *   - variable layout (include/CORA/CORA_problem.h:151-157): rows [0,d*n) are n
+ *     stacked d x p Stiefel blocks, rows [d*n, d*n+r) are r unit rows, rows
+ *     [d*n+r, N) are the n+l translations;  N = n(d+1) + l + r.
+ *   - the caller owns host buffers; the library owns all device memory tied to
+ *     the handle.  One handle = one HIP stream; a handle is not thread-safe,
+ *     independent handles are.
+ *   - `_dev` entry points take DEVICE pointers to the library's resident layout:
+ *     row-major  rows x ld  doubles with ld = cora_ld(ctx) (p rounded up to an
+ *     even number; padding columns are zero) and rows = cora_rows(ctx) in the
+ *     library's internal row order (identity for a 1-GPU handle).  Use
+ *     cora_upload / cora_download to convert from / to the host layout.
+ *   - there is no CPU fallback: every compute entry point fails with
+ *     CORA_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef CORA_HIP_H_
+#define CORA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cora_ctx cora_ctx;
+
+typedef enum {
+  CORA_OK = 0,
+  CORA_ERR_SHAPE = 1,     /* checkMatrixShape failure */
+  CORA_ERR_NOT_READY = 2, /* set_point / precond_setup missing (checkUpToDate) */
+  CORA_ERR_NAN = 3,       /* NaN guard, src/CORA_problem.cpp:898-901 */
+  CORA_ERR_HIP = 4,
+  CORA_ERR_ARG = 5,
+  CORA_ERR_NOMEM = 6
+} cora_status;
+
+/* Preconditioner kinds, include/CORA/CORA_types.h:77 */
+typedef enum {
+  CORA_PRECOND_NONE = 0,
+  CORA_PRECOND_JACOBI = 1,
+  CORA_PRECOND_BLOCK_CHOLESKY = 2,
+  CORA_PRECOND_REGULARIZED_CHOLESKY = 3
+} cora_precond_kind;
+
+/* ---------------------------------------------------------------- handle */
+
+/* Builds a device-resident problem from the assembled data matrix
+ * (`Problem::data_matrix_` after updateProblemData(), src/CORA_problem.cpp:
+ * 500-510, 625-712).  n_trans = n_poses + n_landmarks. */
+int cora_ctx_create(int device, int d, int n_poses, int n_ranges, int n_trans,
+                    const int32_t *rowptr, const int32_t *colidx,
+                    const double *vals, cora_ctx **out);
+
+/* Same, but the handle owns only the rows of partition `rank` of `world`
+ * (pose-aligned, nnz-balanced row partition).  All ranks must pass
+ * the same full matrix.  world == 1 is identical to cora_ctx_create. */
+int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges,
+                         int n_trans, const int32_t *rowptr,
+                         const int32_t *colidx, const double *vals, int rank,
+                         int world, cora_ctx **out);
+
+void cora_ctx_destroy(cora_ctx *ctx);
+
+/* Message of the last failed call on `ctx` (ctx may be NULL for create). */
+const char *cora_last_error(const cora_ctx *ctx);
+
+/* Problem::setRank / incrementRank, include/CORA/CORA_problem.h:327-334.
+ * Invalidates the current point and the preconditioner state. */
+int cora_set_rank(cora_ctx *ctx, int p);
+int cora_get_rank(const cora_ctx *ctx);
+
+/* Use an externally created hipStream_t (e.g. torch's current stream). */
+int cora_set_stream(cora_ctx *ctx, void *hip_stream);
+
+/* Layout queries for the `_dev` API. */
+int cora_ld(const cora_ctx *ctx);            /* row stride (doubles) */
+int cora_ld_for(int k);                      /* row stride used for k columns */
+int64_t cora_rows(const cora_ctx *ctx);      /* rows of a resident vector */
+int64_t cora_shard_rows(const cora_ctx *ctx);  /* rows owned per rank (padded) */
+int64_t cora_shard_begin(const cora_ctx *ctx); /* first owned internal row */
+int64_t cora_nnz(const cora_ctx *ctx);
+int64_t cora_dim(const cora_ctx *ctx);       /* N */
+/* Row permutation: internal row of API row i (length N, int32). */
+int cora_row_map(const cora_ctx *ctx, int32_t *api_to_internal);
+
+/* Statistics of the device format: [0] slices, [1] padded nnz stored in
+ * slices, [2] nnz in long rows, [3] long rows, [4] long-row chunks,
+ * [5] local rows, [6] local nnz, [7] max slice width. */
+int cora_format_stats(const cora_ctx *ctx, int64_t stats[8]);
+
+/* ------------------------------------------- host-pointer operator API */
+
+/* Problem::dataMatrixProduct (Explicit), src/CORA_problem.cpp:742-746.
+ * X, out: N x k. */
+int cora_data_matrix_product(cora_ctx *ctx, const double *X, int ldx, int k,
+                             double *out, int ldo);
+
+/* Problem::evaluateObjective, src/CORA_problem.cpp:759-762. Y: N x p. */
+int cora_evaluate_objective(cora_ctx *ctx, const double *Y, int ldy, double *f);
+
+/* Problem::Euclidean_gradient, src/CORA_problem.cpp:764-770. */
+int cora_euclidean_gradient(cora_ctx *ctx, const double *Y, int ldy,
+                            double *out, int ldo);
+
+/* Problem::Riemannian_gradient(Y), src/CORA_problem.cpp:772-780. */
+int cora_riemannian_gradient(cora_ctx *ctx, const double *Y, int ldy,
+                             double *out, int ldo);
+
+/* Problem::tangent_space_projection(Y, Ydot), src/CORA_problem.cpp:782-820. */
+int cora_tangent_space_projection(cora_ctx *ctx, const double *Y, int ldy,
+                                  const double *V, int ldv, double *out,
+                                  int ldo);
+
+/* Problem::Riemannian_Hessian_vector_product(Y, nablaF_Y, dotY),
+ * src/CORA_problem.cpp:822-867. */
+int cora_riemannian_hessian_vector_product(cora_ctx *ctx, const double *Y,
+                                           int ldy, const double *nablaF_Y,
+                                           int ldg, const double *dotY,
+                                           int ldd, double *out, int ldo);
+
+/* Problem::projectToManifold, src/CORA_problem.cpp:905-934. */
+int cora_project_to_manifold(cora_ctx *ctx, const double *A, int lda,
+                             double *out, int ldo);
+
+/* Problem::retract(Y, V), src/CORA_problem.cpp:936-938. */
+int cora_retract(cora_ctx *ctx, const double *Y, int ldy, const double *V,
+                 int ldv, double *out, int ldo);
+
+/* Problem::updatePreconditioner, src/CORA_problem.cpp:512-623.
+ *  JACOBI: diag(Q)^-1 (:616-618), built on device.
+ *  *_CHOLESKY: `factor` is an opaque host factorization installed with
+ *  cora_precond_set_cholesky (host LL^T + device triangular solves). */
+int cora_precond_setup(cora_ctx *ctx, int kind);
+
+/* Install a sparse Cholesky factor L (CSC, int32, diagonal first in each
+ * column) of P (Q + lambda I)[0:m,0:m] P^T with m = N or N-1
+ * (pin_last_translation, src/CORA_problem.cpp:602-609); perm is new->old. */
+int cora_precond_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp,
+                              const int32_t *Li, const double *Lx,
+                              const int32_t *perm);
+
+/* Problem::precondition(V), src/CORA_problem.cpp:869-903 (no projection;
+ * last row zeroed when the factor has N-1 rows, src/CORA_preconditioners.cpp:
+ * 78-79; NaN guard -> CORA_ERR_NAN). */
+int cora_precondition(cora_ctx *ctx, const double *V, int ldv, double *out,
+                      int ldo);
+
+/* Problem::compute_Lambda_blocks(Y), src/CORA_problem.cpp:1105-1131.
+ * stiefel: d x (d*n) column-major (ld = d); oblique: r. */
+int cora_compute_lambda_blocks(cora_ctx *ctx, const double *Y, int ldy,
+                               double *stiefel, double *oblique);
+
+/* Certificate operator  out = (Q - Lambda(Y)) X  for an N x k block, i.e.
+ * Problem::get_certificate_matrix(Y) (src/CORA_problem.cpp:1162-1166) applied
+ * as the LOBPCG operator (src/CORA_utils.cpp:83).  Uses the Lambda of the
+ * current point (cora_set_point). */
+int cora_certificate_product(cora_ctx *ctx, const double *X, int ldx, int k,
+                             double *out, int ldo);
+
+/* Metric closure <V1, V2> = trace(V1^T V2), src/CORA.cpp:119-122. */
+int cora_inner_product(cora_ctx *ctx, const double *A, int lda,
+                       const double *B, int ldb, int k, double *out);
+
+/* --------------------------------------------- resident (device) API */
+
+/* Allocate / free a resident vector of cora_rows(ctx) x cora_ld_for(k). */
+int cora_dev_alloc(cora_ctx *ctx, int k, double **dptr);
+int cora_dev_free(cora_ctx *ctx, double *dptr);
+
+/* Host column-major N x k  <->  resident row-major layout. */
+int cora_upload(cora_ctx *ctx, const double *host, int ld, int k, double *dptr);
+int cora_download(cora_ctx *ctx, const double *dptr, int k, double *host,
+                  int ld);
+
+/* Make Y the current point: caches Y, nablaF = Q Y, f = 1/2 <Y, Q Y>,
+ * Lambda(Y) and grad = Proj_Y(nablaF) on the device (the QuadraticModel
+ * closure of src/CORA.cpp:58-75 + the objective of :52-55 in one pass). */
+int cora_set_point(cora_ctx *ctx, const double *Y, int ldy);
+int cora_set_point_dev(cora_ctx *ctx, const double *dY);
+
+/* f at the current point (local shard contribution when partitioned). */
+int cora_point_cost(cora_ctx *ctx, double *f);
+/* Device pointers to the cached point data (valid until the next set_point). */
+const double *cora_point_Y_dev(const cora_ctx *ctx);
+const double *cora_point_egrad_dev(const cora_ctx *ctx);
+const double *cora_point_rgrad_dev(const cora_ctx *ctx);
+
+/* out = Q X (k columns; ld = cora_ld_for(k)). */
+int cora_spmm_dev(cora_ctx *ctx, const double *dX, int k, double *dOut);
+/* out = Proj_Y((Q - Lambda) X) at the current point: the Hessian-vector
+ * product of src/CORA_problem.cpp:822-867 with cached Lambda. */
+int cora_hvp_dev(cora_ctx *ctx, const double *dX, double *dOut);
+/* out = (Q - Lambda) X, k columns. */
+int cora_certificate_product_dev(cora_ctx *ctx, const double *dX, int k,
+                                 double *dOut);
+/* out = Proj_Y(V) at the current point. */
+int cora_tangent_space_projection_dev(cora_ctx *ctx, const double *dV,
+                                      double *dOut);
+/* out = Proj_Y(precondition(V)): the `precon` closure, src/CORA.cpp:86-92. */
+int cora_precondition_projected_dev(cora_ctx *ctx, const double *dV,
+                                    double *dOut);
+/* out = projectToManifold(Y + alpha V) with Y the current point. */
+int cora_retract_dev(cora_ctx *ctx, const double *dV, double alpha,
+                     double *dOut);
+int cora_project_to_manifold_dev(cora_ctx *ctx, const double *dA, double *dOut);
+/* Vector ops on resident N x p vectors (local shard rows when partitioned). */
+int cora_axpby_dev(cora_ctx *ctx, double a, const double *dX, double b,
+                   double *dY); /* Y = a X + b Y */
+int cora_copy_dev(cora_ctx *ctx, const double *dX, int k, double *dY);
+int cora_dot_dev(cora_ctx *ctx, const double *dA, const double *dB, int k,
+                 double *out); /* synchronises the stream */
+/* Up to 4 inner products in one pass / one synchronisation. */
+int cora_dots_dev(cora_ctx *ctx, int count, const double *const *dA,
+                  const double *const *dB, double *out);
+
+/* Timing helpers: HIP events on the handle's stream. */
+int cora_timer_start(cora_ctx *ctx);
+int cora_timer_stop_ms(cora_ctx *ctx, float *ms); /* synchronises */
+int cora_sync(cora_ctx *ctx);
+
+/* Test hook: executes the handle's device FORMAT (slices + long rows) on the
+ * host, to validate the format conversion where no GPU exists.  Never used by
+ * any compute entry point. */
+int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
+                                int k, double *out, int ldo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORA_HIP_H_ */
