@@ -767,10 +767,15 @@ int cora_compute_lambda_blocks(cora_ctx *c, const double *Y, int ldy, double *st
   if (L.n > 0 && stiefel)
     HIP_TRY(c, hipMemcpyAsync(stiefel, c->d_lam_st, static_cast<size_t>(L.n) * L.d * L.d * sizeof(double),
                               hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> ob(static_cast<size_t>(std::max(L.r, 1)));
   if (L.r > 0 && oblique)
-    HIP_TRY(c, hipMemcpyAsync(oblique, c->d_lam_ob, static_cast<size_t>(L.r) * sizeof(double),
+    HIP_TRY(c, hipMemcpyAsync(ob.data(), c->d_lam_ob, static_cast<size_t>(L.r) * sizeof(double),
                               hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // the device keeps range rows in its internal (pose-sorted) order
+  if (L.r > 0 && oblique)
+    for (int k = 0; k < L.r; ++k)
+      oblique[k] = ob[static_cast<size_t>(c->F.api2int[static_cast<size_t>(L.d) * L.n + k] - L.rng_base)];
   return CORA_OK;
 }
 

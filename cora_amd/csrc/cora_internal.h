@@ -11,8 +11,11 @@ namespace cora {
 
 constexpr int kWave = 64;         // CDNA4 wavefront
 constexpr int kLongRow = 96;      // translation rows longer than this -> long path
-constexpr int kLongChunk = 2048;  // nnz per long-row workgroup chunk
-constexpr int kSigma = 2048;      // sorting window (rows) for translation slices
+constexpr int kLongChunk = 1024;  // default nnz per long-row chunk (one wavefront each)
+extern int g_long_chunk;
+extern int g_interleave;            // pose-slice slot order (see format_build.cpp)
+constexpr int kSigma = 256;       // default sorting window (rows) for translation slices
+extern int g_sigma;               // tunable copy of kSigma (format_build.cpp)
 constexpr int kMaxLD = 24;
 
 // Row stride (doubles) used for a k-column resident vector.
@@ -22,22 +25,28 @@ inline int ld_for(int k) {
 }
 
 enum SliceType : int32_t {
-  kSliceStiefel = 0,   // rows = whole poses (d consecutive rows each)
-  kSliceOblique = 1,   // unit-sphere rows
-  kSliceEuclid = 2,    // translation rows, identity row order
-  kSliceEuclidPerm = 3 // translation rows, rows given by perm[]
+  kSliceStiefel = 0,   // lane = one pose (its d rotation rows); d x 1 column blocks
+  kSliceOblique = 1,   // lane = one unit-sphere row
+  kSliceEuclid = 2,    // lane = one translation row, identity row order
+  kSliceEuclidPerm = 3 // lane = one translation row, rows given by perm[]
 };
 
-// One wavefront's work: up to 64 rows, `width` nonzero slots per row, stored
-// slot-major ([k][lane]) so that every load is a fully coalesced 512 B / 256 B.
+// One wavefront's work, stored slot-major ([k][lane]) so that every load is a
+// fully coalesced 512 B (values) / 256 B (columns).
+//  - row slices (types 1-3): lane = row, slot k = one nonzero:
+//        col  = scol[coff + k*64 + lane],  val = sval[off + k*64 + lane]
+//  - pose slices (type 0): lane = pose, slot k = one column of the union pattern
+//    of the pose's d rows, carrying d values (a d x 1 block; zero where a row
+//    does not have the column):
+//        col  = scol[coff + k*64 + lane],  val_a = sval[off + (k*d + a)*64 + lane]
 struct SliceDesc {
   int32_t row0;    // first internal row (or offset into perm[] for kSliceEuclidPerm)
   int32_t nrows;   // active lanes
-  int32_t width;   // slots per row
+  int32_t width;   // slots per lane
   int32_t type;    // SliceType
-  int64_t off;     // element offset of slot 0 / lane 0 in sval / scol
+  int64_t off;     // element offset into sval
+  int32_t coff;    // element offset into scol
   int32_t aux0;    // Stiefel: first LOCAL pose index; Oblique: first LOCAL range index
-  int32_t aux1;
 };
 static_assert(sizeof(SliceDesc) == 32, "SliceDesc must be 32 bytes");
 

@@ -16,6 +16,10 @@
 
 namespace cora {
 
+int g_sigma = kSigma;
+int g_long_chunk = kLongChunk;
+int g_interleave = 0;  // measured: no gain on MI355X (kept for the lab)
+
 namespace {
 
 struct RowRef {
@@ -32,15 +36,15 @@ void emit_slice(HostFormat &F, const std::vector<RowRef> &rows, size_t begin,
   s.nrows = static_cast<int32_t>(end - begin);
   s.type = type;
   s.aux0 = aux0;
-  s.aux1 = 0;
   int width = 0;
   for (size_t i = begin; i < end; ++i) width = std::max(width, rows[i].len);
   s.width = width;
   s.off = static_cast<int64_t>(F.sval.size());
+  s.coff = static_cast<int32_t>(F.scol.size());
   F.max_width = std::max(F.max_width, width);
-  const size_t base = F.sval.size();
+  const size_t base = F.sval.size(), cbase = F.scol.size();
   F.sval.resize(base + static_cast<size_t>(width) * kWave, 0.0);
-  F.scol.resize(base + static_cast<size_t>(width) * kWave, 0);
+  F.scol.resize(cbase + static_cast<size_t>(width) * kWave, 0);
   for (int lane = 0; lane < kWave; ++lane) {
     // padding lanes replicate the last active row's columns with zero values
     const size_t src = begin + std::min<size_t>(lane, end - begin - 1);
@@ -50,12 +54,13 @@ void emit_slice(HostFormat &F, const std::vector<RowRef> &rows, size_t begin,
     int32_t fill = rr.len > 0 ? F.api2int[col[p0]] : rr.int_row;
     for (int k = 0; k < width; ++k) {
       const size_t dst = base + static_cast<size_t>(k) * kWave + lane;
+      const size_t cdst = cbase + static_cast<size_t>(k) * kWave + lane;
       if (k < rr.len) {
-        F.scol[dst] = F.api2int[col[p0 + k]];
+        F.scol[cdst] = F.api2int[col[p0 + k]];
         F.sval[dst] = active ? val[p0 + k] : 0.0;
-        fill = F.scol[dst];
+        fill = F.scol[cdst];
       } else {
-        F.scol[dst] = fill;  // padded slot: re-reads a row already in cache
+        F.scol[cdst] = fill;  // padded slot: re-reads a row already in cache
         F.sval[dst] = 0.0;
       }
     }
@@ -89,24 +94,25 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   auto rowlen = [&](int64_t i) { return rowptr[i + 1] - rowptr[i]; };
 
   // ---- 1. owner of every pose / range row / landmark -----------------------
-  std::vector<int> pose_owner(n, 0), range_pose(r, -1), range_owner(r, 0), lm_owner(l, 0);
+  std::vector<int> pose_owner(n, 0), range_pose(r, -1), range_lm(r, -1), range_owner(r, 0), lm_owner(l, 0);
+  const int64_t tb = dn + r;
+  // a range row belongs with the first pose translation it touches (Q23 holds
+  // its two endpoints, src/CORA_problem.cpp:660-663)
+  for (int k = 0; k < r; ++k) {
+    const int64_t row = dn + k;
+    for (int32_t q = rowptr[row]; q < rowptr[row + 1]; ++q) {
+      const int64_t c = col[q];
+      if (c >= tb) {
+        const int64_t t = c - tb;
+        if (t < n) { if (range_pose[k] < 0) range_pose[k] = static_cast<int>(t); }
+        else if (range_lm[k] < 0) range_lm[k] = static_cast<int>(t - n);
+      }
+    }
+  }
   if (world > 1) {
     for (int j = 0; j < l; ++j) lm_owner[j] = j % world;
-    // a range row belongs with the first pose translation it touches
-    const int64_t tb = dn + r;
-    for (int k = 0; k < r; ++k) {
-      const int64_t row = dn + k;
-      int lm = -1;
-      for (int32_t q = rowptr[row]; q < rowptr[row + 1]; ++q) {
-        const int64_t c = col[q];
-        if (c >= tb) {
-          const int64_t t = c - tb;
-          if (t < n) { if (range_pose[k] < 0) range_pose[k] = static_cast<int>(t); }
-          else if (lm < 0) lm = static_cast<int>(t - n);
-        }
-      }
-      if (range_pose[k] < 0) range_owner[k] = lm >= 0 ? lm_owner[lm] : 0;
-    }
+    for (int k = 0; k < r; ++k)
+      if (range_pose[k] < 0) range_owner[k] = range_lm[k] >= 0 ? lm_owner[range_lm[k]] : 0;
     std::vector<int64_t> w(n, 0), lw(world, 0);
     for (int i = 0; i < n; ++i) {
       for (int a = 0; a < d; ++a) w[i] += rowlen(static_cast<int64_t>(i) * d + a);
@@ -169,7 +175,15 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       F.api2int[dn + r + i] = static_cast<int32_t>(b + d * np[g] + nr[g] + cp[g]);
       cp[g]++;
     }
-    for (int k = 0; k < r; ++k) {
+    // range rows follow the order of the pose they hang off, so that the Q23 /
+    // Q32 blocks are banded in the internal order whatever the measurement order
+    std::vector<int32_t> rorder(r);
+    std::iota(rorder.begin(), rorder.end(), 0);
+    std::stable_sort(rorder.begin(), rorder.end(), [&](int32_t a, int32_t b) {
+      const int pa = range_pose[a] < 0 ? n : range_pose[a], pb = range_pose[b] < 0 ? n : range_pose[b];
+      return pa < pb;
+    });
+    for (int32_t k : rorder) {
       const int g = range_owner[k];
       F.api2int[dn + k] = static_cast<int32_t>(shard * g + d * np[g] + cr[g]++);
     }
@@ -181,7 +195,19 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     for (int64_t i = 0; i < N; ++i) F.int2api[F.api2int[i]] = static_cast<int32_t>(i);
   }
 
+  // local pose index each local range row hangs off (work ordering key)
+  std::vector<double> local_range_pose(static_cast<size_t>(std::max(L.nl_ranges, 1)), 0.0);
+  for (int k = 0; k < r; ++k) {
+    if (range_owner[k] != rank) continue;
+    const int64_t li = F.api2int[dn + k] - L.rng_base;
+    double key = L.nl_poses;  // ranges between landmarks go last
+    if (range_pose[k] >= 0 && pose_owner[range_pose[k]] == rank)
+      key = static_cast<double>((F.api2int[static_cast<int64_t>(range_pose[k]) * d] - L.rot_base) / d);
+    local_range_pose[li] = key;
+  }
+
   // ---- 3. local rows -> slices ---------------------------------------------
+  std::vector<double> slice_key;  // position of each slice along the pose chain (work ordering)
   F.slices.clear(); F.sval.clear(); F.scol.clear(); F.perm.clear();
   F.chunks.clear(); F.lval.clear(); F.lcol.clear();
   F.padded_nnz = F.long_nnz = F.nnz_local = 0; F.max_width = 0; F.n_long_rows = 0;
@@ -198,19 +224,74 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     return rr;
   };
 
-  // Stiefel slices: whole poses, in order (the tangent-projection epilogue
-  // needs a pose's d rows in adjacent lanes).
+  // Pose slices: lane = pose.  The d rotation rows of a pose share (almost)
+  // the same column pattern -- Q11 is made of dense d x d blocks and Q13 of
+  // d x 1 columns (src/CORA_problem.cpp:297-377, 639-652) -- so the union
+  // pattern is stored once with d values per column: one 4-byte index and one
+  // X-row gather serve d nonzeros.
   {
-    std::vector<RowRef> rows;
-    rows.reserve(static_cast<size_t>(d) * L.nl_poses);
-    for (int64_t i = 0; i < static_cast<int64_t>(d) * L.nl_poses; ++i)
-      rows.push_back(local_row(L.rot_base + i));
-    const int ps = kWave / d;  // poses per slice
-    for (int p0 = 0; p0 < L.nl_poses; p0 += ps) {
-      const int cnt = std::min(ps, L.nl_poses - p0);
-      emit_slice(F, rows, static_cast<size_t>(p0) * d, static_cast<size_t>(p0 + cnt) * d,
-                 kSliceStiefel, static_cast<int32_t>(L.rot_base + static_cast<int64_t>(p0) * d),
-                 p0, rowptr, col, val);
+    struct PoseCols { std::vector<int32_t> c; std::vector<double> v; };  // v[k*d + a]
+    std::vector<PoseCols> pc(std::min(kWave, std::max(L.nl_poses, 1)));
+    for (int p0 = 0; p0 < L.nl_poses; p0 += kWave) {
+      const int cnt = std::min(kWave, L.nl_poses - p0);
+      int width = 0;
+      for (int q = 0; q < cnt; ++q) {
+        PoseCols &P = pc[q];
+        P.c.clear(); P.v.clear();
+        std::vector<std::pair<int32_t, std::pair<int, double>>> ent;  // (int col, (a, val))
+        for (int a = 0; a < d; ++a) {
+          const RowRef rr = local_row(L.rot_base + static_cast<int64_t>(p0 + q) * d + a);
+          for (int32_t t = rowptr[rr.api_row]; t < rowptr[rr.api_row + 1]; ++t)
+            ent.push_back({F.api2int[col[t]], {a, val[t]}});
+        }
+        std::stable_sort(ent.begin(), ent.end(),
+                         [](const auto &x, const auto &y) { return x.first < y.first; });
+        if (g_interleave) {
+          // keep equal columns adjacent (stable) but visit columns ordered by
+          // (col mod d, col / d): neighbouring poses then read one X row in
+          // consecutive slots, so it is still in L1 when re-referenced
+          std::stable_sort(ent.begin(), ent.end(), [d](const auto &x, const auto &y) {
+            const int xa = x.first % d, ya = y.first % d;
+            return xa != ya ? xa < ya : x.first < y.first;
+          });
+        }
+        for (const auto &e : ent) {
+          if (P.c.empty() || P.c.back() != e.first) {
+            P.c.push_back(e.first);
+            P.v.resize(P.v.size() + d, 0.0);
+          }
+          P.v[(P.c.size() - 1) * d + e.second.first] += e.second.second;
+        }
+        width = std::max(width, static_cast<int>(P.c.size()));
+      }
+      SliceDesc sd{};
+      sd.row0 = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(p0) * d);
+      sd.nrows = cnt;
+      sd.width = width;
+      sd.type = kSliceStiefel;
+      sd.off = static_cast<int64_t>(F.sval.size());
+      sd.coff = static_cast<int32_t>(F.scol.size());
+      sd.aux0 = p0;
+      F.max_width = std::max(F.max_width, width);
+      const size_t vb = F.sval.size(), cb = F.scol.size();
+      F.sval.resize(vb + static_cast<size_t>(width) * d * kWave, 0.0);
+      F.scol.resize(cb + static_cast<size_t>(width) * kWave, 0);
+      for (int lane = 0; lane < kWave; ++lane) {
+        const PoseCols &P = pc[std::min(lane, cnt - 1)];
+        const bool active = lane < cnt;
+        int32_t fill = P.c.empty() ? sd.row0 : P.c[0];
+        for (int k = 0; k < width; ++k) {
+          const bool have = k < static_cast<int>(P.c.size());
+          if (have) fill = P.c[k];
+          F.scol[cb + static_cast<size_t>(k) * kWave + lane] = fill;
+          for (int a = 0; a < d; ++a)
+            F.sval[vb + (static_cast<size_t>(k) * d + a) * kWave + lane] =
+                (have && active) ? P.v[static_cast<size_t>(k) * d + a] : 0.0;
+        }
+      }
+      F.padded_nnz += static_cast<int64_t>(width) * d * kWave;
+      F.slices.push_back(sd);
+      slice_key.push_back(p0);
     }
   }
   // Oblique slices
@@ -223,6 +304,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       emit_slice(F, rows, k0, k0 + cnt, kSliceOblique,
                  static_cast<int32_t>(L.rng_base + k0), static_cast<int32_t>(k0),
                  rowptr, col, val);
+      slice_key.push_back(local_range_pose[k0] + 0.25);
     }
   }
   // Translation rows: long rows -> chunked path; the rest sorted by length
@@ -239,13 +321,13 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           F.lval.push_back(val[p0 + k]);
           F.lcol.push_back(F.api2int[col[p0 + k]]);
         }
-        const int nch = (rr.len + kLongChunk - 1) / kLongChunk;
+        const int nch = (rr.len + g_long_chunk - 1) / g_long_chunk;
         const int32_t first = static_cast<int32_t>(F.chunks.size());
         for (int c = 0; c < nch; ++c) {
           LongChunk ch{};
           ch.row = rr.int_row;
-          ch.k0 = k_begin + c * kLongChunk;
-          ch.k1 = k_begin + std::min(rr.len, (c + 1) * kLongChunk);
+          ch.k0 = k_begin + c * g_long_chunk;
+          ch.k1 = k_begin + std::min(rr.len, (c + 1) * g_long_chunk);
           ch.nchunks = nch;
           ch.first = first;
           ch.slot = F.n_long_rows;
@@ -257,30 +339,61 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         rows.push_back(rr);
       }
     }
-    for (size_t w0 = 0; w0 < rows.size(); w0 += kSigma) {
-      const size_t w1 = std::min(rows.size(), w0 + kSigma);
+    const size_t sigma = static_cast<size_t>(std::max(g_sigma, kWave) / kWave) * kWave;
+    std::vector<double> window_key;
+    for (size_t w0 = 0; w0 < rows.size(); w0 += sigma) {
+      const size_t w1 = std::min(rows.size(), w0 + sigma);
+      window_key.push_back(static_cast<double>(rows[w0].int_row - L.trn_base));
       std::stable_sort(rows.begin() + w0, rows.begin() + w1,
                        [](const RowRef &a, const RowRef &b) { return a.len > b.len; });
     }
     for (size_t k0 = 0; k0 < rows.size(); k0 += kWave) {
       const size_t cnt = std::min<size_t>(kWave, rows.size() - k0);
+      slice_key.push_back(window_key[k0 / sigma] + 0.5 + 1e-3 * static_cast<double>((k0 % sigma) / kWave));
       const int32_t poff = static_cast<int32_t>(F.perm.size());
       for (int lane = 0; lane < kWave; ++lane)
         F.perm.push_back(rows[k0 + std::min<size_t>(lane, cnt - 1)].int_row);
       emit_slice(F, rows, k0, k0 + cnt, kSliceEuclidPerm, poff, 0, rowptr, col, val);
     }
   }
+
+  // ---- 4. work order: walk the pose chain, so that the pose / range /
+  // translation slices that gather the same rows of X run close together in
+  // time (and, with the kernel's per-XCD block chunking, on the same L2).
+  {
+    std::vector<size_t> order(F.slices.size());
+    std::iota(order.begin(), order.end(), size_t{0});
+    std::stable_sort(order.begin(), order.end(),
+                     [&](size_t a, size_t b) { return slice_key[a] < slice_key[b]; });
+    std::vector<SliceDesc> sorted;
+    sorted.reserve(F.slices.size());
+    for (size_t i : order) sorted.push_back(F.slices[i]);
+    F.slices.swap(sorted);
+  }
 }
 
 void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out) {
-  std::vector<double> acc(ld);
+  const int d = F.L.d;
+  std::vector<double> acc(static_cast<size_t>(ld) * 4);
   for (const SliceDesc &s : F.slices) {
     for (int lane = 0; lane < s.nrows; ++lane) {
       std::fill(acc.begin(), acc.end(), 0.0);
+      if (s.type == kSliceStiefel) {
+        for (int k = 0; k < s.width; ++k) {
+          const double *xr = X + static_cast<size_t>(F.scol[s.coff + static_cast<size_t>(k) * kWave + lane]) * ld;
+          for (int a = 0; a < d; ++a) {
+            const double v = F.sval[s.off + (static_cast<size_t>(k) * d + a) * kWave + lane];
+            for (int c = 0; c < ld; ++c) acc[a * ld + c] += v * xr[c];
+          }
+        }
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < ld; ++c)
+            out[(static_cast<size_t>(s.row0) + static_cast<size_t>(lane) * d + a) * ld + c] = acc[a * ld + c];
+        continue;
+      }
       for (int k = 0; k < s.width; ++k) {
-        const size_t e = static_cast<size_t>(s.off) + static_cast<size_t>(k) * kWave + lane;
-        const double v = F.sval[e];
-        const double *xr = X + static_cast<size_t>(F.scol[e]) * ld;
+        const double v = F.sval[s.off + static_cast<size_t>(k) * kWave + lane];
+        const double *xr = X + static_cast<size_t>(F.scol[s.coff + static_cast<size_t>(k) * kWave + lane]) * ld;
         for (int c = 0; c < ld; ++c) acc[c] += v * xr[c];
       }
       const int64_t row = (s.type == kSliceEuclidPerm) ? F.perm[s.row0 + lane] : s.row0 + lane;

@@ -14,7 +14,9 @@ enum Epilogue : int { EPI_NONE = 0, EPI_S = 1, EPI_HVP = 2 };
 struct SpmmArgs {
   const SliceDesc *slices;
   int n_slices;
-  int n_chunks;
+  int n_chunks;        // set by the caller: number of long-row chunks
+  int n_real_chunks;   // filled by launch_spmm
+  int n_slice_blocks;  // filled by launch_spmm
   const double *sval;
   const int32_t *scol;
   const int32_t *perm;

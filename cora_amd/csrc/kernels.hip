@@ -43,6 +43,23 @@ __device__ __forceinline__ double dot_row(const double (&a)[LD], const double (&
   return s;
 }
 
+// Q's value / index streams are read exactly once per product: mark them
+// non-temporal so they do not evict the X rows the gathers re-use from L1/L2.
+#ifndef CORA_STREAM_NT
+#define CORA_STREAM_NT 0
+#endif
+#ifndef CORA_POSE_UNROLL
+#define CORA_POSE_UNROLL 2
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#if CORA_STREAM_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -59,46 +76,6 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm) {
   return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-// Tangent-space projection of one Stiefel row when the d rows of the pose sit
-// in d adjacent lanes (lane `a` of the pose holds row a).
-//   out_a = g_a - sum_b sym(Y G^T)[a][b] Y_b        (StiefelProduct.h:79-81)
-// `m[b]` = <Y_b, g_a> = (Y G^T)[b][a] is computed locally; the transposed
-// entries come from the sibling lanes by wave shuffles.
-template <int LD, int D>
-__device__ __forceinline__ void stiefel_project_lane(const double *__restrict__ Yp,
-                                                     int a, int lane, double (&g)[LD]) {
-  double y[D][LD];
-  double m[D];
-#pragma unroll
-  for (int b = 0; b < D; ++b) {
-    load_row<LD>(Yp + b * LD, y[b]);
-    m[b] = dot_row<LD>(y[b], g);
-  }
-  const int base = lane - a;
-  double s[D];
-#pragma unroll
-  for (int b = 0; b < D; ++b) s[b] = m[b];  // s[a] = m[a] is the diagonal entry
-#pragma unroll
-  for (int st = 1; st < D; ++st) {
-    // I (index a) read from partner b = (a+st)%D the value m_partner[a];
-    // seen from the partner (index a'), that is element (a' - st + D) % D.
-    const int mine = (a + D - st) % D;
-    double pub = m[0];
-#pragma unroll
-    for (int t = 1; t < D; ++t) pub = (mine == t) ? m[t] : pub;
-    const int b = (a + st) % D;
-    const double got = __shfl(pub, base + b, 64);
-#pragma unroll
-    for (int t = 0; t < D; ++t)
-      if (t == b) s[t] = 0.5 * (m[t] + got);
-  }
-#pragma unroll
-  for (int b = 0; b < D; ++b) {
-#pragma unroll
-    for (int c = 0; c < LD; ++c) g[c] = fma(-s[b], y[b][c], g[c]);
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Sliced SpMM with fused epilogues.
 //   EPI_NONE : out = Q X                       (Problem::dataMatrixProduct, :742-746)
@@ -107,78 +84,169 @@ __device__ __forceinline__ void stiefel_project_lane(const double *__restrict__ 
 // One wavefront per slice, lane = row, LD accumulators per lane in registers.
 // Blocks [0, n_chunks) handle chunks of the long (landmark) rows instead.
 // ---------------------------------------------------------------------------
+// One wavefront per chunk of a long (landmark) row.
 template <int LD>
-__device__ __forceinline__ void long_chunk_block(const SpmmArgs &A, int ci, double *sm,
-                                                 int *sflag) {
+__device__ __forceinline__ void long_chunk_wave(const SpmmArgs &A, int ci) {
   const LongChunk ch = A.chunks[ci];
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
   double acc[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
-  for (int k = ch.k0 + tid; k < ch.k1; k += 256) {
-    const double v = A.lval[k];
+#pragma unroll 4
+  for (int k = ch.k0 + lane; k < ch.k1; k += kWave) {
+    const double v = stream_load(A.lval + k);
     double x[LD];
-    load_row<LD>(A.X + static_cast<size_t>(A.lcol[k]) * LD, x);
+    load_row<LD>(A.X + static_cast<size_t>(stream_load(A.lcol + k)) * LD, x);
 #pragma unroll
     for (int j = 0; j < LD; ++j) acc[j] = fma(v, x[j], acc[j]);
   }
-  // block reduce LD values: wave shuffles, then LDS across the 4 waves
-  const int lane = tid & 63, w = tid >> 6;
+  double tot = 0.0;  // lane j < LD ends up with column j
 #pragma unroll
   for (int j = 0; j < LD; ++j) {
     const double v = wave_sum(acc[j]);
-    if (lane == 0) sm[w * LD + j] = v;
+    const double v0 = __shfl(v, 0, 64);
+    if (lane == j) tot = v0;
   }
-  __syncthreads();
-  double tot = 0.0;
-  if (tid < LD) tot = sm[tid] + sm[LD + tid] + sm[2 * LD + tid] + sm[3 * LD + tid];
   double *orow = A.out + static_cast<size_t>(ch.row) * LD;
   if (ch.nchunks == 1) {
-    if (tid < LD) orow[tid] = tot;
+    if (lane < LD) orow[lane] = tot;
     return;
   }
-  // several chunks: publish the partial, the last arriver sums them in chunk
-  // order (deterministic).  Agent-scope release / acquire per the gfx950
-  // inter-workgroup visibility rules.
-  if (tid < LD) A.partials[static_cast<size_t>(ci) * kMaxLD + tid] = tot;
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // several chunks: publish the partial WRITE-THROUGH (sc1 stores, so no L2
+  // release fence is needed), drain, take a ticket; the last arriver re-reads
+  // all partials with sc1 loads (which bypass its L1) and sums them in chunk
+  // order, so the result is deterministic.  gfx950 inter-workgroup hand-off
+  // recipe R1 (cdna_hip_programming.md, Guideline 16).
+  if (lane < LD)
+    __hip_atomic_store(A.partials + static_cast<size_t>(ci) * kMaxLD + lane, tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int last = 0;
+  if (lane == 0) {
     const unsigned old = __hip_atomic_fetch_add(A.tickets + ch.slot, 1u, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (old == static_cast<unsigned>(ch.nchunks - 1));
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(A.tickets + ch.slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    *sflag = last;
+    last = (old == static_cast<unsigned>(ch.nchunks - 1));
+    if (last) __hip_atomic_store(A.tickets + ch.slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
-  if (*sflag && tid < LD) {
+  last = __shfl(last, 0, 64);
+  if (last && lane < LD) {
+    const double *P = A.partials + static_cast<size_t>(ch.first) * kMaxLD + lane;
     double s = 0.0;
-    for (int c = 0; c < ch.nchunks; ++c)
-      s += __hip_atomic_load(A.partials + static_cast<size_t>(ch.first + c) * kMaxLD + tid,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    orow[tid] = s;
+    int c = 0;
+    for (; c + 8 <= ch.nchunks; c += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        t[u] = __hip_atomic_load(P + static_cast<size_t>(c + u) * kMaxLD, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; c < ch.nchunks; ++c)
+      s += __hip_atomic_load(P + static_cast<size_t>(c) * kMaxLD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    orow[lane] = s;
   }
 }
 
+// V_i - sym(Y_i V_i^T) Y_i for one pose held entirely by this thread
+// (StiefelProduct::projectToTangentSpace, include/CORA/StiefelProduct.h:79-81).
+template <int LD, int D>
+__device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
+                                                       double (&v)[D][LD]) {
+  double m[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) m[a][b] = dot_row<LD>(y[a], v[b]);
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      const double s = 0.5 * (m[a][b] + m[b][a]);
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[a][c] = fma(-s, y[b][c], v[a][c]);
+    }
+}
+
+// Pose slice: lane = pose, d x LD accumulators, one X-row gather per d nonzeros.
 template <int LD, int D, int EPI>
-__global__ __launch_bounds__(256) void k_spmm(const SpmmArgs A) {
-  __shared__ double sm[4 * kMaxLD];
-  __shared__ int sflag;
+__device__ __forceinline__ void pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
+  const double *__restrict__ vp = A.sval + sd.off + lane;
+  const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
+  const double *__restrict__ X = A.X;
+  double acc[D][LD];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[a][j] = 0.0;
+#pragma unroll CORA_POSE_UNROLL
+  for (int k = 0; k < sd.width; ++k) {
+    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
+    double v[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+    double x[LD];
+    load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+  }
+  if (lane >= sd.nrows) return;
+  const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(lane) * D;
+  if (EPI != EPI_NONE) {
+    const double *Lp = A.lam_st + static_cast<size_t>(sd.aux0 + lane) * (D * D);
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      double x[LD];
+      load_row<LD>(X + (prow + b) * LD, x);
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double lam = Lp[a * D + b];
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[a][j] = fma(-lam, x[j], acc[a][j]);
+      }
+    }
+    if (EPI == EPI_HVP) {
+      double y[D][LD];
+#pragma unroll
+      for (int b = 0; b < D; ++b) load_row<LD>(A.Y + (prow + b) * LD, y[b]);
+      stiefel_project_thread<LD, D>(y, acc);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) store_row<LD>(A.out + (prow + a) * LD, acc[a]);
+}
+
+#ifndef CORA_SPMM_WAVES_PER_EU
+#define CORA_SPMM_WAVES_PER_EU 2
+#endif
+// The kernel is latency bound unless each wave keeps many loads in flight, so
+// let the register allocator spend registers (>= 2 waves / SIMD) instead of
+// squeezing for occupancy: measured 31.3 -> 20.4 us on the 10^5-pose graph.
+template <int LD, int D, int EPI>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM_WAVES_PER_EU)))
+void k_spmm(const SpmmArgs A) {
+  // one wavefront per block: the dispatcher balances the (uneven) slices
   if (static_cast<int>(blockIdx.x) < A.n_chunks) {
-    long_chunk_block<LD>(A, blockIdx.x, sm, &sflag);
+    if (static_cast<int>(blockIdx.x) < A.n_real_chunks) long_chunk_wave<LD>(A, blockIdx.x);
     return;
   }
-  const int lane = threadIdx.x & 63;
-  const int s = __builtin_amdgcn_readfirstlane(
-      (static_cast<int>(blockIdx.x) - A.n_chunks) * 4 + static_cast<int>(threadIdx.x >> 6));
-  if (s >= A.n_slices) return;
+  const int lane = threadIdx.x;
+  // Slice blocks: XCD x (= blockIdx % 8, observed dispatch order; speed only)
+  // walks its own contiguous eighth of the slice list, so neighbouring slices
+  // share one L2.  n_chunks is padded to a multiple of 8 by the launcher.
+  const int t = static_cast<int>(blockIdx.x) - A.n_chunks;
+  const int per_xcd = (A.n_slices + 7) >> 3;
+  const int s = (t & 7) * per_xcd + (t >> 3);
+  if ((t >> 3) >= per_xcd || s >= A.n_slices) return;
   const SliceDesc sd = A.slices[s];
+  if (sd.type == kSliceStiefel) {
+    pose_slice<LD, D, EPI>(A, sd, lane);
+    return;
+  }
   const double *__restrict__ vp = A.sval + sd.off + lane;
-  const int32_t *__restrict__ cp = A.scol + sd.off + lane;
+  const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
 
   double acc[LD];
@@ -187,60 +255,36 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs A) {
 
 #pragma unroll 4
   for (int k = 0; k < sd.width; ++k) {
-    const double v = vp[static_cast<size_t>(k) * kWave];
-    const int32_t c = cp[static_cast<size_t>(k) * kWave];
+    const double v = stream_load(vp + static_cast<size_t>(k) * kWave);
+    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
     double x[LD];
     load_row<LD>(X + static_cast<size_t>(c) * LD, x);
 #pragma unroll
     for (int j = 0; j < LD; ++j) acc[j] = fma(v, x[j], acc[j]);
   }
 
-  const bool active = lane < sd.nrows;
-  if (sd.type == kSliceStiefel) {
-    const int64_t row = static_cast<int64_t>(sd.row0) + lane;
+  if (lane >= sd.nrows) return;
+  if (sd.type == kSliceOblique) {
+    const size_t row = static_cast<size_t>(sd.row0) + lane;
     if (EPI != EPI_NONE) {
-      // clamp idle lanes onto the last pose so that shuffles / loads stay valid
-      const int lr = active ? lane : sd.nrows - 1;
-      const int q = lr / D, a = lr - q * D;
-      const int lpose = sd.aux0 + q;
-      const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(q) * D;
-      const double *Xp = X + prow * LD;
-      const double *Lp = A.lam_st + static_cast<size_t>(lpose) * (D * D) + a * D;
+      const double lam = A.lam_ob[sd.aux0 + lane];
+      double x[LD];
+      load_row<LD>(X + row * LD, x);
 #pragma unroll
-      for (int b = 0; b < D; ++b) {
-        const double lam = Lp[b];
-        double x[LD];
-        load_row<LD>(Xp + b * LD, x);
+      for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
+      if (EPI == EPI_HVP) {
+        double y[LD];
+        load_row<LD>(A.Y + row * LD, y);
+        const double ip = dot_row<LD>(y, acc);
 #pragma unroll
-        for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
+        for (int j = 0; j < LD; ++j) acc[j] = fma(-ip, y[j], acc[j]);
       }
-      if (EPI == EPI_HVP)
-        stiefel_project_lane<LD, D>(A.Y + prow * LD, a, active ? lane : (q * D + a), acc);
     }
-    if (active) store_row<LD>(A.out + static_cast<size_t>(row) * LD, acc);
-  } else if (sd.type == kSliceOblique) {
-    const int64_t row = static_cast<int64_t>(sd.row0) + lane;
-    if (active) {
-      if (EPI != EPI_NONE) {
-        const double lam = A.lam_ob[sd.aux0 + lane];
-        double x[LD];
-        load_row<LD>(X + static_cast<size_t>(row) * LD, x);
-#pragma unroll
-        for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
-        if (EPI == EPI_HVP) {
-          double y[LD];
-          load_row<LD>(A.Y + static_cast<size_t>(row) * LD, y);
-          const double ip = dot_row<LD>(y, acc);
-#pragma unroll
-          for (int j = 0; j < LD; ++j) acc[j] = fma(-ip, y[j], acc[j]);
-        }
-      }
-      store_row<LD>(A.out + static_cast<size_t>(row) * LD, acc);
-    }
+    store_row<LD>(A.out + row * LD, acc);
   } else {
-    const int64_t row = (sd.type == kSliceEuclidPerm) ? A.perm[sd.row0 + lane]
-                                                      : static_cast<int64_t>(sd.row0) + lane;
-    if (active) store_row<LD>(A.out + static_cast<size_t>(row) * LD, acc);
+    const size_t row = (sd.type == kSliceEuclidPerm) ? static_cast<size_t>(A.perm[sd.row0 + lane])
+                                                     : static_cast<size_t>(sd.row0) + lane;
+    store_row<LD>(A.out + row * LD, acc);
   }
 }
 
@@ -261,28 +305,6 @@ __device__ __forceinline__ Unit unit_of(const RowArgs &R, int64_t u) {
   else if (u < R.nl_poses + R.nl_ranges + R.nl_trans) { x.kind = 2; x.idx = static_cast<int>(u - R.nl_poses - R.nl_ranges); x.row = R.trn_base + x.idx; }
   else { x.kind = -1; x.idx = 0; x.row = 0; }
   return x;
-}
-
-// V_i - sym(Y_i V_i^T) Y_i for one pose held entirely by this thread.
-template <int LD, int D>
-__device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
-                                                       double (&v)[D][LD]) {
-  double m[D][D];
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int b = 0; b < D; ++b) m[a][b] = dot_row<LD>(y[a], v[b]);
-  double s[D][D];
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int b = 0; b < D; ++b) s[a][b] = 0.5 * (m[a][b] + m[b][a]);
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int b = 0; b < D; ++b)
-#pragma unroll
-      for (int c = 0; c < LD; ++c) v[a][c] = fma(-s[a][b], y[b][c], v[a][c]);
 }
 
 // After G = Q Y:  Lambda blocks (:1105-1131), grad = Proj_Y(G) (:772-780) and
@@ -604,13 +626,17 @@ static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
 }
 
 template <int LD, int D>
-static hipError_t launch_spmm_ld(const SpmmArgs &A, int epi, hipStream_t st) {
-  const int grid = A.n_chunks + (A.n_slices + 3) / 4;
-  if (grid == 0) return hipSuccess;
+static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) {
+  SpmmArgs A = A_in;
+  A.n_real_chunks = A.n_chunks;
+  A.n_chunks = (A.n_chunks + 7) & ~7;
+  A.n_slice_blocks = A.n_slices;
+  const int grid = A.n_chunks + 8 * ((A.n_slices + 7) / 8);
+  if (A.n_real_chunks + A.n_slices == 0) return hipSuccess;
   switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(256), 0, st, A); break;
-    case EPI_S: hipLaunchKernelGGL((k_spmm<LD, D, EPI_S>), dim3(grid), dim3(256), 0, st, A); break;
-    default: hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP>), dim3(grid), dim3(256), 0, st, A); break;
+    case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(64), 0, st, A); break;
+    case EPI_S: hipLaunchKernelGGL((k_spmm<LD, D, EPI_S>), dim3(grid), dim3(64), 0, st, A); break;
+    default: hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP>), dim3(grid), dim3(64), 0, st, A); break;
   }
   return hipGetLastError();
 }

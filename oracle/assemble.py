@@ -152,58 +152,46 @@ def assemble(g):
             return n + g.landmarks[s]
         raise ValueError("Unknown translation symbol")
 
+    def coo(rows, cols, vals, shape):
+        return sp.coo_matrix((np.asarray(vals, dtype=float),
+                              (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))),
+                             shape=shape).tocsr()
+
     # ---- ranges (src/CORA_problem.cpp:115-147)
-    Ar = sp.lil_matrix((r, nt))
     Dr = np.zeros(r)
     Or = np.zeros(r)
+    ar_i, ar_j, ar_v = [], [], []
     for k, (a, b, rr, cov) in enumerate(g.ranges):
         Dr[k] = rr
         Or[k] = 1.0 / cov
-        Ar[k, tidx(a)] = -1.0
-        Ar[k, tidx(b)] = 1.0
-    Ar = Ar.tocsr()
+        ar_i += [k, k]
+        ar_j += [tidx(a), tidx(b)]
+        ar_v += [-1.0, 1.0]
+    Ar = coo(ar_i, ar_j, ar_v, (r, nt))
 
     # ---- relative-pose block (src/CORA_problem.cpp:149-295); row order:
     # pose-pose, pose priors, pose-landmark, landmark priors
     npp, nprior, npl, nlp = len(g.rpms), len(g.pose_priors), len(g.rplms), len(g.landmark_priors)
     m = npp + nprior + npl + nlp
-    At = sp.lil_matrix((m, nt))
-    T = sp.lil_matrix((m, dn))
     Ot = np.zeros(m)
-    row = 0
-    for (a, b, R, t, cov) in g.rpms:
+    at_i, at_j, at_v = [], [], []
+    t_i, t_j, t_v = [], [], []
+    edges = [(a, b, t, cov) for (a, b, R, t, cov) in g.rpms]
+    edges += [("O0", s, t, cov) for (s, R, t, cov) in g.pose_priors]
+    edges += [(a, b, t, cov) for (a, b, t, cov) in g.rplms]
+    edges += [("O0", s, p, cov) for (s, p, cov) in g.landmark_priors]
+    for row, (a, b, t, cov) in enumerate(edges):
         Ot[row] = _trans_precision(cov, d)
         i1, i2 = tidx(a), tidx(b)
-        At[row, i1] = -1.0
-        At[row, i2] = 1.0
+        at_i += [row, row]
+        at_j += [i1, i2]
+        at_v += [-1.0, 1.0]
         for c in range(d):
-            T[row, i1 * d + c] = -t[c]
-        row += 1
-    for (s, R, t, cov) in g.pose_priors:
-        Ot[row] = _trans_precision(cov, d)
-        i1, i2 = tidx("O0"), tidx(s)
-        At[row, i1] = -1.0
-        At[row, i2] = 1.0
-        for c in range(d):
-            T[row, i1 * d + c] = -t[c]
-        row += 1
-    for (a, b, t, cov) in g.rplms:
-        Ot[row] = _trans_precision(cov, d)
-        i1, i2 = tidx(a), tidx(b)
-        At[row, i1] = -1.0
-        At[row, i2] = 1.0
-        for c in range(d):
-            T[row, i1 * d + c] = -t[c]
-        row += 1
-    for (s, p, cov) in g.landmark_priors:
-        Ot[row] = _trans_precision(cov, d)
-        i1, i2 = tidx("O0"), tidx(s)
-        At[row, i1] = -1.0
-        At[row, i2] = 1.0
-        for c in range(d):
-            T[row, i1 * d + c] = -p[c]
-        row += 1
-    At, T = At.tocsr(), T.tocsr()
+            t_i.append(row)
+            t_j.append(i1 * d + c)
+            t_v.append(-t[c])
+    At = coo(at_i, at_j, at_v, (m, nt))
+    T = coo(t_i, t_j, t_v, (m, dn))
 
     # ---- rotation connection Laplacian (src/CORA_problem.cpp:297-377)
     ri, ci, vi = [], [], []
