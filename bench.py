@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Riemannian Hessian-vector products per second on the
+synthetic 10^5-pose RA-SLAM graph at relaxation rank p = 5 (BASELINE.json).
+
+A "step" is one Hvp  out = Proj_Y((Q - Lambda) Ydot)  (reference
+src/CORA_problem.cpp:822-867) with every operand resident in HBM:
+  * N = 1: one launch of the fused SpMM+epilogue kernel;
+  * N > 1: the data matrix is row-partitioned over the ranks (pose-aligned,
+    nnz-balanced); each step is an RCCL all-gather of the search direction over
+    xGMI followed by the local kernel (strong scaling on the fixed graph).
+
+Prints ONE JSON line on rank 0.  Launch for N > 1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(d, n, r, N, nnz, p):
+    """SURVEY 8(d) / BASELINE.md section 3 (CSR int32/fp64, X read once, result written once)."""
+    b_spmm = 12 * nnz + 4 * (N + 1) + 16 * N * p
+    b_hvp = b_spmm + 8 * (d * n + r) * p + 8 * (n * d * d + r)
+    return b_spmm, b_hvp
+
+
+def cpu_baseline(rowptr, colidx, vals, dm, p, budget_s):
+    """The oracle's single-threaded Hvp (kind "port") on the same workload; the
+    reference itself is single-threaded (no OpenMP in its CMakeLists.txt)."""
+    from oracle import oracle as orc
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    rng = np.random.default_rng(7)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dm["N"], p)))
+    G = orc.egrad(Q, Y)
+    V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, (dm["N"], p)))
+    t0 = time.perf_counter()
+    ref = orc.hvp(Q, dims, Y, G, V)
+    one = time.perf_counter() - t0
+    reps = max(3, min(2000, int(budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.hvp(Q, dims, Y, G, V)
+    dt = time.perf_counter() - t0
+    return reps / dt, reps, (Y, V, ref)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--poses", type=int, default=100000)
+    ap.add_argument("--rank", type=int, default=5, help="relaxation rank p")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    from cora_amd import capi, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the CORA hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: the C++ host generates the graph and assembles Q ----------
+    n, p = args.poses, args.rank
+    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42)
+    P.update()
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    ctx = capi.Context(dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"], rowptr, colidx, vals,
+                       device=local_rank, rank=rank, world=world)
+    ctx.set_rank(p)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ld, rows, shard = ctx.ld, ctx.rows, ctx.shard_rows
+    b_spmm, b_hvp = algorithmic_bytes(dm["d"], dm["n"], dm["r"], dm["N"], dm["nnz"], p)
+
+    # operands: U(-1,1) seed 7, Y on the manifold, Ydot in T_Y
+    rng = np.random.default_rng(7)
+    Yh = rng.uniform(-1, 1, (dm["N"], p))
+    Vh = rng.uniform(-1, 1, (dm["N"], p))
+    dev = torch.device("cuda", local_rank)
+    y = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
+    x = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
+    out = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
+    ctx.upload(Yh, y.data_ptr())
+    ctx.project_to_manifold_dev(y.data_ptr(), y.data_ptr())
+    if dist is not None:  # every rank projected only its own rows
+        dist.all_gather_into_tensor(y, y[rank * shard * ld:(rank + 1) * shard * ld].clone())
+    ctx.set_point_dev(y.data_ptr())
+    ctx.upload(Vh, x.data_ptr())
+    ctx.tangent_space_projection_dev(x.data_ptr(), x.data_ptr())
+    from cora_amd.dist import RowShardedOperator
+    op = RowShardedOperator(rows, shard, ld, rank, world, dev,
+                            lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr()))
+    x_shard = x[rank * shard * ld:(rank + 1) * shard * ld].clone()  # this rank's rows of Ydot
+
+    def step():
+        op.apply(x_shard)  # all-gather of Ydot (N > 1) + the fused local kernel
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline: the kernel alone, HIP events on the stream it runs on ------
+    x = op.full_x if world > 1 else x_shard  # fully gathered Ydot
+    for _ in range(20):
+        ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+    ctx.sync()
+    reps = 500
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+    kernel_us = ctx.timer_stop_ms() * 1e3 / reps
+    stats = ctx.format_stats()
+    local_frac = stats["local_nnz"] / max(dm["nnz"], 1)
+    achieved = b_hvp * local_frac / kernel_us / 1e3  # GB/s, this rank's share of the bytes
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hvp_traffic.json")
+    if world == 1 and n == 100000 and p == 5 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = None
+    if rank == 0:
+        result = {
+            "metric": "riemannian_hessian_vector_products_per_sec",
+            "value": args.steps / elapsed,
+            "unit": "Hvp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic SE(3) odometry chain, %d poses + %d landmarks + %d range edges (seed 42); "
+                            "Hvp = Proj_Y((Q - Lambda) Ydot) at relaxation rank p=%d; N=%d, nnz(Q)=%d"
+                            % (dm["n"], dm["l"], dm["r"], p, dm["N"], dm["nnz"]),
+                "parallelism": "1 GPU" if world == 1 else
+                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + RCCL all-gather of Ydot" % world,
+                "algorithmic_bytes_per_hvp": b_hvp,
+                "algorithmic_bytes_per_spmm": b_spmm,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "cora::k_spmm<6,3,EPI_HVP>" if p == 5 else "cora::k_spmm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_us": kernel_us,
+                "bytes_per_launch": b_hvp * local_frac,
+            },
+        }
+        if world == 1:
+            cores = os.cpu_count()
+            hv_s, reps_cpu, (Yc, Vc, ref) = cpu_baseline(rowptr, colidx, vals, dm, p, args.cpu_seconds)
+            # parity of the timed GPU path against the CPU result on the same inputs
+            ctx.upload(Yc, y.data_ptr())
+            ctx.set_point_dev(y.data_ptr())
+            ctx.upload(Vc, x.data_ptr())
+            ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+            got = ctx.download(out.data_ptr(), p)
+            result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+            result["cpu_baseline"] = {
+                "value": hv_s,
+                "unit": "Hvp/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "%d Hessian-vector products of the same 10^5-pose workload with oracle/cora_oracle.c "
+                          "(single thread, like the reference; host has %s logical cores)" % (reps_cpu, cores),
+            }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

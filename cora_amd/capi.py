@@ -33,6 +33,13 @@ def load():
     """Loads the in-tree shared library (building it first when stale)."""
     global _LIB
     if _LIB is None:
+        # torch bundles its own libamdhip64.so.7: load it FIRST so that the process has one
+        # HIP runtime (our library then binds to the already-loaded SONAME); the other order
+        # leaves two runtimes and hipSetDevice fails with "no ROCm-capable device".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = _build.LIB
         if _build.needs_build():
             try:

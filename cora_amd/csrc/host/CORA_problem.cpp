@@ -1,0 +1,500 @@
+// Host side of CORA::Problem: registry + data-matrix assembly on the CPU (one
+// pass per problem), operators on the GPU through include/cora_hip.h.
+#include "CORA_problem.h"
+
+#include <cmath>
+#include <iostream>
+
+#include "../../../include/cora_hip.h"
+
+namespace CORA {
+
+namespace {
+std::pair<Key, Key> unordered_pair(const Symbol &a, const Symbol &b) {
+  const Key x = a.key(), y = b.key();
+  return x < y ? std::make_pair(x, y) : std::make_pair(y, x);
+}
+}  // namespace
+
+Problem::Problem(int dim, int relaxation_rank, Formulation formulation, Preconditioner preconditioner)
+    : dim_(dim),
+      relaxation_rank_(relaxation_rank),
+      origin_symbol_(Symbol("O0")),
+      formulation_(formulation),
+      preconditioner_(preconditioner) {
+  if (relaxation_rank < dim) throw std::invalid_argument("relaxation rank must be >= dim");
+  if (formulation != Formulation::Explicit)
+    throw NotImplementedException("Implicit (translation-marginalised) formulation");
+}
+
+// ---- registry: src/CORA_problem.cpp:24-113 ---------------------------------
+void Problem::addPoseVariable(const Symbol &pose_id) {
+  if (pose_symbol_idxs_.find(pose_id) != pose_symbol_idxs_.end())
+    throw std::invalid_argument("Pose variable already exists");
+  pose_symbol_idxs_.insert(std::make_pair(pose_id, static_cast<int>(pose_symbol_idxs_.size())));
+  problem_data_up_to_date_ = false;
+}
+
+void Problem::addLandmarkVariable(const Symbol &landmark_id) {
+  if (landmark_symbol_idxs_.find(landmark_id) != landmark_symbol_idxs_.end())
+    throw std::invalid_argument("Landmark variable already exists");
+  landmark_symbol_idxs_.insert(std::make_pair(landmark_id, static_cast<int>(landmark_symbol_idxs_.size())));
+  problem_data_up_to_date_ = false;
+}
+
+void Problem::addRangeMeasurement(const RangeMeasurement &m) {
+  if (!range_pairs_.insert(unordered_pair(m.first_id, m.second_id)).second) {
+    std::cout << "Found duplicate measure: " << m.first_id.string() << " -> " << m.second_id.string()
+              << std::endl;
+    throw std::invalid_argument("Range measurement already exists");
+  }
+  range_measurements_.push_back(m);
+  problem_data_up_to_date_ = false;
+}
+
+void Problem::addRelativePoseMeasurement(const RelativePoseMeasurement &m) {
+  if (!rpm_pairs_.insert(unordered_pair(m.first_id, m.second_id)).second)
+    throw std::invalid_argument("Relative pose measurement already exists: " + m.first_id.string() +
+                                " -> " + m.second_id.string());
+  rel_pose_pose_measurements_.push_back(m);
+  problem_data_up_to_date_ = false;
+}
+
+void Problem::addRelativePoseLandmarkMeasurement(const RelativePoseLandmarkMeasurement &m) {
+  if (!rplm_pairs_.insert(unordered_pair(m.first_id, m.second_id)).second)
+    throw std::invalid_argument("Relative pose landmark measurement already exists");
+  rel_pose_landmark_measurements_.push_back(m);
+  problem_data_up_to_date_ = false;
+}
+
+void Problem::addOriginPose() {
+  std::cout << "WARNING - using symbol " << origin_symbol_.string()
+            << " to make an 'origin'. Could cause name collision." << std::endl;
+  addPoseVariable(origin_symbol_);
+}
+
+void Problem::addPosePrior(const PosePrior &pose_prior) {
+  if (!pose_prior_ids_.insert(pose_prior.id.key()).second)
+    throw std::invalid_argument("Pose prior already exists");
+  pose_priors_.push_back(pose_prior);
+  problem_data_up_to_date_ = false;
+  if (!has_priors_) {
+    has_priors_ = true;
+    addOriginPose();
+  }
+}
+
+void Problem::addLandmarkPrior(const LandmarkPrior &landmark_prior) {
+  if (!landmark_prior_ids_.insert(landmark_prior.id.key()).second)
+    throw std::invalid_argument("Landmark prior already exists");
+  landmark_priors_.push_back(landmark_prior);
+  problem_data_up_to_date_ = false;
+  if (!has_priors_) {
+    has_priors_ = true;
+    addOriginPose();
+  }
+}
+
+// ---- index helpers: src/CORA_problem.cpp:964-1021 --------------------------
+Index Problem::getRotationIdx(const Symbol &pose_symbol) const {
+  auto it = pose_symbol_idxs_.find(pose_symbol);
+  if (it != pose_symbol_idxs_.end()) return it->second;
+  throw std::invalid_argument("Unknown pose symbol: " + pose_symbol.string());
+}
+
+Index Problem::getRangeIdx(const SymbolPair &p) const {
+  for (size_t i = 0; i < range_measurements_.size(); ++i)
+    if (range_measurements_[i].hasSymbolPair(p)) return static_cast<Index>(i) + numPosesDim();
+  throw std::invalid_argument("Unknown range symbol");
+}
+
+Index Problem::getTranslationIdx(const Symbol &s) const {
+  const Index off = rotAndRangeMatrixSize();
+  auto pit = pose_symbol_idxs_.find(s);
+  if (pit != pose_symbol_idxs_.end()) return pit->second + off;
+  auto lit = landmark_symbol_idxs_.find(s);
+  if (lit != landmark_symbol_idxs_.end()) return lit->second + off + numPoses();
+  throw std::invalid_argument("Unknown translation symbol");
+}
+
+// ---- sub-matrices: src/CORA_problem.cpp:115-377 ----------------------------
+static SparseMatrix diagonal(const std::vector<Scalar> &d) {
+  SparseMatrix m(static_cast<Index>(d.size()), static_cast<Index>(d.size()));
+  std::vector<Triplet> t;
+  for (size_t i = 0; i < d.size(); ++i) t.push_back({static_cast<Index>(i), static_cast<Index>(i), d[i]});
+  m.setFromTriplets(std::move(t));
+  return m;
+}
+
+void Problem::fillRangeSubmatrices() {
+  const Index off = rotAndRangeMatrixSize();
+  const Index r = numRangeMeasurements(), nt = numTranslationalStates();
+  std::vector<Scalar> dist(r), prec(r);
+  std::vector<Triplet> inc;
+  for (Index k = 0; k < r; ++k) {
+    const RangeMeasurement &m = range_measurements_[k];
+    dist[k] = m.r;
+    prec[k] = m.getPrecision();
+    inc.push_back({k, getTranslationIdx(m.first_id) - off, -1.0});
+    inc.push_back({k, getTranslationIdx(m.second_id) - off, 1.0});
+  }
+  data_submatrices_.range_incidence_matrix = SparseMatrix(r, nt);
+  data_submatrices_.range_incidence_matrix.setFromTriplets(std::move(inc));
+  data_submatrices_.range_dist_matrix = diagonal(dist);
+  data_submatrices_.range_precision_matrix = diagonal(prec);
+}
+
+void Problem::fillRelPoseSubmatrices() {
+  fillRotConnLaplacian();
+  const Index npp = numPosePoseMeasurements(), npl = numPoseLandmarkMeasurements();
+  const Index nprior = numPosePriors(), nlp = numLandmarkPriors();
+  const Index m = npp + nprior + npl + nlp;
+  const Index nt = numTranslationalStates(), off = rotAndRangeMatrixSize();
+  std::vector<Scalar> tprec(m), rprec(npp + nprior);
+  std::vector<Triplet> inc, tdata;
+  Index row = 0;
+  auto add = [&](const Symbol &a, const Symbol &b, const Vector &t, Scalar tau) {
+    tprec[row] = tau;
+    const Index id1 = getTranslationIdx(a) - off, id2 = getTranslationIdx(b) - off;
+    inc.push_back({row, id1, -1.0});
+    inc.push_back({row, id2, 1.0});
+    for (int k = 0; k < dim_; ++k) tdata.push_back({row, id1 * dim_ + k, -t(k)});
+    ++row;
+  };
+  // row order: pose-pose, pose priors, pose-landmark, landmark priors (:190-294)
+  for (const auto &rpm : rel_pose_pose_measurements_) {
+    rprec[row] = rpm.getRotPrecision();
+    add(rpm.first_id, rpm.second_id, rpm.t, rpm.getTransPrecision());
+  }
+  for (const auto &pp : pose_priors_) {
+    rprec[row] = pp.getRotPrecision();
+    add(origin_symbol_, pp.id, pp.t, pp.getTransPrecision());
+  }
+  for (const auto &pl : rel_pose_landmark_measurements_) add(pl.first_id, pl.second_id, pl.t, pl.getTransPrecision());
+  for (const auto &lp : landmark_priors_) add(origin_symbol_, lp.id, lp.p, lp.getTransPrecision());
+
+  data_submatrices_.rel_pose_incidence_matrix = SparseMatrix(m, nt);
+  data_submatrices_.rel_pose_incidence_matrix.setFromTriplets(std::move(inc));
+  data_submatrices_.rel_pose_translation_data_matrix = SparseMatrix(m, numPosesDim());
+  data_submatrices_.rel_pose_translation_data_matrix.setFromTriplets(std::move(tdata));
+  data_submatrices_.rel_pose_translation_precision_matrix = diagonal(tprec);
+  data_submatrices_.rel_pose_rotation_precision_matrix = diagonal(rprec);
+}
+
+void Problem::fillRotConnLaplacian() {
+  const Index d = dim_;
+  std::vector<Triplet> t;
+  t.reserve(static_cast<size_t>(2 * (d + d * d)) * (rel_pose_pose_measurements_.size() + pose_priors_.size()));
+  auto add = [&](Index i, Index j, Scalar kappa, const Matrix &R) {
+    for (Index k = 0; k < d; ++k) t.push_back({d * i + k, d * i + k, kappa});
+    for (Index k = 0; k < d; ++k) t.push_back({d * j + k, d * j + k, kappa});
+    for (Index r = 0; r < d; ++r)
+      for (Index c = 0; c < d; ++c) t.push_back({i * d + r, j * d + c, -kappa * R(r, c)});
+    for (Index r = 0; r < d; ++r)
+      for (Index c = 0; c < d; ++c) t.push_back({j * d + r, i * d + c, -kappa * R(c, r)});
+  };
+  for (const auto &m : rel_pose_pose_measurements_)
+    add(getRotationIdx(m.first_id), getRotationIdx(m.second_id), m.getRotPrecision(), m.R);
+  for (const auto &p : pose_priors_)
+    add(getRotationIdx(origin_symbol_), getRotationIdx(p.id), p.getRotPrecision(), p.R);
+  data_submatrices_.rotation_conn_laplacian = SparseMatrix(numPosesDim(), numPosesDim());
+  data_submatrices_.rotation_conn_laplacian.setFromTriplets(std::move(t));
+}
+
+// ---- data matrix: src/CORA_problem.cpp:625-712 ------------------------------
+void Problem::fillDataMatrix() {
+  const auto &S = data_submatrices_;
+  std::vector<Scalar> wt(static_cast<size_t>(S.rel_pose_translation_precision_matrix.rows()));
+  for (size_t i = 0; i < wt.size(); ++i) wt[i] = S.rel_pose_translation_precision_matrix.values[i];
+  std::vector<Scalar> wr(static_cast<size_t>(S.range_precision_matrix.rows()));
+  for (size_t i = 0; i < wr.size(); ++i) wr[i] = S.range_precision_matrix.values[i];
+
+  const SparseMatrix Tt = S.rel_pose_translation_data_matrix.transpose();
+  const SparseMatrix Att = S.rel_pose_incidence_matrix.transpose();
+  const SparseMatrix Art = S.range_incidence_matrix.transpose();
+  const SparseMatrix Q11 = S.rotation_conn_laplacian.plus(Tt.times(&wt, S.rel_pose_translation_data_matrix));
+  const SparseMatrix Q13 = Tt.times(&wt, S.rel_pose_incidence_matrix);
+  const SparseMatrix OmegaRD = S.range_precision_matrix.times(nullptr, S.range_dist_matrix);
+  const SparseMatrix Q22 = OmegaRD.times(nullptr, S.range_dist_matrix);
+  const SparseMatrix Q23 = OmegaRD.times(nullptr, S.range_incidence_matrix);
+  const SparseMatrix Q33 =
+      Att.times(&wt, S.rel_pose_incidence_matrix).plus(Art.times(&wr, S.range_incidence_matrix));
+
+  const Index rot = numPosesDim(), rr = rotAndRangeMatrixSize();
+  std::vector<Triplet> all;
+  auto append = [&all](std::vector<Triplet> t) { all.insert(all.end(), t.begin(), t.end()); };
+  append(Q11.triplets(0, 0));
+  append(Q13.triplets(0, rr));
+  append(Q22.triplets(rot, rot));
+  append(Q23.triplets(rot, rr));
+  append(Q33.triplets(rr, rr));
+  append(Q13.triplets(rr, 0, true));
+  append(Q23.triplets(rr, rot, true));
+  data_matrix_ = SparseMatrix(getDataMatrixSize(), getDataMatrixSize());
+  data_matrix_.setFromTriplets(std::move(all));
+}
+
+void Problem::updateProblemData() {  // src/CORA_problem.cpp:500-510
+  fillRangeSubmatrices();
+  fillRelPoseSubmatrices();
+  fillDataMatrix();
+  ctx_.reset();  // the device copy of Q is rebuilt lazily
+  precond_ready_ = false;
+  problem_data_up_to_date_ = true;
+}
+
+const SparseMatrix &Problem::getDataMatrix() {
+  if (data_matrix_.nonZeros() == 0 || !problem_data_up_to_date_) updateProblemData();
+  return data_matrix_;
+}
+
+int Problem::getDataMatrixSize() const { return numPoses() * (dim_ + 1) + numLandmarks() + numRangeMeasurements(); }
+int Problem::getExpectedVariableSize() const { return getDataMatrixSize(); }
+
+void Problem::checkUpToDate() const {
+  if (!problem_data_up_to_date_)
+    throw std::runtime_error(
+        "The data matrix must be constructed before the objective function can be evaluated. This error "
+        "may be due to the fact that data has been modified since the last call to updateProblemData()");
+}
+
+// ---- device plumbing ---------------------------------------------------------
+void Problem::throwLast(int status, const char *where) const {
+  const std::string msg = std::string(where) + ": " + cora_last_error(ctx_.get());
+  if (status == CORA_ERR_SHAPE) throw std::logic_error(msg);  // MatrixShapeException's base
+  if (status == CORA_ERR_ARG) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+void Problem::ensureContext() const {
+  checkUpToDate();
+  if (!ctx_) {
+    cora_ctx *c = nullptr;
+    const int rc = cora_ctx_create(device_, dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
+                                   data_matrix_.outerIndexPtr(), data_matrix_.innerIndexPtr(),
+                                   data_matrix_.valuePtr(), &c);
+    if (rc != CORA_OK)
+      throw std::runtime_error(std::string("CORA::Problem: cannot create the device problem: ") +
+                               cora_last_error(nullptr));
+    ctx_ = std::shared_ptr<cora_ctx>(c, [](cora_ctx *p) { cora_ctx_destroy(p); });
+  }
+  if (cora_get_rank(ctx_.get()) != relaxation_rank_) {
+    const int rc = cora_set_rank(ctx_.get(), relaxation_rank_);
+    if (rc != CORA_OK) throwLast(rc, "Problem::setRank");
+    // the point / preconditioner state of the handle is rank specific
+  }
+}
+
+void Problem::updatePreconditioner() { ensurePreconditioner(); }
+
+void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
+  ensureContext();
+  if (precond_ready_) return;
+  int kind;
+  switch (preconditioner_) {
+    case Preconditioner::None: kind = CORA_PRECOND_NONE; break;
+    case Preconditioner::Jacobi: kind = CORA_PRECOND_JACOBI; break;
+    case Preconditioner::BlockCholesky: kind = CORA_PRECOND_BLOCK_CHOLESKY; break;
+    default: kind = CORA_PRECOND_REGULARIZED_CHOLESKY; break;
+  }
+  const int rc = cora_precond_setup(ctx_.get(), kind);
+  if (rc != CORA_OK) throwLast(rc, "Problem::updatePreconditioner");
+  precond_ready_ = true;
+}
+
+void Problem::setRank(int r) {
+  if (r < dim_) throw std::invalid_argument("relaxation rank must be >= dim");
+  relaxation_rank_ = r;
+}
+
+#define CORA_CALL(expr, where)                 \
+  do {                                         \
+    const int rc__ = (expr);                   \
+    if (rc__ != CORA_OK) throwLast(rc__, where); \
+  } while (0)
+
+// ---- operators (GPU): src/CORA_problem.cpp:742-938 --------------------------
+Matrix Problem::dataMatrixProduct(const Matrix &Y) const {
+  checkMatrixShape("Problem::dataMatrixProduct::Y", getExpectedVariableSize(), Y.cols(), Y.rows(), Y.cols());
+  ensureContext();
+  Matrix out(Y.rows(), Y.cols());
+  CORA_CALL(cora_data_matrix_product(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), static_cast<int>(Y.cols()),
+                                     out.data(), static_cast<int>(out.rows())),
+            "Problem::dataMatrixProduct");
+  return out;
+}
+
+Scalar Problem::evaluateObjective(const Matrix &Y) const {
+  checkUpToDate();
+  checkMatrixShape("Problem::evaluateObjective::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  ensureContext();
+  Scalar f = 0;
+  CORA_CALL(cora_evaluate_objective(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), &f), "Problem::evaluateObjective");
+  return f;
+}
+
+Matrix Problem::Euclidean_gradient(const Matrix &Y) const {
+  checkUpToDate();
+  checkMatrixShape("Problem::Euclidean_gradient::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  ensureContext();
+  Matrix out(Y.rows(), Y.cols());
+  CORA_CALL(cora_euclidean_gradient(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), out.data(),
+                                    static_cast<int>(out.rows())),
+            "Problem::Euclidean_gradient");
+  return out;
+}
+
+Matrix Problem::Riemannian_gradient(const Matrix &Y) const {
+  checkUpToDate();
+  checkMatrixShape("Problem::Riemannian_gradient::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  ensureContext();
+  Matrix out(Y.rows(), Y.cols());
+  CORA_CALL(cora_riemannian_gradient(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), out.data(),
+                                     static_cast<int>(out.rows())),
+            "Problem::Riemannian_gradient");
+  return out;
+}
+
+Matrix Problem::Riemannian_gradient(const Matrix &Y, const Matrix &NablaF_Y) const {
+  checkUpToDate();
+  return tangent_space_projection(Y, NablaF_Y);
+}
+
+Matrix Problem::tangent_space_projection(const Matrix &Y, const Matrix &Ydot) const {
+  checkMatrixShape("Problem::tangent_space_projection::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  checkMatrixShape("Problem::tangent_space_projection::Ydot", getExpectedVariableSize(), relaxation_rank_,
+                   Ydot.rows(), Ydot.cols());
+  ensureContext();
+  Matrix out(Y.rows(), Y.cols());
+  CORA_CALL(cora_tangent_space_projection(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), Ydot.data(),
+                                          static_cast<int>(Ydot.rows()), out.data(), static_cast<int>(out.rows())),
+            "Problem::tangent_space_projection");
+  return out;
+}
+
+Matrix Problem::Riemannian_Hessian_vector_product(const Matrix &Y, const Matrix &nablaF_Y, const Matrix &dotY) const {
+  checkMatrixShape("Problem::Riemannian_Hessian_vector_product::Y", getExpectedVariableSize(), relaxation_rank_,
+                   Y.rows(), Y.cols());
+  checkMatrixShape("Problem::Riemannian_Hessian_vector_product::nablaF_Y", getExpectedVariableSize(),
+                   relaxation_rank_, nablaF_Y.rows(), nablaF_Y.cols());
+  checkMatrixShape("Problem::Riemannian_Hessian_vector_product::dotY", getExpectedVariableSize(), relaxation_rank_,
+                   dotY.rows(), dotY.cols());
+  ensureContext();
+  Matrix out(Y.rows(), Y.cols());
+  CORA_CALL(cora_riemannian_hessian_vector_product(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), nablaF_Y.data(),
+                                                   static_cast<int>(nablaF_Y.rows()), dotY.data(),
+                                                   static_cast<int>(dotY.rows()), out.data(),
+                                                   static_cast<int>(out.rows())),
+            "Problem::Riemannian_Hessian_vector_product");
+  return out;
+}
+
+Matrix Problem::precondition(const Matrix &V) const {
+  checkMatrixShape("Problem::precondition::input", getExpectedVariableSize(), relaxation_rank_, V.rows(), V.cols());
+  ensurePreconditioner();
+  Matrix out(V.rows(), V.cols());
+  CORA_CALL(cora_precondition(ctx_.get(), V.data(), static_cast<int>(V.rows()), out.data(), static_cast<int>(out.rows())),
+            "Problem::precondition");
+  return out;
+}
+
+Matrix Problem::projectToManifold(const Matrix &A) const {
+  checkMatrixShape("Problem::projectToManifold", getExpectedVariableSize(), relaxation_rank_, A.rows(), A.cols());
+  ensureContext();
+  Matrix out(A.rows(), A.cols());
+  CORA_CALL(cora_project_to_manifold(ctx_.get(), A.data(), static_cast<int>(A.rows()), out.data(),
+                                     static_cast<int>(out.rows())),
+            "Problem::projectToManifold");
+  return out;
+}
+
+Matrix Problem::retract(const Matrix &Y, const Matrix &V) const {
+  checkMatrixShape("Problem::retract::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  checkMatrixShape("Problem::retract::V", getExpectedVariableSize(), relaxation_rank_, V.rows(), V.cols());
+  ensureContext();
+  Matrix out(Y.rows(), Y.cols());
+  CORA_CALL(cora_retract(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), V.data(), static_cast<int>(V.rows()),
+                         out.data(), static_cast<int>(out.rows())),
+            "Problem::retract");
+  return out;
+}
+
+Matrix Problem::getRandomInitialGuess(uint64_t seed) const {  // src/CORA_problem.cpp:1023-1028
+  checkUpToDate();
+  return projectToManifold(Matrix::Random(getExpectedVariableSize(), relaxation_rank_, seed));
+}
+
+// ---- certification pieces: src/CORA_problem.cpp:1105-1166 --------------------
+Problem::LambdaBlocks Problem::compute_Lambda_blocks(const Matrix &Y) const {
+  checkMatrixShape("Problem::compute_Lambda_blocks::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  ensureContext();
+  Matrix st(dim_, std::max(numPosesDim(), 1));
+  Vector ob(std::max(numRangeMeasurements(), 1), 1);
+  CORA_CALL(cora_compute_lambda_blocks(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), st.data(), ob.data()),
+            "Problem::compute_Lambda_blocks");
+  return std::make_pair(st.block(0, 0, dim_, numPosesDim()), ob.block(0, 0, numRangeMeasurements(), 1));
+}
+
+SparseMatrix Problem::compute_Lambda_from_Lambda_blocks(const LambdaBlocks &L, const int &Lambda_size) const {
+  std::vector<Triplet> t;
+  for (Index i = 0; i < numPoses(); ++i)
+    for (Index r = 0; r < dim_; ++r)
+      for (Index c = 0; c < dim_; ++c) t.push_back({i * dim_ + r, i * dim_ + c, L.first(r, i * dim_ + c)});
+  const Index rot = numPosesDim();
+  for (Index i = 0; i < numRangeMeasurements(); ++i) t.push_back({rot + i, rot + i, L.second(i)});
+  SparseMatrix Lambda(Lambda_size, Lambda_size);
+  Lambda.setFromTriplets(std::move(t));
+  return Lambda;
+}
+
+SparseMatrix Problem::get_certificate_matrix(const Matrix &Y) const {
+  const LambdaBlocks L = compute_Lambda_blocks(Y);
+  SparseMatrix Lambda = compute_Lambda_from_Lambda_blocks(L, getDataMatrixSize());
+  for (auto &v : Lambda.values) v = -v;
+  return data_matrix_.plus(Lambda);
+}
+
+// ---- utilities: src/CORA_problem.cpp:1199-1306 -------------------------------
+void Problem::checkVariablesAreValid(const Matrix &Y) const {
+  const Index p = Y.cols();
+  for (Index i = 0; i < numPoses(); ++i) {
+    for (Index a = 0; a < dim_; ++a)
+      for (Index b = 0; b < dim_; ++b) {
+        Scalar s = 0;
+        for (Index c = 0; c < p; ++c) s += Y(i * dim_ + a, c) * Y(i * dim_ + b, c);
+        if (std::abs(s - (a == b ? 1.0 : 0.0)) > 1e-6) {
+          std::cout << "R^T R for pose " << i << " is not the identity" << std::endl;
+          throw std::runtime_error("Pose is not a valid rotation matrix");
+        }
+      }
+  }
+  for (Index j = 0; j < numRangeMeasurements(); ++j) {
+    Scalar s = 0;
+    for (Index c = 0; c < p; ++c) s += Y(numPosesDim() + j, c) * Y(numPosesDim() + j, c);
+    if (std::abs(std::sqrt(s) - 1.0) > 1e-6) {
+      std::cout << "Range " << j << " has norm " << std::sqrt(s) << std::endl;
+      throw std::runtime_error("Range is not a unit vector");
+    }
+  }
+}
+
+Matrix Problem::alignEstimateToOrigin(const Matrix &Y) const {
+  checkVariablesAreValid(Y);
+  Matrix Ya = Y;
+  if (numPoses() > 0) {
+    const Matrix first = Y.block(0, 0, dim_, Y.cols());  // d x p block of the first pose
+    if (Y.cols() != dim_) throw std::runtime_error("alignEstimateToOrigin expects a rank-d solution");
+    Ya = Y * first.transpose();
+  }
+  checkVariablesAreValid(Ya);
+  const Index off = rotAndRangeMatrixSize(), nt = numTranslationalStates();
+  for (Index c = 0; c < Ya.cols(); ++c) {
+    Scalar mean = 0;
+    for (Index i = 0; i < nt; ++i) mean += Ya(off + i, c);
+    mean /= static_cast<Scalar>(std::max<Index>(nt, 1));
+    for (Index i = 0; i < nt; ++i) Ya(off + i, c) -= mean;
+  }
+  return Ya;
+}
+
+}  // namespace CORA

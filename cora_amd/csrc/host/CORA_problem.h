@@ -1,0 +1,168 @@
+// CORA::Problem -- host-side mirror of the reference's class
+// (include/CORA/CORA_problem.h:67-416).  Ingestion, the variable registry and
+// the data-matrix assembly run on the host (they define Q once per problem);
+// every operator of the optimisation hot path is a call through the C ABI of
+// include/cora_hip.h into HIP kernels.  There is no CPU implementation of the
+// operators in this class: without a usable gfx950 device they throw.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "CORA_types.h"
+#include "Measurements.h"
+#include "Symbol.h"
+
+struct cora_ctx;
+
+namespace CORA {
+
+/** include/CORA/CORA_problem.h:31-46 */
+struct CoraDataSubmatrices {
+  SparseMatrix range_incidence_matrix;
+  SparseMatrix range_precision_matrix;
+  SparseMatrix range_dist_matrix;
+  SparseMatrix rel_pose_incidence_matrix;
+  SparseMatrix rel_pose_translation_data_matrix;
+  SparseMatrix rotation_conn_laplacian;
+  SparseMatrix rel_pose_translation_precision_matrix;
+  SparseMatrix rel_pose_rotation_precision_matrix;
+};
+
+class Problem {
+ private:
+  int dim_;
+  bool pin_last_translation_ = true;
+  int relaxation_rank_;
+
+  std::map<Symbol, int> pose_symbol_idxs_;
+  std::map<Symbol, int> landmark_symbol_idxs_;
+  std::vector<RangeMeasurement> range_measurements_;
+  std::vector<RelativePoseMeasurement> rel_pose_pose_measurements_;
+  std::vector<RelativePoseLandmarkMeasurement> rel_pose_landmark_measurements_;
+  Symbol origin_symbol_;
+  std::vector<PosePrior> pose_priors_;
+  std::vector<LandmarkPrior> landmark_priors_;
+  // The reference finds duplicates with std::find over the measurement vectors
+  // (src/CORA_problem.cpp:42,56,69: O(m^2)); same semantics with a hash of the
+  // unordered symbol pair in an ordered set, so that 10^5-edge graphs load in seconds.
+  std::set<std::pair<Key, Key>> range_pairs_, rpm_pairs_, rplm_pairs_;
+  std::set<Key> pose_prior_ids_, landmark_prior_ids_;
+
+  Formulation formulation_;
+  Preconditioner preconditioner_;
+  CoraDataSubmatrices data_submatrices_;
+  bool has_priors_ = false;
+  bool problem_data_up_to_date_ = false;
+  int device_ = 0;
+  mutable std::shared_ptr<cora_ctx> ctx_;
+  mutable bool precond_ready_ = false;
+
+  void checkUpToDate() const;
+  void addOriginPose();
+  void fillRangeSubmatrices();
+  void fillRelPoseSubmatrices();
+  void fillRotConnLaplacian();
+  void fillDataMatrix();
+  void updatePreconditioner();
+  Matrix dataMatrixProduct(const Matrix &Y) const;
+  void ensureContext() const;
+  void ensurePreconditioner() const;
+  [[noreturn]] void throwLast(int status, const char *where) const;
+
+ public:
+  Problem(int dim, int relaxation_rank, Formulation formulation = Formulation::Explicit,
+          Preconditioner preconditioner = Preconditioner::RegularizedCholesky);
+
+  void addPoseVariable(const Symbol &pose_id);
+  void addPoseVariable(const std::string &pose_id) { addPoseVariable(Symbol(pose_id)); }
+  void addLandmarkVariable(const Symbol &landmark_id);
+  void addLandmarkVariable(const std::string &landmark_id) { addLandmarkVariable(Symbol(landmark_id)); }
+  void addRangeMeasurement(const RangeMeasurement &range_measurement);
+  void addRelativePoseMeasurement(const RelativePoseMeasurement &rel_pose_measure);
+  void addRelativePoseLandmarkMeasurement(const RelativePoseLandmarkMeasurement &m);
+  void addPosePrior(const PosePrior &pose_prior);
+  void addLandmarkPrior(const LandmarkPrior &landmark_prior);
+
+  Index getRotationIdx(const Symbol &pose_symbol) const;
+  Index getRangeIdx(const SymbolPair &range_symbol_pair) const;
+  Index getTranslationIdx(const Symbol &trans_symbol) const;
+
+  const CoraDataSubmatrices &getDataSubmatrices() {
+    if (!problem_data_up_to_date_) updateProblemData();
+    return data_submatrices_;
+  }
+  Symbol getOriginSymbol() const { return origin_symbol_; }
+  std::map<Symbol, int> getPoseSymbolMap() const { return pose_symbol_idxs_; }
+  std::map<Symbol, int> getLandmarkSymbolMap() const { return landmark_symbol_idxs_; }
+  const std::vector<RangeMeasurement> &getRangeMeasurements() const { return range_measurements_; }
+  const std::vector<RelativePoseMeasurement> &getRPMs() const { return rel_pose_pose_measurements_; }
+
+  SparseMatrix data_matrix_;
+
+  void updateProblemData();
+  const SparseMatrix &getDataMatrix();
+  int getDataMatrixSize() const;
+  int getExpectedVariableSize() const;
+
+  Formulation getFormulation() const { return formulation_; }
+  Preconditioner getPreconditioner() const { return preconditioner_; }
+  int dim() const { return dim_; }
+  int numPoses() const { return static_cast<int>(pose_symbol_idxs_.size()); }
+  int numPosePoseMeasurements() const { return static_cast<int>(rel_pose_pose_measurements_.size()); }
+  int numPoseLandmarkMeasurements() const { return static_cast<int>(rel_pose_landmark_measurements_.size()); }
+  int numPosePriors() const { return static_cast<int>(pose_priors_.size()); }
+  int numLandmarkPriors() const { return static_cast<int>(landmark_priors_.size()); }
+  int numLandmarks() const { return static_cast<int>(landmark_symbol_idxs_.size()); }
+  int numRangeMeasurements() const { return static_cast<int>(range_measurements_.size()); }
+  int numTranslationalStates() const { return numPoses() + numLandmarks(); }
+  int numPosesDim() const { return dim() * numPoses(); }
+  int rotAndRangeMatrixSize() const { return numPosesDim() + numRangeMeasurements(); }
+
+  /*****  Riemannian optimization functions (all on the GPU)  *******/
+  size_t getRelaxationRank() const { return static_cast<size_t>(relaxation_rank_); }
+  Matrix getRandomInitialGuess(uint64_t seed = 7) const;
+  void incrementRank() { setRank(relaxation_rank_ + 1); }
+  void setRank(int r);
+  void setPreconditioner(Preconditioner p) {
+    preconditioner_ = p;
+    precond_ready_ = false;
+  }
+  void setFormulation(Formulation f) { formulation_ = f; }
+  void setDevice(int device) { device_ = device; }
+
+  Scalar evaluateObjective(const Matrix &Y) const;
+  Matrix Euclidean_gradient(const Matrix &Y) const;
+  Matrix Riemannian_gradient(const Matrix &Y) const;
+  Matrix Riemannian_gradient(const Matrix &Y, const Matrix &NablaF_Y) const;
+  Matrix Riemannian_Hessian_vector_product(const Matrix &Y, const Matrix &NablaF_Y, const Matrix &Ydot) const;
+  Matrix tangent_space_projection(const Matrix &Y, const Matrix &Ydot) const;
+  Matrix precondition(const Matrix &V) const;
+  Matrix projectToManifold(const Matrix &A) const;
+  Matrix retract(const Matrix &Y, const Matrix &V) const;
+
+  /********** Certification **************/
+  using LambdaBlocks = std::pair<Matrix, Vector>;
+  LambdaBlocks compute_Lambda_blocks(const Matrix &Y) const;
+  SparseMatrix compute_Lambda_from_Lambda_blocks(const LambdaBlocks &Lambda_blocks, const int &Lambda_size) const;
+  SparseMatrix get_certificate_matrix(const Matrix &Y) const;
+  CertResults certify_solution(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap,
+                               size_t max_LOBPCG_iters = 500) const;
+
+  /************** Utilities **********************/
+  void checkVariablesAreValid(const Matrix &Y) const;
+  Matrix alignEstimateToOrigin(const Matrix &Y) const;
+
+  /** Device handle behind the operators (for the resident TNT / LOBPCG loops). */
+  cora_ctx *context() const {
+    ensureContext();
+    return ctx_.get();
+  }
+  void ensurePreconditionerReady() const { ensurePreconditioner(); }
+};
+
+}  // namespace CORA

@@ -1,0 +1,254 @@
+// Basic types of the C++ host (mirrors the reference's include/CORA/CORA_types.h
+// without Eigen: the image has no Eigen, and the host only needs column-major
+// dense storage and a CSR container to talk to the C ABI in include/cora_hip.h).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace CORA {
+
+typedef double Scalar;
+typedef std::ptrdiff_t Index;
+
+class NotImplementedException : public std::logic_error {
+ public:
+  explicit NotImplementedException(std::string const &str) : std::logic_error(str + " not implemented") {}
+};
+
+// include/CORA/CORA_types.h:23-39
+class MatrixShapeException : public std::logic_error {
+ public:
+  MatrixShapeException(const std::string &func_name, Index exp_rows, Index exp_cols, Index act_rows,
+                       Index act_cols)
+      : std::logic_error(func_name + ": " + "expected matrix of shape (" + std::to_string(exp_rows) +
+                         ", " + std::to_string(exp_cols) + ") but got (" + std::to_string(act_rows) +
+                         ", " + std::to_string(act_cols) + ")") {}
+};
+inline void checkMatrixShape(const std::string &func_name, Index exp_rows, Index exp_cols, Index act_rows,
+                             Index act_cols) {
+  if (exp_rows != act_rows || exp_cols != act_cols)
+    throw MatrixShapeException(func_name, exp_rows, exp_cols, act_rows, act_cols);
+}
+
+/** Column-major dense matrix of doubles (the storage order of Eigen::MatrixXd,
+ * so data() can be handed to the C ABI with ld = rows()). */
+class Matrix {
+  Index rows_ = 0, cols_ = 0;
+  std::vector<Scalar> a_;
+
+ public:
+  Matrix() = default;
+  Matrix(Index r, Index c) : rows_(r), cols_(c), a_(static_cast<size_t>(r * c), 0.0) {}
+  static Matrix Zero(Index r, Index c) { return Matrix(r, c); }
+  static Matrix Identity(Index r, Index c) {
+    Matrix m(r, c);
+    for (Index i = 0; i < std::min(r, c); ++i) m(i, i) = 1.0;
+    return m;
+  }
+  /** Uniform in [-1, 1] like Eigen's Matrix::Random (src/CORA_problem.cpp:1026). */
+  static Matrix Random(Index r, Index c, uint64_t seed = 0x9E3779B97F4A7C15ull) {
+    Matrix m(r, c);
+    std::mt19937_64 g(seed);
+    std::uniform_real_distribution<Scalar> u(-1.0, 1.0);
+    for (auto &v : m.a_) v = u(g);
+    return m;
+  }
+  Index rows() const { return rows_; }
+  Index cols() const { return cols_; }
+  Index size() const { return rows_ * cols_; }
+  Scalar *data() { return a_.data(); }
+  const Scalar *data() const { return a_.data(); }
+  Scalar &operator()(Index i, Index j) { return a_[static_cast<size_t>(j * rows_ + i)]; }
+  Scalar operator()(Index i, Index j) const { return a_[static_cast<size_t>(j * rows_ + i)]; }
+  Scalar &operator()(Index i) { return a_[static_cast<size_t>(i)]; }
+  Scalar operator()(Index i) const { return a_[static_cast<size_t>(i)]; }
+  void setZero() { std::fill(a_.begin(), a_.end(), 0.0); }
+
+  Matrix block(Index r0, Index c0, Index nr, Index nc) const {
+    Matrix b(nr, nc);
+    for (Index j = 0; j < nc; ++j)
+      for (Index i = 0; i < nr; ++i) b(i, j) = (*this)(r0 + i, c0 + j);
+    return b;
+  }
+  void setBlock(Index r0, Index c0, const Matrix &b) {
+    for (Index j = 0; j < b.cols(); ++j)
+      for (Index i = 0; i < b.rows(); ++i) (*this)(r0 + i, c0 + j) = b(i, j);
+  }
+  Matrix col(Index j) const { return block(0, j, rows_, 1); }
+  Matrix transpose() const {
+    Matrix t(cols_, rows_);
+    for (Index j = 0; j < cols_; ++j)
+      for (Index i = 0; i < rows_; ++i) t(j, i) = (*this)(i, j);
+    return t;
+  }
+  Matrix operator*(const Matrix &o) const {
+    if (cols_ != o.rows_) throw std::invalid_argument("Matrix product: inner dimensions differ");
+    Matrix r(rows_, o.cols_);
+    for (Index j = 0; j < o.cols_; ++j)
+      for (Index k = 0; k < cols_; ++k) {
+        const Scalar b = o(k, j);
+        if (b == 0.0) continue;
+        for (Index i = 0; i < rows_; ++i) r(i, j) += (*this)(i, k) * b;
+      }
+    return r;
+  }
+  Matrix operator+(const Matrix &o) const {
+    checkMatrixShape("Matrix::operator+", rows_, cols_, o.rows_, o.cols_);
+    Matrix r = *this;
+    for (size_t i = 0; i < a_.size(); ++i) r.a_[i] += o.a_[i];
+    return r;
+  }
+  Matrix operator-(const Matrix &o) const {
+    checkMatrixShape("Matrix::operator-", rows_, cols_, o.rows_, o.cols_);
+    Matrix r = *this;
+    for (size_t i = 0; i < a_.size(); ++i) r.a_[i] -= o.a_[i];
+    return r;
+  }
+  Matrix operator*(Scalar s) const {
+    Matrix r = *this;
+    for (auto &v : r.a_) v *= s;
+    return r;
+  }
+  Scalar dot(const Matrix &o) const {
+    checkMatrixShape("Matrix::dot", rows_, cols_, o.rows_, o.cols_);
+    Scalar s = 0;
+    for (size_t i = 0; i < a_.size(); ++i) s += a_[i] * o.a_[i];
+    return s;
+  }
+  Scalar norm() const { return std::sqrt(dot(*this)); }
+  Scalar trace() const {
+    Scalar s = 0;
+    for (Index i = 0; i < std::min(rows_, cols_); ++i) s += (*this)(i, i);
+    return s;
+  }
+  bool hasNaN() const {
+    for (Scalar v : a_)
+      if (v != v) return true;
+    return false;
+  }
+};
+inline Matrix operator*(Scalar s, const Matrix &m) { return m * s; }
+typedef Matrix Vector;  // N x 1
+
+/** Row-major CSR with int32 indices: the layout of the reference's
+ * Eigen::SparseMatrix<Scalar, Eigen::RowMajor> (include/CORA/CORA_types.h:70). */
+struct Triplet {
+  Index r, c;
+  Scalar v;
+};
+class SparseMatrix {
+  Index rows_ = 0, cols_ = 0;
+
+ public:
+  std::vector<int32_t> outer;  // rows + 1
+  std::vector<int32_t> inner;
+  std::vector<Scalar> values;
+
+  SparseMatrix() : outer(1, 0) {}
+  SparseMatrix(Index r, Index c) : rows_(r), cols_(c), outer(static_cast<size_t>(r) + 1, 0) {}
+  Index rows() const { return rows_; }
+  Index cols() const { return cols_; }
+  Index nonZeros() const { return static_cast<Index>(inner.size()); }
+  const int32_t *outerIndexPtr() const { return outer.data(); }
+  const int32_t *innerIndexPtr() const { return inner.data(); }
+  const Scalar *valuePtr() const { return values.data(); }
+
+  /** Duplicates are summed and structural zeros kept, like Eigen's setFromTriplets. */
+  void setFromTriplets(std::vector<Triplet> t) {
+    std::sort(t.begin(), t.end(), [](const Triplet &a, const Triplet &b) {
+      return a.r != b.r ? a.r < b.r : a.c < b.c;
+    });
+    outer.assign(static_cast<size_t>(rows_) + 1, 0);
+    inner.clear();
+    values.clear();
+    Index pr = -1, pc = -1;
+    for (const Triplet &e : t) {
+      if (e.r < 0 || e.r >= rows_ || e.c < 0 || e.c >= cols_)
+        throw std::invalid_argument("SparseMatrix::setFromTriplets: index out of range");
+      if (e.r == pr && e.c == pc) {
+        values.back() += e.v;
+      } else {
+        inner.push_back(static_cast<int32_t>(e.c));
+        values.push_back(e.v);
+        outer[static_cast<size_t>(e.r) + 1]++;
+        pr = e.r;
+        pc = e.c;
+      }
+    }
+    for (Index i = 0; i < rows_; ++i) outer[static_cast<size_t>(i) + 1] += outer[static_cast<size_t>(i)];
+  }
+  std::vector<Triplet> triplets(Index row_off = 0, Index col_off = 0, bool transpose = false) const {
+    std::vector<Triplet> t;
+    t.reserve(inner.size());
+    for (Index i = 0; i < rows_; ++i)
+      for (int32_t q = outer[static_cast<size_t>(i)]; q < outer[static_cast<size_t>(i) + 1]; ++q) {
+        if (transpose) t.push_back({inner[q] + row_off, i + col_off, values[q]});
+        else t.push_back({i + row_off, inner[q] + col_off, values[q]});
+      }
+    return t;
+  }
+  SparseMatrix transpose() const {
+    SparseMatrix r(cols_, rows_);
+    r.setFromTriplets(triplets(0, 0, true));
+    return r;
+  }
+  /** this * diag(w) * other, without pruning (Eigen's conservative product). */
+  SparseMatrix times(const std::vector<Scalar> *w, const SparseMatrix &o) const {
+    if (cols_ != o.rows_) throw std::invalid_argument("SparseMatrix product: inner dimensions differ");
+    std::vector<Triplet> t;
+    for (Index i = 0; i < rows_; ++i)
+      for (int32_t q = outer[static_cast<size_t>(i)]; q < outer[static_cast<size_t>(i) + 1]; ++q) {
+        const Index k = inner[q];
+        const Scalar a = values[q] * (w ? (*w)[static_cast<size_t>(k)] : 1.0);
+        for (int32_t s = o.outer[static_cast<size_t>(k)]; s < o.outer[static_cast<size_t>(k) + 1]; ++s)
+          t.push_back({i, o.inner[s], a * o.values[s]});
+      }
+    SparseMatrix r(rows_, o.cols_);
+    r.setFromTriplets(std::move(t));
+    return r;
+  }
+  SparseMatrix plus(const SparseMatrix &o) const {
+    auto t = triplets();
+    auto u = o.triplets();
+    t.insert(t.end(), u.begin(), u.end());
+    SparseMatrix r(rows_, cols_);
+    r.setFromTriplets(std::move(t));
+    return r;
+  }
+  Matrix operator*(const Matrix &X) const {  // CPU product for tiny host-side checks only
+    Matrix r(rows_, X.cols());
+    for (Index j = 0; j < X.cols(); ++j)
+      for (Index i = 0; i < rows_; ++i) {
+        Scalar s = 0;
+        for (int32_t q = outer[static_cast<size_t>(i)]; q < outer[static_cast<size_t>(i) + 1]; ++q)
+          s += values[q] * X(inner[q], j);
+        r(i, j) = s;
+      }
+    return r;
+  }
+};
+
+enum class Formulation { Explicit, Implicit };  // include/CORA/CORA_types.h:50-55
+
+struct CertResults {  // include/CORA/CORA_types.h:58-64
+  bool is_certified;
+  Scalar theta;
+  Vector x;
+  Matrix all_eigvecs;
+  size_t num_iters;
+};
+
+enum class StiefelRetraction { QR, Polar };
+enum class ObliqueRetraction { Normalize };
+/** include/CORA/CORA_types.h:77 */
+enum class Preconditioner { None, Jacobi, BlockCholesky, RegularizedCholesky };
+enum class Initialization { Random, Odometry };
+
+}  // namespace CORA

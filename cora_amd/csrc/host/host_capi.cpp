@@ -1,0 +1,170 @@
+// Flat C view of the C++ host for ctypes (include/cora_host.h).
+#include "../../../include/cora_host.h"
+
+#include <cstring>
+#include <string>
+
+#include "../../../include/cora_hip.h"
+#include "CORA_problem.h"
+#include "pyfg_text_parser.h"
+#include "synthetic.h"
+
+using namespace CORA;
+
+struct cora_problem {
+  Problem problem;
+  explicit cora_problem(Problem p) : problem(std::move(p)) {}
+};
+
+namespace {
+thread_local std::string g_err;
+
+template <typename F>
+int guarded(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  } catch (...) {
+    g_err = "unknown exception";
+    return 1;
+  }
+}
+
+Preconditioner precondOf(int kind) {
+  switch (kind) {
+    case CORA_PRECOND_NONE: return Preconditioner::None;
+    case CORA_PRECOND_JACOBI: return Preconditioner::Jacobi;
+    case CORA_PRECOND_BLOCK_CHOLESKY: return Preconditioner::BlockCholesky;
+    case CORA_PRECOND_REGULARIZED_CHOLESKY: return Preconditioner::RegularizedCholesky;
+    default: throw std::invalid_argument("unknown preconditioner kind");
+  }
+}
+
+Matrix wrap(const double *a, Index N, Index p) {
+  if (!a) throw std::invalid_argument("missing input matrix");
+  Matrix m(N, p);
+  std::memcpy(m.data(), a, sizeof(double) * static_cast<size_t>(N * p));
+  return m;
+}
+}  // namespace
+
+extern "C" {
+
+const char *cora_host_last_error(void) { return g_err.c_str(); }
+
+int cora_problem_from_pyfg(const char *path, cora_problem **out) {
+  return guarded([&] { *out = new cora_problem(parsePyfgTextToProblem(path)); });
+}
+
+int cora_problem_synthetic(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
+                           int precond, const char *pyfg_out, cora_problem **out) {
+  return guarded([&] {
+    SyntheticSpec sp;
+    sp.dim = dim;
+    sp.num_poses = n_poses;
+    sp.num_landmarks = n_landmarks;
+    sp.num_ranges = n_ranges;
+    sp.num_loop_closures = n_loops;
+    sp.seed = seed;
+    *out = new cora_problem(makeSyntheticProblem(sp, precondOf(precond), pyfg_out ? pyfg_out : ""));
+  });
+}
+
+void cora_problem_destroy(cora_problem *p) { delete p; }
+
+int cora_problem_update(cora_problem *p) {
+  return guarded([&] { p->problem.updateProblemData(); });
+}
+
+int cora_problem_dims(const cora_problem *p, int64_t dims[8]) {
+  return guarded([&] {
+    const Problem &q = p->problem;
+    dims[0] = q.dim();
+    dims[1] = q.numPoses();
+    dims[2] = q.numLandmarks();
+    dims[3] = q.numRangeMeasurements();
+    dims[4] = q.getDataMatrixSize();
+    dims[5] = q.data_matrix_.nonZeros();
+    dims[6] = q.numPosePoseMeasurements();
+    dims[7] = static_cast<int64_t>(q.getRelaxationRank());
+  });
+}
+
+int cora_problem_matrix(cora_problem *p, const char *name, int64_t *rows, int64_t *cols, int64_t *nnz,
+                        const int32_t **rowptr, const int32_t **colidx, const double **vals) {
+  return guarded([&] {
+    const std::string n(name);
+    const SparseMatrix *m = nullptr;
+    const CoraDataSubmatrices &s = p->problem.getDataSubmatrices();
+    if (n == "DataMatrix") m = &p->problem.getDataMatrix();
+    else if (n == "Arange") m = &s.range_incidence_matrix;
+    else if (n == "OmegaRange") m = &s.range_precision_matrix;
+    else if (n == "RangeDistances") m = &s.range_dist_matrix;
+    else if (n == "Apose") m = &s.rel_pose_incidence_matrix;
+    else if (n == "OmegaPose") m = &s.rel_pose_translation_precision_matrix;
+    else if (n == "T") m = &s.rel_pose_translation_data_matrix;
+    else if (n == "RotConLaplacian") m = &s.rotation_conn_laplacian;
+    else throw std::invalid_argument("unknown matrix name " + n);
+    *rows = m->rows();
+    *cols = m->cols();
+    *nnz = m->nonZeros();
+    *rowptr = m->outerIndexPtr();
+    *colidx = m->innerIndexPtr();
+    *vals = m->valuePtr();
+  });
+}
+
+int cora_problem_set_rank(cora_problem *p, int rank) {
+  return guarded([&] { p->problem.setRank(rank); });
+}
+int cora_problem_set_preconditioner(cora_problem *p, int kind) {
+  return guarded([&] { p->problem.setPreconditioner(precondOf(kind)); });
+}
+int cora_problem_set_device(cora_problem *p, int device) {
+  return guarded([&] { p->problem.setDevice(device); });
+}
+
+int cora_problem_op(cora_problem *p, const char *op, const double *A, const double *B, const double *C,
+                    double *out) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    const std::string o(op);
+    Matrix res;
+    if (o == "evaluateObjective") {
+      out[0] = q.evaluateObjective(wrap(A, N, r));
+      return;
+    } else if (o == "Euclidean_gradient") res = q.Euclidean_gradient(wrap(A, N, r));
+    else if (o == "Riemannian_gradient") res = q.Riemannian_gradient(wrap(A, N, r));
+    else if (o == "tangent_space_projection") res = q.tangent_space_projection(wrap(A, N, r), wrap(B, N, r));
+    else if (o == "Riemannian_Hessian_vector_product")
+      res = q.Riemannian_Hessian_vector_product(wrap(A, N, r), wrap(B, N, r), wrap(C, N, r));
+    else if (o == "precondition") res = q.precondition(wrap(A, N, r));
+    else if (o == "projectToManifold") res = q.projectToManifold(wrap(A, N, r));
+    else if (o == "retract") res = q.retract(wrap(A, N, r), wrap(B, N, r));
+    else if (o == "getRandomInitialGuess") res = q.getRandomInitialGuess();
+    else throw std::invalid_argument("unknown operator " + o);
+    std::memcpy(out, res.data(), sizeof(double) * static_cast<size_t>(res.size()));
+  });
+}
+
+int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel, double *oblique) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    auto L = q.compute_Lambda_blocks(wrap(Y, N, r));
+    std::memcpy(stiefel, L.first.data(), sizeof(double) * static_cast<size_t>(L.first.size()));
+    std::memcpy(oblique, L.second.data(), sizeof(double) * static_cast<size_t>(L.second.size()));
+  });
+}
+
+void *cora_problem_context(cora_problem *p) {
+  void *c = nullptr;
+  guarded([&] { c = p->problem.context(); });
+  return c;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""ctypes binding of the C++ host (include/cora_host.h) -- plumbing for tests/ and bench.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _lib():
+    L = capi.load()
+    if not getattr(L, "_host_ready", False):
+        L.cora_host_last_error.restype = C.c_char_p
+        L.cora_problem_destroy.restype = None
+        L.cora_problem_destroy.argtypes = [C.c_void_p]
+        L.cora_problem_context.restype = C.c_void_p
+        L.cora_problem_context.argtypes = [C.c_void_p]
+        L._host_ready = True
+    return L
+
+
+class Problem:
+    """CORA::Problem of the C++ host."""
+
+    def __init__(self, handle):
+        self.L = _lib()
+        self.h = handle
+
+    @staticmethod
+    def from_pyfg(path):
+        L = _lib()
+        h = C.c_void_p()
+        if L.cora_problem_from_pyfg(path.encode(), C.byref(h)):
+            raise HostError(L.cora_host_last_error().decode())
+        return Problem(h)
+
+    @staticmethod
+    def synthetic(dim=3, n_poses=1000, n_landmarks=10, n_ranges=500, n_loops=0, seed=42,
+                  precond=capi.PRECOND_JACOBI, pyfg_out=None):
+        L = _lib()
+        h = C.c_void_p()
+        rc = L.cora_problem_synthetic(dim, n_poses, n_landmarks, n_ranges, n_loops, C.c_uint64(seed), precond,
+                                      pyfg_out.encode() if pyfg_out else None, C.byref(h))
+        if rc:
+            raise HostError(L.cora_host_last_error().decode())
+        return Problem(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cora_problem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise HostError(self.L.cora_host_last_error().decode())
+
+    def update(self):
+        self._chk(self.L.cora_problem_update(self.h))
+
+    def dims(self):
+        d = (C.c_int64 * 8)()
+        self._chk(self.L.cora_problem_dims(self.h, d))
+        keys = ["d", "n", "l", "r", "N", "nnz", "rpm", "rank"]
+        return dict(zip(keys, [int(x) for x in d]))
+
+    def matrix(self, name="DataMatrix"):
+        """(rows, cols, rowptr, colidx, vals) as numpy copies."""
+        rows, cols, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        rp, ci, va = _ip(), _ip(), _dp()
+        self._chk(self.L.cora_problem_matrix(self.h, name.encode(), C.byref(rows), C.byref(cols), C.byref(nnz),
+                                             C.byref(rp), C.byref(ci), C.byref(va)))
+        n = nnz.value
+        rowptr = np.ctypeslib.as_array(rp, shape=(rows.value + 1,)).copy()
+        colidx = np.ctypeslib.as_array(ci, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, np.int32)
+        vals = np.ctypeslib.as_array(va, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0)
+        return rows.value, cols.value, rowptr, colidx, vals
+
+    def scipy_matrix(self, name="DataMatrix"):
+        import scipy.sparse as sp
+        r, c, rp, ci, va = self.matrix(name)
+        return sp.csr_matrix((va, ci, rp), shape=(r, c))
+
+    def set_rank(self, p):
+        self._chk(self.L.cora_problem_set_rank(self.h, int(p)))
+
+    def set_preconditioner(self, kind):
+        self._chk(self.L.cora_problem_set_preconditioner(self.h, int(kind)))
+
+    def set_device(self, dev):
+        self._chk(self.L.cora_problem_set_device(self.h, int(dev)))
+
+    def op(self, name, A=None, B=None, C_=None):
+        dm = self.dims()
+        N, p = dm["N"], dm["rank"]
+
+        def ptr(x):
+            if x is None:
+                return None
+            x = np.asfortranarray(np.asarray(x, dtype=np.float64))
+            if x.shape != (N, p):
+                # let the C++ shape check produce the reference's error text
+                pass
+            keep.append(x)
+            return x.ctypes.data_as(_dp)
+
+        keep = []
+        if name == "evaluateObjective":
+            out = np.zeros(1)
+        else:
+            out = np.zeros((N, p), order="F")
+        self._chk(self.L.cora_problem_op(self.h, name.encode(), ptr(A), ptr(B), ptr(C_), out.ctypes.data_as(_dp)))
+        return float(out[0]) if name == "evaluateObjective" else out
+
+    def lambda_blocks(self, Y):
+        dm = self.dims()
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        st = np.zeros((dm["d"], max(dm["d"] * dm["n"], 1)), order="F")
+        ob = np.zeros(max(dm["r"], 1))
+        self._chk(self.L.cora_problem_lambda_blocks(self.h, Y.ctypes.data_as(_dp), st.ctypes.data_as(_dp),
+                                                    ob.ctypes.data_as(_dp)))
+        return st[:, :dm["d"] * dm["n"]], ob[:dm["r"]]
+
+    def context_ptr(self):
+        c = self.L.cora_problem_context(self.h)
+        if not c:
+            raise HostError(self.L.cora_host_last_error().decode())
+        return c

@@ -1,0 +1,66 @@
+/*
+ * cora_host.h -- flat C view of the C++ host (cora_amd/csrc/host: CORA::Problem,
+ * parsePyfgTextToProblem, solveCORA ...).  The C++ host mirrors the reference's
+ * own C++ interface (include/CORA/CORA.h:19-37, include/CORA/CORA_problem.h:
+ * 67-416, include/CORA/pyfg_text_parser.h:31); this header only exists so that
+ * tests/ and bench.py can drive it through ctypes.  All matrices are
+ * column-major double with an explicit leading dimension.  Every function
+ * returns 0 on success; cora_host_last_error() holds the C++ exception text.
+ */
+#ifndef CORA_HOST_H_
+#define CORA_HOST_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cora_problem cora_problem;
+
+const char *cora_host_last_error(void);
+
+/* parsePyfgTextToProblem (src/pyfg_text_parser.cpp:112) */
+int cora_problem_from_pyfg(const char *path, cora_problem **out);
+/* Synthetic generator of SURVEY 8(d); pyfg_out may be NULL. precond: cora_precond_kind */
+int cora_problem_synthetic(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
+                           int precond, const char *pyfg_out, cora_problem **out);
+void cora_problem_destroy(cora_problem *p);
+
+/* Problem::updateProblemData (src/CORA_problem.cpp:500-510): assembles Q on the host. */
+int cora_problem_update(cora_problem *p);
+/* dims: [0] d, [1] poses, [2] landmarks, [3] ranges, [4] N, [5] nnz(Q), [6] pose-pose
+ * measurements, [7] relaxation rank */
+int cora_problem_dims(const cora_problem *p, int64_t dims[8]);
+/* Borrowed CSR pointers of a matrix by name: "DataMatrix", "Arange", "OmegaRange",
+ * "RangeDistances", "Apose", "OmegaPose", "T", "RotConLaplacian". */
+int cora_problem_matrix(cora_problem *p, const char *name, int64_t *rows, int64_t *cols, int64_t *nnz,
+                        const int32_t **rowptr, const int32_t **colidx, const double **vals);
+
+int cora_problem_set_rank(cora_problem *p, int rank);
+int cora_problem_set_preconditioner(cora_problem *p, int kind);
+int cora_problem_set_device(cora_problem *p, int device);
+
+/* Operators of CORA::Problem, by name (all run on the GPU):
+ *  "evaluateObjective"        A=Y                -> out[0] (scalar)
+ *  "Euclidean_gradient"       A=Y                -> out N x p
+ *  "Riemannian_gradient"      A=Y                -> out
+ *  "tangent_space_projection" A=Y, B=Ydot        -> out
+ *  "Riemannian_Hessian_vector_product" A=Y, B=nablaF_Y, C=Ydot -> out
+ *  "precondition"             A=V                -> out
+ *  "projectToManifold"        A                  -> out
+ *  "retract"                  A=Y, B=V           -> out
+ *  "getRandomInitialGuess"    (none)             -> out
+ * Inputs/outputs are N x p with leading dimension N. */
+int cora_problem_op(cora_problem *p, const char *op, const double *A, const double *B, const double *C,
+                    double *out);
+/* compute_Lambda_blocks(Y): stiefel d x dn (ld d), oblique r */
+int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel, double *oblique);
+
+/* The device handle (cora_ctx*, include/cora_hip.h) behind the problem's operators. */
+void *cora_problem_context(cora_problem *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORA_HOST_H_ */

@@ -1,0 +1,87 @@
+"""CPU checks of the C++ host (cora_amd/csrc/host): PyFG ingestion and data-matrix
+assembly against the reference's golden matrices (reference tests/test_parse_pyfg.cpp,
+tests/test_construct_problem.cpp) and against the numpy oracle; the synthetic
+generator round-trips through its own PyFG output."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from cora_amd import capi, host
+from mmio import read_mm
+from oracle import assemble as asm
+
+NAMES = ["Arange", "OmegaRange", "RangeDistances", "Apose", "OmegaPose", "T", "RotConLaplacian", "DataMatrix"]
+
+
+def test_parse_and_assemble_golden(case):
+    P = host.Problem.from_pyfg(os.path.join(GOLDEN, case, "factor_graph.pyfg"))
+    P.update()
+    for name in NAMES:
+        exp = read_mm(os.path.join(GOLDEN, case, name + ".mm"))
+        got = P.scipy_matrix(name)
+        if exp.shape == (0, 0):
+            assert got.shape[0] == 0 or got.shape[1] == 0, name
+            continue
+        assert exp.shape == got.shape, name
+        assert abs(exp - got).max() < 1e-12, name
+    dm = P.dims()
+    A = asm.assemble(asm.parse_pyfg(os.path.join(GOLDEN, case, "factor_graph.pyfg")))
+    assert (dm["d"], dm["n"], dm["l"], dm["r"], dm["N"]) == (A["d"], A["n"], A["l"], A["r"], A["N"])
+
+
+@pytest.mark.parametrize("dim,loops", [(2, 0), (3, 7)])
+def test_synthetic_roundtrip_and_oracle(tmp_path, dim, loops):
+    path = str(tmp_path / "synth.pyfg")
+    P = host.Problem.synthetic(dim=dim, n_poses=120, n_landmarks=3, n_ranges=60, n_loops=loops, seed=5,
+                               pyfg_out=path)
+    P.update()
+    Q1 = P.scipy_matrix()
+    # the emitted PyFG parses back to the same data matrix (17 significant digits)
+    P2 = host.Problem.from_pyfg(path)
+    P2.update()
+    Q2 = P2.scipy_matrix()
+    assert Q1.shape == Q2.shape
+    assert abs(Q1 - Q2).max() < 1e-9 * abs(Q1).max()
+    # ... and to the oracle's independent parser + assembly
+    A = asm.assemble(asm.parse_pyfg(path))
+    assert abs(A["Q"] - Q2).max() < 1e-9 * abs(Q2).max()
+    dm = P.dims()
+    assert dm["n"] == 120 and dm["l"] == 3 and dm["r"] == 60 and dm["rpm"] >= 119
+    assert abs(Q1 - Q1.T).max() < 1e-9 * abs(Q1).max()
+    # connection-Laplacian structure: rows of Q sum the constant translation null vector
+    ones = np.zeros(dm["N"])
+    ones[dm["d"] * dm["n"] + dm["r"]:] = 1.0
+    assert np.abs(Q1 @ ones).max() < 1e-6 * abs(Q1).max()
+
+
+def test_registry_errors(tmp_path):
+    bad = tmp_path / "dup.pyfg"
+    bad.write_text("VERTEX_SE2 0 A0 0 0 0\nVERTEX_SE2 1 A0 1 0 0\n")
+    with pytest.raises(host.HostError, match="Pose variable already exists"):
+        host.Problem.from_pyfg(str(bad))
+    bad.write_text("VERTEX_SE2 0 A0 0 0 0\nFOO 1 2\n")
+    with pytest.raises(host.HostError, match="Unknown item type"):
+        host.Problem.from_pyfg(str(bad))
+    bad.write_text("VERTEX_XY L0 1 2\nVERTEX_XY L1 1 3\nEDGE_RANGE 0 L0 L1 2.0 1.0\nEDGE_RANGE 0 L1 L0 2.0 1.0\n")
+    with pytest.raises(host.HostError, match="Range measurement already exists"):
+        host.Problem.from_pyfg(str(bad))
+    with pytest.raises(host.HostError, match="Could not open file"):
+        host.Problem.from_pyfg(str(tmp_path / "missing.pyfg"))
+    # operators need the data matrix (checkUpToDate) and then a GPU: no CPU fallback
+    P = host.Problem.synthetic(dim=2, n_poses=10, n_landmarks=1, n_ranges=5)
+    with pytest.raises(host.HostError, match="data matrix must be constructed"):
+        P.op("getRandomInitialGuess")
+
+
+def test_priors_add_origin_pose(tmp_path):
+    f = tmp_path / "prior.pyfg"
+    f.write_text("VERTEX_SE2 0 A0 0 0 0\nVERTEX_SE2 1 A1 1 0 0\n"
+                 "EDGE_SE2 0 A0 A1 1 0 0 1 0 0 1 0 1\n"
+                 "VERTEX_SE2:PRIOR 0 A0 0.5 0.25 0.1 1 0 0 1 0 1\n")
+    P = host.Problem.from_pyfg(str(f))
+    P.update()
+    assert P.dims()["n"] == 3  # A0, A1 and the origin pose O0 (src/CORA_problem.cpp:80-113)
+    A = asm.assemble(asm.parse_pyfg(str(f)))
+    assert abs(A["Q"] - P.scipy_matrix()).max() < 1e-12
