@@ -127,11 +127,11 @@ int cora_problem_set_device(cora_problem *p, int device) {
   return guarded([&] { p->problem.setDevice(device); });
 }
 
-int cora_problem_op(cora_problem *p, const char *op, const double *A, const double *B, const double *C,
-                    double *out) {
+int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, const double *B,
+                    const double *C, double *out) {
   return guarded([&] {
     Problem &q = p->problem;
-    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    const Index N = q.getExpectedVariableSize(), r = cols;
     const std::string o(op);
     Matrix res;
     if (o == "evaluateObjective") {

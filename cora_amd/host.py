@@ -109,18 +109,22 @@ class Problem:
             if x is None:
                 return None
             x = np.asfortranarray(np.asarray(x, dtype=np.float64))
-            if x.shape != (N, p):
-                # let the C++ shape check produce the reference's error text
-                pass
+            if x.shape[0] != N:
+                raise HostError("expected %d rows, got %d" % (N, x.shape[0]))
+            cols.append(x.shape[1])
             keep.append(x)
             return x.ctypes.data_as(_dp)
 
-        keep = []
+        keep, cols = [], []
         if name == "evaluateObjective":
             out = np.zeros(1)
         else:
             out = np.zeros((N, p), order="F")
-        self._chk(self.L.cora_problem_op(self.h, name.encode(), ptr(A), ptr(B), ptr(C_), out.ctypes.data_as(_dp)))
+        pa, pb, pc = ptr(A), ptr(B), ptr(C_)
+        if len(set(cols)) > 1:
+            raise HostError("operands have different column counts: %s" % cols)
+        self._chk(self.L.cora_problem_op(self.h, name.encode(), cols[0] if cols else p, pa, pb, pc,
+                                         out.ctypes.data_as(_dp)))
         return float(out[0]) if name == "evaluateObjective" else out
 
     def lambda_blocks(self, Y):

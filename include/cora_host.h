@@ -51,9 +51,10 @@ int cora_problem_set_device(cora_problem *p, int device);
  *  "projectToManifold"        A                  -> out
  *  "retract"                  A=Y, B=V           -> out
  *  "getRandomInitialGuess"    (none)             -> out
- * Inputs/outputs are N x p with leading dimension N. */
-int cora_problem_op(cora_problem *p, const char *op, const double *A, const double *B, const double *C,
-                    double *out);
+ * Inputs are N x cols with leading dimension N (cols is checked against the relaxation rank by
+ * the C++ methods, like the reference's checkMatrixShape); the output is N x rank. */
+int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, const double *B,
+                    const double *C, double *out);
 /* compute_Lambda_blocks(Y): stiefel d x dn (ld d), oblique r */
 int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel, double *oblique);
 

@@ -1,0 +1,58 @@
+"""GPU parity of the C++ host (CORA::Problem in cora_amd/csrc/host) against the
+oracle: the same checks as reference tests/test_optimizer_helpers.cpp, driven
+through the host's own operator methods."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import EXPECTED_COST, GOLDEN
+from cora_amd import capi, host
+from mmio import read_dense
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_host_operators_golden(case):
+    P = host.Problem.from_pyfg(os.path.join(GOLDEN, case, "factor_graph.pyfg"))
+    P.update()
+    P.set_preconditioner(capi.PRECOND_JACOBI)
+    Y = read_dense(os.path.join(GOLDEN, case, "X_rand_dim2.mm"))
+    assert abs(P.op("evaluateObjective", Y) - EXPECTED_COST[case]) < 1e-9 * max(1, EXPECTED_COST[case])
+    eg = P.op("Euclidean_gradient", Y)
+    assert np.abs(eg - read_dense(os.path.join(GOLDEN, case, "expected_egrad.mm"))).max() < 1e-9
+    rg = P.op("Riemannian_gradient", Y)
+    assert np.abs(rg - read_dense(os.path.join(GOLDEN, case, "expected_rgrad.mm"))).max() < 1e-9
+    dX = read_dense(os.path.join(GOLDEN, case, "rand_dX.mm"))
+    hv = P.op("Riemannian_Hessian_vector_product", Y, eg, dX)
+    assert np.abs(hv - read_dense(os.path.join(GOLDEN, case, "hessProd.mm"))).max() < 1e-9
+    st, ob = P.lambda_blocks(read_dense(os.path.join(GOLDEN, case, "X_gt.mm")))
+    assert np.abs(st).max(initial=0) < 1e-6 and np.abs(ob).max(initial=0) < 1e-6
+
+
+def test_host_operators_synthetic_and_shapes():
+    P = host.Problem.synthetic(dim=3, n_poses=800, n_landmarks=4, n_ranges=500, n_loops=10, seed=8)
+    P.update()
+    dm = P.dims()
+    P.set_rank(5)
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    Y = P.op("getRandomInitialGuess")
+    assert np.abs(Y - orc.project_manifold(dims, Y)).max() < 1e-12  # on the manifold
+    rng = np.random.default_rng(1)
+    V = P.op("tangent_space_projection", Y, rng.uniform(-1, 1, Y.shape))
+    assert np.abs(V - orc.tangent_proj(dims, Y, V)).max() < 1e-12
+    R = P.op("retract", Y, 0.2 * V)
+    assert np.abs(R - orc.retract(dims, Y, 0.2 * V)).max() < 1e-11
+    assert np.abs(P.op("precondition", V) - V / Q.to_scipy().diagonal()[:, None]).max() < 1e-12
+    # shape errors surface as the reference's MatrixShapeException text
+    with pytest.raises(host.HostError, match="expected matrix of shape"):
+        P.L.cora_problem_set_rank(P.h, 4)
+        P.op("evaluateObjective", Y)  # Y has 5 columns, rank is now 4
+    # RegularizedCholesky is not implemented on device: loud failure, no substitution
+    P.set_rank(5)
+    P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
+    with pytest.raises(host.HostError):
+        P.op("precondition", V)
