@@ -459,6 +459,24 @@ int cora_set_point(cora_ctx *c, const double *Y, int ldy) {
   return set_point_dev_impl(c, c->d_Y);
 }
 
+int cora_objective_dev(cora_ctx *c, const double *dY, double *f) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!dY || !f) return fail(c, CORA_ERR_ARG, "null pointer");
+  double *dG;
+  int rc = get_scratch(c, 5, c->ld, &dG);
+  if (rc) return rc;
+  const SpmmArgs A = spmm_args(c, dY, dG);
+  HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_NONE, c->stream));
+  double v = 0.0;
+  const double *a[1] = {dY};
+  const double *b[1] = {dG};
+  rc = cora_dots_dev(c, 1, a, b, &v);
+  if (rc) return rc;
+  *f = 0.5 * v;
+  return CORA_OK;
+}
+
 int cora_point_cost(cora_ctx *c, double *f) {
   if (!c || !f) return CORA_ERR_ARG;
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");

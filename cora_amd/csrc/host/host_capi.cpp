@@ -7,6 +7,7 @@
 #include "../../../include/cora_hip.h"
 #include "CORA_problem.h"
 #include "pyfg_text_parser.h"
+#include "TNT.h"
 #include "synthetic.h"
 
 using namespace CORA;
@@ -158,6 +159,31 @@ int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel
     auto L = q.compute_Lambda_blocks(wrap(Y, N, r));
     std::memcpy(stiefel, L.first.data(), sizeof(double) * static_cast<size_t>(L.first.size()));
     std::memcpy(oblique, L.second.data(), sizeof(double) * static_cast<size_t>(L.second.size()));
+  });
+}
+
+int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, double *x_out, double stats[7]) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    TNTParams prm;
+    if (opts) {
+      if (opts[0] > 0) prm.max_iterations = static_cast<int>(opts[0]);
+      if (opts[1] > 0) prm.max_TPCG_iterations = static_cast<int>(opts[1]);
+      if (opts[2] > 0) prm.gradient_tolerance = opts[2];
+      if (opts[3] > 0) prm.preconditioned_gradient_tolerance = opts[3];
+      if (opts[4] > 0) prm.max_computation_time = opts[4];
+      prm.verbose = opts[5] != 0;
+    }
+    const TNTResult res = TNT(q, wrap(x0, N, r), prm);
+    std::memcpy(x_out, res.x.data(), sizeof(double) * static_cast<size_t>(res.x.size()));
+    stats[0] = res.f;
+    stats[1] = res.gradfx_norm;
+    stats[2] = res.preconditioned_gradfx_norm;
+    stats[3] = static_cast<double>(res.inner_iterations.size());
+    stats[4] = static_cast<double>(res.hessian_vector_products);
+    stats[5] = static_cast<double>(static_cast<int>(res.status));
+    stats[6] = res.elapsed_time;
   });
 }
 

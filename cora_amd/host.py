@@ -136,6 +136,18 @@ class Problem:
                                                     ob.ctypes.data_as(_dp)))
         return st[:, :dm["d"] * dm["n"]], ob[:dm["r"]]
 
+    def tnt(self, x0, max_iterations=0, max_inner=0, grad_tol=0, pgrad_tol=0, max_seconds=0, verbose=False):
+        dm = self.dims()
+        x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))
+        assert x0.shape == (dm["N"], dm["rank"])
+        opts = np.array([max_iterations, max_inner, grad_tol, pgrad_tol, max_seconds, float(verbose)])
+        out = np.zeros_like(x0, order="F")
+        st = np.zeros(7)
+        self._chk(self.L.cora_problem_tnt(self.h, x0.ctypes.data_as(_dp), opts.ctypes.data_as(_dp),
+                                          out.ctypes.data_as(_dp), st.ctypes.data_as(_dp)))
+        return dict(x=out, f=st[0], grad_norm=st[1], pgrad_norm=st[2], iterations=int(st[3]), hvps=int(st[4]),
+                    status=int(st[5]), seconds=st[6])
+
     def context_ptr(self):
         c = self.L.cora_problem_context(self.h)
         if not c:

@@ -195,6 +195,10 @@ int cora_download(cora_ctx *ctx, const double *dptr, int k, double *host,
 int cora_set_point(cora_ctx *ctx, const double *Y, int ldy);
 int cora_set_point_dev(cora_ctx *ctx, const double *dY);
 
+/* f(Y) = 1/2 <Y, Q Y> for a resident Y WITHOUT changing the current point (the
+ * Objective closure of src/CORA.cpp:52-55, used for trial points). Synchronises. */
+int cora_objective_dev(cora_ctx *ctx, const double *dY, double *f);
+
 /* f at the current point (local shard contribution when partitioned). */
 int cora_point_cost(cora_ctx *ctx, double *f);
 /* Device pointers to the cached point data (valid until the next set_point). */

@@ -58,6 +58,13 @@ int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, 
 /* compute_Lambda_blocks(Y): stiefel d x dn (ld d), oblique r */
 int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel, double *oblique);
 
+/* Riemannian TNT (the call of src/CORA.cpp:139-140 with the parameters of :95-109) from x0
+ * (N x rank).  opts (may be NULL): [0] max_iterations, [1] max_TPCG_iterations, [2] gradient
+ * tolerance, [3] preconditioned gradient tolerance, [4] max seconds, [5] verbose.
+ * stats out: [0] f, [1] |grad|, [2] |P grad|, [3] outer iterations, [4] Hessian-vector products,
+ * [5] status (TNTStatus), [6] seconds. */
+int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, double *x_out, double stats[7]);
+
 /* The device handle (cora_ctx*, include/cora_hip.h) behind the problem's operators. */
 void *cora_problem_context(cora_problem *p);
 
