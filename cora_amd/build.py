@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def sources():
-    srcs = [os.path.join(CSRC, f) for f in ("format_build.cpp", "kernels.hip", "capi.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("format_build.cpp", "trisolve_build.cpp", "kernels.hip", "capi.hip")]
     srcs += sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
     return srcs
 

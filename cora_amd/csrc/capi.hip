@@ -43,6 +43,13 @@ struct cora_ctx {
   double *d_diag_inv = nullptr;  // 1/diag(Q), local rows
   double *d_lam_st = nullptr, *d_lam_ob = nullptr;
 
+  // Cholesky preconditioner (level-scheduled triangular solves)
+  TriPlan tri;
+  bool have_chol = false;
+  std::vector<void *> tri_allocs;
+  TriDev d_fwd{}, d_bwd{};
+  BorderDev d_border{};
+
   bool have_point = false;
   double *d_Y = nullptr, *d_G = nullptr, *d_rgrad = nullptr;
   double f = 0.0;
@@ -341,6 +348,8 @@ void cora_ctx_destroy(cora_ctx *c) {
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (void *p : c->user_allocs)
       if (p) (void)hipFree(p);
+    for (void *p : c->tri_allocs)
+      if (p) (void)hipFree(p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -532,13 +541,96 @@ int cora_precond_setup(cora_ctx *c, int kind) {
     c->precond = kind;
     return CORA_OK;
   }
-  return fail(c, CORA_ERR_NOT_READY,
-              "Cholesky preconditioners need a factor installed with cora_precond_set_cholesky");
+  if (kind == CORA_PRECOND_BLOCK_CHOLESKY || kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
+    if (!c->have_chol)
+      return fail(c, CORA_ERR_NOT_READY,
+                  "Cholesky preconditioners need a factor installed with cora_precond_set_cholesky");
+    c->precond = kind;
+    return CORA_OK;
+  }
+  return fail(c, CORA_ERR_ARG, "unknown preconditioner kind");
 }
 
-int cora_precond_set_cholesky(cora_ctx *c, int, const int32_t *, const int32_t *, const double *,
-                              const int32_t *) {
-  return fail(c, CORA_ERR_NOT_READY, "device sparse triangular solve not implemented yet");
+int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
+                              const int32_t *perm) {
+  NEED_DEVICE(c);
+  const int64_t N = c->F.L.N;
+  if (c->F.L.world != 1)
+    return fail(c, CORA_ERR_ARG, "the Cholesky preconditioner does not shard (sequential triangular solves): "
+                                 "use Jacobi on partitioned handles");
+  if (!Lp || !Li || !Lx || !perm || (m != N && m != N - 1))
+    return fail(c, CORA_ERR_ARG, "factor must have N or N-1 rows");
+  std::vector<int32_t> row_of(static_cast<size_t>(m));
+  std::vector<char> seen(static_cast<size_t>(N), 0);
+  for (int i = 0; i < m; ++i) {
+    if (perm[i] < 0 || perm[i] >= N || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
+    seen[perm[i]] = 1;
+    row_of[i] = c->F.api2int[perm[i]];
+  }
+  try {
+    build_tri_plan(m, Lp, Li, Lx, row_of, c->tri);
+  } catch (const std::exception &e) {
+    return fail(c, CORA_ERR_ARG, e.what());
+  }
+  c->tri.zero_row = -1;
+  if (m == N - 1)
+    for (int64_t i = 0; i < N; ++i)
+      if (!seen[i]) c->tri.zero_row = c->F.api2int[i];
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (void *p : c->tri_allocs)
+    if (p) (void)hipFree(p);
+  c->tri_allocs.clear();
+  c->have_chol = false;
+  auto up = [&](auto **dst, const auto &vec) -> hipError_t {
+    using T = typename std::remove_reference<decltype(vec)>::type::value_type;
+    T *p = nullptr;
+    hipError_t e = to_device(&p, vec);
+    if (e == hipSuccess) {
+      c->tri_allocs.push_back(p);
+      *dst = p;
+    }
+    return e;
+  };
+  auto up_tri = [&](TriDev &D, const TriHost &H) -> hipError_t {
+    hipError_t e;
+    if ((e = up(&D.rowptr, H.rowptr)) != hipSuccess) return e;
+    if ((e = up(&D.cols, H.cols)) != hipSuccess) return e;
+    if ((e = up(&D.out_row, H.out_row)) != hipSuccess) return e;
+    if ((e = up(&D.vals, H.vals)) != hipSuccess) return e;
+    if ((e = up(&D.dinv, H.dinv)) != hipSuccess) return e;
+    D.levels = &H.levels;
+    return hipSuccess;
+  };
+  HIP_TRY(c, up_tri(c->d_fwd, c->tri.fwd));
+  HIP_TRY(c, up_tri(c->d_bwd, c->tri.bwd));
+  const BorderHost &B = c->tri.border;
+  BorderDev &D = c->d_border;
+  D.nb = B.nb;
+  D.nchunks = static_cast<int>(B.chunk_row.size());
+  HIP_TRY(c, up(&D.Lbb, B.Lbb));
+  HIP_TRY(c, up(&D.out_row, B.out_row));
+  HIP_TRY(c, up(&D.chunk_row, B.chunk_row));
+  HIP_TRY(c, up(&D.cbeg, B.chunk_begin));
+  HIP_TRY(c, up(&D.cend, B.chunk_end));
+  HIP_TRY(c, up(&D.wcols, B.wcols));
+  HIP_TRY(c, up(&D.wvals, B.wvals));
+  {
+    std::vector<double> part(std::max<size_t>(B.chunk_row.size(), 1) * kMaxLD, 0.0);
+    double *p = nullptr;
+    HIP_TRY(c, to_device(&p, part));
+    c->tri_allocs.push_back(p);
+    D.partial = p;
+  }
+  c->have_chol = true;
+  return CORA_OK;
+}
+
+// out = [ (P^T L L^T P)^-1 V[0:m] ; 0 ]  in place on dOut (already holding V)
+static int chol_solve_inplace(cora_ctx *c, int ld, double *dOut) {
+  HIP_TRY(c, launch_tri_solve(c->d_fwd, c->d_bwd, c->d_border, ld, dOut, c->stream));
+  if (c->tri.zero_row >= 0)  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
+    HIP_TRY(c, launch_zero_row(dOut, static_cast<size_t>(c->tri.zero_row), ld, c->stream));
+  return CORA_OK;
 }
 
 int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut) {
@@ -547,7 +639,14 @@ int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut)
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   const double *scale = nullptr;
   if (c->precond == CORA_PRECOND_JACOBI) scale = c->d_diag_inv;
-  else if (c->precond != CORA_PRECOND_NONE) return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up");
+  else if (c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY) {
+    if (dOut != dV)
+      HIP_TRY(c, hipMemcpyAsync(dOut, dV, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
+    int rc = chol_solve_inplace(c, c->ld, dOut);
+    if (rc) return rc;
+    HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dOut, nullptr, dOut, c->stream));
+    return CORA_OK;
+  } else if (c->precond != CORA_PRECOND_NONE) return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up");
   HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, scale, dOut, c->stream));
   return CORA_OK;
 }
@@ -572,6 +671,15 @@ int cora_axpby_dev(cora_ctx *c, double a, const double *dX, double b, double *dY
   NEED_RANK(c);
   const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
   HIP_TRY(c, launch_axpby(c->F.L.local_rows * c->ld, a, dX + off, b, dY + off, c->stream));
+  return CORA_OK;
+}
+
+int cora_axpby_cols_dev(cora_ctx *c, int k, double a, const double *dX, double b, double *dY) {
+  NEED_DEVICE(c);
+  if (k <= 0 || k > kMaxLD || !dX || !dY) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const int ld = ld_for(k);
+  const size_t off = static_cast<size_t>(c->F.L.base) * ld;
+  HIP_TRY(c, launch_axpby(c->F.L.local_rows * ld, a, dX + off, b, dY + off, c->stream));
   return CORA_OK;
 }
 
@@ -754,16 +862,21 @@ int cora_retract(cora_ctx *c, const double *Y, int ldy, const double *V, int ldv
 int cora_precondition(cora_ctx *c, const double *V, int ldv, double *out, int ldo) {
   NEED_DEVICE(c);
   NEED_RANK(c);
-  if (c->precond != CORA_PRECOND_JACOBI)
+  if (c->precond == CORA_PRECOND_NONE)
     return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up (cora_precond_setup)");
   double *dV, *dO;
   int rc;
   if ((rc = get_scratch(c, 0, c->ld, &dV))) return rc;
   if ((rc = get_scratch(c, 1, c->ld, &dO))) return rc;
-  if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
-  HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
   const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
-  HIP_TRY(c, launch_scale_rows(c->F.L.local_rows, c->ld, c->d_diag_inv, dV + off, dO + off, c->stream));
+  if (c->precond == CORA_PRECOND_JACOBI) {
+    if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
+    HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
+    HIP_TRY(c, launch_scale_rows(c->F.L.local_rows, c->ld, c->d_diag_inv, dV + off, dO + off, c->stream));
+  } else {
+    if ((rc = upload_impl(c, V, ldv, c->p, dO))) return rc;
+    if ((rc = chol_solve_inplace(c, c->ld, dO))) return rc;
+  }
   // NaN guard, src/CORA_problem.cpp:898-901
   HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
   HIP_TRY(c, launch_has_nan(c->F.L.local_rows * c->ld, dO + off, c->d_flag, c->stream));

@@ -5,7 +5,10 @@
 #include <cmath>
 #include <iostream>
 
+#include <cstdlib>
+
 #include "../../../include/cora_hip.h"
+#include "sparse_cholesky.h"
 
 namespace CORA {
 
@@ -287,6 +290,39 @@ void Problem::ensureContext() const {
 
 void Problem::updatePreconditioner() { ensurePreconditioner(); }
 
+// ||Q||_2 = lambda_max(Q) by power iteration with the device SpMM.  The reference
+// estimates it with LOBPCG (block 4, <= 100 iterations, tolerance 1e-2,
+// src/CORA_problem.cpp:556-578); it only scales the regularisation lambda_reg.
+static Scalar spectralNormEstimate(cora_ctx *c, Index N) {
+  double *x = nullptr, *y = nullptr;
+  auto chk = [&](int rc) {
+    if (rc != CORA_OK) throw std::runtime_error(std::string("spectral norm estimate: ") + cora_last_error(c));
+  };
+  chk(cora_dev_alloc(c, 1, &x));
+  chk(cora_dev_alloc(c, 1, &y));
+  Matrix x0 = Matrix::Random(N, 1, 12345);
+  chk(cora_upload(c, x0.data(), static_cast<int>(N), 1, x));
+  double lambda = 0.0, prev = -1.0;
+  for (int it = 0; it < 100; ++it) {
+    chk(cora_spmm_dev(c, x, 1, y));
+    const double *A[2] = {x, y};
+    const double *B[2] = {y, y};
+    double xy, yy, xx;
+    chk(cora_dot_dev(c, x, y, 1, &xy));
+    chk(cora_dot_dev(c, y, y, 1, &yy));
+    chk(cora_dot_dev(c, x, x, 1, &xx));
+    (void)A; (void)B;
+    lambda = xy / xx;
+    if (!(yy > 0.0)) break;
+    chk(cora_axpby_cols_dev(c, 1, 1.0 / std::sqrt(yy), y, 0.0, x));
+    if (it > 5 && std::abs(lambda - prev) <= 1e-3 * std::abs(lambda)) break;
+    prev = lambda;
+  }
+  cora_dev_free(c, x);
+  cora_dev_free(c, y);
+  return lambda;
+}
+
 void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
   ensureContext();
   if (precond_ready_) return;
@@ -296,6 +332,51 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
     case Preconditioner::Jacobi: kind = CORA_PRECOND_JACOBI; break;
     case Preconditioner::BlockCholesky: kind = CORA_PRECOND_BLOCK_CHOLESKY; break;
     default: kind = CORA_PRECOND_REGULARIZED_CHOLESKY; break;
+  }
+  if (kind == CORA_PRECOND_BLOCK_CHOLESKY || kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
+    const Index N = getDataMatrixSize();
+    const int m = static_cast<int>(pin_last_translation_ ? N - 1 : N);
+    const auto perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
+                                   data_matrix_, m);
+    CholeskyFactor F;
+    if (kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
+      // lambda_reg = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 or CORA_REG_CHOLESKY_MAX_COND (:581-591)
+      const Scalar Dnorm = spectralNormEstimate(ctx_.get(), N);
+      Scalar max_cond = 1e6;
+      if (const char *env = std::getenv("CORA_REG_CHOLESKY_MAX_COND")) {
+        max_cond = std::stod(env);
+        std::cout << "Loaded CORA_REG_CHOLESKY_MAX_COND from environment variable: " << max_cond << std::endl;
+      }
+      precond_lambda_ = Dnorm / (max_cond - 1);
+      F = choleskyFactor(data_matrix_, m, precond_lambda_, perm);
+    } else {
+      // documented semantics (include/CORA/CORA_preconditioners.h:28-44): independent factors of the
+      // diagonal blocks (rotations | ranges | translations) of Q + 1e-3 I (:513-543).  The reference's
+      // own loop never advances block_start (src/CORA_preconditioners.cpp:30-41); not reproduced.
+      const Index b1 = numPosesDim(), b2 = rotAndRangeMatrixSize();
+      auto blk = [&](Index i) { return i < b1 ? 0 : (i < b2 ? 1 : 2); };
+      std::vector<Triplet> t;
+      for (Index i = 0; i < N; ++i)
+        for (int32_t q = data_matrix_.outer[i]; q < data_matrix_.outer[i + 1]; ++q)
+          if (blk(i) == blk(data_matrix_.inner[q])) t.push_back({i, data_matrix_.inner[q], data_matrix_.values[q]});
+      SparseMatrix D(N, N);
+      D.setFromTriplets(std::move(t));
+      precond_lambda_ = 1e-3;
+      F = choleskyFactor(D, m, 1e-3, perm);
+    }
+    if (!F.ok) throw std::runtime_error("Problem::updatePreconditioner: regularised data matrix is not positive definite");
+    precond_nnz_ = static_cast<long>(F.nnz());
+    {
+      std::vector<int> depth(static_cast<size_t>(F.n), 1);
+      int h = 0;
+      for (int i = 0; i < F.n; ++i) {
+        if (F.parent[i] >= 0) depth[F.parent[i]] = std::max(depth[F.parent[i]], depth[i] + 1);
+        h = std::max(h, depth[i]);
+      }
+      precond_levels_ = h;
+    }
+    const int rc = cora_precond_set_cholesky(ctx_.get(), m, F.Lp.data(), F.Li.data(), F.Lx.data(), F.perm.data());
+    if (rc != CORA_OK) throwLast(rc, "Problem::updatePreconditioner");
   }
   const int rc = cora_precond_setup(ctx_.get(), kind);
   if (rc != CORA_OK) throwLast(rc, "Problem::updatePreconditioner");

@@ -61,6 +61,9 @@ class Problem {
   int device_ = 0;
   mutable std::shared_ptr<cora_ctx> ctx_;
   mutable bool precond_ready_ = false;
+  mutable Scalar precond_lambda_ = 0;   // regularisation actually used
+  mutable long precond_nnz_ = 0;         // nnz(L)
+  mutable int precond_levels_ = 0;       // height of the elimination tree
 
   void checkUpToDate() const;
   void addOriginPose();
@@ -163,6 +166,9 @@ class Problem {
     return ctx_.get();
   }
   void ensurePreconditionerReady() const { ensurePreconditioner(); }
+  Scalar preconditionerLambda() const { return precond_lambda_; }
+  long preconditionerNnz() const { return precond_nnz_; }
+  int preconditionerLevels() const { return precond_levels_; }
 };
 
 }  // namespace CORA

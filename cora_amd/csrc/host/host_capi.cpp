@@ -8,6 +8,7 @@
 #include "CORA_problem.h"
 #include "pyfg_text_parser.h"
 #include "TNT.h"
+#include "sparse_cholesky.h"
 #include "synthetic.h"
 
 using namespace CORA;
@@ -184,6 +185,40 @@ int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, doub
     stats[4] = static_cast<double>(res.hessian_vector_products);
     stats[5] = static_cast<double>(static_cast<int>(res.status));
     stats[6] = res.elapsed_time;
+  });
+}
+
+int cora_problem_precond_info(cora_problem *p, double info[3]) {
+  return guarded([&] {
+    p->problem.ensurePreconditionerReady();
+    info[0] = p->problem.preconditionerLambda();
+    info[1] = static_cast<double>(p->problem.preconditionerNnz());
+    info[2] = p->problem.preconditionerLevels();
+  });
+}
+
+int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_poses, double *B, int k,
+                                int64_t info[3]) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const SparseMatrix &Q = q.getDataMatrix();
+    const auto perm = coraOrdering(q.dim(), q.numPoses(), q.numRangeMeasurements(), q.numTranslationalStates(),
+                                   Q, m, leaf_poses > 0 ? leaf_poses : 16);
+    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
+    info[0] = F.ok ? 1 : 0;
+    info[1] = F.nnz();
+    int height = 0;
+    if (F.ok) {
+      std::vector<int> depth(static_cast<size_t>(F.n), 1);
+      for (int i = 0; i < F.n; ++i)
+        if (F.parent[i] >= 0) depth[F.parent[i]] = std::max(depth[F.parent[i]], depth[i] + 1);
+      for (int v : depth) height = std::max(height, v);
+      Matrix Bm(m, k);
+      std::memcpy(Bm.data(), B, sizeof(double) * static_cast<size_t>(m) * k);
+      F.solveInPlace(Bm);
+      std::memcpy(B, Bm.data(), sizeof(double) * static_cast<size_t>(m) * k);
+    }
+    info[2] = height;
   });
 }
 

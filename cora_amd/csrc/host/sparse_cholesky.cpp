@@ -1,0 +1,193 @@
+#include "sparse_cholesky.h"
+
+#include <cmath>
+#include <functional>
+#include <numeric>
+#include <stdexcept>
+
+namespace CORA {
+
+std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatrix &Q, int m, int leaf_poses) {
+  const int64_t dn = static_cast<int64_t>(d) * n, tb = dn + r, N = dn + r + nt;
+  if (m != N && m != N - 1) throw std::invalid_argument("coraOrdering: m must be N or N-1");
+  // range row k hangs off the first pose translation it touches
+  std::vector<std::vector<int32_t>> pose_ranges(static_cast<size_t>(n));
+  std::vector<int32_t> loose;
+  for (int k = 0; k < r; ++k) {
+    int pose = -1;
+    for (int32_t q = Q.outer[dn + k]; q < Q.outer[dn + k + 1]; ++q) {
+      const int64_t c = Q.inner[q];
+      if (c >= tb && c - tb < n) { pose = static_cast<int>(c - tb); break; }
+    }
+    if (pose >= 0) pose_ranges[pose].push_back(static_cast<int32_t>(dn + k));
+    else loose.push_back(static_cast<int32_t>(dn + k));
+  }
+  std::vector<int32_t> perm;
+  perm.reserve(static_cast<size_t>(N));
+  auto emit_pose = [&](int i) {
+    for (int a = 0; a < d; ++a) perm.push_back(static_cast<int32_t>(static_cast<int64_t>(i) * d + a));
+    for (int32_t row : pose_ranges[i]) perm.push_back(row);
+    perm.push_back(static_cast<int32_t>(tb + i));
+  };
+  std::function<void(int, int)> nd = [&](int lo, int hi) {  // poses [lo, hi)
+    if (hi - lo <= leaf_poses) {
+      for (int i = lo; i < hi; ++i) emit_pose(i);
+      return;
+    }
+    const int mid = lo + (hi - lo) / 2;
+    nd(lo, mid);
+    nd(mid + 1, hi);
+    emit_pose(mid);
+  };
+  nd(0, n);
+  for (int32_t row : loose) perm.push_back(row);
+  for (int j = n; j < nt; ++j) perm.push_back(static_cast<int32_t>(tb + j));
+  if (m == N - 1) {  // drop the pinned last variable (src/CORA_problem.cpp:602-609)
+    std::vector<int32_t> q;
+    q.reserve(perm.size());
+    for (int32_t v : perm)
+      if (v != N - 1) q.push_back(v);
+    perm.swap(q);
+  }
+  if (static_cast<int64_t>(perm.size()) != m) throw std::logic_error("coraOrdering: size mismatch");
+  return perm;
+}
+
+CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm) {
+  CholeskyFactor F;
+  const int n = m;
+  F.n = n;
+  if (static_cast<int>(perm.size()) != n) throw std::invalid_argument("choleskyFactor: bad permutation size");
+  F.perm = perm;
+  F.iperm.assign(static_cast<size_t>(A.rows()), -1);
+  for (int i = 0; i < n; ++i) F.iperm[perm[i]] = i;
+
+  // upper triangle of P A P^T by columns == rows of A restricted to iperm <= k
+  std::vector<int32_t> Cp(static_cast<size_t>(n) + 1, 0);
+  for (int k = 0; k < n; ++k) {
+    const int old = perm[k];
+    int cnt = 0;
+    bool diag = false;
+    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+      const int i = F.iperm[A.inner[q]];
+      if (i >= 0 && i <= k) { ++cnt; diag |= (i == k); }
+    }
+    if (!diag) ++cnt;  // room for the shift on a structurally missing diagonal
+    Cp[k + 1] = Cp[k] + cnt;
+  }
+  std::vector<int32_t> Ci(static_cast<size_t>(Cp[n]));
+  std::vector<double> Cx(static_cast<size_t>(Cp[n]));
+  for (int k = 0; k < n; ++k) {
+    const int old = perm[k];
+    int32_t w = Cp[k];
+    bool diag = false;
+    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+      const int i = F.iperm[A.inner[q]];
+      if (i >= 0 && i <= k) {
+        Ci[w] = i;
+        Cx[w] = A.values[q] + (i == k ? shift : 0.0);
+        diag |= (i == k);
+        ++w;
+      }
+    }
+    if (!diag) { Ci[w] = k; Cx[w] = shift; ++w; }
+  }
+  // elimination tree
+  F.parent.assign(static_cast<size_t>(n), -1);
+  std::vector<int32_t> anc(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k)
+    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+      int i = Ci[q];
+      while (i != -1 && i < k) {
+        const int nxt = anc[i];
+        anc[i] = k;
+        if (nxt == -1) F.parent[i] = k;
+        i = nxt;
+      }
+    }
+  // column counts (symbolic up-looking pass)
+  std::vector<int32_t> cnt(static_cast<size_t>(n), 0), flag(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k) {
+    flag[k] = k;
+    cnt[k]++;
+    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+      int i = Ci[q];
+      while (i != -1 && i < k && flag[i] != k) {
+        cnt[i]++;
+        flag[i] = k;
+        i = F.parent[i];
+      }
+    }
+  }
+  F.Lp.assign(static_cast<size_t>(n) + 1, 0);
+  int64_t tot = 0;
+  for (int k = 0; k < n; ++k) {
+    F.Lp[k] = static_cast<int32_t>(tot);
+    tot += cnt[k];
+    if (tot > 2000000000LL) throw std::runtime_error("choleskyFactor: factor too large for int32 indexing");
+  }
+  F.Lp[n] = static_cast<int32_t>(tot);
+  F.Li.assign(static_cast<size_t>(tot), 0);
+  F.Lx.assign(static_cast<size_t>(tot), 0.0);
+  std::vector<int32_t> next(F.Lp.begin(), F.Lp.end() - 1), stack(static_cast<size_t>(n));
+  std::vector<double> x(static_cast<size_t>(n), 0.0);
+  std::fill(flag.begin(), flag.end(), -1);
+  F.ok = true;
+  for (int k = 0; k < n; ++k) {
+    int top = n;
+    flag[k] = k;
+    double dk = 0.0;
+    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+      int i = Ci[q];
+      if (i == k) { dk += Cx[q]; continue; }
+      x[i] += Cx[q];
+      int len = 0;
+      while (flag[i] != k) {
+        stack[len++] = i;
+        flag[i] = k;
+        i = F.parent[i];
+      }
+      while (len > 0) stack[--top] = stack[--len];
+    }
+    for (; top < n; ++top) {
+      const int i = stack[top];
+      const double lki = x[i] / F.Lx[F.Lp[i]];
+      x[i] = 0.0;
+      for (int32_t q = F.Lp[i] + 1; q < next[i]; ++q) x[F.Li[q]] -= F.Lx[q] * lki;
+      dk -= lki * lki;
+      const int32_t w = next[i]++;
+      F.Li[w] = k;
+      F.Lx[w] = lki;
+    }
+    if (!(dk > 0.0)) {  // CHOLMOD's "not positive definite" (quick_return_if_not_posdef)
+      F.ok = false;
+      F.failed_column = k;
+      return F;
+    }
+    const int32_t w = next[k]++;
+    F.Li[w] = k;
+    F.Lx[w] = std::sqrt(dk);
+  }
+  return F;
+}
+
+void CholeskyFactor::solveInPlace(Matrix &B) const {
+  if (!ok) throw std::runtime_error("CholeskyFactor::solve: factorisation failed");
+  std::vector<double> y(static_cast<size_t>(n));
+  for (Index c = 0; c < B.cols(); ++c) {
+    for (int i = 0; i < n; ++i) y[i] = B(perm[i], c);
+    for (int j = 0; j < n; ++j) {
+      y[j] /= Lx[Lp[j]];
+      const double yj = y[j];
+      for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) y[Li[q]] -= Lx[q] * yj;
+    }
+    for (int j = n - 1; j >= 0; --j) {
+      double s = y[j];
+      for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) s -= Lx[q] * y[Li[q]];
+      y[j] = s / Lx[Lp[j]];
+    }
+    for (int i = 0; i < n; ++i) B(perm[i], c) = y[i];
+  }
+}
+
+}  // namespace CORA

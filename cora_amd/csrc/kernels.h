@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "cora_internal.h"
+#include "trisolve.h"
 
 namespace cora {
 
@@ -45,6 +46,22 @@ struct DotArgs {
   int64_t n2;        // number of double2 elements
   double *partial;   // [count][gridDim.x]
 };
+
+struct TriDev {  // device copy of a TriHost
+  const int32_t *rowptr, *cols, *out_row;
+  const double *vals, *dinv;
+  const std::vector<TriLevel> *levels;
+};
+struct BorderDev {
+  int nb, nchunks;
+  const double *Lbb;
+  const int32_t *out_row, *chunk_row, *cbeg, *cend, *wcols;
+  const double *wvals;
+  double *partial;
+};
+hipError_t launch_tri_solve(const TriDev &F, const TriDev &B, const BorderDev &border, int ld, double *x,
+                            hipStream_t st);
+hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st);
 
 hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
 hipError_t launch_point_finish(const RowArgs &R, int ld, const double *Y, const double *G,

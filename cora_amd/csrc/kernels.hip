@@ -614,6 +614,118 @@ __global__ __launch_bounds__(256) void k_download(int64_t N, int k, int ld, cons
 }
 
 // ---------------------------------------------------------------------------
+// Level-scheduled sparse triangular solves (Cholesky preconditioner apply,
+// reference src/CORA_preconditioners.cpp:46-83).  Rows of one level are
+// independent; G lanes cooperate on a row.  In place on x.
+// ---------------------------------------------------------------------------
+template <int LD, int G>
+__global__ __launch_bounds__(256) void k_tri_level(const int32_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ cols,
+                                                   const double *__restrict__ vals,
+                                                   const double *__restrict__ dinv,
+                                                   const int32_t *__restrict__ out_row, int begin, int end,
+                                                   double *__restrict__ x) {
+  const int gt = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int row = begin + gt / G, g = gt % G;
+  const bool ok = row < end;
+  double acc[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+  if (ok) {
+    const int e = rowptr[row + 1];
+    for (int k = rowptr[row] + g; k < e; k += G) {
+      const double v = vals[k];
+      double t[LD];
+      load_row<LD>(x + static_cast<size_t>(cols[k]) * LD, t);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acc[j] = fma(v, t[j], acc[j]);
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+  }
+  if (ok && g == 0) {
+    double *xr = x + static_cast<size_t>(out_row[row]) * LD;
+    double t[LD];
+    load_row<LD>(xr, t);
+    const double di = dinv[row];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) t[j] = (t[j] - acc[j]) * di;
+    store_row<LD>(xr, t);
+  }
+}
+
+// partial[chunk][j] = sum over the chunk of W[k, c] * x[c][j]  (dense border rows of L)
+template <int LD>
+__global__ __launch_bounds__(256) void k_border_dot(const int32_t *__restrict__ cbeg,
+                                                    const int32_t *__restrict__ cend,
+                                                    const int32_t *__restrict__ wcols,
+                                                    const double *__restrict__ wvals,
+                                                    const double *__restrict__ x, double *__restrict__ partial) {
+  __shared__ double sm[4 * kMaxLD];
+  const int ci = blockIdx.x;
+  double acc[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+#pragma unroll 4
+  for (int k = cbeg[ci] + threadIdx.x; k < cend[ci]; k += 256) {
+    const double v = wvals[k];
+    double t[LD];
+    load_row<LD>(x + static_cast<size_t>(wcols[k]) * LD, t);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[j] = fma(v, t[j], acc[j]);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < LD; ++j) {
+    const double v = wave_sum(acc[j]);
+    if (lane == 0) sm[w * LD + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < LD)
+    partial[static_cast<size_t>(ci) * kMaxLD + threadIdx.x] =
+        sm[threadIdx.x] + sm[LD + threadIdx.x] + sm[2 * LD + threadIdx.x] + sm[3 * LD + threadIdx.x];
+}
+
+// forward substitution through the dense border block (one wave; lane j = column j)
+template <int LD>
+__global__ __launch_bounds__(64) void k_border_fwd(int nb, const double *__restrict__ Lbb,
+                                                   const int32_t *__restrict__ out_row, int nchunks,
+                                                   const int32_t *__restrict__ chunk_row,
+                                                   const double *__restrict__ partial, double *__restrict__ x) {
+  const int j = threadIdx.x;
+  if (j >= LD) return;
+  int c = 0;
+  for (int k = 0; k < nb; ++k) {
+    double acc = 0.0;
+    for (; c < nchunks && chunk_row[c] == k; ++c) acc += partial[static_cast<size_t>(c) * kMaxLD + j];
+    for (int q = 0; q < k; ++q) acc = fma(Lbb[static_cast<size_t>(k) * nb + q], x[static_cast<size_t>(out_row[q]) * LD + j], acc);
+    double *xr = x + static_cast<size_t>(out_row[k]) * LD + j;
+    *xr = (*xr - acc) / Lbb[static_cast<size_t>(k) * nb + k];
+  }
+}
+
+template <int LD>
+__global__ __launch_bounds__(64) void k_border_bwd(int nb, const double *__restrict__ Lbb,
+                                                   const int32_t *__restrict__ out_row, double *__restrict__ x) {
+  const int j = threadIdx.x;
+  if (j >= LD) return;
+  for (int k = nb - 1; k >= 0; --k) {
+    double acc = 0.0;
+    for (int q = k + 1; q < nb; ++q) acc = fma(Lbb[static_cast<size_t>(q) * nb + k], x[static_cast<size_t>(out_row[q]) * LD + j], acc);
+    double *xr = x + static_cast<size_t>(out_row[k]) * LD + j;
+    *xr = (*xr - acc) / Lbb[static_cast<size_t>(k) * nb + k];
+  }
+}
+
+__global__ void k_zero_row(double *x, size_t row, int ld) {
+  if (static_cast<int>(threadIdx.x) < ld) x[row * ld + threadIdx.x] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 #define CORA_LD_CASES(M) M(2) M(4) M(6) M(8) M(10) M(12) M(16) M(20) M(24)
@@ -750,6 +862,55 @@ hipError_t launch_download(int64_t N, int k, int ld, const double *src, const in
                            double *dst, hipStream_t st) {
   if (N * k <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_download, dim3(grid_for(N * k)), dim3(256), 0, st, N, k, ld, src, api2int, dst);
+  return hipGetLastError();
+}
+
+}  // namespace cora
+
+namespace cora {
+
+template <int LD>
+static hipError_t tri_level_ld(const TriDev &T, const TriLevel &lv, double *x, hipStream_t st) {
+  const int rows = lv.end - lv.begin;
+  if (rows <= 0) return hipSuccess;
+  const int64_t threads = static_cast<int64_t>(rows) * lv.lanes;
+  const int grid = static_cast<int>((threads + 255) / 256);
+  if (lv.lanes == 1)
+    hipLaunchKernelGGL((k_tri_level<LD, 1>), dim3(grid), dim3(256), 0, st, T.rowptr, T.cols, T.vals, T.dinv, T.out_row, lv.begin, lv.end, x);
+  else if (lv.lanes == 8)
+    hipLaunchKernelGGL((k_tri_level<LD, 8>), dim3(grid), dim3(256), 0, st, T.rowptr, T.cols, T.vals, T.dinv, T.out_row, lv.begin, lv.end, x);
+  else
+    hipLaunchKernelGGL((k_tri_level<LD, 64>), dim3(grid), dim3(256), 0, st, T.rowptr, T.cols, T.vals, T.dinv, T.out_row, lv.begin, lv.end, x);
+  return hipGetLastError();
+}
+
+template <int LD>
+static hipError_t tri_solve_ld(const TriDev &F, const TriDev &Bk, const BorderDev &B, double *x, hipStream_t st) {
+  hipError_t e;
+  for (const TriLevel &lv : *F.levels)
+    if ((e = tri_level_ld<LD>(F, lv, x, st)) != hipSuccess) return e;
+  if (B.nb > 0) {
+    if (B.nchunks > 0)
+      hipLaunchKernelGGL((k_border_dot<LD>), dim3(B.nchunks), dim3(256), 0, st, B.cbeg, B.cend, B.wcols, B.wvals, x, B.partial);
+    hipLaunchKernelGGL((k_border_fwd<LD>), dim3(1), dim3(64), 0, st, B.nb, B.Lbb, B.out_row, B.nchunks, B.chunk_row, B.partial, x);
+    hipLaunchKernelGGL((k_border_bwd<LD>), dim3(1), dim3(64), 0, st, B.nb, B.Lbb, B.out_row, x);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  for (const TriLevel &lv : *Bk.levels)
+    if ((e = tri_level_ld<LD>(Bk, lv, x, st)) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+hipError_t launch_tri_solve(const TriDev &F, const TriDev &Bk, const BorderDev &B, int ld, double *x, hipStream_t st) {
+#define CASE(L) \
+  if (ld == L) return tri_solve_ld<L>(F, Bk, B, x, st);
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st) {
+  hipLaunchKernelGGL(k_zero_row, dim3(1), dim3(64), 0, st, x, row, ld);
   return hipGetLastError();
 }
 

@@ -148,6 +148,21 @@ class Problem:
         return dict(x=out, f=st[0], grad_norm=st[1], pgrad_norm=st[2], iterations=int(st[3]), hvps=int(st[4]),
                     status=int(st[5]), seconds=st[6])
 
+    def precond_info(self):
+        info = np.zeros(3)
+        self._chk(self.L.cora_problem_precond_info(self.h, info.ctypes.data_as(_dp)))
+        return dict(lam=info[0], nnz=int(info[1]), levels=int(info[2]))
+
+    def cholesky_solve(self, B, m=None, shift=0.0, leaf_poses=16):
+        dm = self.dims()
+        m = dm["N"] - 1 if m is None else m
+        B = np.asfortranarray(np.array(B, dtype=np.float64, copy=True))
+        assert B.shape[0] == m
+        info = (C.c_int64 * 3)()
+        self._chk(self.L.cora_problem_cholesky_solve(self.h, int(m), C.c_double(shift), int(leaf_poses),
+                                                     B.ctypes.data_as(_dp), B.shape[1], info))
+        return B, dict(ok=bool(info[0]), nnz=int(info[1]), height=int(info[2]))
+
     def context_ptr(self):
         c = self.L.cora_problem_context(self.h)
         if not c:

@@ -227,6 +227,8 @@ int cora_project_to_manifold_dev(cora_ctx *ctx, const double *dA, double *dOut);
 /* Vector ops on resident N x p vectors (local shard rows when partitioned). */
 int cora_axpby_dev(cora_ctx *ctx, double a, const double *dX, double b,
                    double *dY); /* Y = a X + b Y */
+/* Same for vectors allocated with k columns (cora_dev_alloc(ctx, k, ..)). */
+int cora_axpby_cols_dev(cora_ctx *ctx, int k, double a, const double *dX, double b, double *dY);
 int cora_copy_dev(cora_ctx *ctx, const double *dX, int k, double *dY);
 int cora_dot_dev(cora_ctx *ctx, const double *dA, const double *dB, int k,
                  double *out); /* synchronises the stream */

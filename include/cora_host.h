@@ -65,6 +65,16 @@ int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel
  * [5] status (TNTStatus), [6] seconds. */
 int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, double *x_out, double stats[7]);
 
+/* After a preconditioned call: [0] regularisation lambda used, [1] nnz(L), [2] elimination-tree height. */
+int cora_problem_precond_info(cora_problem *p, double info[3]);
+
+/* Host sparse Cholesky of (Q + shift I)[0:m,0:m] in the CORA nested-dissection order (the
+ * CHOLMOD stand-in, cora_amd/csrc/host/sparse_cholesky.h); m = N or N-1.  Solves for the k
+ * right-hand sides in B (m x k, ld m) in place.  info: [0] ok (0/1), [1] nnz(L), [2] height of
+ * the elimination tree. */
+int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_poses, double *B, int k,
+                                int64_t info[3]);
+
 /* The device handle (cora_ctx*, include/cora_hip.h) behind the problem's operators. */
 void *cora_problem_context(cora_problem *p);
 

@@ -54,14 +54,24 @@ def stpcg(hess, precon, g, Delta, prm):
     return s, math.sqrt(sig2), it
 
 
-def tnt(Q, dm, x0, precond="jacobi", **kw):
+def tnt(Q, dm, x0, precond="jacobi", lam=None, **kw):
+    """precond: "jacobi" | "none" | "chol" (RegularizedCholesky, src/CORA_problem.cpp:544-614, with
+    the regularisation `lam` and the last translation pinned)."""
     prm = dict(DEFAULTS)
     prm.update(kw)
     dinv = 1.0 / orc.diag(Q)
+    chol = None
+    if precond == "chol":
+        import scipy.sparse as sp
+        M = (Q.to_scipy() + lam * sp.eye(dm.N)).tocsr()[:dm.N - 1, :dm.N - 1]
+        chol = orc.Cholesky(orc.CSR.from_scipy(M))
+        assert chol.ok
 
     def precon_at(Y):
         if precond == "jacobi":
             return lambda V: orc.tangent_proj(dm, Y, V * dinv[:, None])
+        if precond == "chol":
+            return lambda V: chol.precond(dm, Y, V)
         return lambda V: orc.tangent_proj(dm, Y, V)
 
     x = np.asfortranarray(x0)

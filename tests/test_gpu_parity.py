@@ -148,7 +148,7 @@ def test_rank_change_and_errors():
         Ybad = np.zeros((dm.N - 1, 6), order="F")
         c.evaluateObjective(Ybad)  # leading dimension < N -> shape error
     assert e.value.code == 1
-    with pytest.raises(capi.CoraError):
+    with pytest.raises(capi.CoraError):  # no factor installed yet
         c.precond_setup(capi.PRECOND_REGULARIZED_CHOLESKY)
 
 

@@ -62,3 +62,68 @@ def test_tnt_synthetic_noisy(d, n, p, loops):
     rg = orc.rgrad(Q, dims, got["x"])
     assert abs(np.linalg.norm(rg) - got["grad_norm"]) < 1e-6 * max(1.0, got["grad_norm"])
     assert abs(orc.cost(Q, got["x"]) - got["f"]) < 1e-10 * abs(got["f"])
+
+
+def test_cholesky_preconditioner_apply():
+    """blockCholeskySolve semantics (src/CORA_preconditioners.cpp:46-83) on the device's
+    level-scheduled triangular solves: N-1 leading rows solved, last row zero."""
+    import scipy.sparse as sp
+    P = host.Problem.synthetic(dim=3, n_poses=900, n_landmarks=5, n_ranges=600, n_loops=8, seed=13,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    P.set_rank(5)
+    Q, dims = _oracle_problem(P)
+    info = P.precond_info()
+    assert info["lam"] > 0 and info["nnz"] > dims.N
+    # lambda_reg = ||Q||_2 / (1e6 - 1), src/CORA_problem.cpp:591 (norm estimated to ~1e-2 like the reference)
+    import scipy.sparse.linalg as spl
+    lmax = spl.eigsh(Q.to_scipy(), k=1, which="LA", return_eigenvectors=False)[0]
+    assert abs(info["lam"] * (1e6 - 1) - lmax) < 0.03 * lmax
+    V = np.random.default_rng(3).standard_normal((dims.N, 5))
+    out = P.op("precondition", V)
+    assert np.all(out[-1] == 0.0)
+    M = (Q.to_scipy() + info["lam"] * sp.eye(dims.N)).tocsr()[:dims.N - 1, :dims.N - 1]
+    ref = orc.Cholesky(orc.CSR.from_scipy(M)).solve(V[:-1])
+    assert np.abs(out[:-1] - ref).max() < 1e-8 * np.abs(ref).max()
+    res = M @ out[:-1] - V[:-1]
+    assert np.abs(res).max() < 1e-9 * np.abs(V).max() * 10
+    # BlockCholesky: documented semantics, three DISTINCT diagonal blocks (SURVEY section 2, note on the
+    # reference's coincidentally-passing 2-block test)
+    P.set_preconditioner(capi.PRECOND_BLOCK_CHOLESKY)
+    out = P.op("precondition", V)
+    Qs = Q.to_scipy().tocsr()
+    b1, b2 = dims.dn, dims.dn + dims.r
+    ref = np.zeros_like(V)
+    for lo, hi in ((0, b1), (b1, b2), (b2, dims.N - 1)):
+        blk = (Qs[lo:hi, lo:hi] + 1e-3 * sp.eye(hi - lo)).tocsc()
+        ref[lo:hi] = spl.spsolve(blk, V[lo:hi])
+    assert np.abs(out - ref).max() < 1e-8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("d,n,p,loops", [(3, 400, 4, 0), (2, 600, 3, 10)])
+def test_tnt_regularized_cholesky(d, n, p, loops):
+    """The reference's default configuration: RegularizedCholesky-preconditioned TNT.  Stage 1 runs
+    from a random point (long, chaotic trajectory: only sanity-checked); stage 2 restarts both solvers
+    from the same small perturbation of the stage-1 solution, where they must agree to 1e-8."""
+    P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=4, n_ranges=n // 2, n_loops=loops, seed=31,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    P.set_rank(p)
+    Q, dims = _oracle_problem(P)
+    x0 = orc.project_manifold(dims, np.random.default_rng(5).uniform(-1, 1, (dims.N, p)))
+    f0 = orc.cost(Q, x0)
+    s1 = P.tnt(x0, max_seconds=120)
+    assert s1["f"] < 1e-4 * f0  # the exact preconditioner gets there (Jacobi stalls at ~3e-2 f0)
+    lam = P.precond_info()["lam"]
+    xi = orc.tangent_proj(dims, s1["x"], np.random.default_rng(6).standard_normal((dims.N, p)))
+    x1 = orc.retract(dims, s1["x"], 1e-3 * xi)
+    got = P.tnt(x1, max_seconds=120)
+    ref = otnt.tnt(Q, dims, x1, precond="chol", lam=lam)
+    # both runs end by the relative-decrease rule (1e-6, src/CORA.cpp:107), which bounds how well two
+    # correct implementations can agree: 1e-5 relative here, 1e-8 when the gradient test fires
+    tol = 1e-8 if got["status"] in (0, 1) else 1e-5
+    assert abs(got["f"] - ref["f"]) <= tol * abs(ref["f"]) + 1e-9
+    assert got["f"] <= orc.cost(Q, x1)
+    assert abs(got["iterations"] - (ref["iterations"] - 1)) <= 3
+    rg = orc.rgrad(Q, dims, got["x"])
+    assert abs(np.linalg.norm(rg) - got["grad_norm"]) < 1e-6 * max(1.0, got["grad_norm"])
