@@ -736,6 +736,44 @@ int cora_dot_dev(cora_ctx *c, const double *dA, const double *dB, int k, double 
   return CORA_OK;
 }
 
+int cora_gram_dev(cora_ctx *c, const double *dA, int ka, const double *dB, int kb, double *G) {
+  NEED_DEVICE(c);
+  if (!dA || !dB || !G || ka <= 0 || kb <= 0 || ka > kMaxLD || kb > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const int nblocks = 256, nel = ka * kb;
+  int rc = ensure_red(c, static_cast<size_t>(nel) * nblocks + nel);
+  if (rc) return rc;
+  double *dout = c->d_red + static_cast<size_t>(nel) * nblocks;
+  HIP_TRY(c, launch_gram(c->F.L.base, c->F.L.local_rows, dA, ka, dB, kb, c->d_red, nblocks, dout, c->stream));
+  std::vector<double> tmp(static_cast<size_t>(nel));
+  HIP_TRY(c, hipMemcpyAsync(tmp.data(), dout, nel * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int a = 0; a < ka; ++a)  // device result is row-major ka x kb
+    for (int b = 0; b < kb; ++b) G[static_cast<size_t>(b) * ka + a] = tmp[static_cast<size_t>(a) * kb + b];
+  return CORA_OK;
+}
+
+int cora_combine_dev(cora_ctx *c, int n, const double *const *dX, const int *k, const double *const *C, int kout,
+                     double *dOut) {
+  NEED_DEVICE(c);
+  if (n < 1 || n > 4 || !dX || !k || !C || !dOut || kout <= 0 || kout > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  std::vector<double> coef;
+  int coff[4] = {0, 0, 0, 0};
+  for (int b = 0; b < n; ++b) {
+    if (k[b] <= 0 || k[b] > kMaxLD || !dX[b] || !C[b]) return fail(c, CORA_ERR_ARG, "bad block");
+    if (dX[b] == dOut) return fail(c, CORA_ERR_ARG, "output aliases an input block");
+    coff[b] = static_cast<int>(coef.size());
+    for (int i = 0; i < k[b]; ++i)
+      for (int j = 0; j < kout; ++j) coef.push_back(C[b][static_cast<size_t>(j) * k[b] + i]);  // row-major on device
+  }
+  int rc = ensure_red(c, coef.size() + 8);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_red, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // coef is a stack-lifetime host buffer
+  HIP_TRY(c, launch_combine(c->F.L.base, c->F.L.local_rows, n, dX, k, coff, c->d_red, static_cast<int>(coef.size()),
+                            kout, dOut, c->stream));
+  return CORA_OK;
+}
+
 int cora_timer_start(cora_ctx *c) {
   NEED_DEVICE(c);
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

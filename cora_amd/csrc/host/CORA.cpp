@@ -1,0 +1,177 @@
+#include "CORA.h"
+
+#include <algorithm>
+#include <cmath>
+#include <iostream>
+
+#include "dense.h"
+
+namespace CORA {
+
+namespace {
+void printIfVerbose(bool verbose, const std::string &msg) {
+  if (verbose) std::cout << msg << std::endl;
+}
+Scalar thresholdVal(Scalar v, Scalar lo, Scalar hi) { return v < lo ? lo : (v > hi ? hi : v); }
+}  // namespace
+
+CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank, bool verbose, bool log_iterates,
+                     bool show_iterates, CoraSolveInfo *info, const TNTParams *params_override) {
+  checkMatrixShape("solveCora::Explicit", problem.getDataMatrixSize(), x0.cols(), x0.rows(), x0.cols());
+  if (log_iterates)
+    std::cout << "WARNING: Logging iterates will slow down the optimization process.  This is intended for "
+                 "debugging and viz purposes only."
+              << std::endl;
+  // TNT parameters: src/CORA.cpp:95-109
+  TNTParams params;
+  if (params_override) params = *params_override;
+  params.verbose = show_iterates;
+  params.log_iterates = log_iterates;
+  // certification parameters: src/CORA.cpp:111-116
+  const Scalar MIN_CERT_ETA = 1e-7, MAX_CERT_ETA = 1e-1, REL_CERT_ETA = 5e-6;
+  const int LOBPCG_BLOCK_SIZE = 10;
+  Scalar eta = 0;
+
+  CoraTntResult result;
+  Matrix X = problem.projectToManifold(x0);
+  CertResults cert;
+  cert.is_certified = false;
+  cert.theta = 0;
+  Matrix eigvec_bootstrap;
+  std::vector<Matrix> iterates;
+  bool first_loop = true;
+  int levels = 0;
+  long hvps = 0;
+  while (static_cast<int>(problem.getRelaxationRank()) <= max_relaxation_rank) {
+    ++levels;
+    printIfVerbose(verbose, "\nSolving problem at rank " + std::to_string(problem.getRelaxationRank()));
+    result = TNT(problem, X, params);
+    hvps += result.hessian_vector_products;
+    printIfVerbose(verbose, "Obtained solution with objective value: " + std::to_string(result.f));
+    if (log_iterates)
+      for (const Matrix &it : result.iterates) iterates.push_back(it);
+    eta = thresholdVal(result.f * REL_CERT_ETA, MIN_CERT_ETA, MAX_CERT_ETA);
+    if (first_loop) {
+      eigvec_bootstrap = result.x;
+      first_loop = false;
+    } else {
+      eigvec_bootstrap = cert.all_eigvecs;
+    }
+    cert = problem.certify_solution(result.x, eta, LOBPCG_BLOCK_SIZE, eigvec_bootstrap);
+    printIfVerbose(verbose, "Result is certified: " + std::to_string(cert.is_certified) + " with eta: " +
+                                std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
+    if (std::isnan(cert.theta)) throw std::runtime_error("Theta is NaN");
+    if (cert.is_certified) {
+      X = result.x;
+      break;
+    }
+    const Scalar SADDLE_GRAD_TOL = 1e-4, PRECON_SADDLE_GRAD_TOL = 1e-4;
+    problem.incrementRank();
+    X = saddleEscape(problem, result.x, cert.theta, cert.x, SADDLE_GRAD_TOL, PRECON_SADDLE_GRAD_TOL);
+  }
+  // project to rank d and refine (src/CORA.cpp:198-233)
+  if (X.cols() > problem.dim()) {
+    printIfVerbose(verbose, "\nProjecting solution to rank " + std::to_string(problem.dim()) + " and refining.");
+    X = projectSolution(problem, X, verbose);
+    problem.setRank(problem.dim());
+    result = TNT(problem, X, params);
+    hvps += result.hessian_vector_products;
+    printIfVerbose(verbose, "\nObtained FINAL solution with objective value: " + std::to_string(result.f));
+    if (log_iterates)
+      for (const Matrix &it : result.iterates) iterates.push_back(it);
+    printIfVerbose(verbose, "Checking certification of refined solution.");
+    eta = thresholdVal(result.f * REL_CERT_ETA, MIN_CERT_ETA, MAX_CERT_ETA);
+    cert = problem.certify_solution(result.x, eta, LOBPCG_BLOCK_SIZE, Matrix());
+  }
+  printIfVerbose(verbose, "Final solution is certified: " + std::to_string(cert.is_certified) + " with eta: " +
+                              std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
+  if (info) {
+    info->certified = cert.is_certified;
+    info->eta = eta;
+    info->theta = cert.theta;
+    info->final_rank = static_cast<int>(problem.getRelaxationRank());
+    info->staircase_levels = levels;
+    info->hessian_vector_products = hvps;
+  }
+  return std::make_pair(result, iterates);
+}
+
+Matrix saddleEscape(const Problem &problem, const Matrix &Y, Scalar theta, const Vector &v,
+                    Scalar gradient_tolerance, Scalar preconditioned_gradient_tolerance) {
+  // src/CORA.cpp:245-350
+  const size_t r = problem.getRelaxationRank();
+  if (static_cast<Index>(r) != Y.cols() + 1)
+    throw std::runtime_error("Relaxation rank: " + std::to_string(r) +
+                             " should be one greater than the number of columns in Y: " +
+                             std::to_string(Y.cols()) +
+                             ". This may happen if the relaxation rank is not incremented before attempting "
+                             "saddle escape");
+  Matrix Y_aug(Y.rows(), static_cast<Index>(r));
+  Y_aug.setBlock(0, 0, Y);
+  const Scalar FY = problem.evaluateObjective(Y_aug);
+  Matrix Ydot(Y.rows(), static_cast<Index>(r));
+  for (Index i = 0; i < Y.rows(); ++i) Ydot(i, static_cast<Index>(r) - 1) = v(i);
+
+  const Scalar alpha_min = 1e-6;
+  Scalar alpha = std::max(16 * alpha_min, 100 * gradient_tolerance / std::fabs(theta));
+  std::vector<double> alphas, fvals;
+  while (alpha >= alpha_min) {
+    const Matrix Ytest = problem.retract(Y_aug, Ydot * alpha);
+    const Scalar FYtest = problem.evaluateObjective(Ytest);
+    const Matrix grad = problem.Riemannian_gradient(Ytest);
+    const Scalar gn = grad.norm();
+    const Scalar pgn = problem.tangent_space_projection(Ytest, problem.precondition(grad)).norm();
+    alphas.push_back(alpha);
+    fvals.push_back(FYtest);
+    if (FYtest < FY && gn > gradient_tolerance && pgn > preconditioned_gradient_tolerance) return Ytest;
+    alpha /= 2;
+  }
+  const auto it = std::min_element(fvals.begin(), fvals.end());
+  const size_t k = static_cast<size_t>(std::distance(fvals.begin(), it));
+  if (fvals[k] < FY) return problem.retract(Y_aug, Ydot * alphas[k]);
+  std::cout << "WARNING! BACKTRACKING LINE SEARCH FAILED TO ESCAPE FROM SADDLE POINT! (Try decreasing the "
+               "preconditioned gradient norm tolerance)"
+            << std::endl;
+  return Y_aug;
+}
+
+Matrix projectSolution(const Problem &problem, const Matrix &Y, bool verbose) {
+  // src/CORA.cpp:352-441.  Thin SVD of the N x p iterate through the p x p Gram matrix
+  // (Y = U S V^T  =>  U_d S_d = Y V_d): runs once per solve, on the host.
+  const int d = problem.dim(), n = problem.numPoses(), r = problem.numRangeMeasurements();
+  checkMatrixShape("projectSolution", problem.getExpectedVariableSize(), Y.cols(), Y.rows(), Y.cols());
+  const Index p = Y.cols();
+  Vector ev;
+  Matrix V;
+  symmetricEigen(Y.transpose() * Y, ev, V);  // ascending
+  Matrix Vd(p, d);
+  for (int k = 0; k < d; ++k)
+    for (Index i = 0; i < p; ++i) Vd(i, k) = V(i, p - 1 - k);  // d largest singular directions
+  if (verbose) {
+    printIfVerbose(verbose, "Singular values of Y: ");
+    for (Index k = p - 1; k >= 0; --k) printIfVerbose(verbose, std::to_string(std::sqrt(std::max(ev(k), 0.0))));
+  }
+  Matrix Yd = Y * Vd;
+  size_t ng0 = 0;
+  for (int i = 0; i < n; ++i)
+    if (determinant(Yd.block(static_cast<Index>(i) * d, 0, d, d)) > 0) ++ng0;
+  printIfVerbose(verbose, "Out of " + std::to_string(n) + " blocks, " + std::to_string(ng0) +
+                              " have positive determinant.");
+  if (n > 0 && ng0 < static_cast<size_t>(n) / 2) {
+    for (Index i = 0; i < Yd.rows(); ++i) Yd(i, d - 1) = -Yd(i, d - 1);  // Yd * diag(1,..,1,-1)
+  }
+  for (int i = 0; i < n; ++i)
+    Yd.setBlock(static_cast<Index>(i) * d, 0, projectToSOd(Yd.block(static_cast<Index>(i) * d, 0, d, d)));
+  const Index rot = problem.numPosesDim();
+  for (Index j = 0; j < r; ++j) {
+    Scalar s = 0;
+    for (int c = 0; c < d; ++c) s += Yd(rot + j, c) * Yd(rot + j, c);
+    s = std::sqrt(s);
+    if (s > 0)
+      for (int c = 0; c < d; ++c) Yd(rot + j, c) /= s;
+  }
+  problem.checkVariablesAreValid(Yd);
+  return Yd;
+}
+
+}  // namespace CORA

@@ -579,3 +579,54 @@ Matrix Problem::alignEstimateToOrigin(const Matrix &Y) const {
 }
 
 }  // namespace CORA
+
+// ---- certification: src/CORA_problem.cpp:1030-1103 ---------------------------
+#include "CORA_utils.h"
+#include "dense.h"
+
+namespace CORA {
+
+CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap,
+                                      size_t max_LOBPCG_iters) const {
+  checkMatrixShape("Problem::certify_solution::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
+  const Index N = getDataMatrixSize(), p = Y.cols();
+  // ratio of the extreme singular values of Y from the p x p Gram matrix (:1039-1049)
+  {
+    Vector ev;
+    Matrix V;
+    symmetricEigen(Y.transpose() * Y, ev, V);
+    const Scalar smax = std::sqrt(std::max(ev(p - 1), 0.0)), smin = std::sqrt(std::max(ev(0), 0.0));
+    if (smax / smin > 1e6) {
+      CertResults r;
+      r.is_certified = true;
+      r.theta = 0;
+      r.x = Vector::Zero(N, 1);
+      r.all_eigvecs = Matrix::Zero(N, static_cast<Index>(nx));
+      r.num_iters = 0;
+      return r;
+    }
+  }
+  // S = Q - Lambda(Y): Lambda on the device (also leaves Y as the handle's current point, so the
+  // certificate operator below uses the same Lambda), S assembled on the host for the Cholesky test
+  const SparseMatrix S = get_certificate_matrix(Y);
+  cora_ctx *c = ctx_.get();
+  const Index num_eigvecs = std::min<Index>(std::max<Index>(static_cast<Index>(nx), p + 2), N);
+  if (N < p) throw std::invalid_argument("The number of rows of S must be greater than or equal to the number of columns of Y");
+  Matrix X0 = Matrix::Random(N, num_eigvecs, 0xC0FFEEull);
+  if (eigvec_bootstrap.rows() == N)
+    X0.setBlock(0, 0, eigvec_bootstrap.block(0, 0, N, std::min(eigvec_bootstrap.cols(), num_eigvecs)));
+  const auto perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_,
+                                 static_cast<int>(N));
+  DeviceOperator Sop = [c](const double *dX, int k, double *dOut) {
+    if (cora_certificate_product_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
+  };
+  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop);
+  while (std::isnan(results.theta)) {  // :1076-1083
+    std::cout << "NaN in theta -- result not certified" << std::endl;
+    eta *= 2;
+    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop);
+  }
+  return results;
+}
+
+}  // namespace CORA

@@ -1,0 +1,123 @@
+#include "CORA_utils.h"
+
+#include <cmath>
+#include <memory>
+#include <numeric>
+
+#include "../../../include/cora_hip.h"
+#include "dense.h"
+#include "sparse_cholesky.h"
+
+namespace CORA {
+
+CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X0, size_t max_iters,
+                              const std::vector<int32_t> &perm_in, cora_ctx *ctx,
+                              const std::optional<DeviceOperator> &S_op,
+                              const std::optional<DeviceOperator> &precond) {
+  const Index n = S.rows();
+  CertResults results;
+  results.theta = 0;
+  results.num_iters = 0;
+  // STEP 1: Cholesky of M = S + eta I  (src/CORA_utils.cpp:28-51)
+  std::vector<int32_t> perm = perm_in;
+  if (perm.empty()) {
+    perm.resize(static_cast<size_t>(n));
+    std::iota(perm.begin(), perm.end(), 0);
+  }
+  const CholeskyFactor F = choleskyFactor(S, static_cast<int>(n), eta, perm);
+  const bool PSD = F.ok;
+  results.is_certified = PSD;
+  if (PSD) {
+    results.x = Vector::Zero(n, 1);
+    results.all_eigvecs = Matrix();
+    return results;
+  }
+  if (n <= 100) {  // dense path (:63-74)
+    Matrix D(n, n);
+    for (Index i = 0; i < n; ++i)
+      for (int32_t q = S.outer[i]; q < S.outer[i + 1]; ++q) D(i, S.inner[q]) += S.values[q];
+    Vector ev;
+    Matrix V;
+    symmetricEigen(D, ev, V);
+    results.theta = ev(0);
+    results.x = V.col(0);
+    results.all_eigvecs = V;
+    return results;
+  }
+  // STEP 2/3: LOBPCG on M with the stopping rule x' S x < -eta/2 (:83-167)
+  std::shared_ptr<cora_ctx> tmp;
+  DeviceOperator Sop;
+  if (S_op) {
+    Sop = *S_op;
+  } else {
+    cora_ctx *c = nullptr;  // any symmetric S is a CORA problem with 0 poses, 0 ranges, n translations
+    if (cora_ctx_create(0, 3, 0, 0, static_cast<int>(n), S.outerIndexPtr(), S.innerIndexPtr(), S.valuePtr(), &c) !=
+        CORA_OK)
+      throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(nullptr));
+    tmp.reset(c, cora_ctx_destroy);
+    ctx = c;
+    Sop = [c](const double *dX, int k, double *dOut) {
+      if (cora_spmm_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
+    };
+  }
+  cora_ctx *c = ctx;
+  DeviceOperator Mop = [&, c](const double *dX, int k, double *dOut) {
+    Sop(dX, k, dOut);
+    if (eta != 0.0 && cora_axpby_cols_dev(c, k, eta, dX, 1.0, dOut) != CORA_OK)
+      throw std::runtime_error(cora_last_error(c));
+  };
+  LOBPCGStop stopfun = [eta](size_t, const std::vector<Scalar> &Theta, const double *, int) {
+    return (Theta[0] - eta) < -eta / 2;  // X orthonormal: x' S x = theta_M - eta
+  };
+  // STEP 2: unpreconditioned LOBPCG for 1 % of the iteration budget (:104-119)
+  const double unprecon_iter_frac = .01;
+  LOBPCGResult r = LOBPCG(c, Mop, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0,
+                          stopfun);
+  size_t iters = r.num_iters;
+  if (!(r.Theta(0) - eta < -eta / 2)) {
+    // STEP 3 (:129-167): the "hard" case.  The reference builds an ILDL preconditioner here
+    // (libs/Preconditioners, absent).  Instead the block is seeded with the direction of
+    // non-positive curvature that the failed factorisation of step 1 yields for free
+    // (z' M z = d_k <= 0, i.e. z' S z <= -eta): Rayleigh-Ritz can only improve on it, so the
+    // stopping rule x' S x < -eta/2 is always reachable; `precond` (e.g. the regularised-Cholesky
+    // solve) is used when the caller has one.
+    Matrix X0s = X0;
+    if (!F.negative_direction.empty()) {
+      const Index m0 = X0.cols() < 24 ? X0.cols() + 1 : X0.cols();
+      X0s = Matrix(n, m0);
+      X0s.setBlock(0, 0, X0.block(0, 0, n, std::min<Index>(X0.cols(), m0 - 1)));
+      for (Index i = 0; i < n; ++i) X0s(i, m0 - 1) = F.negative_direction[static_cast<size_t>(i)];
+    }
+    r = LOBPCG(c, Mop, precond, X0s, 1, static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters), 0.0, stopfun);
+    iters += r.num_iters;
+  }
+  results.x = r.X.col(0);
+  // curvature along x, recomputed from S like the reference (:124-127)
+  {
+    const Matrix Sx = S * results.x;
+    results.theta = results.x.dot(Sx);
+  }
+  results.all_eigvecs = r.X;
+  results.num_iters = iters;
+  return results;
+}
+
+Matrix projectToSOd(const Matrix &M) {
+  // polar factor via the eigen-decomposition of M^T M (d <= 3), with the determinant fix of
+  // src/CORA_utils.cpp:188-202 (flip the last left singular vector when det(U) det(V) < 0)
+  const Index d = M.rows();
+  Vector ev;
+  Matrix V;
+  symmetricEigen(M.transpose() * M, ev, V);  // ascending: smallest singular value first
+  Matrix U(d, d);
+  for (Index k = 0; k < d; ++k) {
+    const Matrix uk = M * V.col(k);
+    const Scalar s = std::sqrt(std::max(ev(k), 0.0));
+    for (Index i = 0; i < d; ++i) U(i, k) = s > 0 ? uk(i) / s : 0.0;
+  }
+  if (determinant(U) * determinant(V) < 0)
+    for (Index i = 0; i < d; ++i) U(i, 0) = -U(i, 0);  // the column of the SMALLEST singular value
+  return U * V.transpose();
+}
+
+}  // namespace CORA

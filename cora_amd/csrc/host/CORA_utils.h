@@ -1,0 +1,39 @@
+// fast_verification / projectToSOd (reference include/CORA/CORA_utils.h:35-64,
+// src/CORA_utils.cpp:17-202).
+#pragma once
+
+#include <optional>
+#include <vector>
+
+#include "CORA_problem.h"
+#include "CORA_types.h"
+#include "LOBPCG.h"
+
+namespace CORA {
+
+/**
+ * Algorithm 3 of "Accelerating Certifiable Estimation with Preconditioned
+ * Eigensolvers" as the reference implements it (src/CORA_utils.cpp:17-186):
+ *  1. PSD test of M = S + eta I by sparse Cholesky (success <=> is_certified);
+ *  2. if not PSD and n <= 100: dense eigen-decomposition of S (theta = lambda_min);
+ *  3. otherwise LOBPCG on M (block X0, nev = 1) until x' S x < -eta / 2.
+ * The operator S*X runs on the GPU: `op` when given (the problem's own handle,
+ * certificate operator at its current point), else a temporary handle built from S.
+ * `perm` (new -> old) is the fill-reducing order for step 1 (natural order if empty).
+ * Deviation: the reference switches to ILDL-preconditioned LOBPCG after 1 % of the
+ * iterations (:140-167, libs/Preconditioners absent); here `precond` (optional, e.g. the
+ * regularised-Cholesky solve) is used for all iterations.
+ */
+CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X0, size_t max_iters = 1000,
+                              const std::vector<int32_t> &perm = {}, cora_ctx *ctx = nullptr,
+                              const std::optional<DeviceOperator> &S_op = std::nullopt,
+                              const std::optional<DeviceOperator> &precond = std::nullopt);
+
+inline CertResults fast_verification(const SparseMatrix &S, Scalar eta, size_t nx, size_t max_iters = 1000) {
+  return fast_verification(S, eta, Matrix::Random(S.rows(), static_cast<Index>(nx)), max_iters);
+}
+
+/** Nearest rotation to a d x d matrix (src/CORA_utils.cpp:188-202). */
+Matrix projectToSOd(const Matrix &M);
+
+}  // namespace CORA

@@ -1,0 +1,185 @@
+#include "LOBPCG.h"
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/cora_hip.h"
+#include "dense.h"
+
+namespace CORA {
+
+namespace {
+
+struct Blocks {
+  cora_ctx *c;
+  int m;
+  std::vector<double *> owned;
+  Blocks(cora_ctx *ctx, int m_) : c(ctx), m(m_) {}
+  ~Blocks() {
+    for (double *p : owned) cora_dev_free(c, p);
+  }
+  void chk(int rc, const char *w) const {
+    if (rc != CORA_OK) throw std::runtime_error(std::string("LOBPCG: ") + w + ": " + cora_last_error(c));
+  }
+  double *alloc() {
+    double *p = nullptr;
+    chk(cora_dev_alloc(c, m, &p), "alloc");
+    owned.push_back(p);
+    return p;
+  }
+  Matrix gram(const double *a, const double *b) const {
+    Matrix G(m, m);
+    chk(cora_gram_dev(c, a, m, b, m, G.data()), "gram");
+    return G;
+  }
+  // out = sum_i X_i C_i  (C_i: m x m host matrices)
+  void combine(std::vector<const double *> xs, const std::vector<Matrix> &Cs, double *out) const {
+    std::vector<int> k(xs.size(), m);
+    std::vector<const double *> cp;
+    for (const Matrix &C : Cs) cp.push_back(C.data());
+    chk(cora_combine_dev(c, static_cast<int>(xs.size()), xs.data(), k.data(), cp.data(), m, out), "combine");
+  }
+};
+
+Matrix sub(const Matrix &M, Index r0, Index c0, Index nr, Index nc) { return M.block(r0, c0, nr, nc); }
+
+}  // namespace
+
+LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<DeviceOperator> &T, const Matrix &X0,
+                    size_t nev, size_t max_iters, Scalar tau, const std::optional<LOBPCGStop> &stop) {
+  const int N = static_cast<int>(X0.rows()), m = static_cast<int>(X0.cols());
+  if (m < 1 || m > 24) throw std::invalid_argument("LOBPCG: block size must be in [1, 24]");
+  if (static_cast<size_t>(m) < nev) throw std::invalid_argument("LOBPCG: block smaller than nev");
+  Blocks B(c, m);
+  double *X = B.alloc(), *AX = B.alloc(), *W = B.alloc(), *AW = B.alloc(), *P = B.alloc(), *AP = B.alloc(),
+         *t1 = B.alloc(), *t2 = B.alloc(), *t3 = B.alloc(), *t4 = B.alloc();
+  B.chk(cora_upload(c, X0.data(), N, m, t1), "upload");
+
+  // X <- orthonormal basis of span(X0): X0 V D^-1/2
+  {
+    Vector ev;
+    Matrix V;
+    symmetricEigen(B.gram(t1, t1), ev, V);
+    Matrix C(m, m);
+    for (int j = 0; j < m; ++j) {
+      if (!(ev(j) > 1e-14 * ev(m - 1))) throw std::runtime_error("LOBPCG: initial block is rank deficient");
+      for (int i = 0; i < m; ++i) C(i, j) = V(i, j) / std::sqrt(ev(j));
+    }
+    B.combine({t1}, {C}, X);
+  }
+  A(X, m, AX);
+  std::vector<Scalar> theta(static_cast<size_t>(m));
+  {  // initial Rayleigh-Ritz
+    Vector ev;
+    Matrix V;
+    Matrix H = B.gram(X, AX);
+    for (int i = 0; i < m; ++i)
+      for (int j = i + 1; j < m; ++j) H(i, j) = H(j, i) = 0.5 * (H(i, j) + H(j, i));
+    symmetricEigen(H, ev, V);
+    B.combine({X}, {V}, t1);
+    B.combine({AX}, {V}, t2);
+    std::swap(X, t1);
+    std::swap(AX, t2);
+    for (int i = 0; i < m; ++i) theta[i] = ev(i);
+  }
+  bool haveP = false;
+  LOBPCGResult res;
+  size_t it = 0;
+  for (; it < max_iters; ++it) {
+    if (stop && (*stop)(it, theta, X, m)) break;
+    // R = AX - X diag(theta)   (into W)
+    Matrix D(m, m), I = Matrix::Identity(m, m);
+    for (int i = 0; i < m; ++i) D(i, i) = -theta[i];
+    B.combine({AX, X}, {I, D}, t1);
+    // residual norms of the wanted pairs
+    const Matrix RR = B.gram(t1, t1);
+    size_t nconv = 0;
+    for (size_t k = 0; k < nev; ++k)
+      if (std::sqrt(std::max(RR(k, k), 0.0)) <= tau * std::max(std::abs(theta[k]), 1e-300)) ++nconv;
+    res.num_converged = nconv;
+    if (tau > 0 && nconv == nev) break;
+    if (T) (*T)(t1, m, W);
+    else std::swap(W, t1);
+    // W <- (I - X X^T) W, then orthonormalise W
+    {
+      Matrix XtW = B.gram(X, W);
+      for (Index i = 0; i < XtW.size(); ++i) XtW.data()[i] = -XtW.data()[i];
+      B.combine({W, X}, {I, XtW}, t1);
+      Vector ev;
+      Matrix V;
+      symmetricEigen(B.gram(t1, t1), ev, V);
+      Matrix C(m, m);
+      const double top = std::max(ev(m - 1), 1e-300);
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) C(i, j) = ev(j) > 1e-20 * top ? V(i, j) / std::sqrt(ev(j)) : 0.0;
+      B.combine({t1}, {C}, W);
+    }
+    A(W, m, AW);
+    // Rayleigh-Ritz on S = [X W P]
+    const int nb = haveP ? 3 : 2, ns = nb * m;
+    const double *S[3] = {X, W, P}, *AS[3] = {AX, AW, AP};
+    Matrix GA(ns, ns), GB(ns, ns);
+    for (int a = 0; a < nb; ++a)
+      for (int b = a; b < nb; ++b) {
+        const Matrix ga = B.gram(S[a], AS[b]), gb = B.gram(S[a], S[b]);
+        for (int i = 0; i < m; ++i)
+          for (int j = 0; j < m; ++j) {
+            GA(a * m + i, b * m + j) = ga(i, j);
+            GA(b * m + j, a * m + i) = ga(i, j);
+            GB(a * m + i, b * m + j) = gb(i, j);
+            GB(b * m + j, a * m + i) = gb(i, j);
+          }
+      }
+    for (int i = 0; i < ns; ++i)
+      for (int j = i + 1; j < ns; ++j) {
+        GA(i, j) = GA(j, i) = 0.5 * (GA(i, j) + GA(j, i));
+        GB(i, j) = GB(j, i) = 0.5 * (GB(i, j) + GB(j, i));
+      }
+    // generalised problem GA c = theta GB c through an orthonormal basis of GB's range
+    Vector eb;
+    Matrix Vb;
+    symmetricEigen(GB, eb, Vb);
+    std::vector<int> keep;
+    for (int j = 0; j < ns; ++j)
+      if (eb(j) > 1e-10 * eb(ns - 1)) keep.push_back(j);
+    const int nk = static_cast<int>(keep.size());
+    if (nk < m) break;  // basis collapsed: converged to machine precision
+    Matrix Z(ns, nk);
+    for (int jj = 0; jj < nk; ++jj)
+      for (int i = 0; i < ns; ++i) Z(i, jj) = Vb(i, keep[jj]) / std::sqrt(eb(keep[jj]));
+    Matrix Hr = Z.transpose() * GA * Z;
+    for (int i = 0; i < nk; ++i)
+      for (int j = i + 1; j < nk; ++j) Hr(i, j) = Hr(j, i) = 0.5 * (Hr(i, j) + Hr(j, i));
+    Vector er;
+    Matrix Vr;
+    symmetricEigen(Hr, er, Vr);
+    const Matrix C = Z * sub(Vr, 0, 0, nk, m);  // ns x m coefficients of the new X
+    std::vector<Matrix> Cb;
+    for (int a = 0; a < nb; ++a) Cb.push_back(sub(C, a * m, 0, m, m));
+    // new P = [W P] C_wp,  new X = X C_x + new P
+    {
+      std::vector<const double *> s, as;
+      std::vector<Matrix> cs;
+      for (int a = 1; a < nb; ++a) { s.push_back(S[a]); as.push_back(AS[a]); cs.push_back(Cb[a]); }
+      B.combine(s, cs, t1);   // new P
+      B.combine(as, cs, t2);  // new AP
+    }
+    B.combine({X, t1}, {Cb[0], I}, t3);    // new X
+    B.combine({AX, t2}, {Cb[0], I}, t4);   // new AX
+    std::swap(P, t1);
+    std::swap(AP, t2);
+    std::swap(X, t3);
+    std::swap(AX, t4);
+    haveP = true;
+    for (int i = 0; i < m; ++i) theta[i] = er(i);
+  }
+  res.num_iters = it;
+  res.Theta = Vector(m, 1);
+  for (int i = 0; i < m; ++i) res.Theta(i) = theta[i];
+  res.X = Matrix(N, m);
+  B.chk(cora_download(c, X, m, res.X.data(), N), "download");
+  return res;
+}
+
+}  // namespace CORA

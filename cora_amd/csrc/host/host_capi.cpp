@@ -1,12 +1,14 @@
 // Flat C view of the C++ host for ctypes (include/cora_host.h).
 #include "../../../include/cora_host.h"
 
+#include <chrono>
 #include <cstring>
 #include <string>
 
 #include "../../../include/cora_hip.h"
 #include "CORA_problem.h"
 #include "pyfg_text_parser.h"
+#include "CORA.h"
 #include "TNT.h"
 #include "sparse_cholesky.h"
 #include "synthetic.h"
@@ -185,6 +187,65 @@ int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, doub
     stats[4] = static_cast<double>(res.hessian_vector_products);
     stats[5] = static_cast<double>(static_cast<int>(res.status));
     stats[6] = res.elapsed_time;
+  });
+}
+
+int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, double out[3], double *x) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    const Matrix Ym = wrap(Y, N, r);
+    const CertResults c = q.certify_solution(Ym, eta, static_cast<size_t>(nx), Ym);
+    out[0] = c.is_certified ? 1.0 : 0.0;
+    out[1] = c.theta;
+    out[2] = static_cast<double>(c.num_iters);
+    if (x) std::memcpy(x, c.x.data(), sizeof(double) * static_cast<size_t>(c.x.size()));
+  });
+}
+
+int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                double eta, const double *X0, int nx, int max_iters, double out[3], double *x) {
+  return guarded([&] {
+    SparseMatrix S(n, n);
+    S.outer.assign(rowptr, rowptr + n + 1);
+    S.inner.assign(colidx, colidx + rowptr[n]);
+    S.values.assign(vals, vals + rowptr[n]);
+    const Matrix X = X0 ? wrap(X0, n, nx) : Matrix::Random(n, nx, 99);
+    const CertResults c = fast_verification(S, eta, X, static_cast<size_t>(max_iters));
+    out[0] = c.is_certified ? 1.0 : 0.0;
+    out[1] = c.theta;
+    out[2] = static_cast<double>(c.num_iters);
+    if (x) std::memcpy(x, c.x.data(), sizeof(double) * static_cast<size_t>(c.x.size()));
+  });
+}
+
+int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verbose, const double *opts,
+                       double *x_out, double stats[9]) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    TNTParams prm;
+    if (opts) {
+      if (opts[0] > 0) prm.max_iterations = static_cast<int>(opts[0]);
+      if (opts[1] > 0) prm.max_TPCG_iterations = static_cast<int>(opts[1]);
+      if (opts[2] > 0) prm.gradient_tolerance = opts[2];
+      if (opts[3] > 0) prm.preconditioned_gradient_tolerance = opts[3];
+      if (opts[4] > 0) prm.max_computation_time = opts[4];
+    }
+    CoraSolveInfo info;
+    const auto t0 = std::chrono::steady_clock::now();
+    const CoraResult res = solveCORA(q, wrap(x0, N, r), max_rank, verbose != 0, false, false, &info, &prm);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::memcpy(x_out, res.first.x.data(), sizeof(double) * static_cast<size_t>(res.first.x.size()));
+    stats[0] = res.first.f;
+    stats[1] = res.first.gradfx_norm;
+    stats[2] = info.certified ? 1.0 : 0.0;
+    stats[3] = info.eta;
+    stats[4] = info.theta;
+    stats[5] = info.final_rank;
+    stats[6] = info.staircase_levels;
+    stats[7] = static_cast<double>(info.hessian_vector_products);
+    stats[8] = secs;
   });
 }
 

@@ -162,6 +162,23 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
     if (!(dk > 0.0)) {  // CHOLMOD's "not positive definite" (quick_return_if_not_posdef)
       F.ok = false;
       F.failed_column = k;
+      // direction of non-positive curvature from the failing pivot: solve L11^T y = l_k
+      std::vector<double> y(static_cast<size_t>(k) + 1, 0.0);
+      for (int j = 0; j < k; ++j)
+        for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
+          if (F.Li[q] == k) y[j] = F.Lx[q];  // l_k (row k of L)
+      for (int j = k - 1; j >= 0; --j) {
+        double s = y[j];
+        for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
+          if (F.Li[q] < k) s -= F.Lx[q] * y[F.Li[q]];
+        y[j] = s / F.Lx[F.Lp[j]];
+      }
+      F.negative_direction.assign(static_cast<size_t>(A.rows()), 0.0);
+      double nrm = 1.0;
+      for (int j = 0; j < k; ++j) nrm += y[j] * y[j];
+      nrm = std::sqrt(nrm);
+      for (int j = 0; j < k; ++j) F.negative_direction[perm[j]] = -y[j] / nrm;
+      F.negative_direction[perm[k]] = 1.0 / nrm;
       return F;
     }
     const int32_t w = next[k]++;

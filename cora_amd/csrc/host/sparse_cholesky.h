@@ -28,6 +28,9 @@ struct CholeskyFactor {
   std::vector<int32_t> perm;  // new -> old
   std::vector<int32_t> iperm; // old -> new
   std::vector<int32_t> parent;  // elimination tree
+  /** When !ok: unit vector z (original order, size = A.rows()) with z^T (A + shift I) z <= 0, built
+   * from the failing pivot: z = [-L11^-T l_k; 1; 0] has z^T M z = d_k <= 0. */
+  std::vector<double> negative_direction;
   int64_t nnz() const { return static_cast<int64_t>(Li.size()); }
   /** Solve A X = B in place (B: n x k, column-major). */
   void solveInPlace(Matrix &B) const;

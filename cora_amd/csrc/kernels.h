@@ -61,6 +61,10 @@ struct BorderDev {
 };
 hipError_t launch_tri_solve(const TriDev &F, const TriDev &B, const BorderDev &border, int ld, double *x,
                             hipStream_t st);
+hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
+                       double *partial, int nblocks, double *out, hipStream_t st);
+hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double *const *x, const int *kx,
+                          const int *coff, const double *coef, int ncoef, int kout, double *out, hipStream_t st);
 hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st);
 
 hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);

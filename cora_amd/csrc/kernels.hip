@@ -614,6 +614,83 @@ __global__ __launch_bounds__(256) void k_download(int64_t N, int k, int ld, cons
 }
 
 // ---------------------------------------------------------------------------
+// Tall-skinny block kernels for the eigensolver (LOBPCG Rayleigh-Ritz):
+//   Gram:    G = A^T B            (A: rows x ka, B: rows x kb; ka, kb <= 24)
+//   combine: Out = sum_i X_i C_i  (X_i: rows x k_i, C_i: k_i x kout, small, in `coef`)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gram(int64_t row0, int64_t rows, const double *__restrict__ A, int lda,
+                                              int ka, const double *__restrict__ B, int ldb, int kb,
+                                              double *__restrict__ partial) {
+  __shared__ double sa[32 * 24], sb[32 * 24];
+  const int nel = ka * kb;
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r_begin = static_cast<int64_t>(blockIdx.x) * per, r_end = min(rows, r_begin + per);
+  for (int64_t r = r_begin; r < r_end; r += 32) {
+    const int nr = static_cast<int>(min<int64_t>(32, r_end - r));
+    __syncthreads();
+    for (int t = threadIdx.x; t < nr * ka; t += 256) sa[t] = A[(row0 + r + t / ka) * lda + t % ka];
+    for (int t = threadIdx.x; t < nr * kb; t += 256) sb[t] = B[(row0 + r + t / kb) * ldb + t % kb];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int el = threadIdx.x + e * 256;
+      if (el < nel) {
+        const int ia = el / kb, ib = el - ia * kb;
+        double s = acc[e];
+        for (int q = 0; q < nr; ++q) s = fma(sa[q * ka + ia], sb[q * kb + ib], s);
+        acc[e] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int el = threadIdx.x + e * 256;
+    if (el < nel) partial[static_cast<size_t>(el) * gridDim.x + blockIdx.x] = acc[e];
+  }
+}
+
+// out[el] = sum_b partial[el * nblocks + b], one thread per element (fixed order)
+__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ partial, int nblocks, int nel,
+                                                     double *__restrict__ out) {
+  const int el = blockIdx.x * 256 + threadIdx.x;
+  if (el >= nel) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[static_cast<size_t>(el) * nblocks + b];
+  out[el] = s;
+}
+
+struct CombineArgs {
+  const double *x[4];
+  int kx[4], ldx[4], coff[4];  // coff: offset of C_i in coef (row-major k_i x kout)
+  int nblocks, kout, ldo;
+};
+
+__global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, CombineArgs A,
+                                                 const double *__restrict__ coef, int ncoef,
+                                                 double *__restrict__ out) {
+  extern __shared__ double sc[];
+  for (int t = threadIdx.x; t < ncoef; t += 256) sc[t] = coef[t];
+  __syncthreads();
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; r < rows;
+       r += static_cast<int64_t>(gridDim.x) * 256) {
+    double o[24];
+    for (int j = 0; j < A.kout; ++j) o[j] = 0.0;
+    for (int b = 0; b < A.nblocks; ++b) {
+      const double *xr = A.x[b] + (row0 + r) * A.ldx[b];
+      const double *C = sc + A.coff[b];
+      for (int i = 0; i < A.kx[b]; ++i) {
+        const double v = xr[i];
+        for (int j = 0; j < A.kout; ++j) o[j] = fma(v, C[i * A.kout + j], o[j]);
+      }
+    }
+    double *orow = out + (row0 + r) * A.ldo;
+    for (int j = 0; j < A.kout; ++j) orow[j] = o[j];
+    for (int j = A.kout; j < A.ldo; ++j) orow[j] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Level-scheduled sparse triangular solves (Cholesky preconditioner apply,
 // reference src/CORA_preconditioners.cpp:46-83).  Rows of one level are
 // independent; G lanes cooperate on a row.  In place on x.
@@ -911,6 +988,32 @@ hipError_t launch_tri_solve(const TriDev &F, const TriDev &Bk, const BorderDev &
 
 hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st) {
   hipLaunchKernelGGL(k_zero_row, dim3(1), dim3(64), 0, st, x, row, ld);
+  return hipGetLastError();
+}
+
+}  // namespace cora
+
+namespace cora {
+
+hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
+                       double *partial, int nblocks, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_gram, dim3(nblocks), dim3(256), 0, st, row0, rows, A, ld_for(ka), ka, B, ld_for(kb), kb, partial);
+  const int nel = ka * kb;
+  hipLaunchKernelGGL(k_gram_reduce, dim3((nel + 255) / 256), dim3(256), 0, st, partial, nblocks, nel, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double *const *x, const int *kx,
+                          const int *coff, const double *coef, int ncoef, int kout, double *out, hipStream_t st) {
+  CombineArgs A;
+  for (int b = 0; b < 4; ++b) { A.x[b] = nullptr; A.kx[b] = 0; A.ldx[b] = 0; A.coff[b] = 0; }
+  for (int b = 0; b < nblocks; ++b) { A.x[b] = x[b]; A.kx[b] = kx[b]; A.ldx[b] = ld_for(kx[b]); A.coff[b] = coff[b]; }
+  A.nblocks = nblocks;
+  A.kout = kout;
+  A.ldo = ld_for(kout);
+  const int grid = static_cast<int>(std::min<int64_t>((rows + 255) / 256, 2048));
+  hipLaunchKernelGGL(k_combine, dim3(std::max(grid, 1)), dim3(256), ncoef * sizeof(double), st, row0, rows, A, coef,
+                     ncoef, out);
   return hipGetLastError();
 }
 

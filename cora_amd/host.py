@@ -148,6 +148,27 @@ class Problem:
         return dict(x=out, f=st[0], grad_norm=st[1], pgrad_norm=st[2], iterations=int(st[3]), hvps=int(st[4]),
                     status=int(st[5]), seconds=st[6])
 
+    def certify(self, Y, eta, nx=10):
+        dm = self.dims()
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        out = np.zeros(3)
+        x = np.zeros(dm["N"])
+        self._chk(self.L.cora_problem_certify(self.h, Y.ctypes.data_as(_dp), C.c_double(eta), int(nx),
+                                              out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
+        return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
+
+    def solve(self, x0, max_rank=10, verbose=False, max_seconds=0, max_iterations=0):
+        dm = self.dims()
+        x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))
+        opts = np.array([max_iterations, 0, 0, 0, max_seconds, 0.0])
+        out = np.zeros((dm["N"], dm["d"]), order="F")
+        st = np.zeros(9)
+        self._chk(self.L.cora_problem_solve(self.h, x0.ctypes.data_as(_dp), int(max_rank), int(verbose),
+                                            opts.ctypes.data_as(_dp), out.ctypes.data_as(_dp),
+                                            st.ctypes.data_as(_dp)))
+        return dict(x=out, f=st[0], grad_norm=st[1], certified=bool(st[2]), eta=st[3], theta=st[4],
+                    final_rank=int(st[5]), levels=int(st[6]), hvps=int(st[7]), seconds=st[8])
+
     def precond_info(self):
         info = np.zeros(3)
         self._chk(self.L.cora_problem_precond_info(self.h, info.ctypes.data_as(_dp)))
@@ -168,3 +189,28 @@ class Problem:
         if not c:
             raise HostError(self.L.cora_host_last_error().decode())
         return c
+
+
+def fast_verification(S, eta, X0=None, nx=1, max_iters=1000):
+    """CORA::fast_verification on an arbitrary symmetric scipy sparse matrix."""
+    import scipy.sparse as sp
+    L = _lib()
+    S = sp.csr_matrix(S)
+    S.sort_indices()
+    n = S.shape[0]
+    rp = np.ascontiguousarray(S.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(S.indices, dtype=np.int32)
+    va = np.ascontiguousarray(S.data, dtype=np.float64)
+    out = np.zeros(3)
+    x = np.zeros(n)
+    xp = None
+    if X0 is not None:
+        X0 = np.asfortranarray(np.asarray(X0, dtype=np.float64).reshape(n, -1))
+        nx = X0.shape[1]
+        xp = X0.ctypes.data_as(_dp)
+    rc = L.cora_host_fast_verification(n, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), va.ctypes.data_as(_dp),
+                                       C.c_double(eta), xp, int(nx), int(max_iters), out.ctypes.data_as(_dp),
+                                       x.ctypes.data_as(_dp))
+    if rc:
+        raise HostError(L.cora_host_last_error().decode())
+    return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)

@@ -236,6 +236,16 @@ int cora_dot_dev(cora_ctx *ctx, const double *dA, const double *dB, int k,
 int cora_dots_dev(cora_ctx *ctx, int count, const double *const *dA,
                   const double *const *dB, double *out);
 
+/* Tall-skinny block operations for the eigensolver (Rayleigh-Ritz of LOBPCG, which the reference
+ * takes from libs/Optimization: src/CORA_utils.cpp:113-119).  Blocks are resident vectors with ka /
+ * kb <= 24 columns.
+ *   gram:    G = A^T B -> host, column-major ka x kb (synchronises)
+ *   combine: Out = sum_{i<n} X_i C_i, C_i host column-major k_i x kout (ld k_i), n <= 4;
+ *            Out must not alias an input. */
+int cora_gram_dev(cora_ctx *ctx, const double *dA, int ka, const double *dB, int kb, double *G);
+int cora_combine_dev(cora_ctx *ctx, int n, const double *const *dX, const int *k, const double *const *C,
+                     int kout, double *dOut);
+
 /* Timing helpers: HIP events on the handle's stream. */
 int cora_timer_start(cora_ctx *ctx);
 int cora_timer_stop_ms(cora_ctx *ctx, float *ms); /* synchronises */

@@ -65,6 +65,23 @@ int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel
  * [5] status (TNTStatus), [6] seconds. */
 int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, double *x_out, double stats[7]);
 
+/* Problem::certify_solution(Y, eta, nx, bootstrap = Y) (src/CORA_problem.cpp:1030-1103).
+ * out: [0] is_certified, [1] theta, [2] LOBPCG iterations; x: N (direction of negative curvature or 0). */
+int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, double out[3], double *x);
+
+/* fast_verification(S, eta, X0) (src/CORA_utils.cpp:17-186) for an arbitrary symmetric sparse S
+ * (CSR, n x n).  X0: n x nx or NULL for a random block.  out: [0] is_certified, [1] theta,
+ * [2] iterations; x: n. */
+int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                double eta, const double *X0, int nx, int max_iters, double out[3], double *x);
+
+/* solveCORA (src/CORA.cpp:26-243) from x0 (N x rank): Riemannian staircase up to max_rank, final
+ * projection to rank d and refinement.  x_out: N x d.  opts as in cora_problem_tnt (may be NULL).
+ * stats: [0] f, [1] |grad|, [2] certified, [3] eta, [4] theta, [5] final rank, [6] staircase levels,
+ * [7] Hessian-vector products, [8] seconds. */
+int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verbose, const double *opts,
+                       double *x_out, double stats[9]);
+
 /* After a preconditioned call: [0] regularisation lambda used, [1] nnz(L), [2] elimination-tree height. */
 int cora_problem_precond_info(cora_problem *p, double info[3]);
 

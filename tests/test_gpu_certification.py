@@ -1,0 +1,90 @@
+"""Certification on the GPU path, mirroring reference tests/test_certification.cpp:45-125,
+plus sign agreement with the oracle (Cholesky success of S + eta I and lambda_min(S))."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN
+from cora_amd import capi, host
+from mmio import read_dense, read_mm
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_certified(res):
+    assert res["is_certified"]
+    assert abs(res["theta"]) < 1e-6
+    assert np.abs(res["x"]).max() < 1e-6
+
+
+def _check_not_certified(res, theta, x):
+    assert not res["is_certified"]
+    assert abs(res["theta"] - theta) < 1e-6
+    assert min(np.abs(res["x"] - x).max(), np.abs(res["x"] + x).max()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [10, 1000])
+def test_generic_verification(n):
+    # reference testIdentityMatrixVerification (n = 10 dense path, n = 1000 LOBPCG path)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, n)
+    x /= np.linalg.norm(x)
+    I = np.eye(n)
+    _check_certified(host.fast_verification(sp.csr_matrix(I), 0.0, X0=x))
+    _check_certified(host.fast_verification(sp.csr_matrix(I), 0.0, nx=1))
+    A = I - np.outer(x, x)
+    _check_certified(host.fast_verification(sp.csr_matrix(A), 1e-8, X0=x))
+    _check_certified(host.fast_verification(sp.csr_matrix(A), 1e-8, nx=1))
+    B = I - 2 * np.outer(x, x)
+    _check_not_certified(host.fast_verification(sp.csr_matrix(B), 0.0, X0=x), -1.0, x)
+    _check_not_certified(host.fast_verification(sp.csr_matrix(B), 0.0, nx=1), -1.0, x)
+
+
+def test_small_ra_slam_verification():
+    case = "small_ra_slam_problem"
+    P = host.Problem.from_pyfg(os.path.join(GOLDEN, case, "factor_graph.pyfg"))
+    P.update()
+    Xgt = read_dense(os.path.join(GOLDEN, case, "X_gt.mm"))
+    res = P.certify(Xgt, 1e-6, nx=1)
+    _check_certified(res)
+    X0 = read_dense(os.path.join(GOLDEN, case, "X_rand_dim2.mm"))
+    res = P.certify(X0, 1e-6, nx=1)
+    assert not res["is_certified"]
+    S = read_mm(os.path.join(GOLDEN, case, "S_rand.mm")).toarray()
+    assert abs(res["theta"] - res["x"] @ S @ res["x"]) < 1e-6
+    assert abs(res["theta"] - np.linalg.eigvalsh(S)[0]) < 1e-6  # N = 24: dense path gives lambda_min
+
+
+@pytest.mark.parametrize("d,n,p", [(3, 300, 3), (2, 400, 4)])
+def test_certification_sign_matches_oracle(d, n, p):
+    """Large-N path (LOBPCG on the device operator): the decision must agree exactly with the
+    oracle's Cholesky test, and a returned direction must have curvature < -eta/2."""
+    P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=3, n_ranges=n // 2, seed=17,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    P.set_rank(p)
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    rng = np.random.default_rng(4)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dims.N, p)))
+    sol = P.tnt(Y, max_seconds=60)
+    for point in (Y, sol["x"]):
+        f = orc.cost(Q, point)
+        eta = min(max(f * 5e-6, 1e-7), 1e-1)  # src/CORA.cpp:112-114,154
+        res = P.certify(point, eta)
+        Sd = orc.certificate_matrix_dense(Q, dims, point)
+        ok = orc.Cholesky(orc.CSR.from_scipy(sp.csr_matrix(Sd + eta * np.eye(dims.N)))).ok
+        assert res["is_certified"] == ok
+        lam_min = np.linalg.eigvalsh(Sd)[0]
+        assert (lam_min + eta > 0) == ok or abs(lam_min + eta) < 1e-9 * abs(lam_min)
+        if not ok:
+            x = res["x"]
+            assert abs(np.linalg.norm(x) - 1) < 1e-8
+            assert abs(res["theta"] - x @ Sd @ x) < 1e-8 * max(1.0, abs(res["theta"]))
+            assert res["theta"] < -eta / 2
+            assert res["theta"] >= lam_min - 1e-8 * abs(lam_min)
