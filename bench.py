@@ -77,12 +77,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the CORA hot path has no CPU fallback")
+    # CORA_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of the N > 1 path
+    # on a 1-GPU box); the driver's runs use the default "nccl" (= RCCL) with one GPU per rank.
+    backend = os.environ.get("CORA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload: the C++ host generates the graph and assembles Q ----------
     n, p = args.poses, args.rank
@@ -162,6 +170,14 @@ def main():
         except Exception:
             traffic = None
 
+    # N > 1: gather one product and keep it for the parity check on rank 0
+    gathered = None
+    if dist is not None:
+        y_shard = op.apply(x_shard).clone()
+        gathered = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, y_shard)
+        torch.cuda.synchronize()
+
     result = None
     if rank == 0:
         result = {
@@ -198,6 +214,18 @@ def main():
                 "bytes_per_launch": b_hvp * local_frac,
             },
         }
+        if world > 1:
+            # parity of the sharded product against the CPU oracle on the same operands
+            from oracle import oracle as orc
+            Qo = orc.CSR(rowptr, colidx, vals, dm["N"])
+            dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+            m = ctx.row_map().astype(np.int64)
+            full = gathered.cpu().numpy().reshape(rows, ld)
+            got = full[m][:, :p]
+            Yc = y.cpu().numpy().reshape(rows, ld)[m][:, :p]
+            Vc = op.full_x.cpu().numpy().reshape(rows, ld)[m][:, :p]
+            ref = orc.hvp(Qo, dims, Yc, orc.egrad(Qo, Yc), Vc)
+            result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
         if world == 1:
             cores = os.cpu_count()
             hv_s, reps_cpu, (Yc, Vc, ref) = cpu_baseline(rowptr, colidx, vals, dm, p, args.cpu_seconds)
