@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -49,6 +50,10 @@ struct cora_ctx {
   std::vector<void *> tri_allocs;
   TriDev d_fwd{}, d_bwd{};
   BorderDev d_border{};
+  // the ~2 x (tree height) tiny launches of one solve are replayed as a hipGraph, keyed by the
+  // vector they run on (the solver applies the preconditioner to the same buffers every iteration)
+  struct TriGraph { int ld; double *x; hipGraphExec_t exec; };
+  std::vector<TriGraph> tri_graphs;
 
   bool have_point = false;
   double *d_Y = nullptr, *d_G = nullptr, *d_rgrad = nullptr;
@@ -69,6 +74,8 @@ struct cora_ctx {
   std::vector<void *> user_allocs;
   std::string err;
 };
+
+static void drop_tri_graphs(cora_ctx *c);
 
 namespace {
 
@@ -348,6 +355,7 @@ void cora_ctx_destroy(cora_ctx *c) {
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (void *p : c->user_allocs)
       if (p) (void)hipFree(p);
+    drop_tri_graphs(c);
     for (void *p : c->tri_allocs)
       if (p) (void)hipFree(p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -384,6 +392,7 @@ int cora_get_rank(const cora_ctx *c) { return c ? c->p : 0; }
 int cora_set_stream(cora_ctx *c, void *hip_stream) {
   NEED_DEVICE(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drop_tri_graphs(c);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->stream = static_cast<hipStream_t>(hip_stream);
   c->own_stream = false;
@@ -433,6 +442,7 @@ int cora_dev_free(cora_ctx *c, double *dptr) {
   for (auto &p : c->user_allocs)
     if (p == dptr) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      drop_tri_graphs(c);  // a cached graph may point at this buffer
       (void)hipFree(dptr);
       p = nullptr;
       return CORA_OK;
@@ -577,6 +587,7 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
     for (int64_t i = 0; i < N; ++i)
       if (!seen[i]) c->tri.zero_row = c->F.api2int[i];
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drop_tri_graphs(c);
   for (void *p : c->tri_allocs)
     if (p) (void)hipFree(p);
   c->tri_allocs.clear();
@@ -625,11 +636,46 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
   return CORA_OK;
 }
 
-// out = [ (P^T L L^T P)^-1 V[0:m] ; 0 ]  in place on dOut (already holding V)
-static int chol_solve_inplace(cora_ctx *c, int ld, double *dOut) {
+static void drop_tri_graphs(cora_ctx *c) {
+  for (auto &g : c->tri_graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  c->tri_graphs.clear();
+}
+
+static int chol_solve_launches(cora_ctx *c, int ld, double *dOut) {
   HIP_TRY(c, launch_tri_solve(c->d_fwd, c->d_bwd, c->d_border, ld, dOut, c->stream));
   if (c->tri.zero_row >= 0)  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
     HIP_TRY(c, launch_zero_row(dOut, static_cast<size_t>(c->tri.zero_row), ld, c->stream));
+  return CORA_OK;
+}
+
+// out = [ (P^T L L^T P)^-1 V[0:m] ; 0 ]  in place on dOut (already holding V)
+static int chol_solve_inplace(cora_ctx *c, int ld, double *dOut) {
+  static const bool use_graph = std::getenv("CORA_NO_GRAPH") == nullptr;
+  if (!use_graph) return chol_solve_launches(c, ld, dOut);
+  for (auto &g : c->tri_graphs)
+    if (g.ld == ld && g.x == dOut) {
+      HIP_TRY(c, hipGraphLaunch(g.exec, c->stream));
+      return CORA_OK;
+    }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = chol_solve_launches(c, ld, dOut);
+  const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc != CORA_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  HIP_TRY(c, e);
+  hipGraphExec_t exec = nullptr;
+  HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
+  if (c->tri_graphs.size() >= 8) {  // keep the cache small
+    (void)hipGraphExecDestroy(c->tri_graphs.front().exec);
+    c->tri_graphs.erase(c->tri_graphs.begin());
+  }
+  c->tri_graphs.push_back({ld, dOut, exec});
+  HIP_TRY(c, hipGraphLaunch(exec, c->stream));
   return CORA_OK;
 }
 
