@@ -49,7 +49,7 @@ __device__ __forceinline__ double dot_row(const double (&a)[LD], const double (&
 #define CORA_STREAM_NT 0
 #endif
 #ifndef CORA_POSE_UNROLL
-#define CORA_POSE_UNROLL 2
+#define CORA_POSE_UNROLL 3
 #endif
 template <typename T>
 __device__ __forceinline__ T stream_load(const T *p) {
