@@ -204,7 +204,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "cora::k_spmm<6,3,EPI_HVP>" if p == 5 else "cora::k_spmm",
+                "kernel": "cora::k_spmm<%d, 3, 2> (LD=%d, d=3, EPI_HVP)" % (ld, ld),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -746,7 +746,7 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
     D.b[j] = (j < count) ? dB[j] + off : nullptr;
   }
   D.count = count;
-  D.n2 = c->F.L.local_rows * c->ld / 2;
+  D.n2 = c->F.L.local_rows * c->ld;
   int rc = ensure_red(c, 4 * 512);
   if (rc) return rc;
   D.partial = c->d_red;
@@ -769,7 +769,7 @@ int cora_dot_dev(cora_ctx *c, const double *dA, const double *dB, int k, double 
   D.a[0] = dA + off;
   D.b[0] = dB + off;
   D.count = 1;
-  D.n2 = c->F.L.local_rows * ld / 2;
+  D.n2 = c->F.L.local_rows * ld;
   int rc = ensure_red(c, 4 * 512);
   if (rc) return rc;
   D.partial = c->d_red;

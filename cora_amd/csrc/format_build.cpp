@@ -17,6 +17,7 @@
 namespace cora {
 
 int g_sigma = kSigma;
+int g_pad_even = 0;
 int g_long_chunk = kLongChunk;
 int g_interleave = 0;  // measured: no gain on MI355X (kept for the lab)
 

@@ -43,7 +43,7 @@ struct DotArgs {
   const double *a[4];
   const double *b[4];
   int count;
-  int64_t n2;        // number of double2 elements
+  int64_t n2;        // number of doubles (launch_dots halves it for the double2 kernel)
   double *partial;   // [count][gridDim.x]
 };
 

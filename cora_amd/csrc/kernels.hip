@@ -19,20 +19,30 @@ namespace cora {
 // ---------------------------------------------------------------------------
 template <int LD>
 __device__ __forceinline__ void load_row(const double *__restrict__ p, double (&x)[LD]) {
-  const double2 *q = reinterpret_cast<const double2 *>(p);
+  if constexpr (LD % 2 == 0) {  // 16-byte aligned rows: dwordx4
+    const double2 *q = reinterpret_cast<const double2 *>(p);
 #pragma unroll
-  for (int j = 0; j < LD / 2; ++j) {
-    const double2 t = q[j];
-    x[2 * j] = t.x;
-    x[2 * j + 1] = t.y;
+    for (int j = 0; j < LD / 2; ++j) {
+      const double2 t = q[j];
+      x[2 * j] = t.x;
+      x[2 * j + 1] = t.y;
+    }
+  } else {  // odd row stride: rows are only 8-byte aligned
+#pragma unroll
+    for (int j = 0; j < LD; ++j) x[j] = p[j];
   }
 }
 
 template <int LD>
 __device__ __forceinline__ void store_row(double *__restrict__ p, const double (&x)[LD]) {
-  double2 *q = reinterpret_cast<double2 *>(p);
+  if constexpr (LD % 2 == 0) {
+    double2 *q = reinterpret_cast<double2 *>(p);
 #pragma unroll
-  for (int j = 0; j < LD / 2; ++j) q[j] = make_double2(x[2 * j], x[2 * j + 1]);
+    for (int j = 0; j < LD / 2; ++j) q[j] = make_double2(x[2 * j], x[2 * j + 1]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < LD; ++j) p[j] = x[j];
+  }
 }
 
 template <int LD>
@@ -53,8 +63,10 @@ __device__ __forceinline__ double dot_row(const double (&a)[LD], const double (&
 #endif
 template <typename T>
 __device__ __forceinline__ T stream_load(const T *p) {
-#if CORA_STREAM_NT
+#if CORA_STREAM_NT == 1
   return __builtin_nontemporal_load(p);
+#elif CORA_STREAM_NT == 2  // sc1: served by L2, does not allocate in the CU's L1
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
   return *p;
 #endif
@@ -528,6 +540,15 @@ __global__ __launch_bounds__(256) void k_project_manifold(const RowArgs R, const
 // ---------------------------------------------------------------------------
 // flat vector kernels over the local shard (contiguous doubles)
 // ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_axpby1(int64_t n, double a, const double *__restrict__ x, double b,
+                                                double *__restrict__ y) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const double yv = (b != 0.0) ? y[i] : 0.0;
+    y[i] = fma(a, x[i], b * yv);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_axpby(int64_t n2, double a, const double2 *__restrict__ x,
                                                double b, double2 *__restrict__ y) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n2;
@@ -545,6 +566,24 @@ __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const 
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * 256)
     y[i] = scale[i / ld] * x[i];
+}
+
+// scalar variant for odd lengths / 8-byte aligned shards
+__global__ __launch_bounds__(256) void k_dots1(DotArgs D) {
+  __shared__ double sm[4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < D.count) acc[j] = fma(D.a[j][i], D.b[j][i], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < D.count) {
+      const double t = block_sum_256(acc[j], sm);
+      if (threadIdx.x == 0) D.partial[static_cast<size_t>(j) * gridDim.x + blockIdx.x] = t;
+    }
 }
 
 // up to 4 inner products in one pass; partial[j * gridDim.x + block]
@@ -805,7 +844,7 @@ __global__ void k_zero_row(double *x, size_t row, int ld) {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-#define CORA_LD_CASES(M) M(2) M(4) M(6) M(8) M(10) M(12) M(16) M(20) M(24)
+#define CORA_LD_CASES(M) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(16) M(20) M(24)
 
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
   int64_t g = (n + per_block - 1) / per_block;
@@ -895,10 +934,17 @@ hipError_t launch_project_manifold(const RowArgs &R, int ld, const double *A, co
   return hipErrorInvalidValue;
 }
 
+static inline bool vec2_ok(int64_t n, const void *a, const void *b) {
+  return (n % 2 == 0) && (reinterpret_cast<uintptr_t>(a) % 16 == 0) && (reinterpret_cast<uintptr_t>(b) % 16 == 0);
+}
+
 hipError_t launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_axpby, dim3(grid_for(n / 2)), dim3(256), 0, st, n / 2, a,
-                     reinterpret_cast<const double2 *>(x), b, reinterpret_cast<double2 *>(y));
+  if (vec2_ok(n, x, y))
+    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n / 2)), dim3(256), 0, st, n / 2, a,
+                       reinterpret_cast<const double2 *>(x), b, reinterpret_cast<double2 *>(y));
+  else
+    hipLaunchKernelGGL(k_axpby1, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, b, y);
   return hipGetLastError();
 }
 
@@ -909,10 +955,17 @@ hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const do
   return hipGetLastError();
 }
 
-hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st) {
+// D.n2 holds the number of DOUBLES; the vectorised kernel is used when everything is 16-byte aligned
+hipError_t launch_dots(const DotArgs &D_in, int *nblocks, hipStream_t st) {
+  DotArgs D = D_in;
+  bool vec = (D.n2 % 2 == 0);
+  for (int j = 0; j < D.count; ++j)
+    vec = vec && reinterpret_cast<uintptr_t>(D.a[j]) % 16 == 0 && reinterpret_cast<uintptr_t>(D.b[j]) % 16 == 0;
+  if (vec) D.n2 /= 2;
   const int grid = grid_for(D.n2, 256, 512);
   *nblocks = grid;
-  hipLaunchKernelGGL(k_dots, dim3(grid), dim3(256), 0, st, D);
+  if (vec) hipLaunchKernelGGL(k_dots, dim3(grid), dim3(256), 0, st, D);
+  else hipLaunchKernelGGL(k_dots1, dim3(grid), dim3(256), 0, st, D);
   return hipGetLastError();
 }
 

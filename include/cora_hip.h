@@ -23,8 +23,8 @@
  *     the handle.  One handle = one HIP stream; a handle is not thread-safe,
  *     independent handles are.
  *   - `_dev` entry points take DEVICE pointers to the library's resident layout:
- *     row-major  rows x ld  doubles with ld = cora_ld(ctx) (p rounded up to an
- *     even number; padding columns are zero) and rows = cora_rows(ctx) in the
+ *     row-major  rows x ld  doubles with ld = cora_ld(ctx) (= p up to 12 columns,
+ *     the next multiple of 4 above; padding columns are zero) and rows = cora_rows(ctx) in the
  *     library's internal row order (identity for a 1-GPU handle).  Use
  *     cora_upload / cora_download to convert from / to the host layout.
  *   - there is no CPU fallback: every compute entry point fails with

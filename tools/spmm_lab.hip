@@ -95,10 +95,12 @@ T *dev(const std::vector<T> &v) {
 int main(int argc, char **argv) {
   if (argc < 2) { printf("usage: spmm_lab q.bin [sigma] [p] [chunkmode]\n"); return 1; }
   if (argc > 2) g_sigma = atoi(argv[2]);
+  if (getenv("LAB_ODD")) g_pad_even = !atoi(getenv("LAB_ODD"));
   if (getenv("LAB_INTER")) g_interleave = atoi(getenv("LAB_INTER"));
   if (getenv("LAB_CHUNK")) g_long_chunk = atoi(getenv("LAB_CHUNK"));
   const int p = argc > 3 ? atoi(argv[3]) : 5;
   const bool nolong = argc > 4 && atoi(argv[4]) >= 0;
+  if (getenv("LAB_ODD")) g_pad_even = !atoi(getenv("LAB_ODD"));
   const int LD = ld_for(p);
   FILE *f = fopen(argv[1], "rb");
   int64_t hdr[5];
