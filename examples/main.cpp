@@ -1,0 +1,51 @@
+// Command-line driver with the flow of the reference's examples/main.cpp:
+//   parse PyFG -> updateProblemData -> random initial guess -> solveCORA(max_rank 10)
+//   -> alignEstimateToOrigin, then print the result and optionally save a TUM trajectory.
+// Build:  hipcc -O2 -std=c++17 -Iinclude -Icora_amd/csrc/host examples/main.cpp \
+//               -Lcora_amd/lib -lcora_hip -Wl,-rpath,$PWD/cora_amd/lib -o cora_main
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "CORA.h"
+#include "io.h"
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    std::cout << "Usage: " << argv[0] << " [input .pyfg file] [--jacobi] [--tum out.tum] [--max-rank r]" << std::endl;
+    return 1;
+  }
+  int max_rank = 10;
+  std::string tum;
+  bool jacobi = false;
+  for (int i = 2; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--jacobi") jacobi = true;
+    else if (a == "--tum" && i + 1 < argc) tum = argv[++i];
+    else if (a == "--max-rank" && i + 1 < argc) max_rank = std::atoi(argv[++i]);
+  }
+  try {
+    CORA::Problem problem = CORA::parsePyfgTextToProblem(argv[1]);
+    if (jacobi) problem.setPreconditioner(CORA::Preconditioner::Jacobi);
+    problem.updateProblemData();
+    std::printf("poses %d  landmarks %d  ranges %d  N %d  nnz(Q) %ld\n", problem.numPoses(), problem.numLandmarks(),
+                problem.numRangeMeasurements(), problem.getDataMatrixSize(),
+                static_cast<long>(problem.data_matrix_.nonZeros()));
+    const CORA::Matrix x0 = problem.getRandomInitialGuess();
+    CORA::CoraSolveInfo info;
+    const CORA::CoraResult soln = CORA::solveCORA(problem, x0, max_rank, /*verbose=*/true, false, false, &info);
+    const CORA::Matrix aligned = problem.alignEstimateToOrigin(soln.first.x);
+    std::printf("final cost %.9g  |grad| %.3e  certified %d  theta %.3e  staircase levels %d  Hvps %ld  %.3f s\n",
+                soln.first.f, soln.first.gradfx_norm, static_cast<int>(info.certified), info.theta,
+                info.staircase_levels, info.hessian_vector_products, soln.first.elapsed_time);
+    if (!tum.empty()) {
+      CORA::saveSolnToTum(problem, aligned, tum);
+      std::cout << "wrote " << tum << std::endl;
+    }
+  } catch (const std::exception &e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    return 2;
+  }
+  return 0;
+}
