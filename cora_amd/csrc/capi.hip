@@ -412,6 +412,15 @@ int cora_row_map(const cora_ctx *c, int32_t *api_to_internal) {
   return CORA_OK;
 }
 
+int cora_precond_stats(const cora_ctx *c, int64_t s[4]) {
+  if (!c || !s) return CORA_ERR_ARG;
+  s[0] = c->have_chol ? static_cast<int64_t>(c->tri.fwd.levels.size()) : 0;
+  s[1] = c->have_chol ? static_cast<int64_t>(c->tri.bwd.levels.size()) : 0;
+  s[2] = c->have_chol ? c->tri.nnzL : 0;
+  s[3] = c->have_chol ? c->tri.border.nb : 0;
+  return CORA_OK;
+}
+
 int cora_format_stats(const cora_ctx *c, int64_t s[8]) {
   if (!c || !s) return CORA_ERR_ARG;
   s[0] = static_cast<int64_t>(c->F.slices.size());
@@ -604,11 +613,9 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
   };
   auto up_tri = [&](TriDev &D, const TriHost &H) -> hipError_t {
     hipError_t e;
-    if ((e = up(&D.rowptr, H.rowptr)) != hipSuccess) return e;
+    if ((e = up(&D.sn, H.sn)) != hipSuccess) return e;
     if ((e = up(&D.cols, H.cols)) != hipSuccess) return e;
-    if ((e = up(&D.out_row, H.out_row)) != hipSuccess) return e;
     if ((e = up(&D.vals, H.vals)) != hipSuccess) return e;
-    if ((e = up(&D.dinv, H.dinv)) != hipSuccess) return e;
     D.levels = &H.levels;
     return hipSuccess;
   };
@@ -621,6 +628,12 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
   HIP_TRY(c, up(&D.Lbb, B.Lbb));
   HIP_TRY(c, up(&D.out_row, B.out_row));
   HIP_TRY(c, up(&D.chunk_row, B.chunk_row));
+  {
+    std::vector<int32_t> rcp(static_cast<size_t>(B.nb) + 1, 0);
+    for (int32_t r : B.chunk_row) rcp[static_cast<size_t>(r) + 1]++;
+    for (int k = 0; k < B.nb; ++k) rcp[k + 1] += rcp[k];
+    HIP_TRY(c, up(&D.row_chunk_ptr, rcp));
+  }
   HIP_TRY(c, up(&D.cbeg, B.chunk_begin));
   HIP_TRY(c, up(&D.cend, B.chunk_end));
   HIP_TRY(c, up(&D.wcols, B.wcols));

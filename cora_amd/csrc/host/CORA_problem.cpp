@@ -336,8 +336,10 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
   if (kind == CORA_PRECOND_BLOCK_CHOLESKY || kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
     const Index N = getDataMatrixSize();
     const int m = static_cast<int>(pin_last_translation_ ? N - 1 : N);
+    int leaf = 8;
+    if (const char *env = std::getenv("CORA_ND_LEAF")) leaf = std::max(1, std::atoi(env));
     const auto perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
-                                   data_matrix_, m);
+                                   data_matrix_, m, leaf);
     CholeskyFactor F;
     if (kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
       // lambda_reg = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 or CORA_REG_CHOLESKY_MAX_COND (:581-591)

@@ -48,14 +48,15 @@ struct DotArgs {
 };
 
 struct TriDev {  // device copy of a TriHost
-  const int32_t *rowptr, *cols, *out_row;
-  const double *vals, *dinv;
+  const TriSn *sn;
+  const int32_t *cols;
+  const double *vals;
   const std::vector<TriLevel> *levels;
 };
 struct BorderDev {
   int nb, nchunks;
   const double *Lbb;
-  const int32_t *out_row, *chunk_row, *cbeg, *cend, *wcols;
+  const int32_t *out_row, *chunk_row, *row_chunk_ptr, *cbeg, *cend, *wcols;
   const double *wvals;
   double *partial;
 };

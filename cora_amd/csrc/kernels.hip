@@ -735,42 +735,74 @@ __global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, Com
 // independent; G lanes cooperate on a row.  In place on x.
 // ---------------------------------------------------------------------------
 template <int LD, int G>
-__global__ __launch_bounds__(256) void k_tri_level(const int32_t *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void k_tri_level(const TriSn *__restrict__ sns,
                                                    const int32_t *__restrict__ cols,
-                                                   const double *__restrict__ vals,
-                                                   const double *__restrict__ dinv,
-                                                   const int32_t *__restrict__ out_row, int begin, int end,
+                                                   const double *__restrict__ vals, int begin, int end,
                                                    double *__restrict__ x) {
   const int gt = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  const int row = begin + gt / G, g = gt % G;
-  const bool ok = row < end;
-  double acc[LD];
+  const int sn = begin + gt / G, g = gt % G;
+  const bool ok = sn < end;
+  const TriSn R = sns[ok ? sn : begin];  // one record: no pointer chasing
+  const int b = ok ? R.nrows : 0;
+  // right-hand sides of the supernode's own rows: in flight while the external part is gathered
+  double xv[kTriSn][LD];
 #pragma unroll
-  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+  for (int t = 0; t < kTriSn; ++t) {
+#pragma unroll
+    for (int j = 0; j < LD; ++j) xv[t][j] = 0.0;
+    if (t < b && g == 0) load_row<LD>(x + static_cast<size_t>(R.out_row[t]) * LD, xv[t]);
+  }
+  // external part: the G lanes stride over ALL external entries of the supernode (independent
+  // gathers); the row position an entry belongs to is packed in the top 4 index bits
+  double acc[kTriSn][LD];
+#pragma unroll
+  for (int t = 0; t < kTriSn; ++t)
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[t][j] = 0.0;
   if (ok) {
-    const int e = rowptr[row + 1];
-    for (int k = rowptr[row] + g; k < e; k += G) {
+#pragma unroll 2
+    for (int k = R.ext_begin + g; k < R.ext_end; k += G) {
       const double v = vals[k];
-      double t[LD];
-      load_row<LD>(x + static_cast<size_t>(cols[k]) * LD, t);
+      const int32_t ct = cols[k];
+      const int tag = ct >> 28;
+      double xx[LD];
+      load_row<LD>(x + static_cast<size_t>(ct & 0x0FFFFFFF) * LD, xx);
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acc[j] = fma(v, t[j], acc[j]);
+      for (int t = 0; t < kTriSn; ++t) {
+        const double vt = (t == tag) ? v : 0.0;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[t][j] = fma(vt, xx[j], acc[t][j]);
+      }
     }
   }
   if (G > 1) {
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1)
+    for (int t = 0; t < kTriSn; ++t)
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+      for (int off = G / 2; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[t][j] += __shfl_xor(acc[t][j], off, 64);
   }
-  if (ok && g == 0) {
-    double *xr = x + static_cast<size_t>(out_row[row]) * LD;
-    double t[LD];
-    load_row<LD>(xr, t);
-    const double di = dinv[row];
+  if (!ok || g != 0) return;
+  // internal triangular block in registers
+  double y[kTriSn][LD];
 #pragma unroll
-    for (int j = 0; j < LD; ++j) t[j] = (t[j] - acc[j]) * di;
-    store_row<LD>(xr, t);
+  for (int t = 0; t < kTriSn; ++t) {
+    if (t < b) {
+      double v[LD];
+#pragma unroll
+      for (int j = 0; j < LD; ++j) v[j] = xv[t][j] - acc[t][j];
+#pragma unroll
+      for (int q = 0; q < t; ++q) {
+        const double l = R.lint[t * (t - 1) / 2 + q];
+#pragma unroll
+        for (int j = 0; j < LD; ++j) v[j] = fma(-l, y[q][j], v[j]);
+      }
+      const double di = R.dinv[t];
+#pragma unroll
+      for (int j = 0; j < LD; ++j) y[t][j] = v[j] * di;
+      store_row<LD>(x + static_cast<size_t>(R.out_row[t]) * LD, y[t]);
+    }
   }
 }
 
@@ -806,21 +838,42 @@ __global__ __launch_bounds__(256) void k_border_dot(const int32_t *__restrict__ 
         sm[threadIdx.x] + sm[LD + threadIdx.x] + sm[2 * LD + threadIdx.x] + sm[3 * LD + threadIdx.x];
 }
 
-// forward substitution through the dense border block (one wave; lane j = column j)
+// forward substitution through the dense border block.  One 256-thread block: the chunk partials
+// of every border row are summed in parallel (fixed assignment and order -> deterministic), then
+// lane j < LD runs the tiny dense substitution for column j.
 template <int LD>
-__global__ __launch_bounds__(64) void k_border_fwd(int nb, const double *__restrict__ Lbb,
-                                                   const int32_t *__restrict__ out_row, int nchunks,
-                                                   const int32_t *__restrict__ chunk_row,
-                                                   const double *__restrict__ partial, double *__restrict__ x) {
-  const int j = threadIdx.x;
-  if (j >= LD) return;
-  int c = 0;
+__global__ __launch_bounds__(256) void k_border_fwd(int nb, const double *__restrict__ Lbb,
+                                                    const int32_t *__restrict__ out_row, int nchunks,
+                                                    const int32_t *__restrict__ row_chunk_ptr,
+                                                    const double *__restrict__ partial, double *__restrict__ x) {
+  extern __shared__ double sums[];  // [nb][LD]
+  constexpr int TPC = 256 / 32;     // threads cooperating on one column (LD <= 24 < 32)
+  const int j = threadIdx.x & 31, w = threadIdx.x >> 5;
+  __shared__ double red[TPC][32];
   for (int k = 0; k < nb; ++k) {
-    double acc = 0.0;
-    for (; c < nchunks && chunk_row[c] == k; ++c) acc += partial[static_cast<size_t>(c) * kMaxLD + j];
-    for (int q = 0; q < k; ++q) acc = fma(Lbb[static_cast<size_t>(k) * nb + q], x[static_cast<size_t>(out_row[q]) * LD + j], acc);
-    double *xr = x + static_cast<size_t>(out_row[k]) * LD + j;
-    *xr = (*xr - acc) / Lbb[static_cast<size_t>(k) * nb + k];
+    double s = 0.0;
+    if (j < LD)
+      for (int c = row_chunk_ptr[k] + w; c < row_chunk_ptr[k + 1]; c += TPC)
+        s += partial[static_cast<size_t>(c) * kMaxLD + j];
+    red[w][j] = s;
+    __syncthreads();
+    if (w == 0 && j < LD) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < TPC; ++q) t += red[q][j];
+      sums[k * LD + j] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < LD) {
+    const int c = threadIdx.x;
+    for (int k = 0; k < nb; ++k) {
+      double acc = sums[k * LD + c];
+      for (int q = 0; q < k; ++q)
+        acc = fma(Lbb[static_cast<size_t>(k) * nb + q], x[static_cast<size_t>(out_row[q]) * LD + c], acc);
+      double *xr = x + static_cast<size_t>(out_row[k]) * LD + c;
+      *xr = (*xr - acc) / Lbb[static_cast<size_t>(k) * nb + k];
+    }
   }
 }
 
@@ -1001,16 +1054,14 @@ namespace cora {
 
 template <int LD>
 static hipError_t tri_level_ld(const TriDev &T, const TriLevel &lv, double *x, hipStream_t st) {
-  const int rows = lv.end - lv.begin;
-  if (rows <= 0) return hipSuccess;
-  const int64_t threads = static_cast<int64_t>(rows) * lv.lanes;
+  const int sns = lv.end - lv.begin;
+  if (sns <= 0) return hipSuccess;
+  const int64_t threads = static_cast<int64_t>(sns) * lv.lanes;
   const int grid = static_cast<int>((threads + 255) / 256);
-  if (lv.lanes == 1)
-    hipLaunchKernelGGL((k_tri_level<LD, 1>), dim3(grid), dim3(256), 0, st, T.rowptr, T.cols, T.vals, T.dinv, T.out_row, lv.begin, lv.end, x);
-  else if (lv.lanes == 8)
-    hipLaunchKernelGGL((k_tri_level<LD, 8>), dim3(grid), dim3(256), 0, st, T.rowptr, T.cols, T.vals, T.dinv, T.out_row, lv.begin, lv.end, x);
+  if (lv.lanes == 8)
+    hipLaunchKernelGGL((k_tri_level<LD, 8>), dim3(grid), dim3(256), 0, st, T.sn, T.cols, T.vals, lv.begin, lv.end, x);
   else
-    hipLaunchKernelGGL((k_tri_level<LD, 64>), dim3(grid), dim3(256), 0, st, T.rowptr, T.cols, T.vals, T.dinv, T.out_row, lv.begin, lv.end, x);
+    hipLaunchKernelGGL((k_tri_level<LD, 64>), dim3(grid), dim3(256), 0, st, T.sn, T.cols, T.vals, lv.begin, lv.end, x);
   return hipGetLastError();
 }
 
@@ -1022,7 +1073,7 @@ static hipError_t tri_solve_ld(const TriDev &F, const TriDev &Bk, const BorderDe
   if (B.nb > 0) {
     if (B.nchunks > 0)
       hipLaunchKernelGGL((k_border_dot<LD>), dim3(B.nchunks), dim3(256), 0, st, B.cbeg, B.cend, B.wcols, B.wvals, x, B.partial);
-    hipLaunchKernelGGL((k_border_fwd<LD>), dim3(1), dim3(64), 0, st, B.nb, B.Lbb, B.out_row, B.nchunks, B.chunk_row, B.partial, x);
+    hipLaunchKernelGGL((k_border_fwd<LD>), dim3(1), dim3(256), static_cast<size_t>(B.nb) * LD * sizeof(double), st, B.nb, B.Lbb, B.out_row, B.nchunks, B.row_chunk_ptr, B.partial, x);
     hipLaunchKernelGGL((k_border_bwd<LD>), dim3(1), dim3(64), 0, st, B.nb, B.Lbb, B.out_row, x);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }

@@ -11,14 +11,33 @@
 
 namespace cora {
 
+constexpr int kTriSn = 6;  // max rows of a supernode (its partial sums live in registers)
+
 struct TriLevel {
-  int32_t begin, end;  // range of ordered rows
-  int32_t lanes;       // lanes cooperating on one row: 1, 8 or 64
+  int32_t begin, end;  // range of supernodes
+  int32_t lanes;       // lanes cooperating on one supernode: 1, 8 or 64
 };
 
-struct TriHost {          // one direction, rows ordered by level
-  std::vector<int32_t> rowptr, cols, out_row;
-  std::vector<double> vals, dinv;
+// One direction.  Rows are grouped into small chain supernodes (consecutive rows on a path of
+// the elimination tree, at most kTriSn of them: typically the d rotation rows, range rows and
+// translation of one pose).  A supernode is one unit of the level schedule: its external
+// dependencies (rows of earlier levels) are gathered with full memory parallelism, then the
+// tiny internal triangular block is solved in registers -- ~3x fewer levels than row by row.
+// Everything a lane group needs about its supernode in ONE record addressed by the supernode
+// index alone (no pointer chasing: a level is a chain of dependent loads, so each removed
+// indirection is ~1 us per level).
+struct TriSn {
+  int32_t ext_begin, ext_end;   // external entries in cols / vals
+  int32_t nrows, pad;
+  int32_t out_row[kTriSn];      // internal row of each of its rows, in processing order
+  double dinv[kTriSn];          // 1 / L_ii
+  double lint[kTriSn * (kTriSn - 1) / 2];  // internal coefficients, packed: (t, q<t) at t(t-1)/2 + q
+};
+
+struct TriHost {
+  std::vector<TriSn> sn;                // supernodes in level order
+  std::vector<int32_t> cols;            // EXTERNAL entries: internal row | (row position << 28)
+  std::vector<double> vals;
   std::vector<TriLevel> levels;
 };
 

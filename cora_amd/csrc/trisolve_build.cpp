@@ -9,7 +9,8 @@ namespace {
 constexpr int kBorderRowNnz = 4096;   // rows of L longer than this form the dense border
 constexpr int kBorderChunk = 2048;
 
-int lanes_for(int max_len) { return max_len <= 12 ? 1 : (max_len <= 192 ? 8 : 64); }
+// lanes per supernode from the largest number of external entries of a supernode in the level
+int lanes_for(int max_len) { return max_len <= 96 ? 8 : 64; }
 }  // namespace
 
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
@@ -67,63 +68,82 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     B.wvals.insert(B.wvals.end(), wv[k].begin(), wv[k].end());
   }
 
-  // ---- forward levels (non-border rows): level = 1 + max level of dependencies
-  std::vector<int32_t> lev(first_border, 0);
-  int height = 0;
-  for (int i = 0; i < first_border; ++i) {
-    int l = 0;
-    for (int32_t q = rptr[i]; q < rptr[i + 1]; ++q) l = std::max(l, lev[rcol[q]] + 1);
-    lev[i] = l;
-    height = std::max(height, l + 1);
+  // ---- small chain supernodes over the non-border rows.  parent(j) = first off-diagonal row of column j.
+  const int nr = first_border;
+  std::vector<int32_t> parent(nr, -1), nchild(nr, 0);
+  for (int j = 0; j < nr; ++j)
+    if (Lp[j] + 1 < Lp[j + 1] && Li[Lp[j] + 1] < nr) parent[j] = Li[Lp[j] + 1];
+  for (int j = 0; j < nr; ++j)
+    if (parent[j] >= 0) nchild[parent[j]]++;
+  std::vector<int32_t> sn_of(nr, 0), sn_first;
+  for (int i = 0; i < nr; ++i) {
+    const bool extend = i > 0 && parent[i - 1] == i && nchild[i] == 1 && (i - sn_first.back()) < kTriSn;
+    if (!extend) sn_first.push_back(i);
+    sn_of[i] = static_cast<int32_t>(sn_first.size()) - 1;
   }
-  auto emit = [&](TriHost &T, const std::vector<int32_t> &level_of, int nlev, auto row_begin, auto row_end,
-                  auto col_at, auto val_at, auto diag_of, bool descending) {
-    std::vector<std::vector<int32_t>> rows(nlev);
-    for (int i = 0; i < first_border; ++i) rows[level_of[i]].push_back(i);
-    T.rowptr.assign(1, 0);
-    for (int l = 0; l < nlev; ++l) {
-      const int L = descending ? nlev - 1 - l : l;
-      if (rows[L].empty()) continue;
-      TriLevel tl;
-      tl.begin = static_cast<int32_t>(T.out_row.size());
-      int maxlen = 0;
-      for (int32_t i : rows[L]) {
-        const int32_t b = row_begin(i), e = row_end(i);
-        maxlen = std::max(maxlen, e - b);
-        for (int32_t q = b; q < e; ++q) {
-          T.cols.push_back(row_of[col_at(q)]);
-          T.vals.push_back(val_at(q));
+  const int nsn = static_cast<int>(sn_first.size());
+  sn_first.push_back(nr);
+
+  auto emit = [&](TriHost &T, bool backward, auto row_begin, auto row_end, auto col_at, auto val_at) {
+    std::vector<int32_t> lev(nsn, 0);
+    int height = 0;
+    auto visit = [&](int s) {
+      int l = 0;
+      for (int i = sn_first[s]; i < sn_first[s + 1]; ++i)
+        for (int32_t q = row_begin(i); q < row_end(i); ++q) {
+          const int j = col_at(q);
+          if (j < nr && sn_of[j] != s) l = std::max(l, lev[sn_of[j]] + 1);
         }
-        T.rowptr.push_back(static_cast<int32_t>(T.cols.size()));
-        T.out_row.push_back(row_of[i]);
-        T.dinv.push_back(1.0 / diag_of(i));
+      lev[s] = l;
+      height = std::max(height, l + 1);
+    };
+    if (!backward) for (int s = 0; s < nsn; ++s) visit(s);
+    else for (int s = nsn - 1; s >= 0; --s) visit(s);
+    std::vector<std::vector<int32_t>> by_level(height);
+    for (int s = 0; s < nsn; ++s) by_level[lev[s]].push_back(s);
+    for (int l = 0; l < height; ++l) {
+      TriLevel tl;
+      tl.begin = static_cast<int32_t>(T.sn.size());
+      int maxlen = 0;
+      for (int32_t s : by_level[l]) {
+        const int lo = sn_first[s], hi = sn_first[s + 1], bsz = hi - lo;
+        TriSn R{};
+        R.ext_begin = static_cast<int32_t>(T.cols.size());
+        R.nrows = bsz;
+        auto pos = [&](int i) { return backward ? hi - 1 - i : i - lo; };  // processing position of row i
+        for (int t = 0; t < kTriSn; ++t) { R.out_row[t] = row_of[backward ? hi - 1 : lo]; R.dinv[t] = 0.0; }
+        for (int t = 0; t < bsz; ++t) {
+          const int i = backward ? hi - 1 - t : lo + t;
+          for (int32_t q = row_begin(i); q < row_end(i); ++q) {
+            const int j = col_at(q);
+            if (j < nr && sn_of[j] == s) {
+              const int pq = pos(j);
+              if (pq >= t) throw std::logic_error("cora: supernode dependency out of order");
+              R.lint[t * (t - 1) / 2 + pq] += val_at(q);
+            } else {
+              if (row_of[j] >= (1 << 28)) throw std::runtime_error("cora: too many rows for the packed triangular-solve index");
+              T.cols.push_back(row_of[j] | (t << 28));  // position of the row inside its supernode in the top bits
+              T.vals.push_back(val_at(q));
+            }
+          }
+          R.out_row[t] = row_of[i];
+          R.dinv[t] = 1.0 / Lx[Lp[i]];
+        }
+        R.ext_end = static_cast<int32_t>(T.cols.size());
+        maxlen = std::max(maxlen, R.ext_end - R.ext_begin);
+        T.sn.push_back(R);
       }
-      tl.end = static_cast<int32_t>(T.out_row.size());
+      tl.end = static_cast<int32_t>(T.sn.size());
       tl.lanes = lanes_for(maxlen);
       T.levels.push_back(tl);
     }
+    return height;
   };
-  emit(P.fwd, lev, height, [&](int i) { return rptr[i]; }, [&](int i) { return rptr[i + 1]; },
-       [&](int32_t q) { return rcol[q]; }, [&](int32_t q) { return rval[q]; },
-       [&](int i) { return Lx[Lp[i]]; }, false);
-
-  // ---- backward (L^T x = y, pull over the columns of L): x_j needs x_i for the
-  // rows i > j of column j; border rows are solved first, so they count as level -1.
-  std::vector<int32_t> blev(first_border, 0);
-  int bheight = 0;
-  for (int j = first_border - 1; j >= 0; --j) {
-    int l = 0;
-    for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
-      const int i = Li[q];
-      if (i < first_border) l = std::max(l, blev[i] + 1);
-    }
-    blev[j] = l;
-    bheight = std::max(bheight, l + 1);
-  }
-  emit(P.bwd, blev, bheight, [&](int j) { return Lp[j] + 1; }, [&](int j) { return Lp[j + 1]; },
-       [&](int32_t q) { return Li[q]; }, [&](int32_t q) { return Lx[q]; },
-       [&](int j) { return Lx[Lp[j]]; }, false);
-  P.height = std::max(height, bheight);
+  const int hf = emit(P.fwd, false, [&](int i) { return rptr[i]; }, [&](int i) { return rptr[i + 1]; },
+                      [&](int32_t q) { return rcol[q]; }, [&](int32_t q) { return rval[q]; });
+  const int hb = emit(P.bwd, true, [&](int j) { return Lp[j] + 1; }, [&](int j) { return Lp[j + 1]; },
+                      [&](int32_t q) { return Li[q]; }, [&](int32_t q) { return Lx[q]; });
+  P.height = std::max(hf, hb);
 }
 
 }  // namespace cora

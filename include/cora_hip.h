@@ -156,6 +156,10 @@ int cora_precond_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp,
                               const int32_t *Li, const double *Lx,
                               const int32_t *perm);
 
+/* Triangular-solve schedule of the installed factor: [0] forward levels, [1] backward levels,
+ * [2] nnz(L), [3] dense border rows. */
+int cora_precond_stats(const cora_ctx *ctx, int64_t stats[4]);
+
 /* Problem::precondition(V), src/CORA_problem.cpp:869-903 (no projection;
  * last row zeroed when the factor has N-1 rows, src/CORA_preconditioners.cpp:
  * 78-79; NaN guard -> CORA_ERR_NAN). */
