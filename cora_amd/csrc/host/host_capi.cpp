@@ -7,6 +7,7 @@
 
 #include "../../../include/cora_hip.h"
 #include "CORA_problem.h"
+#include "odometry_init.h"
 #include "pyfg_text_parser.h"
 #include "CORA.h"
 #include "TNT.h"
@@ -150,6 +151,7 @@ int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, 
     else if (o == "projectToManifold") res = q.projectToManifold(wrap(A, N, r));
     else if (o == "retract") res = q.retract(wrap(A, N, r), wrap(B, N, r));
     else if (o == "getRandomInitialGuess") res = q.getRandomInitialGuess();
+    else if (o == "getOdomInitialization") res = getOdomInitialization(q);
     else throw std::invalid_argument("unknown operator " + o);
     std::memcpy(out, res.data(), sizeof(double) * static_cast<size_t>(res.size()));
   });

@@ -51,6 +51,7 @@ int cora_problem_set_device(cora_problem *p, int device);
  *  "projectToManifold"        A                  -> out
  *  "retract"                  A=Y, B=V           -> out
  *  "getRandomInitialGuess"    (none)             -> out
+ *  "getOdomInitialization"    (none)             -> out   (examples/paper_experiments.cpp:426-534)
  * Inputs are N x cols with leading dimension N (cols is checked against the relaxation rank by
  * the C++ methods, like the reference's checkMatrixShape); the output is N x rank. */
 int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, const double *B,
