@@ -41,3 +41,14 @@ for name, fn, by in (("spmm", lambda: c.spmm_dev(x, p, o), b_spmm), ("hvp", lamb
     ms = c.timer_stop_ms()
     us = ms * 1e3 / reps
     print("%s: %.2f us  %.2f MB algorithmic  %.0f GB/s (%.1f%% of 8 TB/s)" % (name, us, by / 1e6, by / us / 1e3, by / us / 1e3 / 80))
+
+# PCIe-inclusive rate of the host-pointer entry point (3 uploads + 1 download per call)
+import time as _t
+G = c.Euclidean_gradient(Y)
+Vh = rng.uniform(-1, 1, (dm.N, p))
+c.Riemannian_Hessian_vector_product(Y, G, Vh)
+t0 = _t.perf_counter()
+for _ in range(5):
+    c.Riemannian_Hessian_vector_product(Y, G, Vh)
+dt = (_t.perf_counter() - t0) / 5
+print("host-pointer Hvp (PCIe inclusive): %.2f ms per call = %.0f Hvp/s" % (dt * 1e3, 1 / dt))
