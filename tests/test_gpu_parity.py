@@ -178,3 +178,36 @@ def test_partitioned_handles_match_single():
         c.close()
     assert relerr(total, ref) < REL
     assert abs(fsum - orc.cost(Q, Y)) < 1e-11 * orc.cost(Q, Y)
+
+
+@pytest.mark.parametrize("k", [1, 2, 9, 11, 12, 13, 17, 24])
+def test_wide_blocks_every_row_stride(k):
+    """Every compiled row stride (LD = k up to 12, then 16 / 20 / 24): Q*X and (Q - Lambda) X on
+    k-column blocks (the LOBPCG block sizes of certification), plus Gram / combine kernels."""
+    A, Q, dm = make_problem(d=3, n=400, n_landmarks=3, n_ranges=250, n_loops=5, seed=12)
+    p = 4
+    c = ctx_for(Q, dm, p)
+    rng = np.random.default_rng(k)
+    Y = orc.project_manifold(dm, rng.uniform(-1, 1, (dm.N, p)))
+    c.set_point(Y)
+    X = rng.standard_normal((dm.N, k))
+    assert relerr(c.dataMatrixProduct(X), orc.spmm(Q, X)) < REL
+    st, ob = orc.lambda_blocks(Q, dm, Y)
+    assert relerr(c.certificate_product(X), orc.S_apply(Q, dm, st, ob, X)) < REL
+    assert abs(c.inner_product(X, X) - orc.inner(X, X)) < 1e-12 * orc.inner(X, X)
+
+
+def test_rank_up_to_24():
+    A, Q, dm = make_problem(d=3, n=200, n_landmarks=2, n_ranges=100, seed=3)
+    rng = np.random.default_rng(0)
+    for p in (9, 11, 16, 24):
+        c = ctx_for(Q, dm, p)
+        Y = orc.project_manifold(dm, rng.uniform(-1, 1, (dm.N, p)))
+        G = orc.egrad(Q, Y)
+        V = orc.tangent_proj(dm, Y, rng.uniform(-1, 1, (dm.N, p)))
+        assert relerr(c.Riemannian_Hessian_vector_product(Y, G, V), orc.hvp(Q, dm, Y, G, V)) < REL
+        assert np.abs(c.retract(Y, 0.3 * V) - orc.retract(dm, Y, 0.3 * V)).max() < 1e-11
+        c.close()
+    c = ctx_for(Q, dm, 3)
+    with pytest.raises(capi.CoraError):
+        c.set_rank(25)
