@@ -36,6 +36,7 @@ struct cora_ctx {
   int32_t *d_scol = nullptr;
   int32_t *d_perm = nullptr;
   LongChunk *d_chunks = nullptr;
+  int32_t *d_chunk_order = nullptr;
   double *d_lval = nullptr;
   int32_t *d_lcol = nullptr;
   double *d_partials = nullptr;
@@ -155,6 +156,7 @@ SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
   A.scol = c->d_scol;
   A.perm = c->d_perm;
   A.chunks = c->d_chunks;
+  A.chunk_order = c->d_chunk_order;
   A.lval = c->d_lval;
   A.lcol = c->d_lcol;
   A.partials = c->d_partials;
@@ -307,6 +309,7 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
   CREATE_TRY(to_device(&c->d_scol, F.scol));
   CREATE_TRY(to_device(&c->d_perm, F.perm));
   CREATE_TRY(to_device(&c->d_chunks, F.chunks));
+  CREATE_TRY(to_device(&c->d_chunk_order, F.chunk_order));
   CREATE_TRY(to_device(&c->d_lval, F.lval));
   CREATE_TRY(to_device(&c->d_lcol, F.lcol));
   CREATE_TRY(to_device(&c->d_api2int, F.api2int));
@@ -346,7 +349,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_rank_state(c);
-    void *ptrs[] = {c->d_slices, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_lval, c->d_lcol,
+    void *ptrs[] = {c->d_slices, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
                     c->d_stage, c->d_red, c->d_scalars, c->d_flag};
     for (void *p : ptrs)

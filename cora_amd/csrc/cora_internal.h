@@ -87,6 +87,8 @@ struct HostFormat {
   std::vector<int32_t> scol;
   std::vector<int32_t> perm;      // internal rows for kSliceEuclidPerm slices
   std::vector<LongChunk> chunks;
+  std::vector<int32_t> chunk_order;  // launch order of the chunks: by first column, so that chunks of
+                                     // different long rows that read the same region of X run together
   std::vector<double> lval;
   std::vector<int32_t> lcol;
   int n_long_rows = 0;

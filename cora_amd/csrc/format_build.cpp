@@ -358,6 +358,15 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     }
   }
 
+  // long-row chunks: launch order by the region of X they read
+  F.chunk_order.resize(F.chunks.size());
+  std::iota(F.chunk_order.begin(), F.chunk_order.end(), 0);
+  std::stable_sort(F.chunk_order.begin(), F.chunk_order.end(), [&](int32_t a, int32_t b) {
+    const int32_t ca = F.chunks[a].k1 > F.chunks[a].k0 ? F.lcol[F.chunks[a].k0] : 0;
+    const int32_t cb = F.chunks[b].k1 > F.chunks[b].k0 ? F.lcol[F.chunks[b].k0] : 0;
+    return ca < cb;
+  });
+
   // ---- 4. work order: walk the pose chain, so that the pose / range /
   // translation slices that gather the same rows of X run close together in
   // time (and, with the kernel's per-XCD block chunking, on the same L2).

@@ -22,6 +22,7 @@ struct SpmmArgs {
   const int32_t *scol;
   const int32_t *perm;
   const LongChunk *chunks;
+  const int32_t *chunk_order;
   const double *lval;
   const int32_t *lcol;
   double *partials;    // [n_chunks][kMaxLD]

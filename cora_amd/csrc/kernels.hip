@@ -241,7 +241,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM
 void k_spmm(const SpmmArgs A) {
   // one wavefront per block: the dispatcher balances the (uneven) slices
   if (static_cast<int>(blockIdx.x) < A.n_chunks) {
-    if (static_cast<int>(blockIdx.x) < A.n_real_chunks) long_chunk_wave<LD>(A, blockIdx.x);
+    // chunk blocks, also one contiguous range of the (column-sorted) launch order per XCD
+    const int tc = static_cast<int>(blockIdx.x);
+    const int cper = A.n_chunks >> 3;  // n_chunks is a multiple of 8
+    const int pos = (tc & 7) * cper + (tc >> 3);
+    if (pos < A.n_real_chunks) long_chunk_wave<LD>(A, A.chunk_order[pos]);
     return;
   }
   const int lane = threadIdx.x;

@@ -117,7 +117,7 @@ int main(int argc, char **argv) {
   build_format(d, n, r, nt, rowptr.data(), col.data(), val.data(), 0, 1, F);
   if (nolong) {
     const int mode = atoi(argv[4]);  // 0: drop chunks; 1: empty single-chunk rows; 2: empty multi-chunk rows
-    if (mode == 0) F.chunks.clear();
+    if (mode == 0) { F.chunks.clear(); F.chunk_order.clear(); }
     for (auto &ch : F.chunks) {
       ch.k1 = ch.k0;
       if (mode == 1) { ch.nchunks = 1; }
@@ -145,6 +145,7 @@ int main(int argc, char **argv) {
   A.scol = dev(F.scol);
   A.perm = dev(F.perm);
   A.chunks = dev(F.chunks);
+  A.chunk_order = dev(F.chunk_order);
   A.lval = dev(F.lval);
   A.lcol = dev(F.lcol);
   std::vector<double> part(std::max<size_t>(F.chunks.size(), 1) * kMaxLD, 0.0);
