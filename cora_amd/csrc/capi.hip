@@ -45,16 +45,18 @@ struct cora_ctx {
   double *d_diag_inv = nullptr;  // 1/diag(Q), local rows
   double *d_lam_st = nullptr, *d_lam_ob = nullptr;
 
-  // Cholesky preconditioner (level-scheduled triangular solves)
-  TriPlan tri;
-  bool have_chol = false;
-  std::vector<void *> tri_allocs;
-  TriDev d_fwd{}, d_bwd{};
-  BorderDev d_border{};
-  // the ~2 x (tree height) tiny launches of one solve are replayed as a hipGraph, keyed by the
-  // vector they run on (the solver applies the preconditioner to the same buffers every iteration)
-  struct TriGraph { int ld; double *x; hipGraphExec_t exec; };
-  std::vector<TriGraph> tri_graphs;
+  // sparse Cholesky factors resident on the device (level-scheduled triangular solves):
+  // the preconditioner's (Q + lambda I)[0:m] and, for the translation-implicit formulation,
+  // the translation Laplacian Q33[0:nt-1]
+  struct DevFactor {
+    TriPlan plan;
+    TriDev fwd{}, bwd{};
+    BorderDev border{};
+    std::vector<void *> allocs;
+    bool ready = false;
+  };
+  DevFactor precond_f, implicit_f;
+  bool implicit = false;  // Formulation::Implicit active
 
   bool have_point = false;
   double *d_Y = nullptr, *d_G = nullptr, *d_rgrad = nullptr;
@@ -76,7 +78,8 @@ struct cora_ctx {
   std::string err;
 };
 
-static void drop_tri_graphs(cora_ctx *c);
+struct cora_ctx;
+static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut);  // formulation-aware
 
 namespace {
 
@@ -248,8 +251,8 @@ int point_finish(cora_ctx *c) {
 int set_point_dev_impl(cora_ctx *c, const double *dY) {
   if (dY != c->d_Y)
     HIP_TRY(c, hipMemcpyAsync(c->d_Y, dY, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
-  const SpmmArgs A = spmm_args(c, c->d_Y, c->d_G);
-  HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_NONE, c->stream));
+  const int rc = apply_product(c, c->d_Y, c->ld, EPI_NONE, c->d_G);
+  if (rc) return rc;
   return point_finish(c);
 }
 
@@ -358,9 +361,9 @@ void cora_ctx_destroy(cora_ctx *c) {
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (void *p : c->user_allocs)
       if (p) (void)hipFree(p);
-    drop_tri_graphs(c);
-    for (void *p : c->tri_allocs)
-      if (p) (void)hipFree(p);
+    for (auto *f : {&c->precond_f, &c->implicit_f})
+      for (void *p : f->allocs)
+        if (p) (void)hipFree(p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -395,7 +398,6 @@ int cora_get_rank(const cora_ctx *c) { return c ? c->p : 0; }
 int cora_set_stream(cora_ctx *c, void *hip_stream) {
   NEED_DEVICE(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  drop_tri_graphs(c);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->stream = static_cast<hipStream_t>(hip_stream);
   c->own_stream = false;
@@ -417,10 +419,11 @@ int cora_row_map(const cora_ctx *c, int32_t *api_to_internal) {
 
 int cora_precond_stats(const cora_ctx *c, int64_t s[4]) {
   if (!c || !s) return CORA_ERR_ARG;
-  s[0] = c->have_chol ? static_cast<int64_t>(c->tri.fwd.levels.size()) : 0;
-  s[1] = c->have_chol ? static_cast<int64_t>(c->tri.bwd.levels.size()) : 0;
-  s[2] = c->have_chol ? c->tri.nnzL : 0;
-  s[3] = c->have_chol ? c->tri.border.nb : 0;
+  const auto &f = c->precond_f;
+  s[0] = f.ready ? static_cast<int64_t>(f.plan.fwd.levels.size()) : 0;
+  s[1] = f.ready ? static_cast<int64_t>(f.plan.bwd.levels.size()) : 0;
+  s[2] = f.ready ? f.plan.nnzL : 0;
+  s[3] = f.ready ? f.plan.border.nb : 0;
   return CORA_OK;
 }
 
@@ -454,7 +457,6 @@ int cora_dev_free(cora_ctx *c, double *dptr) {
   for (auto &p : c->user_allocs)
     if (p == dptr) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      drop_tri_graphs(c);  // a cached graph may point at this buffer
       (void)hipFree(dptr);
       p = nullptr;
       return CORA_OK;
@@ -497,8 +499,7 @@ int cora_objective_dev(cora_ctx *c, const double *dY, double *f) {
   double *dG;
   int rc = get_scratch(c, 5, c->ld, &dG);
   if (rc) return rc;
-  const SpmmArgs A = spmm_args(c, dY, dG);
-  HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_NONE, c->stream));
+  if ((rc = apply_product(c, dY, c->ld, EPI_NONE, dG))) return rc;
   double v = 0.0;
   const double *a[1] = {dY};
   const double *b[1] = {dG};
@@ -522,9 +523,7 @@ const double *cora_point_rgrad_dev(const cora_ctx *c) { return (c && c->have_poi
 int cora_spmm_dev(cora_ctx *c, const double *dX, int k, double *dOut) {
   NEED_DEVICE(c);
   if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
-  const SpmmArgs A = spmm_args(c, dX, dOut);
-  HIP_TRY(c, launch_spmm(A, ld_for(k), c->F.L.d, EPI_NONE, c->stream));
-  return CORA_OK;
+  return apply_product(c, dX, ld_for(k), EPI_NONE, dOut);
 }
 
 int cora_hvp_dev(cora_ctx *c, const double *dX, double *dOut) {
@@ -532,9 +531,7 @@ int cora_hvp_dev(cora_ctx *c, const double *dX, double *dOut) {
   NEED_RANK(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dX || !dOut) return fail(c, CORA_ERR_ARG, "null pointer");
-  const SpmmArgs A = spmm_args(c, dX, dOut);
-  HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP, c->stream));
-  return CORA_OK;
+  return apply_product(c, dX, c->ld, EPI_HVP, dOut);
 }
 
 int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *dOut) {
@@ -564,7 +561,7 @@ int cora_precond_setup(cora_ctx *c, int kind) {
     return CORA_OK;
   }
   if (kind == CORA_PRECOND_BLOCK_CHOLESKY || kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
-    if (!c->have_chol)
+    if (!c->precond_f.ready)
       return fail(c, CORA_ERR_NOT_READY,
                   "Cholesky preconditioners need a factor installed with cora_precond_set_cholesky");
     c->precond = kind;
@@ -573,43 +570,25 @@ int cora_precond_setup(cora_ctx *c, int kind) {
   return fail(c, CORA_ERR_ARG, "unknown preconditioner kind");
 }
 
-int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
-                              const int32_t *perm) {
-  NEED_DEVICE(c);
-  const int64_t N = c->F.L.N;
-  if (c->F.L.world != 1)
-    return fail(c, CORA_ERR_ARG, "the Cholesky preconditioner does not shard (sequential triangular solves): "
-                                 "use Jacobi on partitioned handles");
-  if (!Lp || !Li || !Lx || !perm || (m != N && m != N - 1))
-    return fail(c, CORA_ERR_ARG, "factor must have N or N-1 rows");
-  std::vector<int32_t> row_of(static_cast<size_t>(m));
-  std::vector<char> seen(static_cast<size_t>(N), 0);
-  for (int i = 0; i < m; ++i) {
-    if (perm[i] < 0 || perm[i] >= N || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
-    seen[perm[i]] = 1;
-    row_of[i] = c->F.api2int[perm[i]];
-  }
+// Builds the level schedule of a factor and uploads it.  row_of[i] = internal row of permuted variable i.
+static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int32_t *Lp, const int32_t *Li,
+                          const double *Lx, const std::vector<int32_t> &row_of) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (void *p : f.allocs)
+    if (p) (void)hipFree(p);
+  f.allocs.clear();
+  f.ready = false;
   try {
-    build_tri_plan(m, Lp, Li, Lx, row_of, c->tri);
+    build_tri_plan(m, Lp, Li, Lx, row_of, f.plan);
   } catch (const std::exception &e) {
     return fail(c, CORA_ERR_ARG, e.what());
   }
-  c->tri.zero_row = -1;
-  if (m == N - 1)
-    for (int64_t i = 0; i < N; ++i)
-      if (!seen[i]) c->tri.zero_row = c->F.api2int[i];
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  drop_tri_graphs(c);
-  for (void *p : c->tri_allocs)
-    if (p) (void)hipFree(p);
-  c->tri_allocs.clear();
-  c->have_chol = false;
   auto up = [&](auto **dst, const auto &vec) -> hipError_t {
     using T = typename std::remove_reference<decltype(vec)>::type::value_type;
     T *p = nullptr;
     hipError_t e = to_device(&p, vec);
     if (e == hipSuccess) {
-      c->tri_allocs.push_back(p);
+      f.allocs.push_back(p);
       *dst = p;
     }
     return e;
@@ -622,10 +601,10 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
     D.levels = &H.levels;
     return hipSuccess;
   };
-  HIP_TRY(c, up_tri(c->d_fwd, c->tri.fwd));
-  HIP_TRY(c, up_tri(c->d_bwd, c->tri.bwd));
-  const BorderHost &B = c->tri.border;
-  BorderDev &D = c->d_border;
+  HIP_TRY(c, up_tri(f.fwd, f.plan.fwd));
+  HIP_TRY(c, up_tri(f.bwd, f.plan.bwd));
+  const BorderHost &B = f.plan.border;
+  BorderDev &D = f.border;
   D.nb = B.nb;
   D.nchunks = static_cast<int>(B.chunk_row.size());
   HIP_TRY(c, up(&D.Lbb, B.Lbb));
@@ -645,54 +624,137 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
     std::vector<double> part(std::max<size_t>(B.chunk_row.size(), 1) * kMaxLD, 0.0);
     double *p = nullptr;
     HIP_TRY(c, to_device(&p, part));
-    c->tri_allocs.push_back(p);
+    f.allocs.push_back(p);
     D.partial = p;
   }
-  c->have_chol = true;
+  f.ready = true;
   return CORA_OK;
 }
 
-static void drop_tri_graphs(cora_ctx *c) {
-  for (auto &g : c->tri_graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  c->tri_graphs.clear();
-}
-
-static int chol_solve_launches(cora_ctx *c, int ld, double *dOut) {
-  HIP_TRY(c, launch_tri_solve(c->d_fwd, c->d_bwd, c->d_border, ld, dOut, c->stream));
-  if (c->tri.zero_row >= 0)  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
-    HIP_TRY(c, launch_zero_row(dOut, static_cast<size_t>(c->tri.zero_row), ld, c->stream));
+// x[rows of the factor] <- (P^T L L^T P)^-1 x[rows of the factor], in place on a resident vector
+static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, double *x) {
+  HIP_TRY(c, launch_tri_solve(f.fwd, f.bwd, f.border, ld, x, c->stream));
   return CORA_OK;
 }
 
-// out = [ (P^T L L^T P)^-1 V[0:m] ; 0 ]  in place on dOut (already holding V)
+int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
+                              const int32_t *perm) {
+  NEED_DEVICE(c);
+  const int64_t N = c->F.L.N;
+  if (c->F.L.world != 1)
+    return fail(c, CORA_ERR_ARG, "the Cholesky preconditioner does not shard (sequential triangular solves): "
+                                 "use Jacobi on partitioned handles");
+  if (!Lp || !Li || !Lx || !perm || (m != N && m != N - 1))
+    return fail(c, CORA_ERR_ARG, "factor must have N or N-1 rows");
+  std::vector<int32_t> row_of(static_cast<size_t>(m));
+  std::vector<char> seen(static_cast<size_t>(N), 0);
+  for (int i = 0; i < m; ++i) {
+    if (perm[i] < 0 || perm[i] >= N || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
+    seen[perm[i]] = 1;
+    row_of[i] = c->F.api2int[perm[i]];
+  }
+  const int rc = install_factor(c, c->precond_f, m, Lp, Li, Lx, row_of);
+  if (rc) return rc;
+  c->precond_f.plan.zero_row = -1;
+  if (m == N - 1)
+    for (int64_t i = 0; i < N; ++i)
+      if (!seen[i]) c->precond_f.plan.zero_row = c->F.api2int[i];
+  return CORA_OK;
+}
+
+// out = [ (Q + lambda I)[0:m]^-1 V[0:m] ; 0 ]  in place on dOut (already holding V)
 static int chol_solve_inplace(cora_ctx *c, int ld, double *dOut) {
-  static const bool use_graph = std::getenv("CORA_NO_GRAPH") == nullptr;
-  if (!use_graph) return chol_solve_launches(c, ld, dOut);
-  for (auto &g : c->tri_graphs)
-    if (g.ld == ld && g.x == dOut) {
-      HIP_TRY(c, hipGraphLaunch(g.exec, c->stream));
-      return CORA_OK;
-    }
-  hipGraph_t graph = nullptr;
-  HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  const int rc = chol_solve_launches(c, ld, dOut);
-  const hipError_t e = hipStreamEndCapture(c->stream, &graph);
-  if (rc != CORA_OK) {
-    if (graph) (void)hipGraphDestroy(graph);
-    return rc;
-  }
-  HIP_TRY(c, e);
-  hipGraphExec_t exec = nullptr;
-  HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  (void)hipGraphDestroy(graph);
-  if (c->tri_graphs.size() >= 8) {  // keep the cache small
-    (void)hipGraphExecDestroy(c->tri_graphs.front().exec);
-    c->tri_graphs.erase(c->tri_graphs.begin());
-  }
-  c->tri_graphs.push_back({ld, dOut, exec});
-  HIP_TRY(c, hipGraphLaunch(exec, c->stream));
+  int rc = factor_solve(c, c->precond_f, ld, dOut);
+  if (rc) return rc;
+  if (c->precond_f.plan.zero_row >= 0)  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
+    HIP_TRY(c, launch_zero_row(dOut, static_cast<size_t>(c->precond_f.plan.zero_row), ld, c->stream));
   return CORA_OK;
+}
+
+// ---- translation-implicit formulation (src/CORA_problem.cpp:714-753) ------------------------
+// Q_impl Y = Qmain Y - B M^-1 B^T Y with M = Q33[0:nt-1] = top rows of Q [Y; t; 0] for
+// t = -M^-1 (B^T Y), and B^T Y = translation rows of Q [Y; 0].  Two explicit products and
+// one triangular solve on the translation block; vectors keep N rows, translation rows of the
+// input are ignored and translation rows of the output are zero.
+static int implicit_lift(cora_ctx *c, const double *dX, int ld, double *w0, double *w1) {
+  const Layout &L = c->F.L;
+  const size_t toff = static_cast<size_t>(L.trn_base) * ld;
+  const size_t tbytes = static_cast<size_t>(L.nl_trans) * ld * sizeof(double);
+  HIP_TRY(c, hipMemcpyAsync(w0, dX, vec_bytes(c, ld), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(w0 + toff, 0, tbytes, c->stream));
+  SpmmArgs A = spmm_args(c, w0, w1);
+  HIP_TRY(c, launch_spmm(A, ld, L.d, EPI_NONE, c->stream));                      // w1[trans] = B^T X
+  const size_t last = static_cast<size_t>(L.trn_base) + L.nl_trans - 1;           // pinned translation
+  HIP_TRY(c, launch_zero_row(w1, last, ld, c->stream));
+  int rc = factor_solve(c, c->implicit_f, ld, w1);                                 // w1[trans] = M^-1 B^T X
+  if (rc) return rc;
+  HIP_TRY(c, launch_axpby(static_cast<int64_t>(L.nl_trans) * ld, -1.0, w1 + toff, 0.0, w0 + toff, c->stream));
+  HIP_TRY(c, launch_zero_row(w0, last, ld, c->stream));                            // w0 = [X; t; 0]
+  return CORA_OK;
+}
+
+static int implicit_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut) {
+  if (!c->implicit_f.ready)
+    return fail(c, CORA_ERR_NOT_READY, "implicit formulation needs cora_implicit_set_cholesky");
+  double *w0, *w1;
+  int rc;
+  if ((rc = get_scratch(c, 3, ld, &w0))) return rc;
+  if ((rc = get_scratch(c, 4, ld, &w1))) return rc;
+  if ((rc = implicit_lift(c, dX, ld, w0, w1))) return rc;
+  SpmmArgs A = spmm_args(c, w0, dOut);
+  HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
+  const Layout &L = c->F.L;
+  HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(L.trn_base) * ld, 0,
+                            static_cast<size_t>(L.nl_trans) * ld * sizeof(double), c->stream));
+  return CORA_OK;
+}
+
+// one product in the active formulation
+static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut) {
+  if (c->implicit) return implicit_product(c, dX, ld, epi, dOut);
+  const SpmmArgs A = spmm_args(c, dX, dOut);
+  HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
+  return CORA_OK;
+}
+
+int cora_implicit_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
+                               const int32_t *perm) {
+  NEED_DEVICE(c);
+  const Layout &L = c->F.L;
+  if (L.world != 1) return fail(c, CORA_ERR_ARG, "the implicit formulation is single-GPU");
+  if (!Lp || !Li || !Lx || !perm || m != L.nt - 1) return fail(c, CORA_ERR_ARG, "factor must have n + l - 1 rows");
+  const int64_t tb = static_cast<int64_t>(L.d) * L.n + L.r;
+  std::vector<int32_t> row_of(static_cast<size_t>(m));
+  std::vector<char> seen(static_cast<size_t>(L.nt), 0);
+  for (int i = 0; i < m; ++i) {
+    if (perm[i] < 0 || perm[i] >= L.nt - 1 || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
+    seen[perm[i]] = 1;
+    row_of[i] = c->F.api2int[tb + perm[i]];
+  }
+  return install_factor(c, c->implicit_f, m, Lp, Li, Lx, row_of);
+}
+
+int cora_set_formulation(cora_ctx *c, int implicit) {
+  if (!c) return CORA_ERR_ARG;
+  if (implicit && !c->implicit_f.ready)
+    return fail(c, CORA_ERR_NOT_READY, "implicit formulation needs cora_implicit_set_cholesky");
+  if (c->implicit != (implicit != 0)) {
+    c->implicit = implicit != 0;
+    c->have_point = false;  // cached QY / Lambda belong to the other operator
+  }
+  return CORA_OK;
+}
+
+int cora_translation_explicit_dev(cora_ctx *c, const double *dY, int k, double *dOut) {
+  NEED_DEVICE(c);
+  if (!dY || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  if (!c->implicit_f.ready)
+    return fail(c, CORA_ERR_NOT_READY, "implicit formulation needs cora_implicit_set_cholesky");
+  double *w1;
+  int rc;
+  if ((rc = get_scratch(c, 4, ld_for(k), &w1))) return rc;
+  if (dOut == dY) return fail(c, CORA_ERR_ARG, "output aliases the input");
+  return implicit_lift(c, dY, ld_for(k), dOut, w1);  // dOut = [Y; -M^-1 B^T Y; 0]
 }
 
 int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut) {
@@ -704,8 +766,14 @@ int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut)
   else if (c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY) {
     if (dOut != dV)
       HIP_TRY(c, hipMemcpyAsync(dOut, dV, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
+    if (c->implicit)  // V_lift = [V; 0], src/CORA_problem.cpp:878-884
+      HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(c->F.L.trn_base) * c->ld, 0,
+                                static_cast<size_t>(c->F.L.nl_trans) * c->ld * sizeof(double), c->stream));
     int rc = chol_solve_inplace(c, c->ld, dOut);
     if (rc) return rc;
+    if (c->implicit)
+      HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(c->F.L.trn_base) * c->ld, 0,
+                                static_cast<size_t>(c->F.L.nl_trans) * c->ld * sizeof(double), c->stream));
     HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dOut, nullptr, dOut, c->stream));
     return CORA_OK;
   } else if (c->precond != CORA_PRECOND_NONE) return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up");

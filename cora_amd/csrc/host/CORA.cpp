@@ -17,7 +17,14 @@ Scalar thresholdVal(Scalar v, Scalar lo, Scalar hi) { return v < lo ? lo : (v > 
 
 CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank, bool verbose, bool log_iterates,
                      bool show_iterates, CoraSolveInfo *info, const TNTParams *params_override) {
-  checkMatrixShape("solveCora::Explicit", problem.getDataMatrixSize(), x0.cols(), x0.rows(), x0.cols());
+  if (problem.getFormulation() == Formulation::Explicit) {
+    checkMatrixShape("solveCora::Explicit", problem.getDataMatrixSize(), x0.cols(), x0.rows(), x0.cols());
+  } else {  // src/CORA.cpp:33-40
+    std::cout << "Solving problem in translation implicit mode. Make sure that the initial guess only contains "
+                 "rotation and range variables."
+              << std::endl;
+    checkMatrixShape("solveCora::Implicit", problem.rotAndRangeMatrixSize(), x0.cols(), x0.rows(), x0.cols());
+  }
   if (log_iterates)
     std::cout << "WARNING: Logging iterates will slow down the optimization process.  This is intended for "
                  "debugging and viz purposes only."
@@ -53,6 +60,8 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     eta = thresholdVal(result.f * REL_CERT_ETA, MIN_CERT_ETA, MAX_CERT_ETA);
     if (first_loop) {
       eigvec_bootstrap = result.x;
+      if (problem.getFormulation() == Formulation::Implicit)  // src/CORA.cpp:158-164
+        eigvec_bootstrap = problem.getTranslationExplicitSolution(eigvec_bootstrap);
       first_loop = false;
     } else {
       eigvec_bootstrap = cert.all_eigvecs;

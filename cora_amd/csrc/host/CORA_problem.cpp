@@ -26,8 +26,6 @@ Problem::Problem(int dim, int relaxation_rank, Formulation formulation, Precondi
       formulation_(formulation),
       preconditioner_(preconditioner) {
   if (relaxation_rank < dim) throw std::invalid_argument("relaxation rank must be >= dim");
-  if (formulation != Formulation::Explicit)
-    throw NotImplementedException("Implicit (translation-marginalised) formulation");
 }
 
 // ---- registry: src/CORA_problem.cpp:24-113 ---------------------------------
@@ -252,7 +250,22 @@ const SparseMatrix &Problem::getDataMatrix() {
 }
 
 int Problem::getDataMatrixSize() const { return numPoses() * (dim_ + 1) + numLandmarks() + numRangeMeasurements(); }
-int Problem::getExpectedVariableSize() const { return getDataMatrixSize(); }
+int Problem::getExpectedVariableSize() const {  // src/CORA_problem.cpp:944-952
+  return formulation_ == Formulation::Implicit ? rotAndRangeMatrixSize() : getDataMatrixSize();
+}
+
+// Device vectors always have getDataMatrixSize() rows; in the implicit formulation the host-side
+// variable is the leading rotAndRangeMatrixSize() rows and the translation rows are zero.
+const Matrix &Problem::lifted(const Matrix &M, Matrix &tmp) const {
+  if (formulation_ != Formulation::Implicit) return M;
+  tmp = Matrix::Zero(getDataMatrixSize(), M.cols());
+  tmp.setBlock(0, 0, M);
+  return tmp;
+}
+Matrix Problem::lowered(Matrix &&M) const {
+  if (formulation_ != Formulation::Implicit) return std::move(M);
+  return M.block(0, 0, rotAndRangeMatrixSize(), M.cols());
+}
 
 void Problem::checkUpToDate() const {
   if (!problem_data_up_to_date_)
@@ -280,6 +293,12 @@ void Problem::ensureContext() const {
       throw std::runtime_error(std::string("CORA::Problem: cannot create the device problem: ") +
                                cora_last_error(nullptr));
     ctx_ = std::shared_ptr<cora_ctx>(c, [](cora_ctx *p) { cora_ctx_destroy(p); });
+    implicit_ready_ = false;
+  }
+  if (formulation_ == Formulation::Implicit && !implicit_ready_) fillImplicitFormulationMatrices();
+  {
+    const int rc = cora_set_formulation(ctx_.get(), formulation_ == Formulation::Implicit ? 1 : 0);
+    if (rc != CORA_OK) throwLast(rc, "Problem::setFormulation");
   }
   if (cora_get_rank(ctx_.get()) != relaxation_rank_) {
     const int rc = cora_set_rank(ctx_.get(), relaxation_rank_);
@@ -289,6 +308,38 @@ void Problem::ensureContext() const {
 }
 
 void Problem::updatePreconditioner() { ensurePreconditioner(); }
+
+// src/CORA_problem.cpp:714-740.  The reference keeps Qmain, [Q13; Q23] without its last column and
+// chol(Q33[0:nt-1, 0:nt-1]) on the host; here Q is already resident in full, so only the factor of
+// the reduced translation block is computed (host sparse Cholesky) and handed to the device.
+void Problem::fillImplicitFormulationMatrices() const {
+  if (formulation_ != Formulation::Implicit)
+    throw std::invalid_argument(
+        "Implicit formulation matrices should only be filled when the problem is in implicit formulation mode");
+  const Index tb = rotAndRangeMatrixSize(), nt = numTranslationalStates(), m = nt - 1;
+  if (m < 1) throw std::invalid_argument("the implicit formulation needs at least two translational states");
+  std::vector<Triplet> t;
+  for (Index i = 0; i < m; ++i)
+    for (int32_t q = data_matrix_.outer[tb + i]; q < data_matrix_.outer[tb + i + 1]; ++q) {
+      const Index j = data_matrix_.inner[q] - tb;
+      if (j >= 0 && j < m) t.push_back({i, j, data_matrix_.values[q]});
+    }
+  SparseMatrix M(m, m);
+  M.setFromTriplets(std::move(t));
+  // same nested-dissection order as the preconditioner, restricted to the translations
+  int leaf = 8;
+  if (const char *env = std::getenv("CORA_ND_LEAF")) leaf = std::max(1, std::atoi(env));
+  SparseMatrix none(nt, nt);
+  const auto perm = coraOrdering(0, numPoses(), 0, static_cast<int>(nt), none, static_cast<int>(m), leaf);
+  const CholeskyFactor F = choleskyFactor(M, static_cast<int>(m), 0.0, perm);
+  if (!F.ok)
+    throw std::runtime_error("Problem::fillImplicitFormulationMatrices: the reduced translation block of Q is "
+                             "not positive definite (disconnected measurement graph?)");
+  const int rc = cora_implicit_set_cholesky(ctx_.get(), static_cast<int>(m), F.Lp.data(), F.Li.data(), F.Lx.data(),
+                                            F.perm.data());
+  if (rc != CORA_OK) throwLast(rc, "Problem::fillImplicitFormulationMatrices");
+  implicit_ready_ = true;
+}
 
 // ||Q||_2 = lambda_max(Q) by power iteration with the device SpMM.  The reference
 // estimates it with LOBPCG (block 4, <= 100 iterations, tolerance 1e-2,
@@ -343,7 +394,10 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
     CholeskyFactor F;
     if (kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
       // lambda_reg = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 or CORA_REG_CHOLESKY_MAX_COND (:581-591)
+      // ||D||_2 of the full data matrix in either formulation (:556-578 works on data_matrix_)
+      cora_set_formulation(ctx_.get(), 0);
       const Scalar Dnorm = spectralNormEstimate(ctx_.get(), N);
+      cora_set_formulation(ctx_.get(), formulation_ == Formulation::Implicit ? 1 : 0);
       Scalar max_cond = 1e6;
       if (const char *env = std::getenv("CORA_REG_CHOLESKY_MAX_COND")) {
         max_cond = std::stod(env);
@@ -397,22 +451,29 @@ void Problem::setRank(int r) {
   } while (0)
 
 // ---- operators (GPU): src/CORA_problem.cpp:742-938 --------------------------
+// LIFT(M) is M itself in the explicit formulation and [M; 0] in the implicit one (see lifted()).
+#define LIFT(M, name) \
+  Matrix name##_tmp;  \
+  const Matrix &name = lifted(M, name##_tmp)
+
 Matrix Problem::dataMatrixProduct(const Matrix &Y) const {
   checkMatrixShape("Problem::dataMatrixProduct::Y", getExpectedVariableSize(), Y.cols(), Y.rows(), Y.cols());
   ensureContext();
-  Matrix out(Y.rows(), Y.cols());
-  CORA_CALL(cora_data_matrix_product(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), static_cast<int>(Y.cols()),
+  LIFT(Y, Yl);
+  Matrix out(Yl.rows(), Yl.cols());
+  CORA_CALL(cora_data_matrix_product(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), static_cast<int>(Yl.cols()),
                                      out.data(), static_cast<int>(out.rows())),
             "Problem::dataMatrixProduct");
-  return out;
+  return lowered(std::move(out));
 }
 
 Scalar Problem::evaluateObjective(const Matrix &Y) const {
   checkUpToDate();
   checkMatrixShape("Problem::evaluateObjective::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   ensureContext();
+  LIFT(Y, Yl);
   Scalar f = 0;
-  CORA_CALL(cora_evaluate_objective(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), &f), "Problem::evaluateObjective");
+  CORA_CALL(cora_evaluate_objective(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), &f), "Problem::evaluateObjective");
   return f;
 }
 
@@ -420,22 +481,24 @@ Matrix Problem::Euclidean_gradient(const Matrix &Y) const {
   checkUpToDate();
   checkMatrixShape("Problem::Euclidean_gradient::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   ensureContext();
-  Matrix out(Y.rows(), Y.cols());
-  CORA_CALL(cora_euclidean_gradient(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), out.data(),
+  LIFT(Y, Yl);
+  Matrix out(Yl.rows(), Yl.cols());
+  CORA_CALL(cora_euclidean_gradient(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), out.data(),
                                     static_cast<int>(out.rows())),
             "Problem::Euclidean_gradient");
-  return out;
+  return lowered(std::move(out));
 }
 
 Matrix Problem::Riemannian_gradient(const Matrix &Y) const {
   checkUpToDate();
   checkMatrixShape("Problem::Riemannian_gradient::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   ensureContext();
-  Matrix out(Y.rows(), Y.cols());
-  CORA_CALL(cora_riemannian_gradient(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), out.data(),
+  LIFT(Y, Yl);
+  Matrix out(Yl.rows(), Yl.cols());
+  CORA_CALL(cora_riemannian_gradient(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), out.data(),
                                      static_cast<int>(out.rows())),
             "Problem::Riemannian_gradient");
-  return out;
+  return lowered(std::move(out));
 }
 
 Matrix Problem::Riemannian_gradient(const Matrix &Y, const Matrix &NablaF_Y) const {
@@ -448,11 +511,13 @@ Matrix Problem::tangent_space_projection(const Matrix &Y, const Matrix &Ydot) co
   checkMatrixShape("Problem::tangent_space_projection::Ydot", getExpectedVariableSize(), relaxation_rank_,
                    Ydot.rows(), Ydot.cols());
   ensureContext();
-  Matrix out(Y.rows(), Y.cols());
-  CORA_CALL(cora_tangent_space_projection(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), Ydot.data(),
-                                          static_cast<int>(Ydot.rows()), out.data(), static_cast<int>(out.rows())),
+  LIFT(Y, Yl);
+  LIFT(Ydot, Vl);
+  Matrix out(Yl.rows(), Yl.cols());
+  CORA_CALL(cora_tangent_space_projection(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), Vl.data(),
+                                          static_cast<int>(Vl.rows()), out.data(), static_cast<int>(out.rows())),
             "Problem::tangent_space_projection");
-  return out;
+  return lowered(std::move(out));
 }
 
 Matrix Problem::Riemannian_Hessian_vector_product(const Matrix &Y, const Matrix &nablaF_Y, const Matrix &dotY) const {
@@ -463,43 +528,74 @@ Matrix Problem::Riemannian_Hessian_vector_product(const Matrix &Y, const Matrix 
   checkMatrixShape("Problem::Riemannian_Hessian_vector_product::dotY", getExpectedVariableSize(), relaxation_rank_,
                    dotY.rows(), dotY.cols());
   ensureContext();
-  Matrix out(Y.rows(), Y.cols());
-  CORA_CALL(cora_riemannian_hessian_vector_product(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), nablaF_Y.data(),
-                                                   static_cast<int>(nablaF_Y.rows()), dotY.data(),
-                                                   static_cast<int>(dotY.rows()), out.data(),
+  LIFT(Y, Yl);
+  LIFT(nablaF_Y, Gl);
+  LIFT(dotY, Vl);
+  Matrix out(Yl.rows(), Yl.cols());
+  CORA_CALL(cora_riemannian_hessian_vector_product(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), Gl.data(),
+                                                   static_cast<int>(Gl.rows()), Vl.data(),
+                                                   static_cast<int>(Vl.rows()), out.data(),
                                                    static_cast<int>(out.rows())),
             "Problem::Riemannian_Hessian_vector_product");
-  return out;
+  return lowered(std::move(out));
 }
 
 Matrix Problem::precondition(const Matrix &V) const {
   checkMatrixShape("Problem::precondition::input", getExpectedVariableSize(), relaxation_rank_, V.rows(), V.cols());
   ensurePreconditioner();
-  Matrix out(V.rows(), V.cols());
-  CORA_CALL(cora_precondition(ctx_.get(), V.data(), static_cast<int>(V.rows()), out.data(), static_cast<int>(out.rows())),
+  LIFT(V, Vl);
+  Matrix out(Vl.rows(), Vl.cols());
+  CORA_CALL(cora_precondition(ctx_.get(), Vl.data(), static_cast<int>(Vl.rows()), out.data(), static_cast<int>(out.rows())),
             "Problem::precondition");
-  return out;
+  return lowered(std::move(out));
 }
 
 Matrix Problem::projectToManifold(const Matrix &A) const {
   checkMatrixShape("Problem::projectToManifold", getExpectedVariableSize(), relaxation_rank_, A.rows(), A.cols());
   ensureContext();
-  Matrix out(A.rows(), A.cols());
-  CORA_CALL(cora_project_to_manifold(ctx_.get(), A.data(), static_cast<int>(A.rows()), out.data(),
+  LIFT(A, Al);
+  Matrix out(Al.rows(), Al.cols());
+  CORA_CALL(cora_project_to_manifold(ctx_.get(), Al.data(), static_cast<int>(Al.rows()), out.data(),
                                      static_cast<int>(out.rows())),
             "Problem::projectToManifold");
-  return out;
+  return lowered(std::move(out));
 }
 
 Matrix Problem::retract(const Matrix &Y, const Matrix &V) const {
   checkMatrixShape("Problem::retract::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   checkMatrixShape("Problem::retract::V", getExpectedVariableSize(), relaxation_rank_, V.rows(), V.cols());
   ensureContext();
-  Matrix out(Y.rows(), Y.cols());
-  CORA_CALL(cora_retract(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), V.data(), static_cast<int>(V.rows()),
+  LIFT(Y, Yl);
+  LIFT(V, Vl);
+  Matrix out(Yl.rows(), Yl.cols());
+  CORA_CALL(cora_retract(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), Vl.data(), static_cast<int>(Vl.rows()),
                          out.data(), static_cast<int>(out.rows())),
             "Problem::retract");
-  return out;
+  return lowered(std::move(out));
+}
+
+// src/CORA_problem.cpp:1168-1197: [Y; -chol(Q33red) \ (B^T Y); 0], computed on the device
+Matrix Problem::getTranslationExplicitSolution(const Matrix &Y) const {
+  checkMatrixShape("Problem::getTranslationExplicitSolution::Y", rotAndRangeMatrixSize(), Y.cols(), Y.rows(), Y.cols());
+  if (formulation_ != Formulation::Implicit)
+    throw std::invalid_argument("getTranslationExplicitSolution needs the implicit formulation");
+  ensureContext();
+  cora_ctx *c = ctx_.get();
+  const int k = static_cast<int>(Y.cols()), N = getDataMatrixSize();
+  Matrix Yl_tmp;
+  const Matrix &Yl = lifted(Y, Yl_tmp);
+  double *dY = nullptr, *dX = nullptr;
+  CORA_CALL(cora_dev_alloc(c, k, &dY), "Problem::getTranslationExplicitSolution");
+  CORA_CALL(cora_dev_alloc(c, k, &dX), "Problem::getTranslationExplicitSolution");
+  Matrix Xfull(N, k);
+  int rc = cora_upload(c, Yl.data(), N, k, dY);
+  if (rc == CORA_OK) rc = cora_translation_explicit_dev(c, dY, k, dX);
+  if (rc == CORA_OK) rc = cora_download(c, dX, k, Xfull.data(), N);
+  cora_dev_free(c, dY);
+  cora_dev_free(c, dX);
+  if (rc != CORA_OK) throwLast(rc, "Problem::getTranslationExplicitSolution");
+  checkVariablesAreValid(Xfull);
+  return Xfull;
 }
 
 Matrix Problem::getRandomInitialGuess(uint64_t seed) const {  // src/CORA_problem.cpp:1023-1028
@@ -511,9 +607,10 @@ Matrix Problem::getRandomInitialGuess(uint64_t seed) const {  // src/CORA_proble
 Problem::LambdaBlocks Problem::compute_Lambda_blocks(const Matrix &Y) const {
   checkMatrixShape("Problem::compute_Lambda_blocks::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   ensureContext();
+  LIFT(Y, Yl);
   Matrix st(dim_, std::max(numPosesDim(), 1));
   Vector ob(std::max(numRangeMeasurements(), 1), 1);
-  CORA_CALL(cora_compute_lambda_blocks(ctx_.get(), Y.data(), static_cast<int>(Y.rows()), st.data(), ob.data()),
+  CORA_CALL(cora_compute_lambda_blocks(ctx_.get(), Yl.data(), static_cast<int>(Yl.rows()), st.data(), ob.data()),
             "Problem::compute_Lambda_blocks");
   return std::make_pair(st.block(0, 0, dim_, numPosesDim()), ob.block(0, 0, numRangeMeasurements(), 1));
 }
@@ -569,6 +666,7 @@ Matrix Problem::alignEstimateToOrigin(const Matrix &Y) const {
     if (Y.cols() != dim_) throw std::runtime_error("alignEstimateToOrigin expects a rank-d solution");
     Ya = Y * first.transpose();
   }
+  if (formulation_ == Formulation::Implicit) Ya = getTranslationExplicitSolution(Ya);  // :1250-1252
   checkVariablesAreValid(Ya);
   const Index off = rotAndRangeMatrixSize(), nt = numTranslationalStates();
   for (Index c = 0; c < Ya.cols(); ++c) {
@@ -627,6 +725,21 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
     std::cout << "NaN in theta -- result not certified" << std::endl;
     eta *= 2;
     results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop);
+  }
+  if (!results.is_certified && formulation_ == Formulation::Implicit) {  // :1085-1100
+    // leading (rotation + range) part of the direction, and its Rayleigh quotient with the
+    // simplified certificate Q_impl - Lambda
+    const Index m = rotAndRangeMatrixSize();
+    Vector v = results.x.block(0, 0, m, 1);
+    const Scalar nv = v.norm();
+    if (nv > 0) v = v * (1.0 / nv);
+    results.x = v;
+    const LambdaBlocks Lb = compute_Lambda_blocks(Y);
+    const Vector Sx = dataMatrixProduct(v) - compute_Lambda_from_Lambda_blocks(Lb, static_cast<int>(m)) * v;
+    Scalar th = 0;
+    for (Index i = 0; i < m; ++i) th += v(i) * Sx(i);
+    results.theta = th;
+    if (std::isnan(results.theta)) throw std::runtime_error("NaN in theta -- result not certified and implicit form");
   }
   return results;
 }

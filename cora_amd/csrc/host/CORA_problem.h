@@ -61,6 +61,7 @@ class Problem {
   int device_ = 0;
   mutable std::shared_ptr<cora_ctx> ctx_;
   mutable bool precond_ready_ = false;
+  mutable bool implicit_ready_ = false;  // chol(Q33[0:nt-1]) installed on the handle
   mutable Scalar precond_lambda_ = 0;   // regularisation actually used
   mutable long precond_nnz_ = 0;         // nnz(L)
   mutable int precond_levels_ = 0;       // height of the elimination tree
@@ -75,6 +76,7 @@ class Problem {
   Matrix dataMatrixProduct(const Matrix &Y) const;
   void ensureContext() const;
   void ensurePreconditioner() const;
+  void fillImplicitFormulationMatrices() const;
   [[noreturn]] void throwLast(int status, const char *where) const;
 
  public:
@@ -159,6 +161,10 @@ class Problem {
   /************** Utilities **********************/
   void checkVariablesAreValid(const Matrix &Y) const;
   Matrix alignEstimateToOrigin(const Matrix &Y) const;
+  Matrix getTranslationExplicitSolution(const Matrix &Y) const;
+  /** Host variable <-> device row count: identity when explicit; [M; 0] / leading rows when implicit. */
+  const Matrix &lifted(const Matrix &M, Matrix &tmp) const;
+  Matrix lowered(Matrix &&M) const;
 
   /** Device handle behind the operators (for the resident TNT / LOBPCG loops). */
   cora_ctx *context() const {

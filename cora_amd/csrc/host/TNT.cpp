@@ -118,14 +118,17 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
   Dev D(c, p);
   double *x = D.alloc(), *xprop = D.alloc(), *s = D.alloc(), *r = D.alloc(), *v = D.alloc(), *pk = D.alloc(),
          *Hp = D.alloc(), *Pg = D.alloc();
-  const int N = static_cast<int>(x0.rows());
-  D.chk(cora_upload(c, x0.data(), N, p, x), "cora_upload");
+  // device vectors carry every row of Q; an implicit-formulation iterate is [x; 0] there
+  Matrix x0_tmp;
+  const Matrix &x0l = problem.lifted(x0, x0_tmp);
+  const int N = static_cast<int>(x0l.rows());
+  D.chk(cora_upload(c, x0l.data(), N, p, x), "cora_upload");
 
   TNTResult res;
   auto download = [&](const double *d) {
     Matrix m(N, p);
     D.chk(cora_download(c, d, p, m.data(), N), "cora_download");
-    return m;
+    return problem.lowered(std::move(m));
   };
   // f, grad (cached on the device by set_point), preconditioned gradient
   D.chk(cora_set_point_dev(c, x), "cora_set_point_dev");

@@ -128,6 +128,12 @@ int cora_problem_set_rank(cora_problem *p, int rank) {
 int cora_problem_set_preconditioner(cora_problem *p, int kind) {
   return guarded([&] { p->problem.setPreconditioner(precondOf(kind)); });
 }
+int cora_problem_set_formulation(cora_problem *p, int implicit) {
+  return guarded([&] { p->problem.setFormulation(implicit ? Formulation::Implicit : Formulation::Explicit); });
+}
+int cora_problem_variable_size(cora_problem *p, int64_t *rows) {
+  return guarded([&] { *rows = p->problem.getExpectedVariableSize(); });
+}
 int cora_problem_set_device(cora_problem *p, int device) {
   return guarded([&] { p->problem.setDevice(device); });
 }
@@ -152,6 +158,8 @@ int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, 
     else if (o == "retract") res = q.retract(wrap(A, N, r), wrap(B, N, r));
     else if (o == "getRandomInitialGuess") res = q.getRandomInitialGuess();
     else if (o == "getOdomInitialization") res = getOdomInitialization(q);
+    else if (o == "getTranslationExplicitSolution") res = q.getTranslationExplicitSolution(wrap(A, N, r));
+    else if (o == "alignEstimateToOrigin") res = q.alignEstimateToOrigin(wrap(A, N, r));
     else throw std::invalid_argument("unknown operator " + o);
     std::memcpy(out, res.data(), sizeof(double) * static_cast<size_t>(res.size()));
   });
@@ -197,7 +205,8 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
     Problem &q = p->problem;
     const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
     const Matrix Ym = wrap(Y, N, r);
-    const CertResults c = q.certify_solution(Ym, eta, static_cast<size_t>(nx), Ym);
+    const Matrix boot = q.getFormulation() == Formulation::Implicit ? q.getTranslationExplicitSolution(Ym) : Ym;
+    const CertResults c = q.certify_solution(Ym, eta, static_cast<size_t>(nx), boot);
     out[0] = c.is_certified ? 1.0 : 0.0;
     out[1] = c.theta;
     out[2] = static_cast<double>(c.num_iters);

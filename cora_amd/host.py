@@ -98,12 +98,22 @@ class Problem:
     def set_preconditioner(self, kind):
         self._chk(self.L.cora_problem_set_preconditioner(self.h, int(kind)))
 
+    def set_formulation(self, implicit):
+        """Formulation::Implicit (translations marginalised) when true, Explicit otherwise."""
+        self._chk(self.L.cora_problem_set_formulation(self.h, int(bool(implicit))))
+
+    def variable_size(self):
+        """Problem::getExpectedVariableSize(): N when explicit, d*n + r when implicit."""
+        rows = C.c_int64()
+        self._chk(self.L.cora_problem_variable_size(self.h, C.byref(rows)))
+        return rows.value
+
     def set_device(self, dev):
         self._chk(self.L.cora_problem_set_device(self.h, int(dev)))
 
     def op(self, name, A=None, B=None, C_=None):
         dm = self.dims()
-        N, p = dm["N"], dm["rank"]
+        N, p = self.variable_size(), dm["rank"]
 
         def ptr(x):
             if x is None:
@@ -118,9 +128,10 @@ class Problem:
         keep, cols = [], []
         if name == "evaluateObjective":
             out = np.zeros(1)
-        else:
-            out = np.zeros((N, p), order="F")
         pa, pb, pc = ptr(A), ptr(B), ptr(C_)
+        if name != "evaluateObjective":
+            full = name in ("getOdomInitialization", "getTranslationExplicitSolution", "alignEstimateToOrigin")
+            out = np.zeros((dm["N"] if full else N, cols[0] if cols else p), order="F")
         if len(set(cols)) > 1:
             raise HostError("operands have different column counts: %s" % cols)
         self._chk(self.L.cora_problem_op(self.h, name.encode(), cols[0] if cols else p, pa, pb, pc,
@@ -139,7 +150,7 @@ class Problem:
     def tnt(self, x0, max_iterations=0, max_inner=0, grad_tol=0, pgrad_tol=0, max_seconds=0, verbose=False):
         dm = self.dims()
         x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))
-        assert x0.shape == (dm["N"], dm["rank"])
+        assert x0.shape == (self.variable_size(), dm["rank"])
         opts = np.array([max_iterations, max_inner, grad_tol, pgrad_tol, max_seconds, float(verbose)])
         out = np.zeros_like(x0, order="F")
         st = np.zeros(7)
@@ -161,7 +172,7 @@ class Problem:
         dm = self.dims()
         x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))
         opts = np.array([max_iterations, 0, 0, 0, max_seconds, 0.0])
-        out = np.zeros((dm["N"], dm["d"]), order="F")
+        out = np.zeros((self.variable_size(), dm["d"]), order="F")
         st = np.zeros(9)
         self._chk(self.L.cora_problem_solve(self.h, x0.ctypes.data_as(_dp), int(max_rank), int(verbose),
                                             opts.ctypes.data_as(_dp), out.ctypes.data_as(_dp),

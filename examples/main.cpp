@@ -10,29 +10,35 @@
 
 #include "CORA.h"
 #include "io.h"
+#include "odometry_init.h"
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    std::cout << "Usage: " << argv[0] << " [input .pyfg file] [--jacobi] [--tum out.tum] [--max-rank r]" << std::endl;
+    std::cout << "Usage: " << argv[0] << " [input .pyfg file] [--jacobi] [--implicit] [--odom-init] [--tum out.tum] [--max-rank r]" << std::endl;
     return 1;
   }
   int max_rank = 10;
   std::string tum;
-  bool jacobi = false;
+  bool jacobi = false, implicit = false, odom = false;
   for (int i = 2; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--jacobi") jacobi = true;
+    else if (a == "--implicit") implicit = true;   // "formulation": "Implicit" of examples/config.json
+    else if (a == "--odom-init") odom = true;      // "init_type": "Odom"
     else if (a == "--tum" && i + 1 < argc) tum = argv[++i];
     else if (a == "--max-rank" && i + 1 < argc) max_rank = std::atoi(argv[++i]);
   }
   try {
     CORA::Problem problem = CORA::parsePyfgTextToProblem(argv[1]);
     if (jacobi) problem.setPreconditioner(CORA::Preconditioner::Jacobi);
+    if (implicit) problem.setFormulation(CORA::Formulation::Implicit);
     problem.updateProblemData();
     std::printf("poses %d  landmarks %d  ranges %d  N %d  nnz(Q) %ld\n", problem.numPoses(), problem.numLandmarks(),
                 problem.numRangeMeasurements(), problem.getDataMatrixSize(),
                 static_cast<long>(problem.data_matrix_.nonZeros()));
-    const CORA::Matrix x0 = problem.getRandomInitialGuess();
+    CORA::Matrix x0 = odom ? CORA::getOdomInitialization(problem) : problem.getRandomInitialGuess();
+    if (odom && implicit)  // examples/paper_experiments.cpp:623-625
+      x0 = x0.block(0, 0, problem.rotAndRangeMatrixSize(), x0.cols());
     CORA::CoraSolveInfo info;
     const CORA::CoraResult soln = CORA::solveCORA(problem, x0, max_rank, /*verbose=*/true, false, false, &info);
     const CORA::Matrix aligned = problem.alignEstimateToOrigin(soln.first.x);

@@ -160,6 +160,20 @@ int cora_precond_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp,
  * [2] nnz(L), [3] dense border rows. */
 int cora_precond_stats(const cora_ctx *ctx, int64_t stats[4]);
 
+/* Translation-implicit formulation (Formulation::Implicit, src/CORA_problem.cpp:714-753):
+ *   dataMatrixProduct(Y) = Qmain Y - B L^-1 B^T Y,  L L^T = Q33[0:nt-1, 0:nt-1].
+ * cora_implicit_set_cholesky installs that factor (CSC, diagonal first per column; perm is
+ * new -> old index inside the translation block); cora_set_formulation(ctx, 1) then switches every
+ * product (spmm / objective / set_point / hvp) to the implicit operator.  Vectors keep N rows:
+ * translation rows of inputs are ignored, translation rows of outputs are zero (callers pass and
+ * read the leading d*n + r rows).  cora_certificate_product* always applies the explicit S, like
+ * the reference's certify_solution (:1054-1058).  cora_translation_explicit_dev =
+ * getTranslationExplicitSolution (:1168-1197): out = [Y; -L^-1 B^T Y; 0]. */
+int cora_implicit_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp, const int32_t *Li,
+                               const double *Lx, const int32_t *perm);
+int cora_set_formulation(cora_ctx *ctx, int implicit);
+int cora_translation_explicit_dev(cora_ctx *ctx, const double *dY, int k, double *dOut);
+
 /* Problem::precondition(V), src/CORA_problem.cpp:869-903 (no projection;
  * last row zeroed when the factor has N-1 rows, src/CORA_preconditioners.cpp:
  * 78-79; NaN guard -> CORA_ERR_NAN). */

@@ -40,6 +40,12 @@ int cora_problem_matrix(cora_problem *p, const char *name, int64_t *rows, int64_
 int cora_problem_set_rank(cora_problem *p, int rank);
 int cora_problem_set_preconditioner(cora_problem *p, int kind);
 int cora_problem_set_device(cora_problem *p, int device);
+/* Problem::setFormulation (include/CORA/CORA_problem.h:338): implicit != 0 selects
+ * Formulation::Implicit, where the variable is the leading d*n + r rows (rotations and ranges)
+ * and the translations are eliminated analytically (src/CORA_problem.cpp:714-753). */
+int cora_problem_set_formulation(cora_problem *p, int implicit);
+/* Problem::getExpectedVariableSize (src/CORA_problem.cpp:944-952) */
+int cora_problem_variable_size(cora_problem *p, int64_t *rows);
 
 /* Operators of CORA::Problem, by name (all run on the GPU):
  *  "evaluateObjective"        A=Y                -> out[0] (scalar)
@@ -52,8 +58,11 @@ int cora_problem_set_device(cora_problem *p, int device);
  *  "retract"                  A=Y, B=V           -> out
  *  "getRandomInitialGuess"    (none)             -> out
  *  "getOdomInitialization"    (none)             -> out   (examples/paper_experiments.cpp:426-534)
- * Inputs are N x cols with leading dimension N (cols is checked against the relaxation rank by
- * the C++ methods, like the reference's checkMatrixShape); the output is N x rank. */
+ *  "getTranslationExplicitSolution" A=Y (implicit) -> out (d+1)n + r + l rows (src/CORA_problem.cpp:1168)
+ *  "alignEstimateToOrigin"    A=Y (rank d)       -> out (d+1)n + r + l rows (src/CORA_problem.cpp:1234)
+ * Inputs are N x cols with leading dimension N = cora_problem_variable_size() (cols is checked
+ * against the relaxation rank by the C++ methods, like the reference's checkMatrixShape); the
+ * output is N x rank unless stated otherwise. */
 int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, const double *B,
                     const double *C, double *out);
 /* compute_Lambda_blocks(Y): stiefel d x dn (ld d), oblique r */

@@ -199,6 +199,58 @@ def precond_jacobi(Q, dm, Y, V):
     return out
 
 
+class Implicit:
+    """Translation-implicit formulation, restated from src/CORA_problem.cpp:714-753 (matrices),
+    :745-753 (product), :822-867 (Hessian-vector product with the implicit product),
+    :1168-1197 (translation recovery).  Variables have dn + r rows."""
+
+    def __init__(self, Q, dm):
+        A = Q.to_scipy().tocsr()
+        m = dm.dn + dm.r
+        nt = dm.N - m
+        self.dm_full = dm
+        self.dm = Dims(dm.d, dm.n, dm.r, m)                 # manifold ops on the leading rows only
+        self.Qmain = CSR.from_scipy(A[:m, :m].tocsr())       # :723-724
+        self.B = A[:m, m:m + nt - 1].tocsr()                 # TransOffDiagRed_, :729-731
+        self.chol = Cholesky(CSR.from_scipy(A[m:m + nt - 1, m:m + nt - 1].tocsr()))  # LtransCholRed_, :737-739
+        assert self.chol.ok
+
+    def product(self, Y):                                    # :747-752
+        Y = _f(Y)
+        P2 = self.chol.solve(np.asfortranarray(self.B.T @ Y))
+        return np.asfortranarray(spmm(self.Qmain, Y) - self.B @ P2)
+
+    def cost(self, Y):
+        return 0.5 * float(np.sum(_f(Y) * self.product(Y)))
+
+    def rgrad(self, Y):
+        return tangent_proj(self.dm, Y, self.product(Y))
+
+    def lambda_blocks(self, Y):
+        Y = _f(Y)
+        dm = self.dm
+        QY = self.product(Y)
+        Lst = np.asfortranarray(np.zeros((dm.d, max(dm.dn, 1)), order="F")[:, :dm.dn])
+        lob = np.zeros(max(dm.r, 1))[:dm.r].copy()
+        lib().orc_lambda_blocks(dm.d, dm.n, dm.r, Y.shape[1], _d(Y), dm.N, _d(QY), dm.N, _d(Lst), _d(lob))
+        return Lst, lob
+
+    def hvp(self, Y, Ydot):
+        dm = self.dm
+        Lst, lob = self.lambda_blocks(Y)
+        H = self.product(Ydot)
+        for i in range(dm.n):
+            s = slice(i * dm.d, (i + 1) * dm.d)
+            H[s] -= Lst[:, s] @ Ydot[s]
+        H[dm.dn:dm.dn + dm.r] -= lob[:, None] * Ydot[dm.dn:dm.dn + dm.r]
+        return tangent_proj(dm, Y, H)
+
+    def translation_explicit(self, Y):                       # :1181-1192
+        Y = _f(Y)
+        t = -self.chol.solve(np.asfortranarray(self.B.T @ Y))
+        return np.asfortranarray(np.vstack([Y, t, np.zeros((1, Y.shape[1]))]))
+
+
 class Cholesky:
     """Sparse LL^T of a symmetric CSR matrix; `ok` False <=> not positive definite
     (the reference's `MChol.info() == Eigen::Success`, src/CORA_utils.cpp:51)."""

@@ -72,3 +72,22 @@ def test_solve(dataset):
         assert abs(res["f"] - 734.328) < 2e-3
     print("\n%s: f=%.6f certified=%s rank levels=%d hvps=%d %.2fs" % (name, res["f"], res["certified"],
                                                                       res["levels"], res["hvps"], res["seconds"]))
+
+
+def test_solve_implicit_plaza2():
+    """examples/config.json's own setting ("formulation": "Implicit", RegularizedCholesky, random
+    init): same global optimum as the explicit solve, translations recovered analytically."""
+    P = host.Problem.from_pyfg(os.path.join(DATA, "plaza2.pyfg"))
+    P.update()
+    P.set_formulation(True)
+    dm = P.dims()
+    x0 = P.op("getRandomInitialGuess")
+    assert x0.shape == (dm["d"] * dm["n"] + dm["r"], dm["d"])
+    res = P.solve(x0, max_rank=10, max_seconds=60)
+    assert abs(res["f"] - 734.328) < 2e-3
+    full = P.op("alignEstimateToOrigin", res["x"])
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    assert abs(orc.cost(Q, full) - res["f"]) < 1e-6 * res["f"]
+    print("\nplaza2 implicit: f=%.6f certified=%s levels=%d hvps=%d %.2fs" % (res["f"], res["certified"], res["levels"],
+                                                                            res["hvps"], res["seconds"]))

@@ -6,6 +6,7 @@ tests/test_parse_pyfg.cpp, at 1e-9 (the reference itself uses 1e-6)."""
 import os
 
 import numpy as np
+import pytest
 
 from conftest import EXPECTED_COST, GOLDEN
 from mmio import read_dense, read_mm
@@ -160,3 +161,21 @@ def test_precond_semantics(case):
     assert np.abs(out - ref).max() < 1e-9
     jac = orc.precond_jacobi(Q, dm, Y, V)
     assert np.abs(jac - orc.tangent_proj(dm, Y, V / Qs.diagonal()[:, None])).max() < 1e-12
+
+
+def test_implicit_restatement_is_the_partial_minimum(case):
+    """oracle.Implicit (src/CORA_problem.cpp:714-753, 1168-1197): f_impl(Y) equals the explicit cost
+    at the analytically recovered translations, and no other translations do better."""
+    _, Q, dims = load(case)
+    if dims.N - dims.dn - dims.r < 2:
+        pytest.skip("needs two translational states")
+    I = orc.Implicit(Q, dims)
+    rng = np.random.default_rng(0)
+    Y = orc.project_manifold(I.dm, rng.uniform(-1, 1, (I.dm.N, dims.d + 1)))
+    X = I.translation_explicit(Y)
+    f = I.cost(Y)
+    assert abs(orc.cost(Q, X) - f) < 1e-9 * max(1.0, abs(f))
+    for _ in range(5):
+        Xp = X.copy()
+        Xp[I.dm.N:-1] += 1e-2 * rng.standard_normal(Xp[I.dm.N:-1].shape)
+        assert orc.cost(Q, Xp) >= f - 1e-12 * max(1.0, abs(f))
