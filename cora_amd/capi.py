@@ -95,9 +95,22 @@ class Context:
         self.h = h
         self.p = 0
 
+    @classmethod
+    def from_handle(cls, ptr, d, n_poses, n_ranges, n_trans):
+        """Borrow a cora_ctx owned by someone else (e.g. CORA::Problem::context()); never destroyed here."""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.d, self.n, self.r, self.nt = int(d), int(n_poses), int(n_ranges), int(n_trans)
+        self.N = self.d * self.n + self.r + self.nt
+        self.h = C.c_void_p(ptr)
+        self.p = self.L.cora_get_rank(self.h)
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.cora_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.L.cora_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):

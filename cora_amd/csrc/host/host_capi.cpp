@@ -78,6 +78,29 @@ int cora_problem_synthetic(int dim, int n_poses, int n_landmarks, int n_ranges, 
   });
 }
 
+int cora_problem_synthetic_ex(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
+                              int precond, const double *sigmas, const char *pyfg_out, double *x_gt,
+                              cora_problem **out) {
+  return guarded([&] {
+    SyntheticSpec sp;
+    sp.dim = dim;
+    sp.num_poses = n_poses;
+    sp.num_landmarks = n_landmarks;
+    sp.num_ranges = n_ranges;
+    sp.num_loop_closures = n_loops;
+    sp.seed = seed;
+    if (sigmas) {
+      sp.sigma_t = sigmas[0];
+      sp.sigma_R = sigmas[1];
+      sp.sigma_range = sigmas[2];
+    }
+    Matrix gt;
+    if (x_gt) sp.ground_truth = &gt;
+    *out = new cora_problem(makeSyntheticProblem(sp, precondOf(precond), pyfg_out ? pyfg_out : ""));
+    if (x_gt) std::memcpy(x_gt, gt.data(), sizeof(double) * static_cast<size_t>(gt.size()));
+  });
+}
+
 void cora_problem_destroy(cora_problem *p) { delete p; }
 
 int cora_problem_update(cora_problem *p) {

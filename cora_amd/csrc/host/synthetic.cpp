@@ -57,7 +57,9 @@ Problem makeSyntheticProblem(const SyntheticSpec &sp, Preconditioner precond, co
   if (static_cast<long long>(sp.num_ranges) > static_cast<long long>(n) * std::max(l, 0))
     throw std::invalid_argument("synthetic generator: more ranges than distinct (pose, landmark) pairs");
   std::mt19937_64 g(sp.seed);
-  std::normal_distribution<double> nt(0.0, 0.1), noise_t(0.0, sp.sigma_t), noise_r(0.0, sp.sigma_range);
+  std::normal_distribution<double> nt(0.0, 0.1), unit_t(0.0, 1.0), unit_r(0.0, 1.0);
+  auto noise_t = [&](std::mt19937_64 &e) { return sp.sigma_t * unit_t(e); };
+  auto noise_r = [&](std::mt19937_64 &e) { return sp.sigma_range * unit_r(e); };
   Problem problem(d, d, Formulation::Explicit, precond);
   FILE *fp = pyfg_out.empty() ? nullptr : std::fopen(pyfg_out.c_str(), "w");
   if (!pyfg_out.empty() && !fp) throw std::runtime_error("Could not open " + pyfg_out);
@@ -67,8 +69,12 @@ Problem makeSyntheticProblem(const SyntheticSpec &sp, Preconditioner precond, co
   T[0] = Matrix(d, 1);
   const int rdim = d == 3 ? 3 : 1;
   Matrix cov(d + rdim, d + rdim);
-  for (int i = 0; i < d; ++i) cov(i, i) = sp.sigma_t * sp.sigma_t;
-  for (int i = d; i < d + rdim; ++i) cov(i, i) = sp.sigma_R * sp.sigma_R;
+  // a zero sigma means "no noise drawn"; the stated covariance then keeps the nominal value
+  const SyntheticSpec nominal;
+  const double cov_t = sp.sigma_t > 0 ? sp.sigma_t : nominal.sigma_t, cov_R = sp.sigma_R > 0 ? sp.sigma_R : nominal.sigma_R,
+               cov_r = sp.sigma_range > 0 ? sp.sigma_range : nominal.sigma_range;
+  for (int i = 0; i < d; ++i) cov(i, i) = cov_t * cov_t;
+  for (int i = d; i < d + rdim; ++i) cov(i, i) = cov_R * cov_R;
 
   struct Edge { int i, j; Matrix Rm, tm; };
   std::vector<Edge> edges;
@@ -144,14 +150,29 @@ Problem makeSyntheticProblem(const SyntheticSpec &sp, Preconditioner precond, co
       std::fprintf(fp, "\n");
     }
   }
+  Matrix *gt = sp.ground_truth;
+  const Index tb = static_cast<Index>(d) * n + sp.num_ranges;
+  if (gt) {
+    *gt = Matrix(static_cast<Index>(d + 1) * n + l + sp.num_ranges, d);
+    for (int i = 0; i < n; ++i) {
+      gt->setBlock(static_cast<Index>(i) * d, 0, R[i].transpose());
+      for (int c = 0; c < d; ++c) (*gt)(tb + i, c) = T[i](c);
+    }
+    for (int k = 0; k < l; ++k)
+      for (int c = 0; c < d; ++c) (*gt)(tb + n + k, c) = L[k](c);
+  }
   std::set<std::pair<int, int>> used;
   std::uniform_int_distribution<int> ul(0, std::max(l - 1, 0));
-  const double rcov = sp.sigma_range * sp.sigma_range;
+  const double rcov = cov_r * cov_r;
   while (static_cast<int>(used.size()) < sp.num_ranges) {
     const int i = up(g), k = ul(g);
     if (!used.insert({i, k}).second) continue;
     double dist = 0;
     for (int c = 0; c < d; ++c) dist += (T[i](c) - L[k](c)) * (T[i](c) - L[k](c));
+    if (gt) {
+      const Index row = static_cast<Index>(d) * n + static_cast<Index>(used.size()) - 1;
+      for (int c = 0; c < d; ++c) (*gt)(row, c) = (T[i](c) - L[k](c)) / std::sqrt(dist);  // Arange has +1 at the pose
+    }
     dist = std::abs(std::sqrt(dist) + noise_r(g));
     const Symbol a('A', static_cast<uint64_t>(i)), b('L', static_cast<uint64_t>(k));
     problem.addRangeMeasurement(RangeMeasurement(a, b, dist, rcov));

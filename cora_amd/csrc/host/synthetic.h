@@ -18,6 +18,9 @@ struct SyntheticSpec {
   int num_loop_closures = 0;
   uint64_t seed = 42;
   double sigma_t = 0.05, sigma_R = 0.01, sigma_range = 0.1;
+  /** When set, receives the ground truth as an N x dim point in the explicit layout
+   * ([R_i^T]; unit bearings of the ranges; translations).  With all sigmas 0 it has zero cost. */
+  Matrix *ground_truth = nullptr;
 };
 
 Problem makeSyntheticProblem(const SyntheticSpec &spec, Preconditioner precond = Preconditioner::Jacobi,

@@ -42,14 +42,20 @@ class Problem:
 
     @staticmethod
     def synthetic(dim=3, n_poses=1000, n_landmarks=10, n_ranges=500, n_loops=0, seed=42,
-                  precond=capi.PRECOND_JACOBI, pyfg_out=None):
+                  precond=capi.PRECOND_JACOBI, pyfg_out=None, sigmas=None, ground_truth=False):
+        """SURVEY 8(d) generator.  sigmas = (sigma_t, sigma_R, sigma_range) overrides the noise;
+        ground_truth=True returns (problem, X_gt) with X_gt the N x dim truth in the explicit layout."""
         L = _lib()
         h = C.c_void_p()
-        rc = L.cora_problem_synthetic(dim, n_poses, n_landmarks, n_ranges, n_loops, C.c_uint64(seed), precond,
-                                      pyfg_out.encode() if pyfg_out else None, C.byref(h))
+        sg = np.ascontiguousarray(sigmas, dtype=np.float64) if sigmas is not None else None
+        gt = np.zeros(((dim + 1) * n_poses + n_landmarks + n_ranges, dim), order="F") if ground_truth else None
+        rc = L.cora_problem_synthetic_ex(dim, n_poses, n_landmarks, n_ranges, n_loops, C.c_uint64(seed), precond,
+                                         sg.ctypes.data_as(_dp) if sg is not None else None,
+                                         pyfg_out.encode() if pyfg_out else None,
+                                         gt.ctypes.data_as(_dp) if gt is not None else None, C.byref(h))
         if rc:
             raise HostError(L.cora_host_last_error().decode())
-        return Problem(h)
+        return (Problem(h), gt) if ground_truth else Problem(h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -25,6 +25,13 @@ int cora_problem_from_pyfg(const char *path, cora_problem **out);
 /* Synthetic generator of SURVEY 8(d); pyfg_out may be NULL. precond: cora_precond_kind */
 int cora_problem_synthetic(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
                            int precond, const char *pyfg_out, cora_problem **out);
+/* Same generator with explicit noise levels sigmas = {sigma_t, sigma_R, sigma_range} (NULL: the
+ * defaults 0.05, 0.01, 0.1) and, when x_gt != NULL, the ground truth as a column-major
+ * ((dim+1) n + l + r) x dim point ([R_i^T]; range bearings; translations) -- zero cost when all
+ * sigmas are zero, which gives the tests a known global optimum at any size. */
+int cora_problem_synthetic_ex(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
+                              int precond, const double *sigmas, const char *pyfg_out, double *x_gt,
+                              cora_problem **out);
 void cora_problem_destroy(cora_problem *p);
 
 /* Problem::updateProblemData (src/CORA_problem.cpp:500-510): assembles Q on the host. */

@@ -1,0 +1,179 @@
+"""BASELINE configs 4 and 5 at their full size on one GPU: the 10^5-pose synthetic SE(3) graph
+(+10 landmarks, 50 000 ranges; N = 450 010, nnz ~ 4.55 M) that bench.py times.
+
+Direct parity against the CPU oracle where it finishes in seconds (one Hessian-vector product, one
+certificate product, one preconditioner check), and the size-independent properties of the path:
+self-adjointness and linearity of the Hessian, idempotence of the projections, P (Q + lambda I) v = v,
+and the sign of the certificate against a CPU sparse Cholesky (config 5: "eigenvalue sign checked
+against CPU")."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cora_amd import capi, host
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+N_POSES, N_LANDMARKS, N_RANGES = 100_000, 10, 50_000
+
+
+def _oracle(P):
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    return orc.CSR(rowptr, colidx, vals, dm["N"]), orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+
+
+def _pose_major_order(Q, dims):
+    """Fill-reducing order for the oracle's Cholesky on a chain graph: per pose its rotation rows, the
+    range rows hanging off it and its translation; landmarks last (the same idea as the host's
+    coraOrdering, recomputed here so that the CPU check does not depend on the code under test)."""
+    A = Q.to_scipy().tocsr()
+    d, n, r, N = dims.d, dims.n, dims.r, dims.N
+    tb = d * n + r
+    rng_rows = A[d * n:tb]
+    # pose translation column touched by each range row
+    C = rng_rows[:, tb:tb + n].tocsr()
+    owner = np.full(r, -1, dtype=np.int64)
+    has = np.diff(C.indptr) > 0
+    owner[has] = C.indices[C.indptr[:-1][has]]
+    key = np.empty(N, dtype=np.float64)
+    for a in range(d):
+        key[a:d * n:d] = np.arange(n) + 0.1 * a / d
+    key[d * n:tb] = np.where(owner >= 0, owner + 0.5, n + 1.0)
+    key[tb:tb + n] = np.arange(n) + 0.9
+    key[tb + n:] = n + 2.0
+    return np.argsort(key, kind="stable").astype(np.int32)
+
+
+@pytest.fixture(scope="module")
+def noisy():
+    P = host.Problem.synthetic(dim=3, n_poses=N_POSES, n_landmarks=N_LANDMARKS, n_ranges=N_RANGES, seed=42,
+                               precond=capi.PRECOND_JACOBI)
+    P.update()
+    Q, dims = _oracle(P)
+    assert dims.N == 450_010
+    return P, Q, dims
+
+
+def test_hvp_and_certificate_product_match_oracle(noisy):
+    P, Q, dims = noisy
+    p = 5
+    P.set_rank(p)
+    rng = np.random.default_rng(7)
+    Y = P.op("projectToManifold", rng.uniform(-1, 1, (dims.N, p)))
+    assert np.abs(Y - orc.project_manifold(dims, Y)).max() < 1e-11
+    G = orc.egrad(Q, Y)
+    eg = P.op("Euclidean_gradient", Y)
+    assert np.abs(eg - G).max() < 1e-10 * np.abs(G).max()
+    f = orc.cost(Q, Y)
+    assert abs(P.op("evaluateObjective", Y) - f) < 1e-11 * abs(f)
+    V = P.op("tangent_space_projection", Y, rng.uniform(-1, 1, (dims.N, p)))
+    assert np.abs(V - orc.tangent_proj(dims, Y, V)).max() < 1e-11
+    hv = P.op("Riemannian_Hessian_vector_product", Y, G, V)
+    ref = orc.hvp(Q, dims, Y, G, V)
+    assert np.abs(hv - ref).max() < 1e-10 * np.abs(ref).max()
+    # certificate operator at block size 10 (config 5) through the C ABI of the same handle
+    ctx = capi.Context.from_handle(P.context_ptr(), dims.d, dims.n, dims.r, dims.N - dims.dn - dims.r)
+    Lst, lob = orc.lambda_blocks(Q, dims, Y)
+    st, ob = P.lambda_blocks(Y)
+    assert np.abs(st - Lst).max() < 1e-10 * np.abs(Lst).max() and np.abs(ob - lob).max() < 1e-10 * np.abs(lob).max()
+    X = rng.uniform(-1, 1, (dims.N, 10))   # the handle's current point is Y (set by lambda_blocks)
+    SX = ctx.certificate_product(X)
+    ref = orc.S_apply(Q, dims, Lst, lob, X)
+    assert np.abs(SX - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+def test_hessian_is_linear_and_self_adjoint_on_the_tangent_space(noisy):
+    P, Q, dims = noisy
+    p = 5
+    P.set_rank(p)
+    rng = np.random.default_rng(11)
+    Y = P.op("projectToManifold", rng.uniform(-1, 1, (dims.N, p)))
+    G = P.op("Euclidean_gradient", Y)
+    U = P.op("tangent_space_projection", Y, rng.uniform(-1, 1, (dims.N, p)))
+    V = P.op("tangent_space_projection", Y, rng.uniform(-1, 1, (dims.N, p)))
+    HU = P.op("Riemannian_Hessian_vector_product", Y, G, U)
+    HV = P.op("Riemannian_Hessian_vector_product", Y, G, V)
+    scale = np.linalg.norm(HU) * np.linalg.norm(V)
+    assert abs(np.sum(HU * V) - np.sum(U * HV)) < 1e-11 * scale
+    HW = P.op("Riemannian_Hessian_vector_product", Y, G, 2.0 * U - 0.5 * V)
+    assert np.abs(HW - (2.0 * HU - 0.5 * HV)).max() < 1e-11 * np.abs(HU).max()
+    # the result is tangent; projections are idempotent; retraction by zero is the identity
+    assert np.abs(P.op("tangent_space_projection", Y, HU) - HU).max() < 1e-11 * np.abs(HU).max()
+    assert np.abs(P.op("projectToManifold", Y) - Y).max() < 1e-12
+    assert np.abs(P.op("retract", Y, np.zeros_like(Y)) - Y).max() < 1e-12
+    R = P.op("retract", Y, 0.05 * U)
+    for i in rng.integers(0, dims.n, 200):
+        B = R[3 * i:3 * i + 3]
+        assert np.abs(B @ B.T - np.eye(3)).max() < 1e-12
+    assert np.abs(np.linalg.norm(R[dims.dn:dims.dn + dims.r], axis=1) - 1).max() < 1e-12
+
+
+def test_cholesky_preconditioner_inverts_the_regularised_matrix(noisy):
+    P, Q, dims = noisy
+    p = 5
+    P.set_rank(p)
+    P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
+    try:
+        rng = np.random.default_rng(13)
+        V = rng.uniform(-1, 1, (dims.N, p))
+        V[-1] = 0.0
+        lam = P.precond_info()["lam"]
+        W = orc.spmm(Q, V) + lam * V          # (Q + lambda I) V on the CPU
+        W[-1] = 0.0                            # pinned last variable: leading N-1 block only
+        # remove the coupling of the leading block to the pinned row (it multiplies V[-1] = 0): nothing to do
+        out = P.op("precondition", W)
+        assert np.all(out[-1] == 0.0)
+        assert np.abs(out[:-1] - V[:-1]).max() < 1e-7 * np.abs(V).max()
+        info = P.precond_info()
+        print("\nnnz(L) = %d, levels = %d, lambda = %.3e" % (info["nnz"], info["levels"], info["lam"]))
+    finally:
+        P.set_preconditioner(capi.PRECOND_JACOBI)
+
+
+def test_certification_sign_at_rank_10_matches_cpu_cholesky(noisy):
+    """Config 5: S - Lambda at r = 10 on the 10^5-pose problem; not PSD at a random point."""
+    P, Q, dims = noisy
+    p = 10
+    P.set_rank(p)
+    rng = np.random.default_rng(17)
+    Y = P.op("projectToManifold", rng.uniform(-1, 1, (dims.N, p)))
+    f = orc.cost(Q, Y)
+    eta = min(max(f * 5e-6, 1e-7), 1e-1)
+    res = P.certify(Y, eta, nx=10)
+    # CPU decision: sparse Cholesky of S + eta I
+    Lst, lob = orc.lambda_blocks(Q, dims, Y)
+    blocks = sp.block_diag([Lst[:, 3 * i:3 * i + 3] for i in range(dims.n)], format="csr")
+    Lam = sp.block_diag([blocks, sp.diags(lob), sp.csr_matrix((dims.N - dims.dn - dims.r,) * 2)], format="csr")
+    S = (Q.to_scipy() - Lam + eta * sp.identity(dims.N)).tocsr()
+    S.sort_indices()
+    ok = orc.Cholesky(orc.CSR.from_scipy(S), perm=_pose_major_order(Q, dims)).ok
+    assert res["is_certified"] == ok and not ok
+    x = res["x"]
+    assert abs(np.linalg.norm(x) - 1) < 1e-8
+    Sx = orc.S_apply(Q, dims, Lst, lob, x[:, None])[:, 0]
+    assert abs(res["theta"] - x @ Sx) < 1e-8 * max(1.0, abs(res["theta"]))
+    assert res["theta"] < -eta / 2
+    print("\nconfig 5: theta = %.6e after %d LOBPCG iterations (eta %.2e)" % (res["theta"], res["iters"], eta))
+
+
+def test_certification_of_the_noiseless_ground_truth():
+    """Known global optimum at full size: zero-noise graph, Y = ground truth => Lambda = 0, S = Q >= 0."""
+    P, gt = host.Problem.synthetic(dim=3, n_poses=N_POSES, n_landmarks=N_LANDMARKS, n_ranges=N_RANGES, seed=42,
+                                   precond=capi.PRECOND_JACOBI, sigmas=(0, 0, 0), ground_truth=True)
+    P.update()
+    Q, dims = _oracle(P)
+    scale = abs(Q.val).max()
+    f = P.op("evaluateObjective", gt)
+    assert abs(f) < 1e-9 * scale and abs(orc.cost(Q, gt)) < 1e-9 * scale
+    g = P.op("Riemannian_gradient", gt)
+    assert np.abs(g).max() < 1e-6 * scale * 1e-3
+    # round-off in Lambda(gt) is ~1e-3 here (|Q| ~ 1e10, kilometre-long ranges): use the upper end of the
+    # reference's eta clamp (src/CORA.cpp:112-114) so that the decision has a margin on both sides
+    eta = 1e-1
+    res = P.certify(gt, eta, nx=10)
+    S = (Q.to_scipy() + eta * sp.identity(dims.N)).tocsr()   # Lambda(gt) = 0 up to round-off
+    S.sort_indices()
+    ok = orc.Cholesky(orc.CSR.from_scipy(S), perm=_pose_major_order(Q, dims)).ok
+    assert ok and res["is_certified"]
