@@ -20,7 +20,7 @@ using namespace cora;
 
 namespace {
 thread_local std::string g_create_error;
-constexpr int kScratchSlots = 6;
+constexpr int kScratchSlots = 9;
 }  // namespace
 
 struct cora_ctx {
@@ -48,10 +48,14 @@ struct cora_ctx {
   // sparse Cholesky factors resident on the device (level-scheduled triangular solves):
   // the preconditioner's (Q + lambda I)[0:m] and, for the translation-implicit formulation,
   // the translation Laplacian Q33[0:nt-1]
+  struct DevStage {
+    RowOpDev fwd_a{}, fwd_b{}, bwd_a{}, bwd_b{};
+    BlockOpDev blocks{};
+    bool has_fwd_a = false, has_bwd_a = false, dense = false;
+  };
   struct DevFactor {
-    TriPlan plan;
-    TriDev fwd{}, bwd{};
-    BorderDev border{};
+    TriPlan plan;  // host copy is dropped after upload (only the counts are kept)
+    std::vector<DevStage> stages;
     std::vector<void *> allocs;
     bool ready = false;
   };
@@ -420,10 +424,10 @@ int cora_row_map(const cora_ctx *c, int32_t *api_to_internal) {
 int cora_precond_stats(const cora_ctx *c, int64_t s[4]) {
   if (!c || !s) return CORA_ERR_ARG;
   const auto &f = c->precond_f;
-  s[0] = f.ready ? static_cast<int64_t>(f.plan.fwd.levels.size()) : 0;
-  s[1] = f.ready ? static_cast<int64_t>(f.plan.bwd.levels.size()) : 0;
+  s[0] = f.ready ? static_cast<int64_t>(f.plan.stages.size()) : 0;
+  s[1] = f.ready ? f.plan.nnzW : 0;
   s[2] = f.ready ? f.plan.nnzL : 0;
-  s[3] = f.ready ? f.plan.border.nb : 0;
+  s[3] = f.ready && !f.plan.stages.empty() ? f.plan.stages.back().rows : 0;
   return CORA_OK;
 }
 
@@ -572,14 +576,15 @@ int cora_precond_setup(cora_ctx *c, int kind) {
 
 // Builds the level schedule of a factor and uploads it.  row_of[i] = internal row of permuted variable i.
 static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int32_t *Lp, const int32_t *Li,
-                          const double *Lx, const std::vector<int32_t> &row_of) {
+                          const double *Lx, const std::vector<int32_t> &row_of, int32_t zero_row) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (void *p : f.allocs)
     if (p) (void)hipFree(p);
   f.allocs.clear();
+  f.stages.clear();
   f.ready = false;
   try {
-    build_tri_plan(m, Lp, Li, Lx, row_of, f.plan);
+    build_tri_plan(m, Lp, Li, Lx, row_of, zero_row, f.plan);
   } catch (const std::exception &e) {
     return fail(c, CORA_ERR_ARG, e.what());
   }
@@ -593,47 +598,97 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
     }
     return e;
   };
-  auto up_tri = [&](TriDev &D, const TriHost &H) -> hipError_t {
+  auto up_op = [&](RowOpDev &D, RowOpHost &H) -> hipError_t {
     hipError_t e;
-    if ((e = up(&D.sn, H.sn)) != hipSuccess) return e;
-    if ((e = up(&D.cols, H.cols)) != hipSuccess) return e;
-    if ((e = up(&D.vals, H.vals)) != hipSuccess) return e;
-    D.levels = &H.levels;
+    D.n8 = H.n8;
+    D.n64 = H.n64;
+    D.nlong = static_cast<int>(H.long_out.size());
+    D.nchunks = static_cast<int>(H.chunk_begin.size());
+    if ((e = up(&D.out_row, H.out_row)) != hipSuccess) return e;
+    if ((e = up(&D.begin, H.begin)) != hipSuccess) return e;
+    if ((e = up(&D.end, H.end)) != hipSuccess) return e;
+    if ((e = up(&D.long_out, H.long_out)) != hipSuccess) return e;
+    if ((e = up(&D.long_chunk_ptr, H.long_chunk_ptr)) != hipSuccess) return e;
+    if ((e = up(&D.chunk_begin, H.chunk_begin)) != hipSuccess) return e;
+    if ((e = up(&D.chunk_end, H.chunk_end)) != hipSuccess) return e;
+    if ((e = up(&D.col, H.col)) != hipSuccess) return e;
+    if ((e = up(&D.val, H.val)) != hipSuccess) return e;
+    const std::vector<double> part(static_cast<size_t>(std::max(D.nchunks, 1)) * kMaxLD, 0.0);
+    const double *pp = nullptr;
+    if ((e = up(&pp, part)) != hipSuccess) return e;
+    D.partial = const_cast<double *>(pp);
+    H = RowOpHost();  // the host copy is not needed any more
     return hipSuccess;
   };
-  HIP_TRY(c, up_tri(f.fwd, f.plan.fwd));
-  HIP_TRY(c, up_tri(f.bwd, f.plan.bwd));
-  const BorderHost &B = f.plan.border;
-  BorderDev &D = f.border;
-  D.nb = B.nb;
-  D.nchunks = static_cast<int>(B.chunk_row.size());
-  HIP_TRY(c, up(&D.Lbb, B.Lbb));
-  HIP_TRY(c, up(&D.out_row, B.out_row));
-  HIP_TRY(c, up(&D.chunk_row, B.chunk_row));
-  {
-    std::vector<int32_t> rcp(static_cast<size_t>(B.nb) + 1, 0);
-    for (int32_t r : B.chunk_row) rcp[static_cast<size_t>(r) + 1]++;
-    for (int k = 0; k < B.nb; ++k) rcp[k + 1] += rcp[k];
-    HIP_TRY(c, up(&D.row_chunk_ptr, rcp));
-  }
-  HIP_TRY(c, up(&D.cbeg, B.chunk_begin));
-  HIP_TRY(c, up(&D.cend, B.chunk_end));
-  HIP_TRY(c, up(&D.wcols, B.wcols));
-  HIP_TRY(c, up(&D.wvals, B.wvals));
-  {
-    std::vector<double> part(std::max<size_t>(B.chunk_row.size(), 1) * kMaxLD, 0.0);
-    double *p = nullptr;
-    HIP_TRY(c, to_device(&p, part));
-    f.allocs.push_back(p);
-    D.partial = p;
+  const size_t K = f.plan.stages.size();
+  f.stages.resize(K);
+  for (size_t k = 0; k < K; ++k) {
+    TriStage &S = f.plan.stages[k];
+    cora_ctx::DevStage &D = f.stages[k];
+    D.has_fwd_a = k > 0;
+    D.has_bwd_a = k + 1 < K;
+    D.dense = S.dense;
+    if (D.has_fwd_a) HIP_TRY(c, up_op(D.fwd_a, S.fwd_a));
+    if (S.dense) {
+      BlockOpHost &H = S.blocks_op;
+      D.blocks.nblocks = static_cast<int>(H.nrows.size());
+      HIP_TRY(c, up(&D.blocks.row_begin, H.row_begin));
+      HIP_TRY(c, up(&D.blocks.nrows, H.nrows));
+      HIP_TRY(c, up(&D.blocks.w_off, H.w_off));
+      HIP_TRY(c, up(&D.blocks.rows, H.rows));
+      HIP_TRY(c, up(&D.blocks.w_by_col, H.w_by_col));
+      HIP_TRY(c, up(&D.blocks.w_by_row, H.w_by_row));
+      HIP_TRY(c, up(&D.blocks.ext_ptr, H.ext_ptr));
+      HIP_TRY(c, up(&D.blocks.ext_col, H.ext_col));
+      HIP_TRY(c, up(&D.blocks.ext_val, H.ext_val));
+      H = BlockOpHost();
+      continue;
+    }
+    HIP_TRY(c, up_op(D.fwd_b, S.fwd_b));
+    if (D.has_bwd_a) HIP_TRY(c, up_op(D.bwd_a, S.bwd_a));
+    HIP_TRY(c, up_op(D.bwd_b, S.bwd_b));
   }
   f.ready = true;
   return CORA_OK;
 }
 
-// x[rows of the factor] <- (P^T L L^T P)^-1 x[rows of the factor], in place on a resident vector
-static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, double *x) {
-  HIP_TRY(c, launch_tri_solve(f.fwd, f.bwd, f.border, ld, x, c->stream));
+// out[rows of the factor] = (P^T L L^T P)^-1 rhs[rows of the factor]; rows outside the factor are not
+// written.  rhs and out must be different resident vectors.  A fixed sequence of 4K-2 sparse products
+// (trisolve.h): forward stages ascending, backward stages descending.
+static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, const double *rhs, double *out) {
+  if (rhs == out) return fail(c, CORA_ERR_ARG, "factor_solve: output aliases the right-hand side");
+  const int K = static_cast<int>(f.stages.size());
+  if (K == 0) return CORA_OK;
+  double *t, *t2;
+  int rc;
+  if ((rc = get_scratch(c, 6, ld, &t))) return rc;
+  if ((rc = get_scratch(c, 7, ld, &t2))) return rc;
+  for (int k = 0; k < K; ++k) {  // L y = rhs
+    const cora_ctx::DevStage &S = f.stages[k];
+    if (S.dense) {  // stage 0, never the last one
+      HIP_TRY(c, launch_blockop(S.blocks, ld, false, rhs, out, c->stream));
+      continue;
+    }
+    const double *tk = rhs;
+    if (S.has_fwd_a) {
+      HIP_TRY(c, launch_rowop(S.fwd_a, ld, rhs, out, t, c->stream));   // t_k = rhs_k - L[k,<k] y_<k
+      tk = t;
+    }
+    HIP_TRY(c, launch_rowop(S.fwd_b, ld, nullptr, tk, k == K - 1 ? t2 : out, c->stream));  // y_k = W_k t_k
+  }
+  for (int k = K - 1; k >= 0; --k) {  // L^T x = y
+    const cora_ctx::DevStage &S = f.stages[k];
+    if (S.dense) {
+      HIP_TRY(c, launch_blockop(S.blocks, ld, true, out, out, c->stream));
+      continue;
+    }
+    const double *tk = t2;  // last stage: y_K-1 was left in t2
+    if (S.has_bwd_a) {
+      HIP_TRY(c, launch_rowop(S.bwd_a, ld, out, out, t, c->stream));   // t_k = y_k - L[>k,k]^T x_>k
+      tk = t;
+    }
+    HIP_TRY(c, launch_rowop(S.bwd_b, ld, nullptr, tk, out, c->stream));  // x_k = W_k^T t_k
+  }
   return CORA_OK;
 }
 
@@ -653,22 +708,16 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
     seen[perm[i]] = 1;
     row_of[i] = c->F.api2int[perm[i]];
   }
-  const int rc = install_factor(c, c->precond_f, m, Lp, Li, Lx, row_of);
-  if (rc) return rc;
-  c->precond_f.plan.zero_row = -1;
+  int32_t zero_row = -1;  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
   if (m == N - 1)
     for (int64_t i = 0; i < N; ++i)
-      if (!seen[i]) c->precond_f.plan.zero_row = c->F.api2int[i];
-  return CORA_OK;
+      if (!seen[i]) zero_row = c->F.api2int[i];
+  return install_factor(c, c->precond_f, m, Lp, Li, Lx, row_of, zero_row);
 }
 
-// out = [ (Q + lambda I)[0:m]^-1 V[0:m] ; 0 ]  in place on dOut (already holding V)
-static int chol_solve_inplace(cora_ctx *c, int ld, double *dOut) {
-  int rc = factor_solve(c, c->precond_f, ld, dOut);
-  if (rc) return rc;
-  if (c->precond_f.plan.zero_row >= 0)  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
-    HIP_TRY(c, launch_zero_row(dOut, static_cast<size_t>(c->precond_f.plan.zero_row), ld, c->stream));
-  return CORA_OK;
+// dOut = [ (Q + lambda I)[0:m]^-1 V[0:m] ; 0 ]
+static int chol_solve(cora_ctx *c, int ld, const double *dV, double *dOut) {
+  return factor_solve(c, c->precond_f, ld, dV, dOut);  // the pinned row is zeroed by the plan itself
 }
 
 // ---- translation-implicit formulation (src/CORA_problem.cpp:714-753) ------------------------
@@ -686,9 +735,11 @@ static int implicit_lift(cora_ctx *c, const double *dX, int ld, double *w0, doub
   HIP_TRY(c, launch_spmm(A, ld, L.d, EPI_NONE, c->stream));                      // w1[trans] = B^T X
   const size_t last = static_cast<size_t>(L.trn_base) + L.nl_trans - 1;           // pinned translation
   HIP_TRY(c, launch_zero_row(w1, last, ld, c->stream));
-  int rc = factor_solve(c, c->implicit_f, ld, w1);                                 // w1[trans] = M^-1 B^T X
+  double *w2;
+  int rc = get_scratch(c, 8, ld, &w2);
   if (rc) return rc;
-  HIP_TRY(c, launch_axpby(static_cast<int64_t>(L.nl_trans) * ld, -1.0, w1 + toff, 0.0, w0 + toff, c->stream));
+  if ((rc = factor_solve(c, c->implicit_f, ld, w1, w2))) return rc;                // w2[trans] = M^-1 B^T X
+  HIP_TRY(c, launch_axpby(static_cast<int64_t>(L.nl_trans) * ld, -1.0, w2 + toff, 0.0, w0 + toff, c->stream));
   HIP_TRY(c, launch_zero_row(w0, last, ld, c->stream));                            // w0 = [X; t; 0]
   return CORA_OK;
 }
@@ -731,7 +782,7 @@ int cora_implicit_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int3
     seen[perm[i]] = 1;
     row_of[i] = c->F.api2int[tb + perm[i]];
   }
-  return install_factor(c, c->implicit_f, m, Lp, Li, Lx, row_of);
+  return install_factor(c, c->implicit_f, m, Lp, Li, Lx, row_of, -1);
 }
 
 int cora_set_formulation(cora_ctx *c, int implicit) {
@@ -764,12 +815,18 @@ int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut)
   const double *scale = nullptr;
   if (c->precond == CORA_PRECOND_JACOBI) scale = c->d_diag_inv;
   else if (c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY) {
-    if (dOut != dV)
-      HIP_TRY(c, hipMemcpyAsync(dOut, dV, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
-    if (c->implicit)  // V_lift = [V; 0], src/CORA_problem.cpp:878-884
-      HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(c->F.L.trn_base) * c->ld, 0,
-                                static_cast<size_t>(c->F.L.nl_trans) * c->ld * sizeof(double), c->stream));
-    int rc = chol_solve_inplace(c, c->ld, dOut);
+    const double *rhs = dV;
+    if (c->implicit || dOut == dV) {  // V_lift = [V; 0] (src/CORA_problem.cpp:878-884), or an in-place call
+      double *tmp;
+      int rc = get_scratch(c, 8, c->ld, &tmp);
+      if (rc) return rc;
+      HIP_TRY(c, hipMemcpyAsync(tmp, dV, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
+      if (c->implicit)
+        HIP_TRY(c, hipMemsetAsync(tmp + static_cast<size_t>(c->F.L.trn_base) * c->ld, 0,
+                                  static_cast<size_t>(c->F.L.nl_trans) * c->ld * sizeof(double), c->stream));
+      rhs = tmp;
+    }
+    int rc = chol_solve(c, c->ld, rhs, dOut);
     if (rc) return rc;
     if (c->implicit)
       HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(c->F.L.trn_base) * c->ld, 0,
@@ -1042,8 +1099,8 @@ int cora_precondition(cora_ctx *c, const double *V, int ldv, double *out, int ld
     HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
     HIP_TRY(c, launch_scale_rows(c->F.L.local_rows, c->ld, c->d_diag_inv, dV + off, dO + off, c->stream));
   } else {
-    if ((rc = upload_impl(c, V, ldv, c->p, dO))) return rc;
-    if ((rc = chol_solve_inplace(c, c->ld, dO))) return rc;
+    if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
+    if ((rc = chol_solve(c, c->ld, dV, dO))) return rc;
   }
   // NaN guard, src/CORA_problem.cpp:898-901
   HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));

@@ -24,9 +24,15 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
   }
   std::vector<int32_t> perm;
   perm.reserve(static_cast<size_t>(N));
+  // Range rows first: a range row touches only the two translations it connects, so it is a leaf of
+  // the elimination tree and eliminating it adds no fill (the t-t coupling is already in Q33).  With
+  // the ranges out of the way every pose is a clean chain [rotation rows, translation] and
+  // consecutive poses of a leaf merge into one supernode of the device triangular solves.
+  for (int i = 0; i < n; ++i)
+    for (int32_t row : pose_ranges[i]) perm.push_back(row);
+  for (int32_t row : loose) perm.push_back(row);
   auto emit_pose = [&](int i) {
     for (int a = 0; a < d; ++a) perm.push_back(static_cast<int32_t>(static_cast<int64_t>(i) * d + a));
-    for (int32_t row : pose_ranges[i]) perm.push_back(row);
     perm.push_back(static_cast<int32_t>(tb + i));
   };
   std::function<void(int, int)> nd = [&](int lo, int hi) {  // poses [lo, hi)
@@ -40,7 +46,6 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
     emit_pose(mid);
   };
   nd(0, n);
-  for (int32_t row : loose) perm.push_back(row);
   for (int j = n; j < nt; ++j) perm.push_back(static_cast<int32_t>(tb + j));
   if (m == N - 1) {  // drop the pinned last variable (src/CORA_problem.cpp:602-609)
     std::vector<int32_t> q;

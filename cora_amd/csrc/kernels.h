@@ -48,21 +48,29 @@ struct DotArgs {
   double *partial;   // [count][gridDim.x]
 };
 
-struct TriDev {  // device copy of a TriHost
-  const TriSn *sn;
-  const int32_t *cols;
-  const double *vals;
-  const std::vector<TriLevel> *levels;
+struct RowOpDev {  // device copy of a RowOpHost (trisolve.h)
+  const int32_t *out_row, *begin, *end;
+  int n8, n64;
+  const int32_t *long_out, *long_chunk_ptr, *chunk_begin, *chunk_end;
+  int nlong, nchunks;
+  const int32_t *col;
+  const double *val;
+  double *partial;  // [nchunks][LD]
 };
-struct BorderDev {
-  int nb, nchunks;
-  const double *Lbb;
-  const int32_t *out_row, *chunk_row, *row_chunk_ptr, *cbeg, *cend, *wcols;
-  const double *wvals;
-  double *partial;
+struct BlockOpDev {  // device copy of a BlockOpHost (trisolve.h)
+  const int32_t *row_begin, *nrows;
+  const int64_t *w_off;
+  const int32_t *rows;
+  const double *w_by_col, *w_by_row;
+  const int32_t *ext_ptr, *ext_col;
+  const double *ext_val;
+  int nblocks;
 };
-hipError_t launch_tri_solve(const TriDev &F, const TriDev &B, const BorderDev &border, int ld, double *x,
-                            hipStream_t st);
+// forward: dst[rows] = W src[rows];  backward: dst[rows] = W^T (src[rows] - L[later, rows]^T src[later])
+hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st);
+// dst[out_row] = (src0 ? src0[out_row] : 0) + sum_k val_k * src[col_k] for every row of the product
+hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const double *src, double *dst,
+                        hipStream_t st);
 hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
                        double *partial, int nblocks, double *out, hipStream_t st);
 hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double *const *x, const int *kx,

@@ -734,164 +734,146 @@ __global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, Com
 }
 
 // ---------------------------------------------------------------------------
-// Level-scheduled sparse triangular solves (Cholesky preconditioner apply,
-// reference src/CORA_preconditioners.cpp:46-83).  Rows of one level are
-// independent; G lanes cooperate on a row.  In place on x.
+// Staged sparse Cholesky solves (trisolve.h): every step is one dependency-free
+// sparse product  dst[out_row] = src0[out_row] + sum_k val_k * src[col_k]  over the
+// rows of a stage.  Block ranges of one launch: 8-lane rows, wavefront rows, chunks
+// of the long (landmark) rows, whose partial sums k_rowop_long adds up afterwards.
+// Reference: CHOLMOD solve behind src/CORA_preconditioners.cpp:46-83.
 // ---------------------------------------------------------------------------
-template <int LD, int G>
-__global__ __launch_bounds__(256) void k_tri_level(const TriSn *__restrict__ sns,
-                                                   const int32_t *__restrict__ cols,
-                                                   const double *__restrict__ vals, int begin, int end,
-                                                   double *__restrict__ x) {
-  const int gt = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  const int sn = begin + gt / G, g = gt % G;
-  const bool ok = sn < end;
-  const TriSn R = sns[ok ? sn : begin];  // one record: no pointer chasing
-  const int b = ok ? R.nrows : 0;
-  // right-hand sides of the supernode's own rows: in flight while the external part is gathered
-  double xv[kTriSn][LD];
+template <int LD>
+__device__ __forceinline__ void rowop_entries(const int32_t *__restrict__ col, const double *__restrict__ val,
+                                              const double *__restrict__ src, int k0, int k1, int stride,
+                                              double (&acc)[LD]) {
+#pragma unroll 4
+  for (int k = k0; k < k1; k += stride) {
+    const double v = val[k];
+    double xx[LD];
+    load_row<LD>(src + static_cast<size_t>(col[k]) * LD, xx);
 #pragma unroll
-  for (int t = 0; t < kTriSn; ++t) {
-#pragma unroll
-    for (int j = 0; j < LD; ++j) xv[t][j] = 0.0;
-    if (t < b && g == 0) load_row<LD>(x + static_cast<size_t>(R.out_row[t]) * LD, xv[t]);
-  }
-  // external part: the G lanes stride over ALL external entries of the supernode (independent
-  // gathers); the row position an entry belongs to is packed in the top 4 index bits
-  double acc[kTriSn][LD];
-#pragma unroll
-  for (int t = 0; t < kTriSn; ++t)
-#pragma unroll
-    for (int j = 0; j < LD; ++j) acc[t][j] = 0.0;
-  if (ok) {
-#pragma unroll 2
-    for (int k = R.ext_begin + g; k < R.ext_end; k += G) {
-      const double v = vals[k];
-      const int32_t ct = cols[k];
-      const int tag = ct >> 28;
-      double xx[LD];
-      load_row<LD>(x + static_cast<size_t>(ct & 0x0FFFFFFF) * LD, xx);
-#pragma unroll
-      for (int t = 0; t < kTriSn; ++t) {
-        const double vt = (t == tag) ? v : 0.0;
-#pragma unroll
-        for (int j = 0; j < LD; ++j) acc[t][j] = fma(vt, xx[j], acc[t][j]);
-      }
-    }
-  }
-  if (G > 1) {
-#pragma unroll
-    for (int t = 0; t < kTriSn; ++t)
-#pragma unroll
-      for (int off = G / 2; off > 0; off >>= 1)
-#pragma unroll
-        for (int j = 0; j < LD; ++j) acc[t][j] += __shfl_xor(acc[t][j], off, 64);
-  }
-  if (!ok || g != 0) return;
-  // internal triangular block in registers
-  double y[kTriSn][LD];
-#pragma unroll
-  for (int t = 0; t < kTriSn; ++t) {
-    if (t < b) {
-      double v[LD];
-#pragma unroll
-      for (int j = 0; j < LD; ++j) v[j] = xv[t][j] - acc[t][j];
-#pragma unroll
-      for (int q = 0; q < t; ++q) {
-        const double l = R.lint[t * (t - 1) / 2 + q];
-#pragma unroll
-        for (int j = 0; j < LD; ++j) v[j] = fma(-l, y[q][j], v[j]);
-      }
-      const double di = R.dinv[t];
-#pragma unroll
-      for (int j = 0; j < LD; ++j) y[t][j] = v[j] * di;
-      store_row<LD>(x + static_cast<size_t>(R.out_row[t]) * LD, y[t]);
-    }
+    for (int j = 0; j < LD; ++j) acc[j] = fma(v, xx[j], acc[j]);
   }
 }
 
-// partial[chunk][j] = sum over the chunk of W[k, c] * x[c][j]  (dense border rows of L)
 template <int LD>
-__global__ __launch_bounds__(256) void k_border_dot(const int32_t *__restrict__ cbeg,
-                                                    const int32_t *__restrict__ cend,
-                                                    const int32_t *__restrict__ wcols,
-                                                    const double *__restrict__ wvals,
-                                                    const double *__restrict__ x, double *__restrict__ partial) {
-  __shared__ double sm[4 * kMaxLD];
-  const int ci = blockIdx.x;
+__global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__restrict__ src0,
+                                               const double *__restrict__ src, double *__restrict__ dst) {
+  const int nb8 = (op.n8 + 31) >> 5, nb64 = (op.n64 + 3) >> 2;
+  const int b = static_cast<int>(blockIdx.x);
   double acc[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
-#pragma unroll 4
-  for (int k = cbeg[ci] + threadIdx.x; k < cend[ci]; k += 256) {
-    const double v = wvals[k];
-    double t[LD];
-    load_row<LD>(x + static_cast<size_t>(wcols[k]) * LD, t);
+  if (b < nb8) {  // 32 rows per block, 8 lanes each
+    const int r = (b << 5) + (static_cast<int>(threadIdx.x) >> 3), g = threadIdx.x & 7;
+    const bool ok = r < op.n8;
+    int orow = 0;
+    if (ok) {
+      orow = op.out_row[r];
+      if (src0 && g == 0) load_row<LD>(src0 + static_cast<size_t>(orow) * LD, acc);
+      rowop_entries<LD>(op.col, op.val, src, op.begin[r] + g, op.end[r], 8, acc);
+    }
 #pragma unroll
-    for (int j = 0; j < LD; ++j) acc[j] = fma(v, t[j], acc[j]);
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 4; off > 0; off >>= 1)
 #pragma unroll
-  for (int j = 0; j < LD; ++j) {
-    const double v = wave_sum(acc[j]);
-    if (lane == 0) sm[w * LD + j] = v;
+      for (int j = 0; j < LD; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    if (ok && g == 0) store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
+  } else if (b < nb8 + nb64) {  // one wavefront per row
+    const int r = op.n8 + ((b - nb8) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
+    if (r >= op.n8 + op.n64) return;
+    const int orow = op.out_row[r];
+    if (src0 && g == 0) load_row<LD>(src0 + static_cast<size_t>(orow) * LD, acc);
+    rowop_entries<LD>(op.col, op.val, src, op.begin[r] + g, op.end[r], 64, acc);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[j] = wave_sum(acc[j]);
+    if (g == 0) store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
+  } else {  // one wavefront per chunk of a long row
+    const int ch = ((b - nb8 - nb64) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
+    if (ch >= op.nchunks) return;
+    rowop_entries<LD>(op.col, op.val, src, op.chunk_begin[ch] + g, op.chunk_end[ch], 64, acc);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[j] = wave_sum(acc[j]);
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) op.partial[static_cast<size_t>(ch) * LD + j] = acc[j];
+    }
   }
+}
+
+// dst[long row] = src0[long row] + sum of its chunk partials; one wavefront per row, fixed
+// summation tree (deterministic)
+template <int LD>
+__global__ __launch_bounds__(64) void k_rowop_long(RowOpDev op, const double *__restrict__ src0,
+                                                   double *__restrict__ dst) {
+  const int r = blockIdx.x, g = threadIdx.x;
+  double acc[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+  for (int ch = op.long_chunk_ptr[r] + g; ch < op.long_chunk_ptr[r + 1]; ch += 64)
+#pragma unroll
+    for (int j = 0; j < LD; ++j) acc[j] += op.partial[static_cast<size_t>(ch) * LD + j];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acc[j] = wave_sum(acc[j]);
+  if (g == 0) {
+    const size_t orow = static_cast<size_t>(op.long_out[r]);
+    if (src0) {
+      double b[LD];
+      load_row<LD>(src0 + orow * LD, b);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acc[j] += b[j];
+    }
+    store_row<LD>(dst + orow * LD, acc);
+  }
+}
+
+// Stage 0 in dense form (trisolve.h): one wavefront per block, lane = row of the block.
+//   forward : dst[rows] = W src[rows]
+//   backward: t = src[rows] - L[later, rows]^T src[later rows];  dst[rows] = W^T t   (src may be dst:
+//             a block reads its own rows before it writes them and nobody else reads them)
+template <int LD, bool BWD>
+__global__ __launch_bounds__(256) void k_blockop(BlockOpDev B, const double *src, double *dst) {
+  __shared__ double tl[4][64][LD];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = static_cast<int>(blockIdx.x) * 4 + wv;
+  const bool live = b < B.nblocks;
+  const int nb = live ? B.nrows[b] : 0, rb = live ? B.row_begin[b] : 0;
+  const bool mine = lane < nb;
+  const size_t row = mine ? static_cast<size_t>(B.rows[rb + lane]) : 0;
+  double t[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) t[j] = 0.0;
+  if (mine) {
+    load_row<LD>(src + row * LD, t);
+    if (BWD) {
+      const int e1 = B.ext_ptr[rb + lane + 1];
+#pragma unroll 2
+      for (int k = B.ext_ptr[rb + lane]; k < e1; ++k) {
+        const double v = B.ext_val[k];
+        double xx[LD];
+        load_row<LD>(src + static_cast<size_t>(B.ext_col[k]) * LD, xx);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) t[j] = fma(v, xx[j], t[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LD; ++j) tl[wv][lane][j] = t[j];
   __syncthreads();
-  if (threadIdx.x < LD)
-    partial[static_cast<size_t>(ci) * kMaxLD + threadIdx.x] =
-        sm[threadIdx.x] + sm[LD + threadIdx.x] + sm[2 * LD + threadIdx.x] + sm[3 * LD + threadIdx.x];
-}
-
-// forward substitution through the dense border block.  One 256-thread block: the chunk partials
-// of every border row are summed in parallel (fixed assignment and order -> deterministic), then
-// lane j < LD runs the tiny dense substitution for column j.
-template <int LD>
-__global__ __launch_bounds__(256) void k_border_fwd(int nb, const double *__restrict__ Lbb,
-                                                    const int32_t *__restrict__ out_row, int nchunks,
-                                                    const int32_t *__restrict__ row_chunk_ptr,
-                                                    const double *__restrict__ partial, double *__restrict__ x) {
-  extern __shared__ double sums[];  // [nb][LD]
-  constexpr int TPC = 256 / 32;     // threads cooperating on one column (LD <= 24 < 32)
-  const int j = threadIdx.x & 31, w = threadIdx.x >> 5;
-  __shared__ double red[TPC][32];
-  for (int k = 0; k < nb; ++k) {
-    double s = 0.0;
-    if (j < LD)
-      for (int c = row_chunk_ptr[k] + w; c < row_chunk_ptr[k + 1]; c += TPC)
-        s += partial[static_cast<size_t>(c) * kMaxLD + j];
-    red[w][j] = s;
-    __syncthreads();
-    if (w == 0 && j < LD) {
-      double t = 0.0;
+  double acc[LD];
 #pragma unroll
-      for (int q = 0; q < TPC; ++q) t += red[q][j];
-      sums[k * LD + j] = t;
+  for (int j = 0; j < LD; ++j) acc[j] = 0.0;
+  if (live) {
+    const double *W = (BWD ? B.w_by_row : B.w_by_col) + B.w_off[b];
+    int at = 0;  // start of column q (forward) / row q (backward) in the packed triangle
+#pragma unroll 4
+    for (int q = 0; q < nb; ++q) {
+      // forward: lanes q..nb-1 hold W[lane][q] at at + lane - q;  backward: lanes 0..q hold W[q][lane] at at + lane
+      const bool on = BWD ? (lane <= q) : (lane >= q && mine);
+      const double w = on ? W[at + (BWD ? lane : lane - q)] : 0.0;
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acc[j] = fma(w, tl[wv][q][j], acc[j]);
+      at += BWD ? q + 1 : nb - q;
     }
-    __syncthreads();
   }
-  if (threadIdx.x < LD) {
-    const int c = threadIdx.x;
-    for (int k = 0; k < nb; ++k) {
-      double acc = sums[k * LD + c];
-      for (int q = 0; q < k; ++q)
-        acc = fma(Lbb[static_cast<size_t>(k) * nb + q], x[static_cast<size_t>(out_row[q]) * LD + c], acc);
-      double *xr = x + static_cast<size_t>(out_row[k]) * LD + c;
-      *xr = (*xr - acc) / Lbb[static_cast<size_t>(k) * nb + k];
-    }
-  }
-}
-
-template <int LD>
-__global__ __launch_bounds__(64) void k_border_bwd(int nb, const double *__restrict__ Lbb,
-                                                   const int32_t *__restrict__ out_row, double *__restrict__ x) {
-  const int j = threadIdx.x;
-  if (j >= LD) return;
-  for (int k = nb - 1; k >= 0; --k) {
-    double acc = 0.0;
-    for (int q = k + 1; q < nb; ++q) acc = fma(Lbb[static_cast<size_t>(q) * nb + k], x[static_cast<size_t>(out_row[q]) * LD + j], acc);
-    double *xr = x + static_cast<size_t>(out_row[k]) * LD + j;
-    *xr = (*xr - acc) / Lbb[static_cast<size_t>(k) * nb + k];
-  }
+  if (mine) store_row<LD>(dst + row * LD, acc);
 }
 
 __global__ void k_zero_row(double *x, size_t row, int ld) {
@@ -1057,38 +1039,34 @@ hipError_t launch_download(int64_t N, int k, int ld, const double *src, const in
 namespace cora {
 
 template <int LD>
-static hipError_t tri_level_ld(const TriDev &T, const TriLevel &lv, double *x, hipStream_t st) {
-  const int sns = lv.end - lv.begin;
-  if (sns <= 0) return hipSuccess;
-  const int64_t threads = static_cast<int64_t>(sns) * lv.lanes;
-  const int grid = static_cast<int>((threads + 255) / 256);
-  if (lv.lanes == 8)
-    hipLaunchKernelGGL((k_tri_level<LD, 8>), dim3(grid), dim3(256), 0, st, T.sn, T.cols, T.vals, lv.begin, lv.end, x);
-  else
-    hipLaunchKernelGGL((k_tri_level<LD, 64>), dim3(grid), dim3(256), 0, st, T.sn, T.cols, T.vals, lv.begin, lv.end, x);
+static hipError_t rowop_ld(const RowOpDev &op, const double *src0, const double *src, double *dst, hipStream_t st) {
+  const int grid = ((op.n8 + 31) >> 5) + ((op.n64 + 3) >> 2) + ((op.nchunks + 3) >> 2);
+  if (grid > 0) hipLaunchKernelGGL((k_rowop<LD>), dim3(grid), dim3(256), 0, st, op, src0, src, dst);
+  if (op.nlong > 0) hipLaunchKernelGGL((k_rowop_long<LD>), dim3(op.nlong), dim3(64), 0, st, op, src0, dst);
   return hipGetLastError();
 }
 
 template <int LD>
-static hipError_t tri_solve_ld(const TriDev &F, const TriDev &Bk, const BorderDev &B, double *x, hipStream_t st) {
-  hipError_t e;
-  for (const TriLevel &lv : *F.levels)
-    if ((e = tri_level_ld<LD>(F, lv, x, st)) != hipSuccess) return e;
-  if (B.nb > 0) {
-    if (B.nchunks > 0)
-      hipLaunchKernelGGL((k_border_dot<LD>), dim3(B.nchunks), dim3(256), 0, st, B.cbeg, B.cend, B.wcols, B.wvals, x, B.partial);
-    hipLaunchKernelGGL((k_border_fwd<LD>), dim3(1), dim3(256), static_cast<size_t>(B.nb) * LD * sizeof(double), st, B.nb, B.Lbb, B.out_row, B.nchunks, B.row_chunk_ptr, B.partial, x);
-    hipLaunchKernelGGL((k_border_bwd<LD>), dim3(1), dim3(64), 0, st, B.nb, B.Lbb, B.out_row, x);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-  }
-  for (const TriLevel &lv : *Bk.levels)
-    if ((e = tri_level_ld<LD>(Bk, lv, x, st)) != hipSuccess) return e;
-  return hipSuccess;
+static hipError_t blockop_ld(const BlockOpDev &B, bool backward, const double *src, double *dst, hipStream_t st) {
+  const int grid = (B.nblocks + 3) >> 2;
+  if (grid <= 0) return hipSuccess;
+  if (backward) hipLaunchKernelGGL((k_blockop<LD, true>), dim3(grid), dim3(256), 0, st, B, src, dst);
+  else hipLaunchKernelGGL((k_blockop<LD, false>), dim3(grid), dim3(256), 0, st, B, src, dst);
+  return hipGetLastError();
 }
 
-hipError_t launch_tri_solve(const TriDev &F, const TriDev &Bk, const BorderDev &B, int ld, double *x, hipStream_t st) {
+hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st) {
 #define CASE(L) \
-  if (ld == L) return tri_solve_ld<L>(F, Bk, B, x, st);
+  if (ld == L) return blockop_ld<L>(B, backward, src, dst, st);
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const double *src, double *dst,
+                        hipStream_t st) {
+#define CASE(L) \
+  if (ld == L) return rowop_ld<L>(op, src0, src, dst, st);
   CORA_LD_CASES(CASE)
 #undef CASE
   return hipErrorInvalidValue;

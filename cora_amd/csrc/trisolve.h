@@ -1,9 +1,25 @@
-// Level-scheduled sparse triangular solves on the device for the
-// RegularizedCholesky / BlockCholesky preconditioner (reference
-// src/CORA_preconditioners.cpp:46-83: CHOLMOD `solve` with p right-hand sides).
-// The host supplies L (CSC, diagonal first per column) of P A P^T; indices are
-// remapped to the handle's internal row order so the solves run in place on
-// resident vectors.
+// Sparse Cholesky solves on the device for the RegularizedCholesky / BlockCholesky
+// preconditioner and the translation-implicit formulation (reference
+// src/CORA_preconditioners.cpp:46-83: CHOLMOD `solve` with p right-hand sides;
+// src/CORA_problem.cpp:747-752: LtransCholRed_->solve).
+//
+// A level-scheduled triangular solve is a chain of ~60 dependent launches on these factors
+// (elimination-tree height ~90), each bounded by launch + dependent-load latency, not by
+// bandwidth.  Instead the rows are cut into a few STAGES along the elimination tree -- stage 0 is
+// the union of the small subtrees at the bottom (one per leaf of the nested dissection, <= 48
+// rows), stage 1 the subtrees of what remains (<= 768 rows), ..., the last stage the top of the
+// tree plus the dense landmark rows -- and the diagonal block of every stage (block diagonal: the
+// subtrees of one stage do not touch each other) is inverted explicitly on the host, once.  A
+// solve is then a fixed sequence of dependency-free sparse products
+//
+//   forward, stage k :  t_k = b_k - L[k, <k] y_{<k}       ("a": rows of L)
+//                       y_k = W_k t_k                      ("b": W_k = L[k,k]^-1, sparse)
+//   backward, stage k:  t_k = y_k - L[>k, k]^T x_{>k}      ("a": columns of L)
+//                       x_k = W_k^T t_k                    ("b")
+//
+// i.e. at most 4K-2 launches for K stages (K = 3 at 10^5 poses) that each run at memory speed.  The host
+// supplies L (CSC, diagonal first per column) of P A P^T; indices are remapped to the handle's
+// internal row order so that the products read and write resident vectors directly.
 #pragma once
 
 #include <cstdint>
@@ -11,57 +27,53 @@
 
 namespace cora {
 
-constexpr int kTriSn = 6;  // max rows of a supernode (its partial sums live in registers)
-
-struct TriLevel {
-  int32_t begin, end;  // range of supernodes
-  int32_t lanes;       // lanes cooperating on one supernode: 1, 8 or 64
+// One sparse product over a set of rows: dst[out_row] = src0[out_row] (if any) + sum_k val_k src[col_k].
+// Rows are sorted by length class: [0, n8) short rows (8 lanes each), [n8, n8 + n64) one wavefront
+// each, and `long` rows cut into chunks (one wavefront per chunk, partial sums reduced afterwards).
+struct RowOpHost {
+  std::vector<int32_t> out_row;         // internal row of each short / wavefront row
+  std::vector<int32_t> begin, end;      // its entries in col / val
+  int32_t n8 = 0, n64 = 0;
+  std::vector<int32_t> long_out;        // internal row of each long row
+  std::vector<int32_t> long_chunk_ptr;  // chunks of long row k: [ptr[k], ptr[k+1])
+  std::vector<int32_t> chunk_begin, chunk_end;
+  std::vector<int32_t> col;             // internal source row per entry
+  std::vector<double> val;
+  bool empty() const { return out_row.empty() && long_out.empty(); }
 };
 
-// One direction.  Rows are grouped into small chain supernodes (consecutive rows on a path of
-// the elimination tree, at most kTriSn of them: typically the d rotation rows, range rows and
-// translation of one pose).  A supernode is one unit of the level schedule: its external
-// dependencies (rows of earlier levels) are gathered with full memory parallelism, then the
-// tiny internal triangular block is solved in registers -- ~3x fewer levels than row by row.
-// Everything a lane group needs about its supernode in ONE record addressed by the supernode
-// index alone (no pointer chasing: a level is a chain of dependent loads, so each removed
-// indirection is ~1 us per level).
-struct TriSn {
-  int32_t ext_begin, ext_end;   // external entries in cols / vals
-  int32_t nrows, pad;
-  int32_t out_row[kTriSn];      // internal row of each of its rows, in processing order
-  double dinv[kTriSn];          // 1 / L_ii
-  double lint[kTriSn * (kTriSn - 1) / 2];  // internal coefficients, packed: (t, q<t) at t(t-1)/2 + q
+// Stage 0 in dense form: its blocks are tiny (<= 64 rows, one wavefront each, lane = row) and their
+// inverses nearly full lower triangles, so W is stored without indices, packed twice so that both
+// sweeps read it coalesced: by column for y = W t (lane i reads W_ij, i >= j) and by row for
+// x = W^T t (lane j reads W_ij, j <= i).  The backward coupling to the later stages (columns of L)
+// is applied by the same kernel, lane by lane, before the block product.
+struct BlockOpHost {
+  std::vector<int32_t> row_begin, nrows;  // per block: its rows in `rows`
+  std::vector<int64_t> w_off;             // per block: start of its nb(nb+1)/2 packed entries
+  std::vector<int32_t> rows;              // internal row of every block row (elimination order)
+  std::vector<double> w_by_col, w_by_row;
+  std::vector<int32_t> ext_ptr, ext_col;  // per block row: -L[later, row] entries (backward sweep)
+  std::vector<double> ext_val;
 };
 
-struct TriHost {
-  std::vector<TriSn> sn;                // supernodes in level order
-  std::vector<int32_t> cols;            // EXTERNAL entries: internal row | (row position << 28)
-  std::vector<double> vals;
-  std::vector<TriLevel> levels;
-};
-
-struct BorderHost {       // the trailing dense rows (landmarks) of L
-  int nb = 0;                           // number of border rows
-  std::vector<int32_t> out_row;         // internal row of each border row (elimination order)
-  std::vector<double> Lbb;              // nb x nb dense lower triangle (row-major), incl. diagonal
-  // W = L[border, non-border] in chunked CSR for the forward sweep
-  std::vector<int32_t> chunk_row, chunk_begin, chunk_end;  // per chunk
-  std::vector<int32_t> wcols;
-  std::vector<double> wvals;
+struct TriStage {
+  RowOpHost fwd_a, fwd_b, bwd_a, bwd_b;  // fwd_a is empty for the first stage, bwd_a for the last
+  bool dense = false;                    // stage 0 only: `blocks_op` replaces fwd_b, bwd_a and bwd_b
+  BlockOpHost blocks_op;
+  int32_t rows = 0, blocks = 0;
 };
 
 struct TriPlan {
-  int m = 0;                 // order of the factor
-  int32_t zero_row = -1;     // internal row forced to zero when the factor has N-1 rows
-  TriHost fwd, bwd;
-  BorderHost border;
-  int64_t nnzL = 0;
-  int height = 0;
+  int m = 0;               // order of the factor
+  int32_t zero_row = -1;   // internal row forced to zero when the factor has N-1 rows
+  std::vector<TriStage> stages;
+  int64_t nnzL = 0, nnzW = 0;  // entries of L and of the explicit block inverses
+  int height = 0;              // number of stages
 };
 
-// row_of[i]: internal row of permuted variable i (= api2int[perm[i]]).
+// row_of[i]: internal row of permuted variable i (= api2int[perm[i]]).  zero_row >= 0: an internal
+// row outside the factor that every solve must set to zero (the pinned variable).
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
-                    const std::vector<int32_t> &row_of, TriPlan &plan);
+                    const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &plan);
 
 }  // namespace cora

@@ -6,144 +6,290 @@
 namespace cora {
 
 namespace {
-constexpr int kBorderRowNnz = 4096;   // rows of L longer than this form the dense border
-constexpr int kBorderChunk = 2048;
+constexpr int kBorderRowNnz = 4096;  // rows of L longer than this (landmarks) always belong to the last stage
+constexpr int kFirstCap = 48;        // rows of a stage-0 subtree (one nested-dissection leaf and its range rows)
+constexpr int kCapGrowth = 16;       // stage k subtrees hold up to kFirstCap * kCapGrowth^k rows
+constexpr int kTopCap = 1536;        // stop cutting once this few rows are left: they form the last stage
+constexpr int kShortRow = 64;        // entries: <= this -> 8 lanes per row
+constexpr int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
+constexpr int kChunk = 512;
+constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
 
-// lanes per supernode from the largest number of external entries of a supernode in the level
-int lanes_for(int max_len) { return max_len <= 96 ? 8 : 64; }
+struct RowList {  // rows of one product before they are sorted into length classes
+  std::vector<int32_t> out, ptr{0}, col;
+  std::vector<double> val;
+  void begin_row(int32_t out_row) { out.push_back(out_row); }
+  void add(int32_t c, double v) { col.push_back(c); val.push_back(v); }
+  void end_row() { ptr.push_back(static_cast<int32_t>(col.size())); }
+};
+
+void finalize(const RowList &R, RowOpHost &op) {
+  const int n = static_cast<int>(R.out.size());
+  std::vector<int32_t> s8, s64, sl;
+  for (int i = 0; i < n; ++i) {
+    const int len = R.ptr[i + 1] - R.ptr[i];
+    (len <= kShortRow ? s8 : (len <= kWaveRow ? s64 : sl)).push_back(i);
+  }
+  op = RowOpHost();
+  op.n8 = static_cast<int32_t>(s8.size());
+  op.n64 = static_cast<int32_t>(s64.size());
+  op.col.reserve(R.col.size());
+  op.val.reserve(R.val.size());
+  auto copy_entries = [&](int i) {
+    op.col.insert(op.col.end(), R.col.begin() + R.ptr[i], R.col.begin() + R.ptr[i + 1]);
+    op.val.insert(op.val.end(), R.val.begin() + R.ptr[i], R.val.begin() + R.ptr[i + 1]);
+  };
+  for (const auto *cls : {&s8, &s64})
+    for (int32_t i : *cls) {
+      op.out_row.push_back(R.out[i]);
+      op.begin.push_back(static_cast<int32_t>(op.col.size()));
+      copy_entries(i);
+      op.end.push_back(static_cast<int32_t>(op.col.size()));
+    }
+  op.long_chunk_ptr.push_back(0);
+  for (int32_t i : sl) {
+    op.long_out.push_back(R.out[i]);
+    const int32_t b = static_cast<int32_t>(op.col.size());
+    copy_entries(i);
+    const int32_t e = static_cast<int32_t>(op.col.size());
+    for (int32_t c = b; c < e; c += kChunk) {
+      op.chunk_begin.push_back(c);
+      op.chunk_end.push_back(std::min(e, c + kChunk));
+    }
+    op.long_chunk_ptr.push_back(static_cast<int32_t>(op.chunk_begin.size()));
+  }
+}
 }  // namespace
 
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
-                    const std::vector<int32_t> &row_of, TriPlan &P) {
+                    const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P) {
   P = TriPlan();
   P.m = m;
+  P.zero_row = zero_row;
+  if (m <= 0) return;
   P.nnzL = Lp[m];
-  // ---- row counts of L (strictly lower part)
-  std::vector<int32_t> rcount(m, 0);
+  // ---- elimination tree and row lengths
+  std::vector<int32_t> parent(m, -1), rcount(m, 0);
   for (int j = 0; j < m; ++j) {
     if (Li[Lp[j]] != j) throw std::runtime_error("cora: Cholesky factor must store the diagonal first in each column");
-    for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) rcount[Li[q]]++;
+    for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
+      if (Li[q] <= j || Li[q] >= m) throw std::runtime_error("cora: Cholesky factor has an entry above the diagonal");
+      if (parent[j] < 0 || Li[q] < parent[j]) parent[j] = Li[q];
+      rcount[Li[q]]++;
+    }
   }
-  // ---- border: maximal trailing run of long rows
-  int first_border = m;
+  for (int i = 0; i < m; ++i)
+    if (row_of[i] < 0) throw std::runtime_error("cora: factor row outside the handle");
+  // ---- CSR of the strictly lower part (rows of L, columns ascending)
+  std::vector<int32_t> rptr(static_cast<size_t>(m) + 1, 0);
+  for (int i = 0; i < m; ++i) rptr[i + 1] = rptr[i] + rcount[i];
+  std::vector<int32_t> rcol(static_cast<size_t>(rptr[m]));
+  std::vector<double> rval(static_cast<size_t>(rptr[m]));
+  {
+    std::vector<int32_t> fill(rptr.begin(), rptr.end() - 1);
+    for (int j = 0; j < m; ++j)
+      for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
+        rcol[fill[Li[q]]] = j;
+        rval[fill[Li[q]]++] = Lx[q];
+      }
+  }
+  // ---- stages: repeatedly peel the maximal subtrees of the remaining forest that fit the cap
+  int first_border = m;  // trailing run of long rows: forced into the last stage
   while (first_border > 0 && rcount[first_border - 1] > kBorderRowNnz) --first_border;
-  const int nb = m - first_border;
-  BorderHost &B = P.border;
-  B.nb = nb;
-  B.Lbb.assign(static_cast<size_t>(nb) * nb, 0.0);
-  for (int k = 0; k < nb; ++k) B.out_row.push_back(row_of[first_border + k]);
-
-  // ---- CSR of the strictly lower part restricted to non-border rows (forward, pull)
-  std::vector<int32_t> rptr(first_border + 1, 0);
-  for (int i = 0; i < first_border; ++i) rptr[i + 1] = rptr[i] + rcount[i];
-  std::vector<int32_t> rcol(rptr[first_border]);
-  std::vector<double> rval(rptr[first_border]);
-  std::vector<int32_t> fill(rptr.begin(), rptr.end() - 1);
-  // border rows: W part (columns < first_border) collected per row
-  std::vector<std::vector<int32_t>> wc(nb);
-  std::vector<std::vector<double>> wv(nb);
-  for (int j = 0; j < m; ++j) {
-    for (int32_t q = Lp[j] + (0); q < Lp[j + 1]; ++q) {
-      const int i = Li[q];
-      if (i >= first_border) {
-        const int k = i - first_border;
-        if (j >= first_border) B.Lbb[static_cast<size_t>(k) * nb + (j - first_border)] = Lx[q];
-        else { wc[k].push_back(row_of[j]); wv[k].push_back(Lx[q]); }
-      } else if (i != j) {
-        rcol[fill[i]] = j;
-        rval[fill[i]] = Lx[q];
-        fill[i]++;
+  std::vector<int32_t> stage(m, -1), blk(m, -1), sz(m, 0);
+  int nstage = 0;
+  int64_t remaining = first_border, cap = kFirstCap;
+  while (remaining + (m - first_border) > kTopCap && cap < 4LL * m) {
+    for (int v = 0; v < first_border; ++v) sz[v] = stage[v] < 0 ? 1 : 0;
+    for (int v = 0; v < first_border; ++v) {
+      const int p = parent[v];
+      if (stage[v] < 0 && p >= 0 && p < first_border) sz[p] += sz[v];  // children come before parents
+    }
+    int64_t taken = 0;
+    for (int v = first_border - 1; v >= 0; --v) {
+      if (stage[v] >= 0) continue;
+      const int p = parent[v];
+      if (p >= 0 && p < first_border && stage[p] == nstage) {  // inside a subtree taken in this round
+        stage[v] = nstage;
+        blk[v] = blk[p];
+        ++taken;
+      } else if (sz[v] <= cap) {  // maximal: its parent (if any) was visited and did not fit
+        stage[v] = nstage;
+        blk[v] = v;
+        P.stages.resize(static_cast<size_t>(nstage) + 1);
+        P.stages[nstage].blocks++;
+        ++taken;
       }
     }
+    cap *= kCapGrowth;
+    if (taken == 0) continue;
+    remaining -= taken;
+    ++nstage;
   }
-  for (int k = 0; k < nb; ++k) {
-    const int len = static_cast<int>(wc[k].size());
-    for (int c0 = 0; c0 < len || (c0 == 0 && len == 0); c0 += kBorderChunk) {
-      B.chunk_row.push_back(k);
-      B.chunk_begin.push_back(static_cast<int32_t>(B.wcols.size()) + c0);
-      B.chunk_end.push_back(static_cast<int32_t>(B.wcols.size()) + std::min(len, c0 + kBorderChunk));
-      if (len == 0) break;
+  for (int v = 0; v < m; ++v)
+    if (stage[v] < 0) {
+      stage[v] = nstage;
+      blk[v] = m;  // one block: the top of the tree and the long rows
     }
-    B.wcols.insert(B.wcols.end(), wc[k].begin(), wc[k].end());
-    B.wvals.insert(B.wvals.end(), wv[k].begin(), wv[k].end());
+  const int K = nstage + 1;
+  P.height = K;
+  P.stages.resize(static_cast<size_t>(K));
+  P.stages[K - 1].blocks = 1;
+  for (int v = 0; v < m; ++v) P.stages[stage[v]].rows++;
+  // for L_ij != 0 the column j is a descendant of the row i, and every round takes whole subtrees of
+  // what is left, so stage[j] <= stage[i]
+  // ---- stage 0 in dense form when there is more than one stage and every block fits a wavefront
+  std::vector<int32_t> loc(static_cast<size_t>(m), 0), blk_id(static_cast<size_t>(m), -1);
+  bool dense0 = K > 1;
+  {
+    std::vector<int32_t> bsz(static_cast<size_t>(m) + 1, 0);
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0) bsz[blk[v]]++;
+    for (int v = 0; v <= m && dense0; ++v) dense0 = bsz[v] <= kDenseBlock;
   }
-
-  // ---- small chain supernodes over the non-border rows.  parent(j) = first off-diagonal row of column j.
-  const int nr = first_border;
-  std::vector<int32_t> parent(nr, -1), nchild(nr, 0);
-  for (int j = 0; j < nr; ++j)
-    if (Lp[j] + 1 < Lp[j + 1] && Li[Lp[j] + 1] < nr) parent[j] = Li[Lp[j] + 1];
-  for (int j = 0; j < nr; ++j)
-    if (parent[j] >= 0) nchild[parent[j]]++;
-  std::vector<int32_t> sn_of(nr, 0), sn_first;
-  for (int i = 0; i < nr; ++i) {
-    const bool extend = i > 0 && parent[i - 1] == i && nchild[i] == 1 && (i - sn_first.back()) < kTriSn;
-    if (!extend) sn_first.push_back(i);
-    sn_of[i] = static_cast<int32_t>(sn_first.size()) - 1;
-  }
-  const int nsn = static_cast<int>(sn_first.size());
-  sn_first.push_back(nr);
-
-  auto emit = [&](TriHost &T, bool backward, auto row_begin, auto row_end, auto col_at, auto val_at) {
-    std::vector<int32_t> lev(nsn, 0);
-    int height = 0;
-    auto visit = [&](int s) {
-      int l = 0;
-      for (int i = sn_first[s]; i < sn_first[s + 1]; ++i)
-        for (int32_t q = row_begin(i); q < row_end(i); ++q) {
-          const int j = col_at(q);
-          if (j < nr && sn_of[j] != s) l = std::max(l, lev[sn_of[j]] + 1);
-        }
-      lev[s] = l;
-      height = std::max(height, l + 1);
-    };
-    if (!backward) for (int s = 0; s < nsn; ++s) visit(s);
-    else for (int s = nsn - 1; s >= 0; --s) visit(s);
-    std::vector<std::vector<int32_t>> by_level(height);
-    for (int s = 0; s < nsn; ++s) by_level[lev[s]].push_back(s);
-    for (int l = 0; l < height; ++l) {
-      TriLevel tl;
-      tl.begin = static_cast<int32_t>(T.sn.size());
-      int maxlen = 0;
-      for (int32_t s : by_level[l]) {
-        const int lo = sn_first[s], hi = sn_first[s + 1], bsz = hi - lo;
-        TriSn R{};
-        R.ext_begin = static_cast<int32_t>(T.cols.size());
-        R.nrows = bsz;
-        auto pos = [&](int i) { return backward ? hi - 1 - i : i - lo; };  // processing position of row i
-        for (int t = 0; t < kTriSn; ++t) { R.out_row[t] = row_of[backward ? hi - 1 : lo]; R.dinv[t] = 0.0; }
-        for (int t = 0; t < bsz; ++t) {
-          const int i = backward ? hi - 1 - t : lo + t;
-          for (int32_t q = row_begin(i); q < row_end(i); ++q) {
-            const int j = col_at(q);
-            if (j < nr && sn_of[j] == s) {
-              const int pq = pos(j);
-              if (pq >= t) throw std::logic_error("cora: supernode dependency out of order");
-              R.lint[t * (t - 1) / 2 + pq] += val_at(q);
-            } else {
-              if (row_of[j] >= (1 << 28)) throw std::runtime_error("cora: too many rows for the packed triangular-solve index");
-              T.cols.push_back(row_of[j] | (t << 28));  // position of the row inside its supernode in the top bits
-              T.vals.push_back(val_at(q));
-            }
+  BlockOpHost &D0 = P.stages[0].blocks_op;
+  if (dense0) {
+    P.stages[0].dense = true;
+    // blocks in order of their roots; rows of a block in elimination order
+    std::vector<int32_t> id_of_root(static_cast<size_t>(m), -1), count;
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0 && blk[v] == v) {
+        id_of_root[v] = static_cast<int32_t>(count.size());
+        count.push_back(0);
+      }
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0) {
+        blk_id[v] = id_of_root[blk[v]];
+        loc[v] = count[blk_id[v]]++;
+      }
+    const size_t nblk = count.size();
+    D0.row_begin.assign(nblk, 0);
+    D0.nrows.assign(nblk, 0);
+    D0.w_off.assign(nblk, 0);
+    int32_t rb = 0;
+    int64_t wo = 0;
+    for (size_t b = 0; b < nblk; ++b) {
+      D0.row_begin[b] = rb;
+      D0.nrows[b] = count[b];
+      D0.w_off[b] = wo;
+      rb += count[b];
+      wo += static_cast<int64_t>(count[b]) * (count[b] + 1) / 2;
+    }
+    D0.rows.assign(static_cast<size_t>(rb), 0);
+    D0.w_by_col.assign(static_cast<size_t>(wo), 0.0);
+    D0.w_by_row.assign(static_cast<size_t>(wo), 0.0);
+    D0.ext_ptr.assign(static_cast<size_t>(rb) + 1, 0);
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0) {
+        const int32_t at = D0.row_begin[blk_id[v]] + loc[v];
+        D0.rows[at] = row_of[v];
+        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q)
+          if (stage[Li[q]] > 0) D0.ext_ptr[at + 1]++;
+      }
+    for (int32_t i = 0; i < rb; ++i) D0.ext_ptr[i + 1] += D0.ext_ptr[i];
+    D0.ext_col.assign(static_cast<size_t>(D0.ext_ptr[rb]), 0);
+    D0.ext_val.assign(static_cast<size_t>(D0.ext_ptr[rb]), 0.0);
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0) {
+        int32_t at = D0.ext_ptr[D0.row_begin[blk_id[v]] + loc[v]];
+        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q)
+          if (stage[Li[q]] > 0) {
+            D0.ext_col[at] = row_of[Li[q]];
+            D0.ext_val[at++] = -Lx[q];
           }
-          R.out_row[t] = row_of[i];
-          R.dinv[t] = 1.0 / Lx[Lp[i]];
-        }
-        R.ext_end = static_cast<int32_t>(T.cols.size());
-        maxlen = std::max(maxlen, R.ext_end - R.ext_begin);
-        T.sn.push_back(R);
       }
-      tl.end = static_cast<int32_t>(T.sn.size());
-      tl.lanes = lanes_for(maxlen);
-      T.levels.push_back(tl);
+  }
+  // ---- "a" products: the couplings between stages
+  for (int k = 0; k < K; ++k) {
+    RowList fa, ba;
+    for (int i = 0; i < m; ++i) {
+      if (stage[i] != k) continue;
+      if (k > 0) {  // forward: row i of L restricted to earlier stages
+        fa.begin_row(row_of[i]);
+        for (int32_t q = rptr[i]; q < rptr[i + 1]; ++q) {
+          if (stage[rcol[q]] > k) throw std::logic_error("cora: stage order violates the elimination tree");
+          if (stage[rcol[q]] < k) fa.add(row_of[rcol[q]], -rval[q]);
+        }
+        fa.end_row();
+      }
+      if (k < K - 1 && !(k == 0 && dense0)) {  // backward: column i of L restricted to later stages
+        ba.begin_row(row_of[i]);
+        for (int32_t q = Lp[i] + 1; q < Lp[i + 1]; ++q)
+          if (stage[Li[q]] > k) ba.add(row_of[Li[q]], -Lx[q]);
+        ba.end_row();
+      }
     }
-    return height;
-  };
-  const int hf = emit(P.fwd, false, [&](int i) { return rptr[i]; }, [&](int i) { return rptr[i + 1]; },
-                      [&](int32_t q) { return rcol[q]; }, [&](int32_t q) { return rval[q]; });
-  const int hb = emit(P.bwd, true, [&](int j) { return Lp[j] + 1; }, [&](int j) { return Lp[j + 1]; },
-                      [&](int32_t q) { return Li[q]; }, [&](int32_t q) { return Lx[q]; });
-  P.height = std::max(hf, hb);
+    if (k > 0) finalize(fa, P.stages[k].fwd_a);
+    if (k < K - 1 && !(k == 0 && dense0)) finalize(ba, P.stages[k].bwd_a);
+  }
+  // ---- "b" products: explicit inverse of every diagonal block.  Column j of W = L_bb^-1 solves
+  // L_bb w = e_j and is non-zero only on the path from j to the root of its block.
+  std::vector<double> w(static_cast<size_t>(m), 0.0);
+  std::vector<std::vector<int32_t>> wt_row(static_cast<size_t>(K)), wt_col(static_cast<size_t>(K));
+  std::vector<std::vector<double>> wt_val(static_cast<size_t>(K));
+  std::vector<RowList> bb(static_cast<size_t>(K));
+  for (int j = 0; j < m; ++j) {
+    const int k = stage[j], b = blk[j];
+    const bool dense = k == 0 && dense0;
+    RowList &B = bb[k];
+    if (!dense) B.begin_row(row_of[j]);  // backward "b": x_j = sum_i W_ij t_i  (column j of W)
+    w[j] = 1.0;
+    for (int v = j; v >= 0 && stage[v] == k && blk[v] == b; v = parent[v]) {
+      const double wv = w[v] / Lx[Lp[v]];
+      w[v] = 0.0;
+      if (dense) {
+        const int nb = D0.nrows[blk_id[j]], lj = loc[j], li = loc[v];
+        const int64_t base = D0.w_off[blk_id[j]];
+        D0.w_by_col[base + static_cast<int64_t>(lj) * nb - static_cast<int64_t>(lj) * (lj - 1) / 2 + (li - lj)] = wv;
+        D0.w_by_row[base + static_cast<int64_t>(li) * (li + 1) / 2 + lj] = wv;
+        ++P.nnzW;
+      } else {
+        B.add(row_of[v], wv);
+        wt_row[k].push_back(v);
+        wt_col[k].push_back(j);
+        wt_val[k].push_back(wv);
+      }
+      for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q) {
+        const int i = Li[q];
+        if (i >= m) break;
+        if (stage[i] == k && blk[i] == b) w[i] -= Lx[q] * wv;
+      }
+    }
+    if (!dense) B.end_row();
+  }
+  if (zero_row >= 0) {  // the pinned row rides along as an empty row of the last stage's backward product
+    bb[K - 1].begin_row(zero_row);
+    bb[K - 1].end_row();
+  }
+  for (int k = 0; k < K; ++k) {
+    if (k == 0 && dense0) continue;
+    finalize(bb[k], P.stages[k].bwd_b);
+    bb[k] = RowList();
+    // forward "b": y_i = sum_j W_ij t_j  (row i of W): bucket the triplets by row
+    const size_t nz = wt_row[k].size();
+    P.nnzW += static_cast<int64_t>(nz);
+    std::vector<int32_t> cnt(static_cast<size_t>(m) + 1, 0);
+    for (size_t t = 0; t < nz; ++t) cnt[wt_row[k][t] + 1]++;
+    for (int i = 0; i < m; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1), cc(nz);
+    std::vector<double> vv(nz);
+    for (size_t t = 0; t < nz; ++t) {
+      const int32_t at = pos[wt_row[k][t]]++;
+      cc[at] = wt_col[k][t];
+      vv[at] = wt_val[k][t];
+    }
+    RowList F;
+    for (int i = 0; i < m; ++i) {
+      if (stage[i] != k) continue;
+      F.begin_row(row_of[i]);
+      for (int32_t q = cnt[i]; q < cnt[i + 1]; ++q) F.add(row_of[cc[q]], vv[q]);
+      F.end_row();
+    }
+    finalize(F, P.stages[k].fwd_b);
+    wt_row[k] = std::vector<int32_t>();
+    wt_col[k] = std::vector<int32_t>();
+    wt_val[k] = std::vector<double>();
+  }
 }
 
 }  // namespace cora

@@ -156,8 +156,8 @@ int cora_precond_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp,
                               const int32_t *Li, const double *Lx,
                               const int32_t *perm);
 
-/* Triangular-solve schedule of the installed factor: [0] forward levels, [1] backward levels,
- * [2] nnz(L), [3] dense border rows. */
+/* Device solve plan of the installed factor: [0] stages (a solve is 4*stages - 2 sparse products),
+ * [1] entries of the explicit block inverses, [2] nnz(L), [3] rows of the last stage. */
 int cora_precond_stats(const cora_ctx *ctx, int64_t stats[4]);
 
 /* Translation-implicit formulation (Formulation::Implicit, src/CORA_problem.cpp:714-753):

@@ -11,7 +11,7 @@ P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, se
 P.update(); P.set_rank(p); dm = P.dims()
 t = time.time(); info = P.precond_info(); print("precond setup %.2fs" % (time.time() - t), info)
 import ctypes as C
-st = (C.c_int64 * 4)(); capi.load().cora_precond_stats(C.c_void_p(P.context_ptr()), st); print("tri levels fwd/bwd", st[0], st[1], "border", st[3])
+st = (C.c_int64 * 4)(); capi.load().cora_precond_stats(C.c_void_p(P.context_ptr()), st); print("solve stages", st[0], "nnz(W)", st[1], "nnz(L)", st[2], "top rows", st[3])
 import ctypes as C
 L = capi.load()
 h = C.c_void_p(P.context_ptr())

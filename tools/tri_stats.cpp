@@ -1,0 +1,104 @@
+// Developer tool (CPU only): stage statistics of the device Cholesky-solve plan, and a host
+// emulation of the staged products checked against CholeskyFactor::solveInPlace.
+// hipcc -O2 -std=c++17 -Iinclude -Icora_amd/csrc -Icora_amd/csrc/host tools/tri_stats.cpp -Lcora_amd/lib -lcora_hip -Wl,-rpath,$PWD/cora_amd/lib -o tools/bin/tri_stats
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include "sparse_cholesky.h"
+#include "synthetic.h"
+#include "trisolve.h"
+using cora::RowOpHost;
+static void apply(const RowOpHost &op, const std::vector<double> *src0, const std::vector<double> &src, std::vector<double> &dst) {
+  const int n = op.n8 + op.n64;
+  for (int r = 0; r < n; ++r) {
+    double s = src0 ? (*src0)[op.out_row[r]] : 0.0;
+    for (int k = op.begin[r]; k < op.end[r]; ++k) s += op.val[k] * src[op.col[k]];
+    dst[op.out_row[r]] = s;
+  }
+  for (size_t r = 0; r < op.long_out.size(); ++r) {
+    double s = src0 ? (*src0)[op.long_out[r]] : 0.0;
+    for (int ch = op.long_chunk_ptr[r]; ch < op.long_chunk_ptr[r + 1]; ++ch)
+      for (int k = op.chunk_begin[ch]; k < op.chunk_end[ch]; ++k) s += op.val[k] * src[op.col[k]];
+    dst[op.long_out[r]] = s;
+  }
+}
+static void apply_blocks(const cora::BlockOpHost &B, bool bwd, const std::vector<double> &src, std::vector<double> &dst) {
+  for (size_t b = 0; b < B.nrows.size(); ++b) {
+    const int nb = B.nrows[b], rb = B.row_begin[b];
+    std::vector<double> t(nb), acc(nb, 0.0);
+    for (int l = 0; l < nb; ++l) {
+      t[l] = src[B.rows[rb + l]];
+      if (bwd)
+        for (int k = B.ext_ptr[rb + l]; k < B.ext_ptr[rb + l + 1]; ++k) t[l] += B.ext_val[k] * src[B.ext_col[k]];
+    }
+    const double *W = (bwd ? B.w_by_row.data() : B.w_by_col.data()) + B.w_off[b];
+    int at = 0;
+    for (int q = 0; q < nb; ++q) {
+      for (int l = 0; l < nb; ++l) {
+        if (bwd ? l <= q : l >= q) acc[l] += W[at + (bwd ? l : l - q)] * t[q];
+      }
+      at += bwd ? q + 1 : nb - q;
+    }
+    for (int l = 0; l < nb; ++l) dst[B.rows[rb + l]] = acc[l];
+  }
+}
+static void stat(const char *name, const RowOpHost &op) {
+  std::printf("    %-6s rows8 %7d rows64 %6d long %3zu chunks %5zu entries %9zu\n", name, op.n8, op.n64, op.long_out.size(),
+              op.chunk_begin.size(), op.col.size());
+}
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? std::atoi(argv[1]) : 100000, leaf = argc > 2 ? std::atoi(argv[2]) : 8;
+  CORA::SyntheticSpec sp;
+  sp.num_poses = n; sp.num_ranges = n / 2; sp.num_landmarks = 10; sp.num_loop_closures = argc > 3 ? std::atoi(argv[3]) : 0;
+  CORA::Problem P = CORA::makeSyntheticProblem(sp);
+  P.updateProblemData();
+  const int N = P.getDataMatrixSize(), m = N - 1;
+  const auto perm = CORA::coraOrdering(3, P.numPoses(), P.numRangeMeasurements(), P.numTranslationalStates(), P.data_matrix_, m, leaf);
+  auto t0 = std::chrono::steady_clock::now();
+  const CORA::CholeskyFactor F = CORA::choleskyFactor(P.data_matrix_, m, 9.4e3, perm);
+  auto t1 = std::chrono::steady_clock::now();
+  std::vector<int32_t> row_of(perm.begin(), perm.end());  // internal row = original row here
+  cora::TriPlan plan;
+  cora::build_tri_plan(m, F.Lp.data(), F.Li.data(), F.Lx.data(), row_of, N - 1, plan);
+  auto t2 = std::chrono::steady_clock::now();
+  std::printf("factor %.3f s, plan %.3f s, nnz(L) %ld nnz(W) %ld stages %zu\n", std::chrono::duration<double>(t1 - t0).count(),
+              std::chrono::duration<double>(t2 - t1).count(), (long)plan.nnzL, (long)plan.nnzW, plan.stages.size());
+  for (size_t k = 0; k < plan.stages.size(); ++k) {
+    const auto &S = plan.stages[k];
+    std::printf("  stage %zu: rows %d blocks %d\n", k, S.rows, S.blocks);
+    if (S.dense) {
+      std::printf("    dense: %zu blocks, %zu packed entries, %zu ext entries\n", S.blocks_op.nrows.size(), S.blocks_op.w_by_col.size(), S.blocks_op.ext_col.size());
+      continue;
+    }
+    if (k > 0) stat("fwd_a", S.fwd_a);
+    stat("fwd_b", S.fwd_b);
+    if (k + 1 < plan.stages.size()) stat("bwd_a", S.bwd_a);
+    stat("bwd_b", S.bwd_b);
+  }
+  // emulate
+  std::vector<double> rhs(N, 0.0), out(N, 7.0), t(N, 0.0), t2v(N, 0.0);
+  for (int i = 0; i < m; ++i) rhs[i] = std::sin(0.37 * i) + 0.1;
+  const int K = static_cast<int>(plan.stages.size());
+  for (int k = 0; k < K; ++k) {
+    const auto &S = plan.stages[k];
+    if (S.dense) { apply_blocks(S.blocks_op, false, rhs, out); continue; }
+    const std::vector<double> *tk = &rhs;
+    if (k > 0) { apply(S.fwd_a, &rhs, out, t); tk = &t; }
+    apply(S.fwd_b, nullptr, *tk, k == K - 1 ? t2v : out);
+  }
+  for (int k = K - 1; k >= 0; --k) {
+    const auto &S = plan.stages[k];
+    if (S.dense) { apply_blocks(S.blocks_op, true, out, out); continue; }
+    const std::vector<double> *tk = &t2v;
+    if (k + 1 < K) { apply(S.bwd_a, &out, out, t); tk = &t; }
+    apply(S.bwd_b, nullptr, *tk, out);
+  }
+  CORA::Matrix B(m, 1);
+  for (int i = 0; i < m; ++i) B(i, 0) = rhs[i];
+  F.solveInPlace(B);
+  double err = 0, nrm = 0;
+  for (int i = 0; i < m; ++i) { err = std::max(err, std::fabs(B(i, 0) - out[i])); nrm = std::max(nrm, std::fabs(B(i, 0))); }
+  std::printf("staged vs direct solve: max err %.3e (max |x| %.3e), pinned row %.1e\n", err, nrm, out[N - 1]);
+  return 0;
+}
