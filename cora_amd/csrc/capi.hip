@@ -1175,4 +1175,33 @@ int cora_debug_format_spmm_host(const cora_ctx *c, const double *X, int ldx, int
   return CORA_OK;
 }
 
+int cora_debug_factor_solve_host(int m, const int32_t *Lp, const int32_t *Li, const double *Lx, int k,
+                                 const double *B, double *X, int64_t stats[4]) {
+  if (m <= 0 || !Lp || !Li || !Lx || !B || !X || k <= 0) return CORA_ERR_ARG;
+  try {
+    std::vector<int32_t> row_of(static_cast<size_t>(m));
+    for (int i = 0; i < m; ++i) row_of[i] = i;
+    TriPlan P;
+    build_tri_plan(m, Lp, Li, Lx, row_of, m, P);  // row m plays the pinned variable
+    std::vector<double> rhs(static_cast<size_t>(m) + 1), out(static_cast<size_t>(m) + 1);
+    for (int cc = 0; cc < k; ++cc) {
+      std::copy(B + static_cast<size_t>(cc) * m, B + static_cast<size_t>(cc + 1) * m, rhs.begin());
+      rhs[m] = 1.0;
+      std::fill(out.begin(), out.end(), 7.0);
+      tri_plan_solve_host(P, m + 1, rhs.data(), out.data());
+      if (out[m] != 0.0) return fail(nullptr, CORA_ERR_ARG, "the pinned row was not zeroed");
+      std::copy(out.begin(), out.begin() + m, X + static_cast<size_t>(cc) * m);
+    }
+    if (stats) {
+      stats[0] = static_cast<int64_t>(P.stages.size());
+      stats[1] = P.nnzW;
+      stats[2] = P.nnzL;
+      stats[3] = (!P.stages.empty() && P.stages[0].dense) ? static_cast<int64_t>(P.stages[0].blocks_op.nrows.size()) : 0;
+    }
+  } catch (const std::exception &e) {
+    return fail(nullptr, CORA_ERR_ARG, e.what());
+  }
+  return CORA_OK;
+}
+
 }  // extern "C"

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "cora_internal.h"
 #include "kernels.h"
@@ -824,6 +825,14 @@ __global__ __launch_bounds__(64) void k_rowop_long(RowOpDev op, const double *__
   }
 }
 
+// LDS hand-off between the lanes of one wavefront (no workgroup barrier: the waves of a block work on
+// different blocks of the factor and run different trip counts)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Stage 0 in dense form (trisolve.h): one wavefront per block, lane = row of the block.
 //   forward : dst[rows] = W src[rows]
 //   backward: t = src[rows] - L[later, rows]^T src[later rows];  dst[rows] = W^T t   (src may be dst:
@@ -840,37 +849,60 @@ __global__ __launch_bounds__(256) void k_blockop(BlockOpDev B, const double *src
   double t[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) t[j] = 0.0;
-  if (mine) {
-    load_row<LD>(src + row * LD, t);
-    if (BWD) {
-      const int e1 = B.ext_ptr[rb + lane + 1];
-#pragma unroll 2
-      for (int k = B.ext_ptr[rb + lane]; k < e1; ++k) {
-        const double v = B.ext_val[k];
-        double xx[LD];
-        load_row<LD>(src + static_cast<size_t>(B.ext_col[k]) * LD, xx);
+  if (mine) load_row<LD>(src + row * LD, t);
+  if (BWD && live) {
+    // coupling to the later stages: the lanes stride over ALL entries of the block (independent gathers),
+    // park the products in LDS, and every row then adds up its own segment in entry order
+    const int e0 = B.ext_ptr[rb], e1 = B.ext_ptr[rb + nb];
+    const int my0 = mine ? B.ext_ptr[rb + lane] : 0, my1 = mine ? B.ext_ptr[rb + lane + 1] : 0;
+    for (int base = e0; base < e1; base += 64) {
+      const int k = base + lane;
+      double p[LD];
 #pragma unroll
-        for (int j = 0; j < LD; ++j) t[j] = fma(v, xx[j], t[j]);
+      for (int j = 0; j < LD; ++j) p[j] = 0.0;
+      if (k < e1) {
+        const double v = B.ext_val[k];
+        load_row<LD>(src + static_cast<size_t>(B.ext_col[k]) * LD, p);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) p[j] *= v;
       }
+#pragma unroll
+      for (int j = 0; j < LD; ++j) tl[wv][lane][j] = p[j];
+      wave_lds_sync();
+      const int lo = my0 > base ? my0 : base, hi = my1 < base + 64 ? my1 : base + 64;
+      for (int q = lo; q < hi; ++q)
+#pragma unroll
+        for (int j = 0; j < LD; ++j) t[j] += tl[wv][q - base][j];
+      wave_lds_sync();
     }
   }
 #pragma unroll
   for (int j = 0; j < LD; ++j) tl[wv][lane][j] = t[j];
-  __syncthreads();
+  wave_lds_sync();
   double acc[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
   if (live) {
     const double *W = (BWD ? B.w_by_row : B.w_by_col) + B.w_off[b];
-    int at = 0;  // start of column q (forward) / row q (backward) in the packed triangle
-#pragma unroll 4
-    for (int q = 0; q < nb; ++q) {
-      // forward: lanes q..nb-1 hold W[lane][q] at at + lane - q;  backward: lanes 0..q hold W[q][lane] at at + lane
-      const bool on = BWD ? (lane <= q) : (lane >= q && mine);
-      const double w = on ? W[at + (BWD ? lane : lane - q)] : 0.0;
+    // forward : lanes q..nb-1 hold W[lane][q] at q nb - q(q-1)/2 + lane - q  (column q of the packed triangle)
+    // backward: lanes 0..q    hold W[q][lane] at q(q+1)/2 + lane            (row q)
+    // eight columns per round with unconditional (clamped) loads, so that they are all in flight at once
+    for (int q0 = 0; q0 < nb; q0 += 8) {
+      double w[8];
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acc[j] = fma(w, tl[wv][q][j], acc[j]);
-      at += BWD ? q + 1 : nb - q;
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u;
+        const bool on = q < nb && (BWD ? lane <= q : (lane >= q && mine));
+        const int at = BWD ? q * (q + 1) / 2 + lane : q * nb - q * (q - 1) / 2 + lane - q;
+        const double v = W[on ? at : 0];
+        w[u] = on ? v : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = (q0 + u) & 63;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[j] = fma(w[u], tl[wv][q][j], acc[j]);
+      }
     }
   }
   if (mine) store_row<LD>(dst + row * LD, acc);

@@ -76,4 +76,9 @@ struct TriPlan {
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &plan);
 
+
+// Test hook: runs the plan's products on the host in launch order (rhs, out: `rows` doubles, one
+// right-hand side, indexed by internal row).  Never used by a compute entry point.
+void tri_plan_solve_host(const TriPlan &plan, int64_t rows, const double *rhs, double *out);
+
 }  // namespace cora

@@ -14,6 +14,7 @@ constexpr int kShortRow = 64;        // entries: <= this -> 8 lanes per row
 constexpr int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
 constexpr int kChunk = 512;
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
+constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
 
 struct RowList {  // rows of one product before they are sorted into length classes
   std::vector<int32_t> out, ptr{0}, col;
@@ -113,7 +114,9 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         stage[v] = nstage;
         blk[v] = blk[p];
         ++taken;
-      } else if (sz[v] <= cap) {  // maximal: its parent (if any) was visited and did not fit
+      } else if (sz[v] <= cap && (nstage > 0 || sz[v] >= kMinBlock || p < 0 || p >= first_border)) {
+        // maximal: its parent (if any) was visited and did not fit.  Tiny stage-0 subtrees hanging off a
+        // bigger remainder (single range rows of separator poses) stay with that remainder.
         stage[v] = nstage;
         blk[v] = v;
         P.stages.resize(static_cast<size_t>(nstage) + 1);
@@ -289,6 +292,76 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     wt_row[k] = std::vector<int32_t>();
     wt_col[k] = std::vector<int32_t>();
     wt_val[k] = std::vector<double>();
+  }
+}
+
+
+// ---- test hook: the staged products executed on the host, in the order factor_solve launches them
+namespace {
+void apply_rowop(const RowOpHost &op, const double *src0, const double *src, double *dst) {
+  const int n = op.n8 + op.n64;
+  for (int r = 0; r < n; ++r) {
+    double s = src0 ? src0[op.out_row[r]] : 0.0;
+    for (int32_t k = op.begin[r]; k < op.end[r]; ++k) s += op.val[k] * src[op.col[k]];
+    dst[op.out_row[r]] = s;
+  }
+  for (size_t r = 0; r < op.long_out.size(); ++r) {
+    double s = src0 ? src0[op.long_out[r]] : 0.0;
+    for (int32_t ch = op.long_chunk_ptr[r]; ch < op.long_chunk_ptr[r + 1]; ++ch)
+      for (int32_t k = op.chunk_begin[ch]; k < op.chunk_end[ch]; ++k) s += op.val[k] * src[op.col[k]];
+    dst[op.long_out[r]] = s;
+  }
+}
+void apply_blocks(const BlockOpHost &B, bool bwd, const double *src, double *dst) {
+  std::vector<double> t, acc;
+  for (size_t b = 0; b < B.nrows.size(); ++b) {
+    const int nb = B.nrows[b], rb = B.row_begin[b];
+    t.assign(nb, 0.0);
+    acc.assign(nb, 0.0);
+    for (int l = 0; l < nb; ++l) {
+      t[l] = src[B.rows[rb + l]];
+      if (bwd)
+        for (int32_t k = B.ext_ptr[rb + l]; k < B.ext_ptr[rb + l + 1]; ++k) t[l] += B.ext_val[k] * src[B.ext_col[k]];
+    }
+    const double *W = (bwd ? B.w_by_row.data() : B.w_by_col.data()) + B.w_off[b];
+    int at = 0;
+    for (int q = 0; q < nb; ++q) {
+      for (int l = bwd ? 0 : q; l < (bwd ? q + 1 : nb); ++l) acc[l] += W[at + (bwd ? l : l - q)] * t[q];
+      at += bwd ? q + 1 : nb - q;
+    }
+    for (int l = 0; l < nb; ++l) dst[B.rows[rb + l]] = acc[l];
+  }
+}
+}  // namespace
+
+void tri_plan_solve_host(const TriPlan &P, int64_t rows, const double *rhs, double *out) {
+  const int K = static_cast<int>(P.stages.size());
+  std::vector<double> t(static_cast<size_t>(rows), 0.0), t2(static_cast<size_t>(rows), 0.0);
+  for (int k = 0; k < K; ++k) {
+    const TriStage &S = P.stages[k];
+    if (S.dense) {
+      apply_blocks(S.blocks_op, false, rhs, out);
+      continue;
+    }
+    const double *tk = rhs;
+    if (k > 0) {
+      apply_rowop(S.fwd_a, rhs, out, t.data());
+      tk = t.data();
+    }
+    apply_rowop(S.fwd_b, nullptr, tk, k == K - 1 ? t2.data() : out);
+  }
+  for (int k = K - 1; k >= 0; --k) {
+    const TriStage &S = P.stages[k];
+    if (S.dense) {
+      apply_blocks(S.blocks_op, true, out, out);
+      continue;
+    }
+    const double *tk = t2.data();
+    if (k + 1 < K) {
+      apply_rowop(S.bwd_a, out, out, t.data());
+      tk = t.data();
+    }
+    apply_rowop(S.bwd_b, nullptr, tk, out);
   }
 }
 

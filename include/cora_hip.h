@@ -275,6 +275,13 @@ int cora_sync(cora_ctx *ctx);
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
                                 int k, double *out, int ldo);
 
+/* Test hook: builds the device solve plan (stages, explicit block inverses) of a Cholesky factor
+ * L (CSC, diagonal first per column, m x m) and executes its products on the host, in launch order:
+ * X = (L L^T)^-1 B for k column-major right-hand sides.  stats: [0] stages, [1] entries of the
+ * block inverses, [2] nnz(L), [3] dense stage-0 blocks.  Never used by any compute entry point. */
+int cora_debug_factor_solve_host(int m, const int32_t *Lp, const int32_t *Li, const double *Lx, int k,
+                                 const double *B, double *X, int64_t stats[4]);
+
 #ifdef __cplusplus
 }
 #endif
