@@ -55,6 +55,76 @@ def cpu_baseline(rowptr, colidx, vals, dm, p, budget_s):
     return reps / dt, reps, (Y, V, ref)
 
 
+def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us):
+    """SURVEY 8(d) timing protocol beside the headline number: percentiles of single launches, the plain
+    Q.X product, and one full STPCG iteration (Hvp + preconditioner + inner products + updates,
+    src/CORA.cpp:71-92,119-122) with the reference's default RegularizedCholesky preconditioner."""
+    from cora_amd import capi
+    b_spmm, _ = algorithmic_bytes(dm["d"], dm["n"], dm["r"], dm["N"], dm["nnz"], p)
+    one = []
+    for _ in range(200):
+        ctx.timer_start()
+        ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+        one.append(ctx.timer_stop_ms() * 1e3)
+    one.sort()
+    ctx.timer_start()
+    for _ in range(300):
+        ctx.spmm_dev(x.data_ptr(), p, out.data_ptr())
+    spmm_us = ctx.timer_stop_ms() * 1e3 / 300
+    ex = {
+        "hvp_single_launch_us": {"p10": one[20], "p50": one[100], "p90": one[180],
+                                 "note": "one launch between two events: includes the launch floor that back-to-back launches hide"},
+        "spmm_us": spmm_us,
+        "spmm_GBps": b_spmm / spmm_us / 1e3,
+        "hvp_back_to_back_us": kernel_us,
+    }
+    # full STPCG iteration on the C++ host's own handle with the Cholesky preconditioner installed
+    t0 = time.perf_counter()
+    P.set_rank(p)
+    P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
+    info = P.precond_info()
+    ex["preconditioner_setup_s"] = time.perf_counter() - t0
+    ex["preconditioner"] = {"kind": "RegularizedCholesky", "nnz_L": info["nnz"], "lambda": info["lam"]}
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    v = [h.dev_alloc(p) for _ in range(6)]
+    s, r, z, pk, hp, y = v
+    rng = np.random.default_rng(7)
+    Yh = rng.uniform(-1, 1, (dm["N"], p))
+    h.upload(Yh, y)
+    h.project_to_manifold_dev(y, y)
+    h.set_point_dev(y)
+    h.upload(rng.uniform(-1, 1, (dm["N"], p)), pk)
+    h.tangent_space_projection_dev(pk, pk)
+    h.axpby_dev(1.0, pk, 0.0, r)
+    h.axpby_dev(0.0, pk, 0.0, s)
+
+    def iteration():
+        h.hvp_dev(pk, hp)
+        h.dot_dev(pk, hp, p)
+        h.axpby_dev(1e-3, pk, 1.0, s)
+        h.axpby_dev(1e-3, hp, 1.0, r)
+        h.precondition_projected_dev(r, z)
+        h.dots_dev([(r, r), (r, z)])
+        h.axpby_dev(-1.0, z, 0.5, pk)
+
+    for _ in range(5):
+        iteration()
+    h.sync()
+    t0 = time.perf_counter()
+    reps = 100
+    for _ in range(reps):
+        iteration()
+    h.sync()
+    ex["stpcg_iteration_us"] = (time.perf_counter() - t0) / reps * 1e6
+    h.timer_start()
+    for _ in range(50):
+        h.precondition_projected_dev(r, z)
+    ex["preconditioner_apply_us"] = h.timer_stop_ms() * 1e3 / 50
+    for q in v:
+        h.dev_free(q)
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +306,7 @@ def main():
             ctx.hvp_dev(x.data_ptr(), out.data_ptr())
             got = ctx.download(out.data_ptr(), p)
             result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+            result["extras"] = solver_loop_timings(P, ctx, dm, p, x, out, kernel_us)
             result["cpu_baseline"] = {
                 "value": hv_s,
                 "unit": "Hvp/s",

@@ -305,6 +305,16 @@ class Context:
         self._chk(self.L.cora_dot_dev(self.h, C.c_void_p(a), C.c_void_p(b), int(k), C.byref(v)))
         return v.value
 
+    def dots_dev(self, pairs):
+        """Several inner products with one reduction and one synchronisation (the three metric() calls of
+        an STPCG iteration, src/CORA.cpp:119-122)."""
+        n = len(pairs)
+        A = (C.c_void_p * n)(*[C.c_void_p(a) for a, _ in pairs])
+        B = (C.c_void_p * n)(*[C.c_void_p(b) for _, b in pairs])
+        out = (C.c_double * n)()
+        self._chk(self.L.cora_dots_dev(self.h, n, A, B, out))
+        return [out[i] for i in range(n)]
+
     def point_ptrs(self):
         return (self.L.cora_point_Y_dev(self.h), self.L.cora_point_egrad_dev(self.h),
                 self.L.cora_point_rgrad_dev(self.h))
