@@ -101,8 +101,7 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us):
     def iteration():
         h.hvp_dev(pk, hp)
         h.dot_dev(pk, hp, p)
-        h.axpby_dev(1e-3, pk, 1.0, s)
-        h.axpby_dev(1e-3, hp, 1.0, r)
+        h.axpy2_dev(1e-3, pk, s, 1e-3, hp, r)
         h.precondition_projected_dev(r, z)
         h.dots_dev([(r, r), (r, z)])
         h.axpby_dev(-1.0, z, 0.5, pk)

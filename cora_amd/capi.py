@@ -300,6 +300,10 @@ class Context:
     def axpby_dev(self, a, x, b, y):
         self._chk(self.L.cora_axpby_dev(self.h, C.c_double(a), C.c_void_p(x), C.c_double(b), C.c_void_p(y)))
 
+    def axpy2_dev(self, a1, x1, y1, a2, x2, y2):
+        self._chk(self.L.cora_axpy2_dev(self.h, C.c_double(a1), C.c_void_p(x1), C.c_void_p(y1), C.c_double(a2),
+                                        C.c_void_p(x2), C.c_void_p(y2)))
+
     def dot_dev(self, a, b, k):
         v = C.c_double()
         self._chk(self.L.cora_dot_dev(self.h, C.c_void_p(a), C.c_void_p(b), int(k), C.byref(v)))

@@ -74,6 +74,8 @@ struct cora_ctx {
   double *d_red = nullptr;      // reduction partials
   size_t red_doubles = 0;
   double *d_scalars = nullptr;  // 8 doubles
+  unsigned long long dot_seq = 0;  // h_scalars[7] carries the sequence number of the last finished reduction
+  unsigned *d_ticket = nullptr;  // last-block ticket of the inner-product kernels (zero between launches)
   double *h_scalars = nullptr;  // pinned, 8 doubles
   int *d_flag = nullptr;
   int *h_flag = nullptr;
@@ -241,8 +243,7 @@ int point_finish(cora_ctx *c) {
   HIP_TRY(c, launch_point_finish(R, c->ld, c->d_Y, c->d_G, c->d_rgrad, c->d_lam_st, c->d_lam_ob, c->d_red,
                                  &nblocks, c->stream));
   if (nblocks > 0) {
-    HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->d_scalars, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->h_scalars, c->stream));  // pinned host memory
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->f = c->h_scalars[0];
   } else {
@@ -250,6 +251,17 @@ int point_finish(cora_ctx *c) {
   }
   c->have_point = true;
   return CORA_OK;
+}
+
+// Wait for the inner-product kernel that was just launched: its last block writes the results and then
+// the sequence number into pinned memory, which the host polls -- a few microseconds less than a stream
+// synchronisation, twice per STPCG iteration.  Falls back to the stream if the number never arrives.
+int wait_dots(cora_ctx *c, unsigned long long seq) {
+  volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_scalars + 7);
+  for (long spin = 0; spin < 20000000L; ++spin)
+    if (*flag == seq) return CORA_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return *flag == seq ? CORA_OK : fail(c, CORA_ERR_HIP, "inner-product kernel did not complete");
 }
 
 int set_point_dev_impl(cora_ctx *c, const double *dY) {
@@ -335,7 +347,10 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_lam_ob),
                        std::max<size_t>(F.L.nl_ranges, 1) * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_scalars), 8 * sizeof(double)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), sizeof(unsigned)));
+  CREATE_TRY(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), 8 * sizeof(double)));
+  std::memset(c->h_scalars, 0, 8 * sizeof(double));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_flag), sizeof(int)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_flag), sizeof(int)));
   CREATE_TRY(hipEventCreate(&c->ev0));
@@ -358,7 +373,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     free_rank_state(c);
     void *ptrs[] = {c->d_slices, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
-                    c->d_stage, c->d_red, c->d_scalars, c->d_flag};
+                    c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     for (int i = 0; i < kScratchSlots; ++i)
@@ -861,6 +876,16 @@ int cora_axpby_dev(cora_ctx *c, double a, const double *dX, double b, double *dY
   return CORA_OK;
 }
 
+int cora_axpy2_dev(cora_ctx *c, double a1, const double *dX1, double *dY1, double a2, const double *dX2,
+                   double *dY2) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!dX1 || !dY1 || !dX2 || !dY2 || dY1 == dY2) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
+  HIP_TRY(c, launch_axpy2(c->F.L.local_rows * c->ld, a1, dX1 + off, dY1 + off, a2, dX2 + off, dY2 + off, c->stream));
+  return CORA_OK;
+}
+
 int cora_axpby_cols_dev(cora_ctx *c, int k, double a, const double *dX, double b, double *dY) {
   NEED_DEVICE(c);
   if (k <= 0 || k > kMaxLD || !dX || !dY) return fail(c, CORA_ERR_ARG, "bad arguments");
@@ -891,11 +916,13 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
   int rc = ensure_red(c, 4 * 512);
   if (rc) return rc;
   D.partial = c->d_red;
+  D.ticket = c->d_ticket;
+  D.out = c->h_scalars;  // pinned: the last block writes the results where the host reads them
+  D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+  D.seq = ++c->dot_seq;
   int nblocks = 0;
   HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
-  HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, count, c->d_scalars, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = wait_dots(c, D.seq))) return rc;
   for (int j = 0; j < count; ++j) out[j] = c->h_scalars[j];
   return CORA_OK;
 }
@@ -914,11 +941,13 @@ int cora_dot_dev(cora_ctx *c, const double *dA, const double *dB, int k, double 
   int rc = ensure_red(c, 4 * 512);
   if (rc) return rc;
   D.partial = c->d_red;
+  D.ticket = c->d_ticket;
+  D.out = c->h_scalars;
+  D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+  D.seq = ++c->dot_seq;
   int nblocks = 0;
   HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
-  HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->d_scalars, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = wait_dots(c, D.seq))) return rc;
   *out = c->h_scalars[0];
   return CORA_OK;
 }

@@ -89,9 +89,8 @@ int STPCG(Dev &D, const double *grad, double Delta, const TNTParams &prm, double
       step_M_norm = Delta;
       return iters;
     }
-    D.axpby(alpha, pk, 1.0, s);
+    D.chk(cora_axpy2_dev(c, alpha, pk, s, alpha, Hp, r), "cora_axpy2_dev");  // s += alpha p, r += alpha Hp
     sigma_M2 = sigma_next;
-    D.axpby(alpha, Hp, 1.0, r);
     D.chk(cora_precondition_projected_dev(c, r, v), "precon");
     D.dots2(r, r, r, v, rr_rv);
     if (std::sqrt(rr_rv[0]) <= target) break;

@@ -46,6 +46,10 @@ struct DotArgs {
   int count;
   int64_t n2;        // number of doubles (launch_dots halves it for the double2 kernel)
   double *partial;   // [count][gridDim.x]
+  unsigned *ticket;  // zero between launches; the last block to finish reduces the partials
+  double *out;       // [count] results, written by that block (may be pinned host memory)
+  unsigned long long *seq_out;  // optional (pinned): set to `seq` after the results are visible to the host
+  unsigned long long seq;
 };
 
 struct RowOpDev {  // device copy of a RowOpHost (trisolve.h)
@@ -86,6 +90,8 @@ hipError_t launch_tangent_project(const RowArgs &R, int ld, const double *Y, con
 hipError_t launch_project_manifold(const RowArgs &R, int ld, const double *A, const double *V,
                                    double alpha, double *out, hipStream_t st);
 hipError_t launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t st);
+hipError_t launch_axpy2(int64_t n, double a1, const double *x1, double *y1, double a2, const double *x2,
+                        double *y2, hipStream_t st);
 hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const double *x, double *y,
                              hipStream_t st);
 hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st);

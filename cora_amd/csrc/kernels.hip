@@ -565,12 +565,60 @@ __global__ __launch_bounds__(256) void k_axpby(int64_t n2, double a, const doubl
   }
 }
 
+// y1 += a1 x1 and y2 += a2 x2 in one pass (the two updates of an STPCG iteration, s += alpha p and
+// r += alpha Hp): one launch floor instead of two
+__global__ __launch_bounds__(256) void k_axpy2(int64_t n, double a1, const double *__restrict__ x1,
+                                               double *__restrict__ y1, double a2,
+                                               const double *__restrict__ x2, double *__restrict__ y2) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    y1[i] = fma(a1, x1[i], y1[i]);
+    y2[i] = fma(a2, x2[i], y2[i]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const double *__restrict__ scale,
                                                     const double *__restrict__ x, double *__restrict__ y) {
   const int64_t n = rows * ld;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * 256)
     y[i] = scale[i / ld] * x[i];
+}
+
+// Tail of the inner-product kernels: every block publishes its partial sums write-through, takes a
+// ticket, and the last block to arrive adds all partials in block order (deterministic) and writes the
+// results to D.out -- pinned host memory, so the caller only has to wait for the stream.  Same
+// inter-workgroup hand-off as the long rows of k_spmm.
+__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm) {
+  __shared__ int s_last;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < D.count) {
+      const double t = block_sum_256(acc[j], sm);
+      if (threadIdx.x == 0)
+        __hip_atomic_store(D.partial + static_cast<size_t>(j) * gridDim.x + blockIdx.x, t, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(D.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == gridDim.x - 1);
+    if (s_last) __hip_atomic_store(D.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int j = 0; j < D.count; ++j) {
+    double s = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256)
+      s += __hip_atomic_load(D.partial + static_cast<size_t>(j) * gridDim.x + b, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    const double t = block_sum_256(s, sm);
+    if (threadIdx.x == 0) D.out[j] = t;
+  }
+  if (threadIdx.x == 0 && D.seq_out) {  // results first, then the sequence number the host spins on
+    __threadfence_system();
+    __hip_atomic_store(D.seq_out, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // scalar variant for odd lengths / 8-byte aligned shards
@@ -583,12 +631,7 @@ __global__ __launch_bounds__(256) void k_dots1(DotArgs D) {
     for (int j = 0; j < 4; ++j)
       if (j < D.count) acc[j] = fma(D.a[j][i], D.b[j][i], acc[j]);
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (j < D.count) {
-      const double t = block_sum_256(acc[j], sm);
-      if (threadIdx.x == 0) D.partial[static_cast<size_t>(j) * gridDim.x + blockIdx.x] = t;
-    }
+  dots_finish(D, acc, sm);
 }
 
 // up to 4 inner products in one pass; partial[j * gridDim.x + block]
@@ -605,12 +648,7 @@ __global__ __launch_bounds__(256) void k_dots(DotArgs D) {
         acc[j] = fma(a.x, b.x, fma(a.y, b.y, acc[j]));
       }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (j < D.count) {
-      const double t = block_sum_256(acc[j], sm);
-      if (threadIdx.x == 0) D.partial[static_cast<size_t>(j) * gridDim.x + blockIdx.x] = t;
-    }
+  dots_finish(D, acc, sm);
 }
 
 // out[j] = sum_b partial[j * nblocks + b]   (one 256-thread block, fixed order)
@@ -1016,6 +1054,13 @@ hipError_t launch_axpby(int64_t n, double a, const double *x, double b, double *
                        reinterpret_cast<const double2 *>(x), b, reinterpret_cast<double2 *>(y));
   else
     hipLaunchKernelGGL(k_axpby1, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, b, y);
+  return hipGetLastError();
+}
+
+hipError_t launch_axpy2(int64_t n, double a1, const double *x1, double *y1, double a2, const double *x2,
+                        double *y2, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_axpy2, dim3(grid_for(n)), dim3(256), 0, st, n, a1, x1, y1, a2, x2, y2);
   return hipGetLastError();
 }
 

@@ -245,6 +245,10 @@ int cora_project_to_manifold_dev(cora_ctx *ctx, const double *dA, double *dOut);
 /* Vector ops on resident N x p vectors (local shard rows when partitioned). */
 int cora_axpby_dev(cora_ctx *ctx, double a, const double *dX, double b,
                    double *dY); /* Y = a X + b Y */
+/* Y1 += a1 X1 and Y2 += a2 X2 in one launch: the step and residual updates of an STPCG iteration
+ * (s += alpha p, r += alpha Hp inside Optimization::Riemannian::TNT, called from src/CORA.cpp:139). */
+int cora_axpy2_dev(cora_ctx *ctx, double a1, const double *dX1, double *dY1, double a2, const double *dX2,
+                   double *dY2);
 /* Same for vectors allocated with k columns (cora_dev_alloc(ctx, k, ..)). */
 int cora_axpby_cols_dev(cora_ctx *ctx, int k, double a, const double *dX, double b, double *dY);
 int cora_copy_dev(cora_ctx *ctx, const double *dX, int k, double *dY);
