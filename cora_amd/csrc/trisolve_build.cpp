@@ -71,11 +71,13 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   P.nnzL = Lp[m];
   // ---- elimination tree and row lengths
   std::vector<int32_t> parent(m, -1), rcount(m, 0);
+  bool sorted = true;  // columns with ascending row indices: the rows of a column's own block come first
   for (int j = 0; j < m; ++j) {
     if (Li[Lp[j]] != j) throw std::runtime_error("cora: Cholesky factor must store the diagonal first in each column");
     for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
       if (Li[q] <= j || Li[q] >= m) throw std::runtime_error("cora: Cholesky factor has an entry above the diagonal");
       if (parent[j] < 0 || Li[q] < parent[j]) parent[j] = Li[q];
+      if (q > Lp[j] + 1 && Li[q] < Li[q - 1]) sorted = false;
       rcount[Li[q]]++;
     }
   }
@@ -254,8 +256,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       }
       for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q) {
         const int i = Li[q];
-        if (i >= m) break;
         if (stage[i] == k && blk[i] == b) w[i] -= Lx[q] * wv;
+        else if (sorted) break;  // ancestors outside the block are numbered after all of its rows
       }
     }
     if (!dense) B.end_row();
