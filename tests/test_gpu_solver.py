@@ -66,7 +66,7 @@ def test_tnt_synthetic_noisy(d, n, p, loops):
 
 def test_cholesky_preconditioner_apply():
     """blockCholeskySolve semantics (src/CORA_preconditioners.cpp:46-83) on the device's
-    level-scheduled triangular solves: N-1 leading rows solved, last row zero."""
+    staged solve plan (trisolve.h): N-1 leading rows solved, last row zero."""
     import scipy.sparse as sp
     P = host.Problem.synthetic(dim=3, n_poses=900, n_landmarks=5, n_ranges=600, n_loops=8, seed=13,
                                precond=capi.PRECOND_REGULARIZED_CHOLESKY)
@@ -129,3 +129,26 @@ def test_tnt_regularized_cholesky(d, n, p, loops):
     assert got["iterations"] <= 2 * ref["iterations"] + 3
     rg = orc.rgrad(Q, dims, got["x"])
     assert abs(np.linalg.norm(rg) - got["grad_norm"]) < 1e-6 * max(1.0, got["grad_norm"])
+
+
+@pytest.mark.parametrize("d,n,p", [(2, 5000, 2), (3, 4000, 3), (3, 4000, 4), (2, 6000, 7), (3, 3000, 12), (3, 3000, 16), (3, 2000, 24)])
+def test_cholesky_preconditioner_every_row_stride(d, n, p):
+    """The solve kernels are instantiated per row stride (odd strides use scalar loads, even ones 16-byte
+    loads): every class of stride, on graphs large enough for a three-stage plan with dense leaf blocks."""
+    import ctypes as C
+    import scipy.sparse as sp
+    P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=6, n_ranges=n // 2, n_loops=5, seed=100 + p,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    P.set_rank(p)
+    Q, dims = _oracle_problem(P)
+    info = P.precond_info()
+    st = (C.c_int64 * 4)()
+    capi.load().cora_precond_stats(C.c_void_p(P.context_ptr()), st)
+    assert st[0] >= 2 and st[2] == info["nnz"]
+    V = np.random.default_rng(p).standard_normal((dims.N, p))
+    out = P.op("precondition", V)
+    assert np.all(out[-1] == 0.0)
+    M = (Q.to_scipy() + info["lam"] * sp.eye(dims.N)).tocsr()[:dims.N - 1, :dims.N - 1]
+    res = M @ out[:-1] - V[:-1]
+    assert np.abs(res).max() < 1e-8 * np.abs(V).max()
