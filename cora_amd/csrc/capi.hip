@@ -74,6 +74,7 @@ struct cora_ctx {
   double *d_red = nullptr;      // reduction partials
   size_t red_doubles = 0;
   double *d_scalars = nullptr;  // 8 doubles
+  StpcgState *d_stpcg = nullptr, *h_stpcg = nullptr;  // device-resident STPCG scalars and their pinned mirror
   unsigned long long dot_seq = 0;  // h_scalars[7] carries the sequence number of the last finished reduction
   unsigned *d_ticket = nullptr;  // last-block ticket of the inner-product kernels (zero between launches)
   double *h_scalars = nullptr;  // pinned, 8 doubles
@@ -348,6 +349,8 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
                        std::max<size_t>(F.L.nl_ranges, 1) * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_scalars), 8 * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), sizeof(unsigned)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_stpcg), sizeof(StpcgState)));
+  CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_stpcg), 2 * sizeof(StpcgState)));
   CREATE_TRY(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), 8 * sizeof(double)));
   std::memset(c->h_scalars, 0, 8 * sizeof(double));
@@ -373,7 +376,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     free_rank_state(c);
     void *ptrs[] = {c->d_slices, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
-                    c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket};
+                    c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     for (int i = 0; i < kScratchSlots; ++i)
@@ -384,6 +387,7 @@ void cora_ctx_destroy(cora_ctx *c) {
       for (void *p : f->allocs)
         if (p) (void)hipFree(p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->h_stpcg) (void)hipHostFree(c->h_stpcg);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -920,10 +924,92 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
   D.out = c->h_scalars;  // pinned: the last block writes the results where the host reads them
   D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
   D.seq = ++c->dot_seq;
+  D.mode = DOTS_PLAIN;
+  D.st = D.st_host = nullptr;
   int nblocks = 0;
   HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
   if ((rc = wait_dots(c, D.seq))) return rc;
   for (int j = 0; j < count; ++j) out[j] = c->h_scalars[j];
+  return CORA_OK;
+}
+
+// Steihaug-Toint truncated PCG for  min <g,s> + 1/2 <s,Hs>,  ||s||_M <= Delta, entirely on the device
+// (the inner solver of Optimization::Riemannian::TNT, called from src/CORA.cpp:139-140).  The scalar
+// recurrences live in a StpcgState that the inner-product kernels update themselves, so the host only
+// enqueues iterations -- a few at a time -- and looks at the state's pinned mirror between batches.
+int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_fgr, double theta, int max_iters,
+                   double *dS, double *dR, double *dV, double *dP, double *dHp, int *iters, double *step_M_norm) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  if (!dGrad || !dS || !dR || !dV || !dP || !dHp || !iters || !step_M_norm || max_iters < 0)
+    return fail(c, CORA_ERR_ARG, "bad arguments");
+  if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "the device-resident STPCG is single-GPU");
+  int rc;
+  // s = 0, r = g, v = P r, p = -v
+  if ((rc = cora_axpby_dev(c, 0.0, dGrad, 0.0, dS))) return rc;
+  if ((rc = cora_axpby_dev(c, 1.0, dGrad, 0.0, dR))) return rc;
+  if ((rc = cora_precondition_projected_dev(c, dR, dV))) return rc;
+  if ((rc = cora_axpby_dev(c, -1.0, dV, 0.0, dP))) return rc;
+  double rr_rv[2];
+  const double *A[2] = {dR, dR};
+  const double *B[2] = {dR, dV};
+  if ((rc = cora_dots_dev(c, 2, A, B, rr_rv))) return rc;
+  const double r0 = std::sqrt(rr_rv[0]);
+  StpcgState &H = c->h_stpcg[1];  // staging copy for the upload; h_stpcg[0] is the mirror the kernels write
+  H = StpcgState();
+  H.r_v = rr_rv[1];
+  H.p_M2 = rr_rv[1];
+  H.Delta2 = Delta * Delta;
+  H.target = r0 * std::min(kappa_fgr, std::pow(r0, theta));
+  H.coef_beta = 1.0;
+  H.max_iters = max_iters;
+  c->h_stpcg[0] = H;
+  HIP_TRY(c, hipMemcpyAsync(c->d_stpcg, &H, sizeof(StpcgState), hipMemcpyHostToDevice, c->stream));
+  const int64_t n = c->F.L.local_rows * c->ld;
+  DotArgs D;
+  for (int j = 0; j < 4; ++j) D.a[j] = D.b[j] = nullptr;
+  D.n2 = n;
+  if ((rc = ensure_red(c, 4 * 512))) return rc;
+  D.partial = c->d_red;
+  D.ticket = c->d_ticket;
+  D.out = c->d_scalars;
+  D.st = c->d_stpcg;
+  D.st_host = &c->h_stpcg[0];
+  const int batch = 4;
+  int enqueued = 0;
+  while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
+    unsigned long long seq = 0;
+    for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
+      if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
+      int nblocks = 0;
+      D.count = 1;
+      D.a[0] = dP;
+      D.b[0] = dHp;
+      D.mode = DOTS_STPCG_KAPPA;
+      D.seq_out = nullptr;
+      D.seq = 0;
+      HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
+      HIP_TRY(c, launch_stpcg_update(n, c->d_stpcg, dP, dHp, dS, dR, c->stream));
+      if ((rc = cora_precondition_projected_dev(c, dR, dV))) return rc;
+      D.count = 2;
+      D.a[0] = dR;
+      D.b[0] = dR;
+      D.a[1] = dR;
+      D.b[1] = dV;
+      D.mode = DOTS_STPCG_BETA;
+      D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+      D.seq = seq = ++c->dot_seq;
+      HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
+      HIP_TRY(c, launch_stpcg_direction(n, c->d_stpcg, dV, dP, c->stream));
+    }
+    if ((rc = wait_dots(c, seq))) return rc;
+  }
+  // an iteration that starts at the limit only records the status: flush it so that the mirror is final
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(&H, c->d_stpcg, sizeof(StpcgState), hipMemcpyDeviceToHost));
+  *iters = H.iters;
+  *step_M_norm = H.step_M_norm;
   return CORA_OK;
 }
 
@@ -945,6 +1031,8 @@ int cora_dot_dev(cora_ctx *c, const double *dA, const double *dB, int k, double 
   D.out = c->h_scalars;
   D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
   D.seq = ++c->dot_seq;
+  D.mode = DOTS_PLAIN;
+  D.st = D.st_host = nullptr;
   int nblocks = 0;
   HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
   if ((rc = wait_dots(c, D.seq))) return rc;

@@ -1,6 +1,7 @@
 #include "CORA.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <iostream>
 
@@ -49,10 +50,15 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   bool first_loop = true;
   int levels = 0;
   long hvps = 0;
+  double t_tnt = 0, t_cert = 0, t_escape = 0;
+  using clk = std::chrono::steady_clock;
+  auto since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
   while (static_cast<int>(problem.getRelaxationRank()) <= max_relaxation_rank) {
     ++levels;
     printIfVerbose(verbose, "\nSolving problem at rank " + std::to_string(problem.getRelaxationRank()));
+    auto t0 = clk::now();
     result = TNT(problem, X, params);
+    t_tnt += since(t0);
     hvps += result.hessian_vector_products;
     printIfVerbose(verbose, "Obtained solution with objective value: " + std::to_string(result.f));
     if (log_iterates)
@@ -66,7 +72,9 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     } else {
       eigvec_bootstrap = cert.all_eigvecs;
     }
+    t0 = clk::now();
     cert = problem.certify_solution(result.x, eta, LOBPCG_BLOCK_SIZE, eigvec_bootstrap);
+    t_cert += since(t0);
     printIfVerbose(verbose, "Result is certified: " + std::to_string(cert.is_certified) + " with eta: " +
                                 std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
     if (std::isnan(cert.theta)) throw std::runtime_error("Theta is NaN");
@@ -76,21 +84,27 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     }
     const Scalar SADDLE_GRAD_TOL = 1e-4, PRECON_SADDLE_GRAD_TOL = 1e-4;
     problem.incrementRank();
+    t0 = clk::now();
     X = saddleEscape(problem, result.x, cert.theta, cert.x, SADDLE_GRAD_TOL, PRECON_SADDLE_GRAD_TOL);
+    t_escape += since(t0);
   }
   // project to rank d and refine (src/CORA.cpp:198-233)
   if (X.cols() > problem.dim()) {
     printIfVerbose(verbose, "\nProjecting solution to rank " + std::to_string(problem.dim()) + " and refining.");
     X = projectSolution(problem, X, verbose);
     problem.setRank(problem.dim());
+    auto t0 = clk::now();
     result = TNT(problem, X, params);
+    t_tnt += since(t0);
     hvps += result.hessian_vector_products;
     printIfVerbose(verbose, "\nObtained FINAL solution with objective value: " + std::to_string(result.f));
     if (log_iterates)
       for (const Matrix &it : result.iterates) iterates.push_back(it);
     printIfVerbose(verbose, "Checking certification of refined solution.");
     eta = thresholdVal(result.f * REL_CERT_ETA, MIN_CERT_ETA, MAX_CERT_ETA);
+    t0 = clk::now();
     cert = problem.certify_solution(result.x, eta, LOBPCG_BLOCK_SIZE, Matrix());
+    t_cert += since(t0);
   }
   printIfVerbose(verbose, "Final solution is certified: " + std::to_string(cert.is_certified) + " with eta: " +
                               std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
@@ -101,6 +115,9 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     info->final_rank = static_cast<int>(problem.getRelaxationRank());
     info->staircase_levels = levels;
     info->hessian_vector_products = hvps;
+    info->tnt_seconds = t_tnt;
+    info->certify_seconds = t_cert;
+    info->escape_seconds = t_escape;
   }
   return std::make_pair(result, iterates);
 }

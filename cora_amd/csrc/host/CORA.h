@@ -24,6 +24,7 @@ struct CoraSolveInfo {  // extra observability (the reference only prints these)
   int final_rank = 0;
   int staircase_levels = 0;
   long hessian_vector_products = 0;
+  double tnt_seconds = 0, certify_seconds = 0, escape_seconds = 0;  // wall-clock split of the staircase
 };
 
 CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank = 20, bool verbose = false,

@@ -65,6 +65,13 @@ struct Dev {
 int STPCG(Dev &D, const double *grad, double Delta, const TNTParams &prm, double *s, double *r, double *v,
           double *pk, double *Hp, double &step_M_norm) {
   cora_ctx *c = D.c;
+  if (prm.device_stpcg) {
+    int iters = 0;
+    D.chk(cora_stpcg_dev(c, grad, Delta, prm.kappa_fgr, prm.theta, prm.max_TPCG_iterations, s, r, v, pk, Hp, &iters,
+                         &step_M_norm),
+          "cora_stpcg_dev");
+    return iters;
+  }
   D.axpby(0.0, grad, 0.0, s);   // s = 0
   D.axpby(1.0, grad, 0.0, r);   // r = g
   D.chk(cora_precondition_projected_dev(c, r, v), "precon");

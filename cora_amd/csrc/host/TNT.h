@@ -41,6 +41,9 @@ struct TNTParams {  // values set by the reference: src/CORA.cpp:95-109
   int max_TPCG_iterations = 80;
   int max_iterations = 250;
   Scalar kappa_fgr = 0.1;  // library default
+  /** Run the inner Steihaug-Toint PCG with its scalars on the device (cora_stpcg_dev: no host round
+   * trip per iteration).  false: the same iteration driven from the host, one inner product at a time. */
+  bool device_stpcg = true;
   Scalar theta = 0.8;
   Scalar preconditioned_gradient_tolerance = 1e-6;
   Scalar gradient_tolerance = 1e-6;

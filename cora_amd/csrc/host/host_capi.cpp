@@ -210,6 +210,7 @@ int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, doub
       if (opts[3] > 0) prm.preconditioned_gradient_tolerance = opts[3];
       if (opts[4] > 0) prm.max_computation_time = opts[4];
       prm.verbose = opts[5] != 0;
+      prm.device_stpcg = opts[6] == 0;
     }
     const TNTResult res = TNT(q, wrap(x0, N, r), prm);
     std::memcpy(x_out, res.x.data(), sizeof(double) * static_cast<size_t>(res.x.size()));

@@ -40,6 +40,20 @@ struct RowArgs {
   size_t rot_base, rng_base, trn_base, base;
 };
 
+// Scalars of one Steihaug-Toint PCG solve, resident on the device so that an iteration needs no host
+// round trip: the inner-product kernels update them in their last block, the vector kernels read their
+// coefficients from here.  status: 0 running, 1 residual target met, 2 stopped on the trust-region
+// boundary (or negative curvature), 3 iteration limit.  Once status != 0 all coefficients are neutral, so
+// iterations the host has already enqueued do not change s, r or p.
+struct StpcgState {
+  double r_v, sigma_M2, s_Mp, p_M2;  // recurrences of the M-norms (Conn, Gould & Toint, Alg. 7.5.1)
+  double Delta2, target;
+  double alpha, coef_s, coef_r, coef_v, coef_beta;
+  double kappa, rr, step_M_norm;
+  int iters, status, max_iters, pad;
+};
+enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2 };
+
 struct DotArgs {
   const double *a[4];
   const double *b[4];
@@ -50,6 +64,8 @@ struct DotArgs {
   double *out;       // [count] results, written by that block (may be pinned host memory)
   unsigned long long *seq_out;  // optional (pinned): set to `seq` after the results are visible to the host
   unsigned long long seq;
+  int mode;                     // DOTS_*: what the last block does with the results
+  StpcgState *st, *st_host;     // device state and its pinned mirror (DOTS_STPCG_*)
 };
 
 struct RowOpDev {  // device copy of a RowOpHost (trisolve.h)
@@ -92,6 +108,10 @@ hipError_t launch_project_manifold(const RowArgs &R, int ld, const double *A, co
 hipError_t launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t st);
 hipError_t launch_axpy2(int64_t n, double a1, const double *x1, double *y1, double a2, const double *x2,
                         double *y2, hipStream_t st);
+// s += coef_s p, r += coef_r Hp  /  p = coef_v v + coef_beta p  with the coefficients of the device state
+hipError_t launch_stpcg_update(int64_t n, const StpcgState *S, const double *p, const double *Hp, double *s,
+                               double *r, hipStream_t st);
+hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *v, double *p, hipStream_t st);
 hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const double *x, double *y,
                              hipStream_t st);
 hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st);

@@ -577,6 +577,28 @@ __global__ __launch_bounds__(256) void k_axpy2(int64_t n, double a1, const doubl
   }
 }
 
+// the two vector updates of a device-resident STPCG iteration; coefficients come from the device state
+__global__ __launch_bounds__(256) void k_stpcg_update(int64_t n, const StpcgState *__restrict__ S,
+                                                      const double *__restrict__ p, const double *__restrict__ Hp,
+                                                      double *__restrict__ s, double *__restrict__ r) {
+  const double cs = S->coef_s, cr = S->coef_r;
+  if (cs == 0.0 && cr == 0.0) return;  // solve already finished: enqueued ahead of the host's check
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    s[i] = fma(cs, p[i], s[i]);
+    r[i] = fma(cr, Hp[i], r[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stpcg_direction(int64_t n, const StpcgState *__restrict__ S,
+                                                         const double *__restrict__ v, double *__restrict__ p) {
+  const double cv = S->coef_v, cb = S->coef_beta;
+  if (cv == 0.0 && cb == 1.0) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256)
+    p[i] = fma(cv, v[i], cb * p[i]);
+}
+
 __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const double *__restrict__ scale,
                                                     const double *__restrict__ x, double *__restrict__ y) {
   const int64_t n = rows * ld;
@@ -614,6 +636,52 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
                              __HIP_MEMORY_SCOPE_AGENT);
     const double t = block_sum_256(s, sm);
     if (threadIdx.x == 0) D.out[j] = t;
+    if (threadIdx.x == 0) sm[4 + j] = t;
+  }
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA) {  // after Hp = H p:  kappa = <p, Hp>
+    StpcgState &S = *D.st;
+    if (S.status == 0 && S.iters >= S.max_iters) S.status = 3;
+    if (S.status != 0) {
+      S.coef_s = 0.0;
+      S.coef_r = 0.0;
+    } else {
+      const double kappa = sm[4];
+      S.iters++;
+      S.kappa = kappa;
+      const double alpha = S.r_v / kappa;
+      const double sigma_next = S.sigma_M2 + 2 * alpha * S.s_Mp + alpha * alpha * S.p_M2;
+      if (!(kappa > 0.0) || sigma_next >= S.Delta2) {  // negative curvature / leaves the trust region
+        S.coef_s = (-S.s_Mp + sqrt(S.s_Mp * S.s_Mp + S.p_M2 * (S.Delta2 - S.sigma_M2))) / S.p_M2;
+        S.coef_r = 0.0;
+        S.status = 2;
+        S.step_M_norm = sqrt(S.Delta2);
+      } else {
+        S.alpha = alpha;
+        S.coef_s = alpha;
+        S.coef_r = alpha;
+        S.sigma_M2 = sigma_next;
+        S.step_M_norm = sqrt(sigma_next);
+      }
+    }
+  }
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_BETA) {  // after v = P r:  <r, r>, <r, v>
+    StpcgState &S = *D.st;
+    if (S.status == 0) {
+      S.rr = sm[4];
+      if (sqrt(sm[4]) <= S.target) S.status = 1;
+    }
+    if (S.status != 0) {
+      S.coef_v = 0.0;
+      S.coef_beta = 1.0;
+    } else {
+      const double beta = sm[5] / S.r_v;
+      S.r_v = sm[5];
+      S.coef_v = -1.0;
+      S.coef_beta = beta;
+      S.s_Mp = beta * (S.s_Mp + S.alpha * S.p_M2);
+      S.p_M2 = S.r_v + beta * beta * S.p_M2;
+    }
+    *D.st_host = S;  // pinned mirror for the host's (infrequent) look
   }
   if (threadIdx.x == 0 && D.seq_out) {  // results first, then the sequence number the host spins on
     __threadfence_system();
@@ -623,7 +691,7 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
 
 // scalar variant for odd lengths / 8-byte aligned shards
 __global__ __launch_bounds__(256) void k_dots1(DotArgs D) {
-  __shared__ double sm[4];
+  __shared__ double sm[8];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
        i += static_cast<int64_t>(gridDim.x) * 256) {
@@ -636,7 +704,7 @@ __global__ __launch_bounds__(256) void k_dots1(DotArgs D) {
 
 // up to 4 inner products in one pass; partial[j * gridDim.x + block]
 __global__ __launch_bounds__(256) void k_dots(DotArgs D) {
-  __shared__ double sm[4];
+  __shared__ double sm[8];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
        i += static_cast<int64_t>(gridDim.x) * 256) {
@@ -1061,6 +1129,19 @@ hipError_t launch_axpy2(int64_t n, double a1, const double *x1, double *y1, doub
                         double *y2, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_axpy2, dim3(grid_for(n)), dim3(256), 0, st, n, a1, x1, y1, a2, x2, y2);
+  return hipGetLastError();
+}
+
+hipError_t launch_stpcg_update(int64_t n, const StpcgState *S, const double *p, const double *Hp, double *s,
+                               double *r, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stpcg_update, dim3(grid_for(n)), dim3(256), 0, st, n, S, p, Hp, s, r);
+  return hipGetLastError();
+}
+
+hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *v, double *p, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stpcg_direction, dim3(grid_for(n)), dim3(256), 0, st, n, S, v, p);
   return hipGetLastError();
 }
 

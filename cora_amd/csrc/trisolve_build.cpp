@@ -10,6 +10,9 @@ constexpr int kBorderRowNnz = 4096;  // rows of L longer than this (landmarks) a
 constexpr int kFirstCap = 48;        // rows of a stage-0 subtree (one nested-dissection leaf and its range rows)
 constexpr int kCapGrowth = 16;       // stage k subtrees hold up to kFirstCap * kCapGrowth^k rows
 constexpr int kTopCap = 1536;        // stop cutting once this few rows are left: they form the last stage
+constexpr int64_t kTopInverseNnz = 2000000;  // ... or once the inverse of what is left has this few entries:
+                                             // a launch floor (~5 us) is worth ~25 MB of traffic, so small
+                                             // factors are applied as ONE explicit inverse (2 products)
 constexpr int kShortRow = 64;        // entries: <= this -> 8 lanes per row
 constexpr int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
 constexpr int kChunk = 512;
@@ -102,7 +105,17 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   std::vector<int32_t> stage(m, -1), blk(m, -1), sz(m, 0);
   int nstage = 0;
   int64_t remaining = first_border, cap = kFirstCap;
+  std::vector<int32_t> depth(m, 0);
   while (remaining + (m - first_border) > kTopCap && cap < 4LL * m) {
+    // entries of the explicit inverse of everything not taken yet = sum over its rows of the number of
+    // remaining ancestors (the inverse of a Cholesky factor is non-zero exactly along tree paths)
+    int64_t inv_nnz = 0;
+    for (int v = m - 1; v >= 0; --v)
+      if (stage[v] < 0) {
+        depth[v] = 1 + (parent[v] >= 0 ? depth[parent[v]] : 0);
+        inv_nnz += depth[v];
+      }
+    if (inv_nnz <= kTopInverseNnz) break;
     for (int v = 0; v < first_border; ++v) sz[v] = stage[v] < 0 ? 1 : 0;
     for (int v = 0; v < first_border; ++v) {
       const int p = parent[v];

@@ -153,11 +153,13 @@ class Problem:
                                                     ob.ctypes.data_as(_dp)))
         return st[:, :dm["d"] * dm["n"]], ob[:dm["r"]]
 
-    def tnt(self, x0, max_iterations=0, max_inner=0, grad_tol=0, pgrad_tol=0, max_seconds=0, verbose=False):
+    def tnt(self, x0, max_iterations=0, max_inner=0, grad_tol=0, pgrad_tol=0, max_seconds=0, verbose=False,
+            host_stpcg=False):
         dm = self.dims()
         x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))
         assert x0.shape == (self.variable_size(), dm["rank"])
-        opts = np.array([max_iterations, max_inner, grad_tol, pgrad_tol, max_seconds, float(verbose)])
+        opts = np.array([max_iterations, max_inner, grad_tol, pgrad_tol, max_seconds, float(verbose),
+                         float(host_stpcg)])
         out = np.zeros_like(x0, order="F")
         st = np.zeros(7)
         self._chk(self.L.cora_problem_tnt(self.h, x0.ctypes.data_as(_dp), opts.ctypes.data_as(_dp),

@@ -249,6 +249,18 @@ int cora_axpby_dev(cora_ctx *ctx, double a, const double *dX, double b,
  * (s += alpha p, r += alpha Hp inside Optimization::Riemannian::TNT, called from src/CORA.cpp:139). */
 int cora_axpy2_dev(cora_ctx *ctx, double a1, const double *dX1, double *dY1, double a2, const double *dX2,
                    double *dY2);
+/* The inner solver of the trust-region method -- Steihaug-Toint truncated preconditioned CG on
+ *   min <grad, s> + 1/2 <s, Hess s>   subject to ||s||_M <= Delta
+ * (Optimization::Riemannian::TNT's STPCG, reached from src/CORA.cpp:139-140 with the closures of
+ * :58-92,119-122) -- run entirely on the device at the current point: Hess = cora_hvp_dev, M^-1 =
+ * cora_precondition_projected_dev, inner products and the scalar recurrences in device memory.  Stops
+ * when ||r|| <= ||r0|| min(kappa_fgr, ||r0||^theta), on negative curvature or the trust-region boundary
+ * (step to the boundary), or after max_iters Hessian-vector products.  dS receives the step; dR, dV,
+ * dP, dHp are work vectors (cora_dev_alloc(ctx, p, ..)).  iters = Hessian-vector products used,
+ * step_M_norm = ||s||_M. */
+int cora_stpcg_dev(cora_ctx *ctx, const double *dGrad, double Delta, double kappa_fgr, double theta,
+                   int max_iters, double *dS, double *dR, double *dV, double *dP, double *dHp, int *iters,
+                   double *step_M_norm);
 /* Same for vectors allocated with k columns (cora_dev_alloc(ctx, k, ..)). */
 int cora_axpby_cols_dev(cora_ctx *ctx, int k, double a, const double *dX, double b, double *dY);
 int cora_copy_dev(cora_ctx *ctx, const double *dX, int k, double *dY);

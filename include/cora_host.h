@@ -77,7 +77,8 @@ int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel
 
 /* Riemannian TNT (the call of src/CORA.cpp:139-140 with the parameters of :95-109) from x0
  * (N x rank).  opts (may be NULL): [0] max_iterations, [1] max_TPCG_iterations, [2] gradient
- * tolerance, [3] preconditioned gradient tolerance, [4] max seconds, [5] verbose.
+ * tolerance, [3] preconditioned gradient tolerance, [4] max seconds, [5] verbose, [6] non-zero: drive
+ * the inner STPCG from the host instead of cora_stpcg_dev (7 entries; 0 keeps a default).
  * stats out: [0] f, [1] |grad|, [2] |P grad|, [3] outer iterations, [4] Hessian-vector products,
  * [5] status (TNTStatus), [6] seconds. */
 int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, double *x_out, double stats[7]);
@@ -93,7 +94,7 @@ int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *col
                                 double eta, const double *X0, int nx, int max_iters, double out[3], double *x);
 
 /* solveCORA (src/CORA.cpp:26-243) from x0 (N x rank): Riemannian staircase up to max_rank, final
- * projection to rank d and refinement.  x_out: N x d.  opts as in cora_problem_tnt (may be NULL).
+ * projection to rank d and refinement.  x_out: N x d.  opts[0..4] as in cora_problem_tnt (may be NULL).
  * stats: [0] f, [1] |grad|, [2] certified, [3] eta, [4] theta, [5] final rank, [6] staircase levels,
  * [7] Hessian-vector products, [8] seconds. */
 int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verbose, const double *opts,
