@@ -304,6 +304,15 @@ class Context:
         self._chk(self.L.cora_axpy2_dev(self.h, C.c_double(a1), C.c_void_p(x1), C.c_void_p(y1), C.c_double(a2),
                                         C.c_void_p(x2), C.c_void_p(y2)))
 
+    def stpcg_dev(self, grad, Delta, s, r, v, p, hp, kappa_fgr=0.1, theta=0.8, max_iters=80):
+        """Device-resident Steihaug-Toint PCG at the current point; returns (Hessian-vector products, ||s||_M)."""
+        it = C.c_int()
+        sm = C.c_double()
+        self._chk(self.L.cora_stpcg_dev(self.h, C.c_void_p(grad), C.c_double(Delta), C.c_double(kappa_fgr),
+                                        C.c_double(theta), int(max_iters), C.c_void_p(s), C.c_void_p(r), C.c_void_p(v),
+                                        C.c_void_p(p), C.c_void_p(hp), C.byref(it), C.byref(sm)))
+        return it.value, sm.value
+
     def dot_dev(self, a, b, k):
         v = C.c_double()
         self._chk(self.L.cora_dot_dev(self.h, C.c_void_p(a), C.c_void_p(b), int(k), C.byref(v)))
