@@ -34,10 +34,11 @@ def algorithmic_bytes(d, n, r, N, nnz, p):
     return b_spmm, b_hvp
 
 
-def cpu_baseline(rowptr, colidx, vals, dm, p, budget_s):
-    """The oracle's single-threaded Hvp (kind "port") on the same workload; the
-    reference itself is single-threaded (no OpenMP in its CMakeLists.txt)."""
+def cpu_baseline(rowptr, colidx, vals, dm, p, budget_s, threads=1):
+    """The oracle's Hvp (kind "port") on the same workload.  threads=1 is the reference-equivalent
+    baseline: the reference itself is single-threaded (no OpenMP in its CMakeLists.txt)."""
     from oracle import oracle as orc
+    orc.set_threads(threads)
     Q = orc.CSR(rowptr, colidx, vals, dm["N"])
     dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
     rng = np.random.default_rng(7)
@@ -299,6 +300,17 @@ def main():
             got = ctx.download(out.data_ptr(), p)
             result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
             result["extras"] = solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt)
+            # all-core column of BASELINE.md section 4: the same oracle loops under OpenMP.  A container may see
+            # more logical cores than it may use, so a few thread counts are tried and the best one is reported.
+            best = None
+            for th in sorted({min(t, cores) for t in (8, 16, 32, 64, 128, cores)}):
+                hv, reps_th, _ = cpu_baseline(rowptr, colidx, vals, dm, p, 0.6, threads=th)
+                if best is None or hv > best[0]:
+                    best = (hv, th, reps_th)
+            result["extras"]["cpu_all_cores"] = {
+                "value": best[0], "unit": "Hvp/s", "cores": best[1],
+                "sample": "%d products, same oracle code with OpenMP row-parallel loops; best of several thread "
+                          "counts up to the %d logical cores the host reports" % (best[2], cores)}
             result["cpu_baseline"] = {
                 "value": hv_s,
                 "unit": "Hvp/s",

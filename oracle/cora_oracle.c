@@ -29,6 +29,29 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads used by the row-parallel loops below (SpMM, tangent projection, Hessian-vector product).
+ * The reference is single-threaded (its CMakeLists.txt never enables OpenMP): bench.py times 1 thread as
+ * the reference-equivalent baseline and all cores as the second column of BASELINE.md section 4.  Every
+ * row is computed by one thread in the same order, so results do not depend on the thread count. */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 #define AT(M, ld, i, j) ((M)[(size_t)(j) * (size_t)(ld) + (size_t)(i)])
 
 /* ---- a1: Problem::dataMatrixProduct, Explicit branch ------------------
@@ -56,8 +79,9 @@ void orc_spmm(int N, const int32_t *rowptr, const int32_t *col,
 void orc_spmm_rowwise(int N, const int32_t *rowptr, const int32_t *col,
                       const double *val, const double *X, int ldx, int k,
                       double *out, int ldo) {
-  double acc[64];
+#pragma omp parallel for schedule(static) if (N > 20000)
   for (int i = 0; i < N; ++i) {
+    double acc[64];
     for (int c = 0; c < k; ++c) acc[c] = 0.0;
     for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
       const double v = val[q];
@@ -99,8 +123,9 @@ double orc_cost(int N, const int32_t *rowptr, const int32_t *col,
  * translations: copied. `out` may alias V. */
 void orc_tangent_proj(int d, int n, int r, int N, int p, const double *Y,
                       int ldy, const double *V, int ldv, double *out, int ldo) {
-  double P[16], S[16], tmp[4 * 64];
+#pragma omp parallel for schedule(static) if (n > 5000)
   for (int i = 0; i < n; ++i) {
+    double P[16], S[16], tmp[4 * 64];
     const int r0 = i * d;
     /* P = Y_i V_i^T  (d x d) */
     for (int a = 0; a < d; ++a)
@@ -122,6 +147,7 @@ void orc_tangent_proj(int d, int n, int r, int N, int p, const double *Y,
       for (int c = 0; c < p; ++c) AT(out, ldo, r0 + a, c) = tmp[a * 64 + c];
   }
   const int dn = d * n;
+#pragma omp parallel for schedule(static) if (r > 5000)
   for (int j = dn; j < dn + r; ++j) {
     double ip = 0.0;
     for (int c = 0; c < p; ++c) ip += AT(Y, ldy, j, c) * AT(V, ldv, j, c);
@@ -211,6 +237,7 @@ void orc_hvp(int d, int n, int r, int N, int p, const int32_t *rowptr,
   const int dn = d * n;
   double *H = work; /* N x p, ld N */
   orc_spmm_rowwise(N, rowptr, col, val, Ydot, ldd, p, H, N);
+#pragma omp parallel for schedule(static) if (n > 5000)
   for (int i = 0; i < n; ++i) {
     const int r0 = i * d;
     double P[16], S[16];
@@ -233,6 +260,7 @@ void orc_hvp(int d, int n, int r, int N, int p, const int32_t *rowptr,
     for (int a = 0; a < d; ++a)
       for (int c = 0; c < p; ++c) AT(H, N, r0 + a, c) -= upd[a * 64 + c];
   }
+#pragma omp parallel for schedule(static) if (r > 5000)
   for (int j = dn; j < dn + r; ++j) {
     double w = 0.0;
     for (int c = 0; c < p; ++c) w += AT(G, ldg, j, c) * AT(Y, ldy, j, c);

@@ -38,6 +38,15 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """Threads of the row-parallel oracle loops (1 = like the single-threaded reference)."""
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
 def _d(a):
     return a.ctypes.data_as(_dp)
 
