@@ -53,3 +53,28 @@ def test_solve_cora_synthetic_noisy(d, n):
     ok = orc.Cholesky(orc.CSR.from_scipy(sp.csr_matrix(Sd + eta * np.eye(dims.N)))).ok
     assert res["certified"] == ok
     assert res["final_rank"] == dims.d and res["levels"] >= 1
+
+
+def test_config3_staircase_on_the_10k_pose_graph():
+    """BASELINE config 3: synthetic 10^4-pose SE(3) chain + 5 000 ranges, odometry initialisation, full
+    staircase from r0 = 3.  The noise is unit-variance in the whitened residuals, so the optimum sits near
+    (measurement rows - free parameters) / 2 = #ranges / 2; the returned point is checked against the oracle."""
+    n = 10_000
+    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    Q, dims = _oracle(P)
+    assert dims.N == 45_010
+    x0 = P.op("getOdomInitialization")
+    res = P.solve(x0, max_rank=7, max_seconds=120)
+    X = res["x"]
+    assert X.shape == (dims.N, 3)
+    assert np.abs(X - orc.project_manifold(dims, X)).max() < 1e-9
+    # f = 1/2 <X, QX> cancels twelve digits here (|Q| |X|^2 ~ 1e12 against f ~ 2e3)
+    assert abs(orc.cost(Q, X) - res["f"]) < 1e-6 * res["f"]
+    assert 0.5 * (n // 2) / 2 < res["f"] < 2.0 * (n // 2) / 2      # chi-square sized optimum, not a poor local one
+    assert res["levels"] >= 1 and res["final_rank"] == 3
+    g = orc.rgrad(Q, dims, X)
+    assert abs(np.linalg.norm(g) - res["grad_norm"]) < 1e-6 * max(1.0, res["grad_norm"])
+    print("\nconfig 3: f=%.4f |g|=%.2e certified=%s theta=%.3e eta=%.3e levels=%d hvps=%d %.2fs" % (
+        res["f"], res["grad_norm"], res["certified"], res["theta"], res["eta"], res["levels"], res["hvps"], res["seconds"]))
