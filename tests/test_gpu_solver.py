@@ -170,3 +170,29 @@ def test_device_stpcg_matches_host_driven_loop(precond):
     assert abs(a["hvps"] - b["hvps"]) <= 1
     assert abs(a["f"] - b["f"]) < 1e-9 * abs(b["f"])
     assert np.abs(a["x"] - b["x"]).max() < 1e-7
+
+
+def test_precondition_in_place_and_out_of_place_agree():
+    """cora_precondition_projected_dev(v, v): the staged solve needs distinct right-hand side and output, so
+    the in-place call goes through a scratch copy."""
+    P = host.Problem.synthetic(dim=3, n_poses=3000, n_landmarks=4, n_ranges=1500, n_loops=4, seed=9,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    p = 5
+    P.set_rank(p)
+    P.precond_info()
+    dm = P.dims()
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    y, v, o = h.dev_alloc(p), h.dev_alloc(p), h.dev_alloc(p)
+    rng = np.random.default_rng(2)
+    h.upload(rng.uniform(-1, 1, (dm["N"], p)), y)
+    h.project_to_manifold_dev(y, y)
+    h.set_point_dev(y)
+    h.upload(rng.uniform(-1, 1, (dm["N"], p)), v)
+    h.precondition_projected_dev(v, o)
+    a = h.download(o, p)
+    h.precondition_projected_dev(v, v)
+    b = h.download(v, p)
+    assert np.array_equal(a, b)
+    for q in (y, v, o):
+        h.dev_free(q)
