@@ -185,8 +185,13 @@ def main():
     ctx.upload(Vh, x.data_ptr())
     ctx.tangent_space_projection_dev(x.data_ptr(), x.data_ptr())
     from cora_amd.dist import RowShardedOperator
+    # N > 1: only the rows of Ydot that another rank's part of Q reads are exchanged (one RCCL all-gather of
+    # the packed rows per product); CORA_BENCH_EXCHANGE=shards all-gathers whole shards instead
+    need = None
+    if world > 1 and os.environ.get("CORA_BENCH_EXCHANGE", "rows") == "rows":
+        need = ctx.remote_rows()
     op = RowShardedOperator(rows, shard, ld, rank, world, dev,
-                            lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr()))
+                            lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr()), needed_rows=need)
     x_shard = x[rank * shard * ld:(rank + 1) * shard * ld].clone()  # this rank's rows of Ydot
 
     def step():
@@ -239,6 +244,8 @@ def main():
         y_shard = op.apply(x_shard).clone()
         gathered = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(gathered, y_shard)
+        full_ydot = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(full_ydot, x_shard)
         torch.cuda.synchronize()
 
     result = None
@@ -261,7 +268,9 @@ def main():
                             "Hvp = Proj_Y((Q - Lambda) Ydot) at relaxation rank p=%d; N=%d, nnz(Q)=%d"
                             % (dm["n"], dm["l"], dm["r"], p, dm["N"], dm["nnz"]),
                 "parallelism": "1 GPU" if world == 1 else
-                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + RCCL all-gather of Ydot" % world,
+                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + RCCL all-gather of %s"
+                               % (world, "the %d rows of Ydot (of %d) that other ranks read" % (op.exchanged_rows, rows)
+                                  if op.rows_mode else "Ydot (whole shards)"),
                 "algorithmic_bytes_per_hvp": b_hvp,
                 "algorithmic_bytes_per_spmm": b_spmm,
             },
@@ -286,7 +295,7 @@ def main():
             full = gathered.cpu().numpy().reshape(rows, ld)
             got = full[m][:, :p]
             Yc = y.cpu().numpy().reshape(rows, ld)[m][:, :p]
-            Vc = op.full_x.cpu().numpy().reshape(rows, ld)[m][:, :p]
+            Vc = full_ydot.cpu().numpy().reshape(rows, ld)[m][:, :p]
             ref = orc.hvp(Qo, dims, Yc, orc.egrad(Qo, Yc), Vc)
             result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
         if world == 1:

@@ -153,6 +153,14 @@ class Context:
         self._chk(self.L.cora_row_map(self.h, m.ctypes.data_as(_ip)))
         return m
 
+    def remote_rows(self):
+        """Internal rows outside this rank's shard that its part of Q reads (ascending, int64)."""
+        n = C.c_int64()
+        self._chk(self.L.cora_remote_rows(self.h, None, C.byref(n)))
+        r = np.empty(max(n.value, 1), dtype=np.int32)
+        self._chk(self.L.cora_remote_rows(self.h, r.ctypes.data_as(_ip), C.byref(n)))
+        return r[:n.value].astype(np.int64)
+
     def format_stats(self):
         s = (C.c_int64 * 8)()
         self._chk(self.L.cora_format_stats(self.h, s))

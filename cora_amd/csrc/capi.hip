@@ -440,6 +440,23 @@ int cora_row_map(const cora_ctx *c, int32_t *api_to_internal) {
   return CORA_OK;
 }
 
+int cora_remote_rows(const cora_ctx *c, int32_t *rows, int64_t *count) {
+  if (!c || !count) return CORA_ERR_ARG;
+  const Layout &L = c->F.L;
+  const int64_t lo = L.base, hi = L.base + L.shard_rows;
+  std::vector<char> seen(static_cast<size_t>(L.rows), 0);
+  for (int32_t col : c->F.scol) seen[col] = 1;   // padded slots repeat a real column of their lane
+  for (int32_t col : c->F.lcol) seen[col] = 1;
+  int64_t n = 0;
+  for (int64_t r = 0; r < L.rows; ++r)
+    if (seen[r] && (r < lo || r >= hi)) {
+      if (rows) rows[n] = static_cast<int32_t>(r);
+      ++n;
+    }
+  *count = n;
+  return CORA_OK;
+}
+
 int cora_precond_stats(const cora_ctx *c, int64_t s[4]) {
   if (!c || !s) return CORA_ERR_ARG;
   const auto &f = c->precond_f;

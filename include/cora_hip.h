@@ -99,6 +99,11 @@ int64_t cora_nnz(const cora_ctx *ctx);
 int64_t cora_dim(const cora_ctx *ctx);       /* N */
 /* Row permutation: internal row of API row i (length N, int32). */
 int cora_row_map(const cora_ctx *ctx, int32_t *api_to_internal);
+/* Partitioned handles: the internal rows OUTSIDE this rank's shard that its rows of Q reference, ascending
+ * (the halo of the pose chain plus whatever couples to remote landmarks).  Only these rows of an operand
+ * have to arrive before a product, so the exchange step can all-gather them instead of whole shards
+ * (cora_amd/dist.py).  rows may be NULL to query the count. */
+int cora_remote_rows(const cora_ctx *ctx, int32_t *rows, int64_t *count);
 
 /* Statistics of the device format: [0] slices, [1] padded nnz stored in
  * slices, [2] nnz in long rows, [3] long rows, [4] long-row chunks,

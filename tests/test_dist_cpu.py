@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, rows_mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cora_amd import capi, host
@@ -50,7 +50,12 @@ def _worker(rank, world, port, q):
             mine = (m >= rank * shard) & (m < (rank + 1) * shard)
             oi[m[mine], :k] = out[mine]
 
-        op = RowShardedOperator(rows, shard, ld, rank, world, torch.device("cpu"), local_apply)
+        need = ctx.remote_rows() if rows_mode else None
+        op = RowShardedOperator(rows, shard, ld, rank, world, torch.device("cpu"), local_apply, needed_rows=need)
+        if rows_mode:
+            # rows nobody asked for are never transferred: poison them, the product must not read them
+            op.full_x.fill_(float("nan"))
+            assert 0 < op.exchanged_rows < rows - shard or world == 1
         rng = np.random.default_rng(3)  # same on every rank
         X = rng.standard_normal((dm["N"], k))
         xi = np.zeros((rows, ld))
@@ -65,23 +70,26 @@ def _worker(rank, world, port, q):
         err = float(np.abs(got - ref).max() / np.abs(ref).max())
         d_par = op.dot(x_shard, y_shard)
         d_ref = float((X * ref).sum())
-        q.put((rank, err, abs(d_par - d_ref) / abs(d_ref)))
+        q.put((rank, err, abs(d_par - d_ref) / abs(d_ref), op.exchanged_rows, rows))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_exchange():
+@pytest.mark.parametrize("rows_mode", [False, True])
+def test_two_rank_gloo_exchange(rows_mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, rows_mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, err, derr in res:
+    for rank, err, derr, exchanged, rows in res:
         assert err < 1e-12, (rank, err)
         assert derr < 1e-12, (rank, derr)
+        if rows_mode:
+            assert exchanged < rows // 2   # only the halo and the landmark couplings travel
