@@ -6,7 +6,7 @@
 // A level-scheduled triangular solve is a chain of ~60 dependent launches on these factors
 // (elimination-tree height ~90), each bounded by launch + dependent-load latency, not by
 // bandwidth.  Instead the rows are cut into a few STAGES along the elimination tree -- stage 0 is
-// the union of the small subtrees at the bottom (one per leaf of the nested dissection, <= 48
+// the union of the small subtrees at the bottom (a leaf or two of the nested dissection, <= 64
 // rows), stage 1 the subtrees of what remains (<= 768 rows), ..., the last stage the top of the
 // tree plus the dense landmark rows -- and the diagonal block of every stage (block diagonal: the
 // subtrees of one stage do not touch each other) is inverted explicitly on the host, once.  A

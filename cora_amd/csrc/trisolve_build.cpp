@@ -7,7 +7,9 @@ namespace cora {
 
 namespace {
 constexpr int kBorderRowNnz = 4096;  // rows of L longer than this (landmarks) always belong to the last stage
-constexpr int kFirstCap = 48;        // rows of a stage-0 subtree (one nested-dissection leaf and its range rows)
+constexpr int kFirstCap = 64;        // rows of a stage-0 subtree: what one wavefront holds (a pair of
+                                     // nested-dissection leaves, their separator and range rows); 32 / 40 / 48 /
+                                     // 64 measured 154 / 155 / 162 / 151 us per apply at 10^5 poses
 constexpr int kCapGrowth = 16;       // stage k subtrees hold up to kFirstCap * kCapGrowth^k rows
 constexpr int kTopCap = 1536;        // stop cutting once this few rows are left: they form the last stage
 constexpr int64_t kTopInverseNnz = 2000000;  // ... or once the inverse of what is left has this few entries:
