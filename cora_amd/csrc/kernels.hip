@@ -1161,7 +1161,7 @@ hipError_t launch_dots(const DotArgs &D_in, int *nblocks, hipStream_t st) {
   for (int j = 0; j < D.count; ++j)
     vec = vec && reinterpret_cast<uintptr_t>(D.a[j]) % 16 == 0 && reinterpret_cast<uintptr_t>(D.b[j]) % 16 == 0;
   if (vec) D.n2 /= 2;
-  const int grid = grid_for(D.n2, 256, 512);
+  const int grid = grid_for(D.n2, 256, 256);  // one block per CU: 128 / 256 / 512 / 1024 blocks measured 24.0 / 16.8 / 19.0 / 24.7 us per inner product
   *nblocks = grid;
   if (vec) hipLaunchKernelGGL(k_dots, dim3(grid), dim3(256), 0, st, D);
   else hipLaunchKernelGGL(k_dots1, dim3(grid), dim3(256), 0, st, D);
