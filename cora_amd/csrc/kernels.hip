@@ -721,6 +721,21 @@ __global__ __launch_bounds__(256) void k_dots(DotArgs D) {
   dots_finish(D, acc, sm);
 }
 
+// <r, r> and <r, v> in one pass that reads r once (the second reduction of an STPCG iteration)
+__global__ __launch_bounds__(256) void k_dots_rr_rv(DotArgs D) {
+  __shared__ double sm[8];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double2 *r = reinterpret_cast<const double2 *>(D.a[0]);
+  const double2 *v = reinterpret_cast<const double2 *>(D.b[1]);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const double2 a = r[i], b = v[i];
+    acc[0] = fma(a.x, a.x, fma(a.y, a.y, acc[0]));
+    acc[1] = fma(a.x, b.x, fma(a.y, b.y, acc[1]));
+  }
+  dots_finish(D, acc, sm);
+}
+
 // out[j] = sum_b partial[j * nblocks + b]   (one 256-thread block, fixed order)
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int nblocks,
                                                          int count, double *__restrict__ out) {
@@ -1163,7 +1178,9 @@ hipError_t launch_dots(const DotArgs &D_in, int *nblocks, hipStream_t st) {
   if (vec) D.n2 /= 2;
   const int grid = grid_for(D.n2, 256, 256);  // one block per CU: 128 / 256 / 512 / 1024 blocks measured 24.0 / 16.8 / 19.0 / 24.7 us per inner product
   *nblocks = grid;
-  if (vec) hipLaunchKernelGGL(k_dots, dim3(grid), dim3(256), 0, st, D);
+  if (vec && D.count == 2 && D.a[0] == D.b[0] && D.a[1] == D.a[0])
+    hipLaunchKernelGGL(k_dots_rr_rv, dim3(grid), dim3(256), 0, st, D);
+  else if (vec) hipLaunchKernelGGL(k_dots, dim3(grid), dim3(256), 0, st, D);
   else hipLaunchKernelGGL(k_dots1, dim3(grid), dim3(256), 0, st, D);
   return hipGetLastError();
 }
