@@ -78,6 +78,50 @@ int cora_problem_synthetic(int dim, int n_poses, int n_landmarks, int n_ranges, 
   });
 }
 
+// ---- programmatic construction: the add* methods of CORA::Problem (include/CORA/CORA_problem.h:202-262)
+int cora_problem_new(int dim, int rank, int implicit, int precond, cora_problem **out) {
+  return guarded([&] {
+    *out = new cora_problem(Problem(dim, rank, implicit ? Formulation::Implicit : Formulation::Explicit, precondOf(precond)));
+  });
+}
+int cora_problem_add_pose(cora_problem *p, const char *id) {
+  return guarded([&] { p->problem.addPoseVariable(Symbol(std::string(id))); });
+}
+int cora_problem_add_landmark(cora_problem *p, const char *id) {
+  return guarded([&] { p->problem.addLandmarkVariable(Symbol(std::string(id))); });
+}
+int cora_problem_add_range(cora_problem *p, const char *a, const char *b, double dist, double cov) {
+  return guarded([&] { p->problem.addRangeMeasurement(RangeMeasurement(Symbol(std::string(a)), Symbol(std::string(b)), dist, cov)); });
+}
+int cora_problem_add_rel_pose(cora_problem *p, const char *a, const char *b, const double *R, const double *t,
+                              const double *cov) {
+  return guarded([&] {
+    const Index d = p->problem.dim(), c = d == 3 ? 6 : 3;
+    p->problem.addRelativePoseMeasurement(
+        RelativePoseMeasurement(Symbol(std::string(a)), Symbol(std::string(b)), wrap(R, d, d), wrap(t, d, 1), wrap(cov, c, c)));
+  });
+}
+int cora_problem_add_rel_pose_landmark(cora_problem *p, const char *a, const char *b, const double *t,
+                                       const double *cov) {
+  return guarded([&] {
+    const Index d = p->problem.dim();
+    p->problem.addRelativePoseLandmarkMeasurement(
+        RelativePoseLandmarkMeasurement(Symbol(std::string(a)), Symbol(std::string(b)), wrap(t, d, 1), wrap(cov, d, d)));
+  });
+}
+int cora_problem_add_pose_prior(cora_problem *p, const char *id, const double *R, const double *t, const double *cov) {
+  return guarded([&] {
+    const Index d = p->problem.dim(), c = d == 3 ? 6 : 3;
+    p->problem.addPosePrior(PosePrior(Symbol(std::string(id)), wrap(R, d, d), wrap(t, d, 1), wrap(cov, c, c)));
+  });
+}
+int cora_problem_add_landmark_prior(cora_problem *p, const char *id, const double *pos, const double *cov) {
+  return guarded([&] {
+    const Index d = p->problem.dim();
+    p->problem.addLandmarkPrior(LandmarkPrior(Symbol(std::string(id)), wrap(pos, d, 1), wrap(cov, d, d)));
+  });
+}
+
 int cora_problem_synthetic_ex(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
                               int precond, const double *sigmas, const char *pyfg_out, double *x_gt,
                               cora_problem **out) {

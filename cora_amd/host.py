@@ -57,6 +57,45 @@ class Problem:
             raise HostError(L.cora_host_last_error().decode())
         return (Problem(h), gt) if ground_truth else Problem(h)
 
+    @staticmethod
+    def new(dim, rank=None, implicit=False, precond=capi.PRECOND_REGULARIZED_CHOLESKY):
+        """Empty CORA::Problem to be filled with add_* (the reference's programmatic API)."""
+        L = _lib()
+        h = C.c_void_p()
+        if L.cora_problem_new(int(dim), int(rank or dim), int(bool(implicit)), int(precond), C.byref(h)):
+            raise HostError(L.cora_host_last_error().decode())
+        return Problem(h)
+
+    @staticmethod
+    def _m(a):
+        a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+        return a, a.ctypes.data_as(_dp)
+
+    def add_pose(self, sym):
+        self._chk(self.L.cora_problem_add_pose(self.h, sym.encode()))
+
+    def add_landmark(self, sym):
+        self._chk(self.L.cora_problem_add_landmark(self.h, sym.encode()))
+
+    def add_range(self, a, b, dist, cov):
+        self._chk(self.L.cora_problem_add_range(self.h, a.encode(), b.encode(), C.c_double(dist), C.c_double(cov)))
+
+    def add_rel_pose(self, a, b, R, t, cov):
+        (_, pr), (_, pt), (_, pc) = self._m(R), self._m(t), self._m(cov)
+        self._chk(self.L.cora_problem_add_rel_pose(self.h, a.encode(), b.encode(), pr, pt, pc))
+
+    def add_rel_pose_landmark(self, a, b, t, cov):
+        (_, pt), (_, pc) = self._m(t), self._m(cov)
+        self._chk(self.L.cora_problem_add_rel_pose_landmark(self.h, a.encode(), b.encode(), pt, pc))
+
+    def add_pose_prior(self, sym, R, t, cov):
+        (_, pr), (_, pt), (_, pc) = self._m(R), self._m(t), self._m(cov)
+        self._chk(self.L.cora_problem_add_pose_prior(self.h, sym.encode(), pr, pt, pc))
+
+    def add_landmark_prior(self, sym, pos, cov):
+        (_, pp), (_, pc) = self._m(pos), self._m(cov)
+        self._chk(self.L.cora_problem_add_landmark_prior(self.h, sym.encode(), pp, pc))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.cora_problem_destroy(self.h)

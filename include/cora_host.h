@@ -25,6 +25,21 @@ int cora_problem_from_pyfg(const char *path, cora_problem **out);
 /* Synthetic generator of SURVEY 8(d); pyfg_out may be NULL. precond: cora_precond_kind */
 int cora_problem_synthetic(int dim, int n_poses, int n_landmarks, int n_ranges, int n_loops, uint64_t seed,
                            int precond, const char *pyfg_out, cora_problem **out);
+/* Programmatic construction, one call per add* method of CORA::Problem
+ * (include/CORA/CORA_problem.h:202-262; used like tests/test_construct_problem.cpp:21-99).  Symbols are the
+ * reference's strings ("x1", "L3", ...).  Matrices are column-major: R d x d, t / pos d, cov (d + rotation
+ * dim) square for poses (translation block first, include/CORA/Measurements.h:60-63) and d x d for landmarks. */
+int cora_problem_new(int dim, int rank, int implicit, int precond, cora_problem **out);
+int cora_problem_add_pose(cora_problem *p, const char *id);
+int cora_problem_add_landmark(cora_problem *p, const char *id);
+int cora_problem_add_range(cora_problem *p, const char *a, const char *b, double dist, double cov);
+int cora_problem_add_rel_pose(cora_problem *p, const char *a, const char *b, const double *R, const double *t,
+                              const double *cov);
+int cora_problem_add_rel_pose_landmark(cora_problem *p, const char *a, const char *b, const double *t,
+                                       const double *cov);
+int cora_problem_add_pose_prior(cora_problem *p, const char *id, const double *R, const double *t, const double *cov);
+int cora_problem_add_landmark_prior(cora_problem *p, const char *id, const double *pos, const double *cov);
+
 /* Same generator with explicit noise levels sigmas = {sigma_t, sigma_R, sigma_range} (NULL: the
  * defaults 0.05, 0.01, 0.1) and, when x_gt != NULL, the ground truth as a column-major
  * ((dim+1) n + l + r) x dim point ([R_i^T]; range bearings; translations) -- zero cost when all

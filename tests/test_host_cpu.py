@@ -85,3 +85,61 @@ def test_priors_add_origin_pose(tmp_path):
     assert P.dims()["n"] == 3  # A0, A1 and the origin pose O0 (src/CORA_problem.cpp:80-113)
     A = asm.assemble(asm.parse_pyfg(str(f)))
     assert abs(A["Q"] - P.scipy_matrix()).max() < 1e-12
+
+
+def _submatrices_match(P, case):
+    for name in NAMES:
+        exp = read_mm(os.path.join(GOLDEN, case, name + ".mm"))
+        got = P.scipy_matrix(name)
+        if exp.shape == (0, 0):
+            assert got.shape[0] == 0 or got.shape[1] == 0, name
+            continue
+        assert exp.shape == got.shape, name
+        assert abs(exp - got).max() < 1e-12, name
+
+
+def test_construct_single_odometry_programmatically():
+    """tests/test_construct_problem.cpp:21-76: two poses, one identity-rotation odometry step of 1 m in x,
+    unit covariance, built with the add* methods; the ground truth spans the null space of Q."""
+    dim = 2
+    P = host.Problem.new(dim, rank=5)
+    P.add_pose("x1")
+    P.add_pose("x2")
+    tran = np.array([1.0, 0.0])
+    P.add_rel_pose("x1", "x2", np.eye(2), tran, np.eye(3))
+    P.update()
+    _submatrices_match(P, "single_rpm")
+    Q = P.scipy_matrix()
+    rng = np.random.default_rng(0)
+    X = np.zeros(((dim + 1) * 2, dim))
+    X[0:2] = np.eye(2)
+    X[2:4] = np.eye(2)
+    X[4] = rng.uniform(-1, 1, dim)
+    X[5] = X[4] + tran
+    assert np.linalg.norm(Q @ X) < 1e-12
+    U, _, _ = np.linalg.svd(rng.standard_normal((dim, dim)))
+    assert np.linalg.norm(Q @ (X @ U)) < 1e-12
+    with pytest.raises(host.HostError):
+        P.add_pose("x1")                      # duplicate variable (src/CORA_problem.cpp:24-31)
+    with pytest.raises(host.HostError):
+        P.add_rel_pose("x1", "x2", np.eye(2), tran, np.eye(3))   # duplicate measurement (:52-63)
+
+
+def test_construct_single_range_programmatically():
+    """tests/test_construct_problem.cpp:79-131: two landmarks 2 m apart, one range measurement."""
+    dim = 3
+    P = host.Problem.new(dim, rank=5)
+    P.add_landmark("l1")
+    P.add_landmark("l2")
+    P.add_range("l1", "l2", 2.0, 1.0)
+    P.update()
+    _submatrices_match(P, "single_range")
+    rng = np.random.default_rng(1)
+    l1 = rng.uniform(-1, 1, dim)
+    u = rng.standard_normal(dim)
+    u /= np.linalg.norm(u)
+    X = np.vstack([-u, l1, l1 + 2.0 * u])
+    assert np.linalg.norm(P.scipy_matrix() @ X) < 1e-12
+    with pytest.raises(host.HostError):
+        P.add_range("l1", "l3", 1.0, 1.0)     # unknown symbol is only detected at assembly time
+        P.update()
