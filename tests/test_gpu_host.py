@@ -56,3 +56,28 @@ def test_host_operators_synthetic_and_shapes():
     P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
     out = P.op("precondition", V)
     assert np.all(np.isfinite(out)) and np.all(out[-1] == 0.0)
+
+
+@pytest.mark.parametrize("dim,nsph", [(2, 1), (3, 5)])
+def test_oblique_manifold_functions(dim, nsph):
+    """tests/test_geometry.cpp:11-88 through the product path: a pose-less problem (landmarks and ranges only)
+    is a pure oblique manifold; its operators are the sphere functions the reference tests."""
+    P = host.Problem.new(dim, rank=dim, precond=capi.PRECOND_JACOBI)
+    for k in range(nsph + 1):
+        P.add_landmark("l%d" % k)
+    for k in range(nsph):
+        P.add_range("l%d" % k, "l%d" % (k + 1), 1.0 + 0.5 * k, 1.0)
+    P.update()
+    dm = P.dims()
+    assert (dm["n"], dm["r"], dm["l"]) == (0, nsph, nsph + 1)
+    rng = np.random.default_rng(5)
+    Y = P.op("projectToManifold", rng.uniform(-1, 1, (dm["N"], dim)))
+    assert np.abs(np.linalg.norm(Y[:nsph], axis=1) - 1).max() < 1e-14         # unit rows
+    assert np.abs(P.op("tangent_space_projection", Y, Y)[:nsph]).max() < 1e-14  # Y projects to zero on its own spheres
+    V = P.op("tangent_space_projection", Y, rng.uniform(-1, 1, Y.shape))
+    assert np.linalg.norm(V[:nsph]) > 1e-6
+    assert np.abs(np.sum(V[:nsph] * Y[:nsph], axis=1)).max() < 1e-14          # tangent: <v_j, y_j> = 0
+    R = P.op("retract", Y, V)
+    assert np.abs(np.linalg.norm(R[:nsph], axis=1) - 1).max() < 1e-14
+    assert np.abs(R - Y).max() > 1e-6
+    assert np.abs(R[nsph:] - (Y + V)[nsph:]).max() < 1e-15                     # translations are Euclidean
