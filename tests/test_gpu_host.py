@@ -81,3 +81,76 @@ def test_oblique_manifold_functions(dim, nsph):
     assert np.abs(np.linalg.norm(R[:nsph], axis=1) - 1).max() < 1e-14
     assert np.abs(R - Y).max() > 1e-6
     assert np.abs(R[nsph:] - (Y + V)[nsph:]).max() < 1e-15                     # translations are Euclidean
+
+
+def _rot3(rng, s):
+    w = rng.normal(0, s, 3)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def test_mixed_measurement_types_match_oracle():
+    """Every measurement type of the reference in one graph, built with the add* methods: two robots, inter-robot
+    (pose-pose) ranges, a landmark-landmark range, pose-landmark relative positions, a pose prior and a landmark
+    prior (which add the origin pose, src/CORA_problem.cpp:80-113).  Operators against the oracle on the host's
+    Q, then the full solve."""
+    rng = np.random.default_rng(21)
+    d, n = 3, 60
+    P = host.Problem.new(d, rank=d, precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    truth = {}
+    for rob in "AB":
+        R, t = np.eye(3), rng.uniform(-5, 5, 3)
+        for i in range(n):
+            P.add_pose("%s%d" % (rob, i))
+            truth["%s%d" % (rob, i)] = (R.copy(), t.copy())
+            dR, dt = _rot3(rng, 0.1), np.array([1.0, 0, 0]) + rng.normal(0, 0.1, 3)
+            R, t = R @ dR, t + R @ dt
+    for k in range(3):
+        P.add_landmark("L%d" % k)
+        truth["L%d" % k] = (None, rng.uniform(-20, 20, 3))
+    cov = np.diag([0.05 ** 2] * 3 + [0.01 ** 2] * 3)
+    for rob in "AB":
+        for i in range(n - 1):
+            (Ri, ti), (Rj, tj) = truth["%s%d" % (rob, i)], truth["%s%d" % (rob, i + 1)]
+            P.add_rel_pose("%s%d" % (rob, i), "%s%d" % (rob, i + 1), Ri.T @ Rj @ _rot3(rng, 0.01),
+                           Ri.T @ (tj - ti) + rng.normal(0, 0.05, 3), cov)
+    dist = lambda a, b: float(np.linalg.norm(truth[a][1] - truth[b][1]))
+    for i in range(0, n, 4):                                   # inter-robot ranges: both ends are poses
+        P.add_range("A%d" % i, "B%d" % ((i * 7) % n), dist("A%d" % i, "B%d" % ((i * 7) % n)) + rng.normal(0, 0.1), 0.01)
+    for i in range(0, n, 5):                                   # pose -> landmark ranges
+        P.add_range("B%d" % i, "L%d" % (i % 3), dist("B%d" % i, "L%d" % (i % 3)) + rng.normal(0, 0.1), 0.01)
+    P.add_range("L0", "L1", dist("L0", "L1"), 0.01)            # no pose at either end
+    for i in (3, 17, 40):                                      # relative position of a landmark seen from a pose
+        Ri, ti = truth["A%d" % i]
+        P.add_rel_pose_landmark("A%d" % i, "L2", Ri.T @ (truth["L2"][1] - ti) + rng.normal(0, 0.05, 3), np.eye(3) * 0.05 ** 2)
+    P.add_pose_prior("A0", truth["A0"][0], truth["A0"][1], cov)
+    P.add_landmark_prior("L0", truth["L0"][1], np.eye(3) * 0.1 ** 2)
+    P.update()
+    dm = P.dims()
+    assert dm["n"] == 2 * n + 1 and dm["l"] == 3               # + the origin pose the priors hang off
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    p = 5
+    P.set_rank(p)
+    Y = P.op("getRandomInitialGuess")
+    assert np.abs(Y - orc.project_manifold(dims, Y)).max() < 1e-12
+    f = orc.cost(Q, Y)
+    assert abs(P.op("evaluateObjective", Y) - f) < 1e-11 * abs(f)
+    G = orc.egrad(Q, Y)
+    assert np.abs(P.op("Euclidean_gradient", Y) - G).max() < 1e-11 * np.abs(G).max()
+    V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, Y.shape))
+    ref = orc.hvp(Q, dims, Y, G, V)
+    assert np.abs(P.op("Riemannian_Hessian_vector_product", Y, G, V) - ref).max() < 1e-11 * np.abs(ref).max()
+    import scipy.sparse as sp
+    lam = P.precond_info()["lam"]
+    M = (Q.to_scipy() + lam * sp.eye(dims.N)).tocsr()[:dims.N - 1, :dims.N - 1]
+    out = P.op("precondition", V)
+    assert np.abs(M @ out[:-1] - V[:-1]).max() < 1e-8 * np.abs(V).max()
+    P.set_rank(d)
+    res = P.solve(P.op("getRandomInitialGuess"), max_rank=8, max_seconds=60)
+    X = res["x"]
+    assert abs(orc.cost(Q, X) - res["f"]) < 1e-8 * max(1.0, res["f"])
+    nres = 6 * 2 * (n - 1) + dm["r"] + 9 + 6 + 3               # whitened residual count: optimum ~ half the dof
+    assert res["f"] < nres
