@@ -175,6 +175,17 @@ def test_partitioned_handles_match_single():
         m = c.row_map()
         mine = (m >= c.shard_begin) & (m < c.shard_begin + c.shard_rows)
         total[mine] = got[mine]
+        # only the rows cora_remote_rows lists are read outside the shard: poison all others
+        need = c.remote_rows()
+        assert need.size and np.all((need < c.shard_begin) | (need >= c.shard_begin + c.shard_rows))
+        keep = mine.copy()
+        keep |= np.isin(m, need)
+        Vp = V.copy()
+        Vp[~keep] = np.nan
+        c.upload(Vp, x)
+        c.hvp_dev(x, o)
+        again = c.download(o, p)
+        assert np.array_equal(again[mine], got[mine])
         c.close()
     assert relerr(total, ref) < REL
     assert abs(fsum - orc.cost(Q, Y)) < 1e-11 * orc.cost(Q, Y)
