@@ -194,8 +194,15 @@ def main():
                             lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr()), needed_rows=need)
     x_shard = x[rank * shard * ld:(rank + 1) * shard * ld].clone()  # this rank's rows of Ydot
 
+    if world > 1:
+        op.operand_shard().copy_(x_shard)  # the operand lives in the exchange buffer, as in a resident solver
+
     def step():
-        op.apply(x_shard)  # all-gather of Ydot (N > 1) + the fused local kernel
+        # N > 1: pack + all-gather + scatter of the rows other ranks read, then the fused local kernel
+        if world > 1:
+            op.apply_resident()
+        else:
+            op.apply(x_shard)
 
     def fence():
         torch.cuda.synchronize()

@@ -86,6 +86,25 @@ class RowShardedOperator:
             self.x2d.index_copy_(0, self.recv_idx, self.recv.view(-1, self.ld))
         return self.full_x
 
+    def operand_shard(self):
+        """This rank's rows of the full-length operand: a solver that keeps its vector here skips the copy
+        of apply() and calls apply_resident()."""
+        return self.full_x[self.shard_slice()]
+
+    def apply_resident(self):
+        """apply() for an operand already written to operand_shard()."""
+        if self.world == 1:
+            self.local_apply(self.full_x, self.full_out)
+            return self.full_out
+        if not self.rows_mode:
+            dist.all_gather_into_tensor(self.full_x, self.operand_shard().clone(), group=self.group)
+        else:
+            torch.index_select(self.x2d, 0, self.export_idx, out=self.send.view(-1, self.ld))
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            self.x2d.index_copy_(0, self.recv_idx, self.recv.view(-1, self.ld))
+        self.local_apply(self.full_x, self.full_out)
+        return self.full_out[self.shard_slice()]
+
     def apply(self, x_shard):
         if self.world == 1:  # the shard IS the vector: no exchange, no copy
             self.local_apply(x_shard, self.full_out)

@@ -62,6 +62,8 @@ def _worker(rank, world, port, q, rows_mode):
         xi[m, :k] = X
         x_shard = torch.from_numpy(xi[rank * shard:(rank + 1) * shard].reshape(-1).copy())
         y_shard = op.apply(x_shard).clone()
+        op.operand_shard().copy_(x_shard)
+        assert torch.equal(op.apply_resident(), y_shard)
         # gather the result shards and compare with the oracle on rank 0
         full = torch.zeros(rows * ld, dtype=torch.float64)
         dist.all_gather_into_tensor(full, y_shard)
