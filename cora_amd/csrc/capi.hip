@@ -295,7 +295,17 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
                          const int32_t *colidx, const double *vals, int rank, int world, cora_ctx **out) {
   if (!out) return fail(nullptr, CORA_ERR_ARG, "out is null");
   *out = nullptr;
-  if (!rowptr || !colidx || !vals) return fail(nullptr, CORA_ERR_ARG, "null CSR pointer");
+  if (!rowptr) return fail(nullptr, CORA_ERR_ARG, "null CSR pointer");
+  {  // an empty Q (variables without a single measurement) has no index / value arrays to point at
+    const int64_t N = static_cast<int64_t>(d) * n_poses + n_ranges + n_trans;
+    static const int32_t no_col = 0;
+    static const double no_val = 0.0;
+    if (N > 0 && rowptr[N] == 0) {
+      if (!colidx) colidx = &no_col;
+      if (!vals) vals = &no_val;
+    }
+  }
+  if (!colidx || !vals) return fail(nullptr, CORA_ERR_ARG, "null CSR pointer");
   cora_ctx *c = new (std::nothrow) cora_ctx();
   if (!c) return fail(nullptr, CORA_ERR_NOMEM, "out of host memory");
   try {
