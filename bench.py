@@ -190,8 +190,13 @@ def main():
     need = None
     if world > 1 and os.environ.get("CORA_BENCH_EXCHANGE", "rows") == "rows":
         need = ctx.remote_rows()
-    op = RowShardedOperator(rows, shard, ld, rank, world, dev,
-                            lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr()), needed_rows=need)
+    local = lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr())
+    try:
+        op = RowShardedOperator(rows, shard, ld, rank, world, dev, local, needed_rows=need)
+    except Exception as e:  # planning the row exchange failed on this stack: whole-shard all-gathers still work
+        if rank == 0:
+            print("row exchange unavailable (%r); falling back to whole-shard all-gathers" % (e,), file=sys.stderr)
+        op = RowShardedOperator(rows, shard, ld, rank, world, dev, local, needed_rows=None)
     x_shard = x[rank * shard * ld:(rank + 1) * shard * ld].clone()  # this rank's rows of Ydot
 
     if world > 1:
