@@ -1003,7 +1003,10 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   D.out = c->d_scalars;
   D.st = c->d_stpcg;
   D.st_host = &c->h_stpcg[0];
-  const int batch = 4;
+  // Iterations enqueued between two looks at the state: on small problems an iteration is a dozen launch
+  // floors and the host's wait is what costs, so it runs ahead by four (work enqueued past the stopping point is
+  // neutralised by the state); on large ones an iteration is worth 20 waits and running ahead would waste it.
+  const int batch = n > 1000000 ? 1 : 4;
   int enqueued = 0;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
