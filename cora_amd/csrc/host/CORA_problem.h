@@ -103,6 +103,13 @@ class Problem {
   }
   Symbol getOriginSymbol() const { return origin_symbol_; }
   std::map<Symbol, int> getPoseSymbolMap() const { return pose_symbol_idxs_; }
+  /** Poses of one robot (symbols with character chr) in symbol order, src/CORA_problem.cpp:954-962. */
+  std::vector<Symbol> getPoseSymbols(unsigned char chr) const {
+    std::vector<Symbol> s;
+    for (const auto &kv : pose_symbol_idxs_)
+      if (kv.first.chr() == chr) s.push_back(kv.first);
+    return s;
+  }
   std::map<Symbol, int> getLandmarkSymbolMap() const { return landmark_symbol_idxs_; }
   const std::vector<RangeMeasurement> &getRangeMeasurements() const { return range_measurements_; }
   const std::vector<RelativePoseMeasurement> &getRPMs() const { return rel_pose_pose_measurements_; }

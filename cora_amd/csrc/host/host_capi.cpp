@@ -7,6 +7,7 @@
 
 #include "../../../include/cora_hip.h"
 #include "CORA_problem.h"
+#include "io.h"
 #include "odometry_init.h"
 #include "pyfg_text_parser.h"
 #include "CORA.h"
@@ -359,6 +360,21 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
       std::memcpy(B, Bm.data(), sizeof(double) * static_cast<size_t>(m) * k);
     }
     info[2] = height;
+  });
+}
+
+int cora_problem_save_trajectory(cora_problem *p, const double *X, int g2o, int robot_chr, const char *path) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Matrix soln = wrap(X, q.getDataMatrixSize(), q.dim());
+    if (robot_chr > 0) {
+      const auto syms = q.getPoseSymbols(static_cast<unsigned char>(robot_chr));
+      if (g2o) saveSolnToG20(syms, q, soln, path);
+      else saveSolnToTum(syms, q, soln, path);
+    } else {
+      if (g2o) saveSolnToG20(q, soln, path);
+      else saveSolnToTum(q, soln, path);
+    }
   });
 }
 

@@ -4,19 +4,15 @@
 #include <cstdio>
 #include <stdexcept>
 
+#include "dense.h"
+
 namespace CORA {
 
 namespace {
-// rotation block of pose i as a 3x3 matrix.  Rows of the solution hold R_i^T's columns:
-// Y_i (d x d) = R_i^T in the reference's convention (Y = [R_1 ... R_n]^T stacked), so R_i = Y_i^T.
-void poseRotation(const Problem &p, const Matrix &X, int i, double R[3][3]) {
-  const int d = p.dim();
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b) R[a][b] = (a == b) ? 1.0 : 0.0;
+void quaternion(const Matrix &rot, int d, double q[4]) {  // x y z w of the rotation padded to 3 x 3
+  double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   for (int a = 0; a < d; ++a)
-    for (int b = 0; b < d; ++b) R[a][b] = X(static_cast<Index>(i) * d + b, a);
-}
-void toQuat(const double R[3][3], double q[4]) {  // x y z w
+    for (int b = 0; b < d; ++b) R[a][b] = rot(a, b);
   const double tr = R[0][0] + R[1][1] + R[2][2];
   if (tr > 0) {
     const double s = std::sqrt(tr + 1.0) * 2;
@@ -32,51 +28,85 @@ void toQuat(const double R[3][3], double q[4]) {  // x y z w
     q[3] = (R[1][0] - R[0][1]) / s; q[0] = (R[0][2] + R[2][0]) / s; q[1] = (R[1][2] + R[2][1]) / s; q[2] = 0.25 * s;
   }
 }
-void check(const Problem &p, const Matrix &X) {
-  if (X.rows() != p.getDataMatrixSize() || X.cols() != p.dim())
-    throw std::invalid_argument("trajectory writers expect a rank-d solution of the explicit problem");
+
+std::vector<Symbol> allPoses(const Problem &problem) {
+  const auto map = problem.getPoseSymbolMap();
+  std::vector<Symbol> syms(map.size(), Symbol('A', 0));
+  for (const auto &kv : map) syms[static_cast<size_t>(kv.second)] = kv.first;
+  return syms;
 }
 }  // namespace
 
-void saveSolnToTum(const Problem &p, const Matrix &X, const std::string &fpath) {
-  check(p, X);
+Matrix getTranslation(const Symbol &sym, const Problem &problem, const Matrix &soln) {
+  checkMatrixShape("getTranslation", problem.getDataMatrixSize(), problem.dim(), soln.rows(), soln.cols());
+  return soln.block(problem.getTranslationIdx(sym), 0, 1, problem.dim());
+}
+
+Matrix getRotation(const Symbol &sym, const Problem &problem, const Matrix &soln) {
+  checkMatrixShape("getRotation", problem.getDataMatrixSize(), problem.dim(), soln.rows(), soln.cols());
+  const Index d = problem.dim(), start = problem.getRotationIdx(sym);
+  const Matrix rot = soln.block(start * d, 0, d, d).transpose();
+  const Scalar det = determinant(rot);
+  if (std::abs(det - 1) > 1e-6)
+    throw std::runtime_error("Rotation matrix determinant is: " + std::to_string(det) + " not 1");
+  if ((rot * rot.transpose() - Matrix::Identity(d, d)).norm() > 1e-6)
+    throw std::runtime_error("Rotation matrix is not orthogonal");
+  return rot;
+}
+
+void saveSolnToG20(const std::vector<Symbol> &pose_symbols, const Problem &problem, const Matrix &soln,
+                   const std::string &fpath) {
+  checkMatrixShape("saveSolnToG20", problem.getDataMatrixSize(), problem.dim(), soln.rows(), soln.cols());
   FILE *f = std::fopen(fpath.c_str(), "w");
-  if (!f) throw std::runtime_error("Could not open " + fpath);
-  const int d = p.dim();
-  const Index off = p.rotAndRangeMatrixSize();
-  for (int i = 0; i < p.numPoses(); ++i) {
-    double R[3][3], q[4], t[3] = {0, 0, 0};
-    poseRotation(p, X, i, R);
-    toQuat(R, q);
-    for (int c = 0; c < d; ++c) t[c] = X(off + i, c);
-    std::fprintf(f, "%d %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", i, t[0], t[1], t[2], q[0], q[1], q[2], q[3]);
+  if (!f) throw std::runtime_error("Could not open file " + fpath);
+  try {
+    const int d = problem.dim();
+    for (size_t time = 0; time < pose_symbols.size(); ++time) {
+      const Matrix tran = getTranslation(pose_symbols[time], problem, soln);
+      const Matrix rot = getRotation(pose_symbols[time], problem, soln);
+      const double x = tran(0, 0), y = tran(0, 1), z = d == 2 ? 0.0 : tran(0, 2);
+      if (d == 3) {
+        double q[4];
+        quaternion(rot, d, q);
+        std::fprintf(f, "VERTEX_SE3:QUAT %zu %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", time, x, y, z, q[0], q[1], q[2], q[3]);
+      } else {
+        std::fprintf(f, "VERTEX_SE2 %zu %.9g %.9g %.9g\n", time, x, y, std::atan2(rot(1, 0), rot(0, 0)));
+      }
+    }
+  } catch (...) {
+    std::fclose(f);
+    throw;
   }
   std::fclose(f);
 }
 
-void saveSolnToG20(const Problem &p, const Matrix &X, const std::string &fpath) {
-  check(p, X);
+void saveSolnToTum(const std::vector<Symbol> &pose_symbols, const Problem &problem, const Matrix &soln,
+                   const std::string &fpath) {
+  checkMatrixShape("saveSolnToTum", problem.getDataMatrixSize(), problem.dim(), soln.rows(), soln.cols());
   FILE *f = std::fopen(fpath.c_str(), "w");
-  if (!f) throw std::runtime_error("Could not open " + fpath);
-  const int d = p.dim();
-  const Index off = p.rotAndRangeMatrixSize();
-  for (int i = 0; i < p.numPoses(); ++i) {
-    double R[3][3], q[4];
-    poseRotation(p, X, i, R);
-    if (d == 2) {
-      std::fprintf(f, "VERTEX_SE2 %d %.9f %.9f %.9f\n", i, X(off + i, 0), X(off + i, 1), std::atan2(R[1][0], R[0][0]));
-    } else {
-      toQuat(R, q);
-      std::fprintf(f, "VERTEX_SE3:QUAT %d %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", i, X(off + i, 0), X(off + i, 1),
-                   X(off + i, 2), q[0], q[1], q[2], q[3]);
+  if (!f) throw std::runtime_error("Could not open file " + fpath);
+  try {
+    const int d = problem.dim();
+    for (size_t time = 0; time < pose_symbols.size(); ++time) {
+      const Matrix tran = getTranslation(pose_symbols[time], problem, soln);
+      const Matrix rot = getRotation(pose_symbols[time], problem, soln);
+      double q[4];
+      quaternion(rot, d, q);
+      std::fprintf(f, "%zu %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", time, tran(0, 0), tran(0, 1), d == 2 ? 0.0 : tran(0, 2),
+                   q[0], q[1], q[2], q[3]);
     }
-  }
-  for (int j = 0; j < p.numLandmarks(); ++j) {
-    const Index row = off + p.numPoses() + j;
-    if (d == 2) std::fprintf(f, "VERTEX_XY %d %.9f %.9f\n", p.numPoses() + j, X(row, 0), X(row, 1));
-    else std::fprintf(f, "VERTEX_TRACKXYZ %d %.9f %.9f %.9f\n", p.numPoses() + j, X(row, 0), X(row, 1), X(row, 2));
+  } catch (...) {
+    std::fclose(f);
+    throw;
   }
   std::fclose(f);
+}
+
+void saveSolnToG20(const Problem &problem, const Matrix &soln, const std::string &fpath) {
+  saveSolnToG20(allPoses(problem), problem, soln, fpath);
+}
+void saveSolnToTum(const Problem &problem, const Matrix &soln, const std::string &fpath) {
+  saveSolnToTum(allPoses(problem), problem, soln, fpath);
 }
 
 }  // namespace CORA

@@ -227,6 +227,12 @@ class Problem:
         return dict(x=out, f=st[0], grad_norm=st[1], certified=bool(st[2]), eta=st[3], theta=st[4],
                     final_rank=int(st[5]), levels=int(st[6]), hvps=int(st[7]), seconds=st[8])
 
+    def save_trajectory(self, X, path, g2o=False, robot=None):
+        """saveSolnToTum / saveSolnToG20 for an N x d solution; robot = symbol character or None for all poses."""
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+        self._chk(self.L.cora_problem_save_trajectory(self.h, X.ctypes.data_as(_dp), int(bool(g2o)),
+                                                      ord(robot) if robot else 0, path.encode()))
+
     def precond_info(self):
         info = np.zeros(3)
         self._chk(self.L.cora_problem_precond_info(self.h, info.ctypes.data_as(_dp)))

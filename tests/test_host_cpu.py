@@ -143,3 +143,62 @@ def test_construct_single_range_programmatically():
     with pytest.raises(host.HostError):
         P.add_range("l1", "l3", 1.0, 1.0)     # unknown symbol is only detected at assembly time
         P.update()
+
+
+def test_trajectory_writers(tmp_path):
+    """saveSolnToTum / saveSolnToG20 (src/CORA_utils.cpp:235-346): per-robot pose chains, time stamp = position in
+    the chain, quaternion x y z w, 2-D poses lifted to z = 0; invalid rotations are refused (getRotation :211-233)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(4)
+    d, n = 3, 4
+    P = host.Problem.new(d)
+    rots, trans = {}, {}
+    for rob in "AB":
+        for i in range(n):
+            s = "%s%d" % (rob, i)
+            P.add_pose(s)
+            rots[s], trans[s] = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(), rng.uniform(-5, 5, 3)
+    for rob in "AB":
+        for i in range(n - 1):
+            P.add_rel_pose("%s%d" % (rob, i), "%s%d" % (rob, i + 1), np.eye(3), np.ones(3), np.eye(6))
+    P.add_range("A0", "B0", 1.0, 1.0)
+    P.update()
+    dm = P.dims()
+    order = ["A%d" % i for i in range(n)] + ["B%d" % i for i in range(n)]   # registration order = pose index
+    X = np.zeros((dm["N"], d))
+    for k, s in enumerate(order):
+        X[k * d:(k + 1) * d] = rots[s].T
+        X[d * dm["n"] + dm["r"] + k] = trans[s]
+    X[d * dm["n"]] = [1, 0, 0]
+    for rob in "AB":
+        path = str(tmp_path / ("%s.tum" % rob))
+        P.save_trajectory(X, path, robot=rob)
+        rows = np.loadtxt(path)
+        assert rows.shape == (n, 8) and np.array_equal(rows[:, 0], np.arange(n))
+        for i in range(n):
+            s = "%s%d" % (rob, i)
+            assert np.abs(rows[i, 1:4] - trans[s]).max() < 1e-8
+            assert np.abs(Rotation.from_quat(rows[i, 4:8]).as_matrix() - rots[s]).max() < 1e-7
+    path = str(tmp_path / "all.g2o")
+    P.save_trajectory(X, path, g2o=True)
+    lines = open(path).read().splitlines()
+    assert len(lines) == 2 * n and all(l.startswith("VERTEX_SE3:QUAT %d " % k) for k, l in enumerate(lines))
+    bad = X.copy()
+    bad[0:3] *= 1.1
+    with pytest.raises(host.HostError, match="determinant|orthogonal"):
+        P.save_trajectory(bad, path)
+    # 2-D
+    P2 = host.Problem.new(2)
+    P2.add_pose("A0"); P2.add_pose("A1")
+    P2.add_rel_pose("A0", "A1", np.eye(2), np.array([1.0, 0.0]), np.eye(3))
+    P2.update()
+    th = 0.3
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    X2 = np.vstack([np.eye(2), R.T, [[0.0, 0.0]], [[1.0, 2.0]]])
+    p2 = str(tmp_path / "t.g2o")
+    P2.save_trajectory(X2, p2, g2o=True)
+    l0, l1 = open(p2).read().splitlines()
+    assert l0.split()[:2] == ["VERTEX_SE2", "0"] and abs(float(l1.split()[4]) - th) < 1e-8
+    P2.save_trajectory(X2, str(tmp_path / "t.tum"))
+    rows = np.loadtxt(str(tmp_path / "t.tum"))
+    assert rows[1, 3] == 0.0 and abs(rows[1, 1] - 1.0) < 1e-9 and abs(rows[1, 2] - 2.0) < 1e-9
