@@ -634,6 +634,59 @@ SparseMatrix Problem::get_certificate_matrix(const Matrix &Y) const {
   return data_matrix_.plus(Lambda);
 }
 
+// ---- printProblem: src/CORA_problem.cpp:400-489 -------------------------------
+namespace {
+void printMatrix(const char *label, const Matrix &M) {
+  std::cout << label;
+  for (Index i = 0; i < M.rows(); ++i) {
+    std::cout << (M.rows() > 1 ? "\n  " : " ");
+    for (Index j = 0; j < M.cols(); ++j) std::cout << M(i, j) << (j + 1 < M.cols() ? " " : "");
+  }
+  std::cout << std::endl;
+}
+}  // namespace
+
+void Problem::printProblem() const {
+  auto section = [](bool any, const char *title, const char *none) {
+    std::cout << (any ? title : none) << std::endl;
+    return any;
+  };
+  if (section(numPoses() > 0, "Pose variables:", "No pose variables"))
+    for (const auto &kv : pose_symbol_idxs_) std::cout << kv.first.string() << " -> " << kv.second << std::endl;
+  if (section(numLandmarks() > 0, "\nLandmark variables:", "No landmark variables"))
+    for (const auto &kv : landmark_symbol_idxs_) std::cout << kv.first.string() << " -> " << kv.second << std::endl;
+  if (section(numRangeMeasurements() > 0, "\nRange measurements:", "No range measurements"))
+    for (const auto &m : range_measurements_)
+      std::cout << m.first_id.string() << " -> " << m.second_id.string() << " " << m.r << " " << m.cov << std::endl;
+  if (section(numPosePoseMeasurements() > 0, "\nRelative pose measurements:", "No relative pose measurements"))
+    for (const auto &m : rel_pose_pose_measurements_) {
+      std::cout << m.first_id.string() << " -> " << m.second_id.string() << std::endl;
+      printMatrix("Rot:", m.R);
+      printMatrix("Trans:", m.t.transpose());
+      printMatrix("Cov:", m.cov);
+    }
+  if (section(numPoseLandmarkMeasurements() > 0, "\nRelative pose landmark measurements:",
+              "No relative pose landmark measurements"))
+    for (const auto &m : rel_pose_landmark_measurements_) {
+      std::cout << m.first_id.string() << " -> " << m.second_id.string() << std::endl;
+      printMatrix("Trans:", m.t.transpose());
+      printMatrix("Cov:", m.cov);
+    }
+  if (section(!pose_priors_.empty(), "\nPose priors:", "No pose priors"))
+    for (const auto &m : pose_priors_) {
+      std::cout << m.id.string() << std::endl;
+      printMatrix("Rot:", m.R);
+      printMatrix("Trans:", m.t.transpose());
+      printMatrix("Cov:", m.cov);
+    }
+  if (section(!landmark_priors_.empty(), "\nLandmark priors:", "No landmark priors"))
+    for (const auto &m : landmark_priors_) {
+      std::cout << m.id.string() << std::endl;
+      printMatrix("Position:", m.p.transpose());
+      printMatrix("Cov:", m.cov);
+    }
+}
+
 // ---- utilities: src/CORA_problem.cpp:1199-1306 -------------------------------
 void Problem::checkVariablesAreValid(const Matrix &Y) const {
   const Index p = Y.cols();

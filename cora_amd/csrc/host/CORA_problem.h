@@ -129,6 +129,10 @@ class Problem {
   int numPoseLandmarkMeasurements() const { return static_cast<int>(rel_pose_landmark_measurements_.size()); }
   int numPosePriors() const { return static_cast<int>(pose_priors_.size()); }
   int numLandmarkPriors() const { return static_cast<int>(landmark_priors_.size()); }
+  int getNumPosePriors() const { return numPosePriors(); }          // include/CORA/CORA_problem.h:231-232
+  int getNumLandmarkPriors() const { return numLandmarkPriors(); }
+  /** Human-readable dump of the registry and of every measurement (src/CORA_problem.cpp:400-489). */
+  void printProblem() const;
   int numLandmarks() const { return static_cast<int>(landmark_symbol_idxs_.size()); }
   int numRangeMeasurements() const { return static_cast<int>(range_measurements_.size()); }
   int numTranslationalStates() const { return numPoses() + numLandmarks(); }

@@ -363,6 +363,10 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
   });
 }
 
+int cora_problem_print(cora_problem *p) {
+  return guarded([&] { p->problem.printProblem(); });
+}
+
 int cora_problem_save_trajectory(cora_problem *p, const double *X, int g2o, int robot_chr, const char *path) {
   return guarded([&] {
     Problem &q = p->problem;

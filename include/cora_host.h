@@ -125,6 +125,9 @@ int cora_problem_precond_info(cora_problem *p, double info[3]);
 int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_poses, double *B, int k,
                                 int64_t info[3]);
 
+/* Problem::printProblem (src/CORA_problem.cpp:400-489): registry and measurements on stdout. */
+int cora_problem_print(cora_problem *p);
+
 /* saveSolnToTum / saveSolnToG20 (src/CORA_utils.cpp:235-346) for a rank-d solution of the explicit problem
  * (N x d, e.g. the output of "alignEstimateToOrigin"): one line per pose of robot `robot_chr` (the symbol
  * character, as getPoseSymbols(chr); 0 = every pose in index order), time stamp = position in that list. */
