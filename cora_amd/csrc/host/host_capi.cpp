@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../../include/cora_hip.h"
+#include "CORA_preconditioners.h"
 #include "CORA_problem.h"
 #include "io.h"
 #include "odometry_init.h"
@@ -360,6 +361,19 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
       std::memcpy(B, Bm.data(), sizeof(double) * static_cast<size_t>(m) * k);
     }
     info[2] = height;
+  });
+}
+
+int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int nblocks,
+                                   const int32_t *block_sizes, int rhs_rows, int k, const double *B, double *X) {
+  return guarded([&] {
+    SparseMatrix A(n, n);
+    A.outer.assign(rowptr, rowptr + n + 1);
+    A.inner.assign(colidx, colidx + rowptr[n]);
+    A.values.assign(vals, vals + rowptr[n]);
+    const CholFactorPtrVector F = getBlockCholeskyFactorization(A, std::vector<int>(block_sizes, block_sizes + nblocks));
+    const Matrix x = blockCholeskySolve(F, wrap(B, rhs_rows, k));
+    std::memcpy(X, x.data(), sizeof(double) * static_cast<size_t>(x.size()));
   });
 }
 

@@ -255,6 +255,27 @@ class Problem:
         return c
 
 
+def block_cholesky_solve(A, block_sizes, B):
+    """getBlockCholeskyFactorization + blockCholeskySolve of the reference's public interface, on the host."""
+    import scipy.sparse as sp
+    L = _lib()
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    n = A.shape[0]
+    rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+    va = np.ascontiguousarray(A.data, dtype=np.float64)
+    bs = np.ascontiguousarray(block_sizes, dtype=np.int32)
+    B = np.asfortranarray(np.asarray(B, dtype=np.float64).reshape(len(B), -1))
+    X = np.zeros_like(B, order="F")
+    ip = C.POINTER(C.c_int32)
+    if L.cora_host_block_cholesky_solve(n, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), va.ctypes.data_as(_dp), len(bs),
+                                        bs.ctypes.data_as(ip), B.shape[0], B.shape[1], B.ctypes.data_as(_dp),
+                                        X.ctypes.data_as(_dp)):
+        raise HostError(L.cora_host_last_error().decode())
+    return X
+
+
 def fast_verification(S, eta, X0=None, nx=1, max_iters=1000):
     """CORA::fast_verification on an arbitrary symmetric scipy sparse matrix."""
     import scipy.sparse as sp

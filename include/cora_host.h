@@ -125,6 +125,12 @@ int cora_problem_precond_info(cora_problem *p, double info[3]);
 int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_poses, double *B, int k,
                                 int64_t info[3]);
 
+/* getBlockCholeskyFactorization + blockCholeskySolve (include/CORA/CORA_preconditioners.h:40-44) on the host:
+ * A symmetric CSR n x n, block sizes summing to n, B rhs_rows x k column-major with rhs_rows = n or n + 1
+ * (then the last row of X is zero). */
+int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int nblocks,
+                                   const int32_t *block_sizes, int rhs_rows, int k, const double *B, double *X);
+
 /* Problem::printProblem (src/CORA_problem.cpp:400-489): registry and measurements on stdout. */
 int cora_problem_print(cora_problem *p);
 

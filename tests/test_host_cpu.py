@@ -202,3 +202,35 @@ def test_trajectory_writers(tmp_path):
     P2.save_trajectory(X2, str(tmp_path / "t.tum"))
     rows = np.loadtxt(str(tmp_path / "t.tum"))
     assert rows[1, 3] == 0.0 and abs(rows[1, 1] - 1.0) < 1e-9 and abs(rows[1, 2] - 2.0) < 1e-9
+
+
+def test_block_cholesky_free_functions():
+    """tests/test.cpp:149-214: 6 x 6 matrix with unit diagonal and 0.5 elsewhere, blocks {3, 3}; the solve is the
+    inverse of the block diagonal.  With one more right-hand-side row the last row comes back as zero
+    (src/CORA_preconditioners.cpp:78-80)."""
+    n = 6
+    A = np.full((n, n), 0.5) + 0.5 * np.eye(n)
+    Ablk = np.zeros_like(A)
+    Ablk[:3, :3], Ablk[3:, 3:] = A[:3, :3], A[3:, 3:]
+    inv = np.linalg.inv(Ablk)
+    assert np.abs(host.block_cholesky_solve(A, [3, 3], np.eye(n)) - inv).max() < 1e-12
+    assert np.abs(host.block_cholesky_solve(A, [3, 3], Ablk) - np.eye(n)).max() < 1e-12
+    b = np.arange(1.0, 7.0)
+    assert np.abs(host.block_cholesky_solve(A, [3, 3], b)[:, 0] - inv @ b).max() < 1e-12
+    # three distinct blocks (the reference's loop would factor the first one three times)
+    rng = np.random.default_rng(0)
+    M = rng.standard_normal((9, 9))
+    S = M @ M.T + 9 * np.eye(9)
+    blocks = [2, 3, 4]
+    ref = np.zeros((9, 9))
+    o = 0
+    for s in blocks:
+        ref[o:o + s, o:o + s] = np.linalg.inv(S[o:o + s, o:o + s])
+        o += s
+    assert np.abs(host.block_cholesky_solve(S, blocks, np.eye(9)) - ref).max() < 1e-12
+    x = host.block_cholesky_solve(S, blocks, np.vstack([np.eye(9), np.ones((1, 9))]))
+    assert x.shape == (10, 9) and np.all(x[-1] == 0.0) and np.abs(x[:9] - ref).max() < 1e-12
+    with pytest.raises(host.HostError, match="must sum to A.rows"):
+        host.block_cholesky_solve(S, [2, 3], np.eye(9))
+    with pytest.raises(host.HostError, match="right-hand side"):
+        host.block_cholesky_solve(S, blocks, np.eye(11))
