@@ -3,11 +3,13 @@
 
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "../../../include/cora_hip.h"
 #include "CORA_preconditioners.h"
 #include "CORA_problem.h"
+#include "Manifolds.h"
 #include "io.h"
 #include "odometry_init.h"
 #include "pyfg_text_parser.h"
@@ -374,6 +376,28 @@ int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *
     const CholFactorPtrVector F = getBlockCholeskyFactorization(A, std::vector<int>(block_sizes, block_sizes + nblocks));
     const Matrix x = blockCholeskySolve(F, wrap(B, rhs_rows, k));
     std::memcpy(X, x.data(), sizeof(double) * static_cast<size_t>(x.size()));
+  });
+}
+
+int cora_host_manifold_op(int kind, int k, int p, int n, const char *op, const double *A, const double *B,
+                          uint64_t seed, double *out) {
+  return guarded([&] {
+    const std::string o(op);
+    std::unique_ptr<MatrixManifold> M;
+    Index cols;
+    StiefelProduct *st = nullptr;
+    ObliqueManifold *ob = nullptr;
+    if (kind == 0) { st = new StiefelProduct(k, p, n); M.reset(st); cols = static_cast<Index>(k) * n; }
+    else { ob = new ObliqueManifold(p, n); M.reset(ob); cols = n; }
+    Matrix res;
+    if (o == "projectToManifold") res = M->projectToManifold(wrap(A, p, cols));
+    else if (o == "projectToTangentSpace") res = M->projectToTangentSpace(wrap(A, p, cols), wrap(B, p, cols));
+    else if (o == "retract") res = M->retract(wrap(A, p, cols), wrap(B, p, cols));
+    else if (o == "random_sample") res = st ? st->random_sample(static_cast<unsigned>(seed)) : ob->random_sample(static_cast<unsigned>(seed));
+    else if (o == "innerProduct") { out[0] = M->innerProduct(wrap(A, p, cols), wrap(B, p, cols)); return; }
+    else if (o == "SymBlockDiagProduct" && st) res = st->SymBlockDiagProduct(wrap(A, p, cols), wrap(B, p, cols).transpose(), wrap(B + static_cast<size_t>(p) * cols, p, cols));
+    else throw std::invalid_argument("unknown manifold operation " + o);
+    std::memcpy(out, res.data(), sizeof(double) * static_cast<size_t>(res.size()));
   });
 }
 

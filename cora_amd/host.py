@@ -255,6 +255,20 @@ class Problem:
         return c
 
 
+def manifold_op(kind, op, p, n, k=0, A=None, B=None, seed=0):
+    """StiefelProduct(k, p, n) (kind "stiefel") / ObliqueManifold(p, n) (kind "oblique") of the reference, on the GPU."""
+    L = _lib()
+    cols = k * n if kind == "stiefel" else n
+    f = lambda M: None if M is None else np.asfortranarray(np.asarray(M, dtype=np.float64))
+    A, B = f(A), f(B)
+    out = np.zeros(1) if op == "innerProduct" else np.zeros((p, cols), order="F")
+    if L.cora_host_manifold_op(0 if kind == "stiefel" else 1, int(k), int(p), int(n), op.encode(),
+                               None if A is None else A.ctypes.data_as(_dp), None if B is None else B.ctypes.data_as(_dp),
+                               C.c_uint64(seed), out.ctypes.data_as(_dp)):
+        raise HostError(L.cora_host_last_error().decode())
+    return float(out[0]) if op == "innerProduct" else out
+
+
 def block_cholesky_solve(A, block_sizes, B):
     """getBlockCholeskyFactorization + blockCholeskySolve of the reference's public interface, on the host."""
     import scipy.sparse as sp

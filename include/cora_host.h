@@ -131,6 +131,14 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
 int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int nblocks,
                                    const int32_t *block_sizes, int rhs_rows, int k, const double *B, double *X);
 
+/* The reference's manifold classes (include/CORA/StiefelProduct.h, ObliqueManifold.h, MatrixManifold.h) on the
+ * GPU.  kind 0: StiefelProduct(k, p, n), points p x kn; kind 1: ObliqueManifold(p, n), points p x n
+ * (column-major).  op: "projectToManifold" (A), "projectToTangentSpace" (A = Y, B = V), "retract" (A = Y, B = V),
+ * "random_sample" (seed), "innerProduct" (A, B -> out[0]), "SymBlockDiagProduct" (A; B holds B then C back to
+ * back). */
+int cora_host_manifold_op(int kind, int k, int p, int n, const char *op, const double *A, const double *B,
+                          uint64_t seed, double *out);
+
 /* Problem::printProblem (src/CORA_problem.cpp:400-489): registry and measurements on stdout. */
 int cora_problem_print(cora_problem *p);
 
