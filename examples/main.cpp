@@ -3,11 +3,13 @@
 //   -> alignEstimateToOrigin, then print the result and optionally save a TUM trajectory.
 // Build:  hipcc -O2 -std=c++17 -Iinclude -Icora_amd/csrc/host examples/main.cpp \
 //               -Lcora_amd/lib -lcora_hip -Wl,-rpath,$PWD/cora_amd/lib -o cora_main
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "CORA.h"
 #include "io.h"
@@ -15,11 +17,11 @@
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    std::cout << "Usage: " << argv[0] << " [input .pyfg file] [--jacobi] [--implicit] [--odom-init] [--tum out.tum] [--max-rank r]" << std::endl;
+    std::cout << "Usage: " << argv[0] << " [input .pyfg file] [--jacobi] [--implicit] [--odom-init] [--tum out.tum] [--save-dir dir] [--max-rank r]" << std::endl;
     return 1;
   }
   int max_rank = 10;
-  std::string tum;
+  std::string tum, save_dir;
   bool jacobi = false, implicit = false, odom = false;
   for (int i = 2; i < argc; ++i) {
     const std::string a = argv[i];
@@ -27,6 +29,7 @@ int main(int argc, char **argv) {
     else if (a == "--implicit") implicit = true;   // "formulation": "Implicit" of examples/config.json
     else if (a == "--odom-init") odom = true;      // "init_type": "Odom"
     else if (a == "--tum" && i + 1 < argc) tum = argv[++i];
+    else if (a == "--save-dir" && i + 1 < argc) save_dir = argv[++i];  // cora_<robot>.tum / .g2o per robot, like saveSolutions
     else if (a == "--max-rank" && i + 1 < argc) max_rank = std::atoi(argv[++i]);
   }
   using clk = std::chrono::steady_clock;
@@ -61,6 +64,20 @@ int main(int argc, char **argv) {
     if (!tum.empty()) {
       CORA::saveSolnToTum(problem, aligned, tum);
       std::cout << "wrote " << tum << std::endl;
+    }
+    if (!save_dir.empty()) {  // examples/paper_experiments.cpp:536-592: one trajectory file pair per robot chain
+      std::vector<unsigned char> robots;
+      for (const auto &kv : problem.getPoseSymbolMap())
+        if (!(kv.first == problem.getOriginSymbol()) &&
+            std::find(robots.begin(), robots.end(), kv.first.chr()) == robots.end())
+          robots.push_back(kv.first.chr());
+      for (size_t r = 0; r < robots.size(); ++r) {
+        const auto chain = problem.getPoseSymbols(robots[r]);
+        const std::string base = save_dir + "/cora_" + std::to_string(r);
+        CORA::saveSolnToTum(chain, problem, aligned, base + ".tum");
+        CORA::saveSolnToG20(chain, problem, aligned, base + ".g2o");
+        std::cout << "wrote " << base << ".tum / .g2o (" << chain.size() << " poses of robot '" << robots[r] << "')" << std::endl;
+      }
     }
   } catch (const std::exception &e) {
     std::cerr << "error: " << e.what() << std::endl;
