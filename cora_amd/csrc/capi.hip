@@ -659,6 +659,14 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
     if ((e = up(&D.chunk_end, H.chunk_end)) != hipSuccess) return e;
     if ((e = up(&D.col, H.col)) != hipSuccess) return e;
     if ((e = up(&D.val, H.val)) != hipSuccess) return e;
+    std::vector<int32_t> chunk_row(static_cast<size_t>(D.nchunks), 0);
+    for (int r = 0; r < D.nlong; ++r)
+      for (int32_t ch = H.long_chunk_ptr[r]; ch < H.long_chunk_ptr[r + 1]; ++ch) chunk_row[ch] = r;
+    if ((e = up(&D.chunk_row, chunk_row)) != hipSuccess) return e;
+    const std::vector<unsigned> tick(static_cast<size_t>(std::max(D.nlong, 1)), 0u);
+    const unsigned *tp = nullptr;
+    if ((e = up(&tp, tick)) != hipSuccess) return e;
+    D.tickets = const_cast<unsigned *>(tp);
     const std::vector<double> part(static_cast<size_t>(std::max(D.nchunks, 1)) * kMaxLD, 0.0);
     const double *pp = nullptr;
     if ((e = up(&pp, part)) != hipSuccess) return e;
@@ -678,10 +686,31 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
     if (S.dense) {
       BlockOpHost &H = S.blocks_op;
       D.blocks.nblocks = static_cast<int>(H.nrows.size());
-      HIP_TRY(c, up(&D.blocks.row_begin, H.row_begin));
-      HIP_TRY(c, up(&D.blocks.nrows, H.nrows));
-      HIP_TRY(c, up(&D.blocks.w_off, H.w_off));
-      HIP_TRY(c, up(&D.blocks.rows, H.rows));
+      {
+        // per-row records, padded per block to a multiple of eight (empty masks) + one spare round at the end; the
+        // value arrays get 64 * 65 zero entries: the kernel's prefetch of the next round reads past a block's end
+        std::vector<BlockDesc> desc(H.nrows.size());
+        std::vector<BlockLane> bc, br;
+        for (size_t b = 0; b < desc.size(); ++b) {
+          desc[b] = BlockDesc{H.row_begin[b], H.nrows[b], static_cast<int32_t>(bc.size()), 0, H.w_off[b], 0};
+          for (int l = 0; l < H.nrows[b]; ++l) {
+            const size_t i = static_cast<size_t>(H.row_begin[b]) + l;
+            bc.push_back(BlockLane{H.mask_col[i], H.off_col[i], H.rows[i]});
+            br.push_back(BlockLane{H.mask_row[i], H.off_row[i], H.rows[i]});
+          }
+          while (bc.size() % 8) {
+            bc.push_back(BlockLane{0, 0, 0});
+            br.push_back(BlockLane{0, 0, 0});
+          }
+        }
+        bc.resize(bc.size() + 24, BlockLane{0, 0, 0});
+        br.resize(br.size() + 24, BlockLane{0, 0, 0});
+        H.w_by_col.resize(H.w_by_col.size() + 64 * 65, 0.0);
+        H.w_by_row.resize(H.w_by_row.size() + 64 * 65, 0.0);
+        HIP_TRY(c, up(&D.blocks.desc, desc));
+        HIP_TRY(c, up(&D.blocks.by_col, bc));
+        HIP_TRY(c, up(&D.blocks.by_row, br));
+      }
       HIP_TRY(c, up(&D.blocks.w_by_col, H.w_by_col));
       HIP_TRY(c, up(&D.blocks.w_by_row, H.w_by_row));
       HIP_TRY(c, up(&D.blocks.ext_ptr, H.ext_ptr));

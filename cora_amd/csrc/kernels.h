@@ -75,16 +75,24 @@ struct RowOpDev {  // device copy of a RowOpHost (trisolve.h)
   int nlong, nchunks;
   const int32_t *col;
   const double *val;
-  double *partial;  // [nchunks][LD]
+  const int32_t *chunk_row;  // long-row ordinal of every chunk
+  double *partial;     // [nchunks][kMaxLD]
+  unsigned *tickets;   // [nlong], zero between launches
+  int ablate;          // lab switch (CORA_ABLATE)
 };
-struct BlockOpDev {  // device copy of a BlockOpHost (trisolve.h)
-  const int32_t *row_begin, *nrows;
-  const int64_t *w_off;
-  const int32_t *rows;
+// Device copy of a BlockOpHost (trisolve.h), packed so that everything wave-uniform is one scalar load:
+// a 16-byte descriptor per block and a 16-byte record per block row (its internal row for the lane that
+// owns it; the lane mask and offset of column / row q of W for the wave's loop over q).
+struct BlockDesc { int32_t row_begin, nrows, meta_begin, pad; int64_t w_off; int64_t pad2; };  // 32 bytes
+struct BlockLane { uint64_t mask; int32_t off; int32_t row; };
+struct BlockOpDev {
+  const BlockDesc *desc;
+  const BlockLane *by_col, *by_row;     // [desc.meta_begin + q]: column q of W (forward) / row q of W (backward)
   const double *w_by_col, *w_by_row;
   const int32_t *ext_ptr, *ext_col;
   const double *ext_val;
   int nblocks;
+  int ablate;  // lab switch (CORA_ABLATE)
 };
 // forward: dst[rows] = W src[rows];  backward: dst[rows] = W^T (src[rows] - L[later, rows]^T src[later])
 hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st);

@@ -42,15 +42,19 @@ struct RowOpHost {
   bool empty() const { return out_row.empty() && long_out.empty(); }
 };
 
-// Stage 0 in dense form: its blocks are tiny (<= 64 rows, one wavefront each, lane = row) and their
-// inverses nearly full lower triangles, so W is stored without indices, packed twice so that both
-// sweeps read it coalesced: by column for y = W t (lane i reads W_ij, i >= j) and by row for
-// x = W^T t (lane j reads W_ij, j <= i).  The backward coupling to the later stages (columns of L)
-// is applied by the same kernel, lane by lane, before the block product.
+// Stage 0 in block form: its blocks are tiny (<= 64 rows, one wavefront each, lane = row).  The inverse
+// W = L_bb^-1 of a block is non-zero exactly along the paths of the block's elimination tree, so it is
+// stored without indices as a 64-bit lane mask per column plus the non-zeros in lane order -- packed
+// twice so that both sweeps read it coalesced: by column for y = W t (mask_col[q]: lanes i >= q with
+// W_iq != 0) and by row for x = W^T t (mask_row[q]: lanes j <= q with W_qj != 0).  A lane finds its
+// entry at off + popcount(mask below the lane).  The backward coupling to the later stages (columns
+// of L) is applied by the same kernel before the block product.
 struct BlockOpHost {
   std::vector<int32_t> row_begin, nrows;  // per block: its rows in `rows`
-  std::vector<int64_t> w_off;             // per block: start of its nb(nb+1)/2 packed entries
+  std::vector<int64_t> w_off;             // per block: start of its entries in w_by_col / w_by_row
   std::vector<int32_t> rows;              // internal row of every block row (elimination order)
+  std::vector<uint64_t> mask_col, mask_row;  // per block row q
+  std::vector<int32_t> off_col, off_row;     // per block row q: its first entry, relative to w_off
   std::vector<double> w_by_col, w_by_row;
   std::vector<int32_t> ext_ptr, ext_col;  // per block row: -L[later, row] entries (backward sweep)
   std::vector<double> ext_val;
@@ -69,12 +73,16 @@ struct TriPlan {
   std::vector<TriStage> stages;
   int64_t nnzL = 0, nnzW = 0;  // entries of L and of the explicit block inverses
   int height = 0;              // number of stages
+  bool groups_whole = false;   // see build_tri_plan
 };
 
+// group (optional, size m): variables with the same id >= 0 (the d rotation rows of a pose) are kept in
+// one block; plan.groups_whole tells whether they also sit in adjacent lanes / consecutive positions.
 // row_of[i]: internal row of permuted variable i (= api2int[perm[i]]).  zero_row >= 0: an internal
 // row outside the factor that every solve must set to zero (the pinned variable).
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
-                    const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &plan);
+                    const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &plan,
+                    const std::vector<int32_t> *group = nullptr);
 
 
 // Test hook: runs the plan's products on the host in launch order (rhs, out: `rows` doubles, one

@@ -1,6 +1,7 @@
 #include "trisolve.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace cora {
@@ -12,7 +13,7 @@ constexpr int kFirstCap = 64;        // rows of a stage-0 subtree: what one wave
                                      // 64 measured 154 / 155 / 162 / 151 us per apply at 10^5 poses
 constexpr int kCapGrowth = 16;       // stage k subtrees hold up to kFirstCap * kCapGrowth^k rows
 constexpr int kTopCap = 1536;        // stop cutting once this few rows are left: they form the last stage
-constexpr int64_t kTopInverseNnz = 2000000;  // ... or once the inverse of what is left has this few entries:
+int64_t kTopInverseNnz = 2500000;  // ... or once the inverse of what is left has this few entries:
                                              // a launch floor (~5 us) is worth ~25 MB of traffic, so small
                                              // factors are applied as ONE explicit inverse (2 products)
 constexpr int kShortRow = 64;        // entries: <= this -> 8 lanes per row
@@ -68,7 +69,9 @@ void finalize(const RowList &R, RowOpHost &op) {
 }  // namespace
 
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
-                    const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P) {
+                    const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P,
+                    const std::vector<int32_t> *group) {
+  if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
   P = TriPlan();
   P.m = m;
   P.zero_row = zero_row;
@@ -131,7 +134,9 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         stage[v] = nstage;
         blk[v] = blk[p];
         ++taken;
-      } else if (sz[v] <= cap && (nstage > 0 || sz[v] >= kMinBlock || p < 0 || p >= first_border)) {
+      } else if (sz[v] <= cap && (nstage > 0 || sz[v] >= kMinBlock || p < 0 || p >= first_border) &&
+                 !(group && p >= 0 && (*group)[v] >= 0 && (*group)[v] == (*group)[p])) {
+        // (a group -- the d rotation rows of a pose -- is never cut: its rows share a block)
         // maximal: its parent (if any) was visited and did not fit.  Tiny stage-0 subtrees hanging off a
         // bigger remainder (single range rows of separator poses) stay with that remainder.
         stage[v] = nstage;
@@ -191,13 +196,44 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     for (size_t b = 0; b < nblk; ++b) {
       D0.row_begin[b] = rb;
       D0.nrows[b] = count[b];
-      D0.w_off[b] = wo;
       rb += count[b];
-      wo += static_cast<int64_t>(count[b]) * (count[b] + 1) / 2;
     }
     D0.rows.assign(static_cast<size_t>(rb), 0);
+    D0.mask_col.assign(static_cast<size_t>(rb), 0);
+    D0.mask_row.assign(static_cast<size_t>(rb), 0);
+    D0.off_col.assign(static_cast<size_t>(rb), 0);
+    D0.off_row.assign(static_cast<size_t>(rb), 0);
+    // structure of W: column j is non-zero on the path from j to the root of its block
+    for (int j = 0; j < m; ++j) {
+      if (stage[j] != 0) continue;
+      const int32_t bj = D0.row_begin[blk_id[j]], lj = loc[j];
+      for (int v = j; v >= 0 && stage[v] == 0 && blk[v] == blk[j]; v = parent[v]) {
+        D0.mask_col[bj + lj] |= 1ull << loc[v];
+        D0.mask_row[bj + loc[v]] |= 1ull << lj;
+      }
+    }
+    wo = 0;
+    for (size_t b = 0; b < nblk; ++b) {
+      D0.w_off[b] = wo;
+      int32_t oc = 0, orw = 0;
+      for (int l = 0; l < count[b]; ++l) {
+        const size_t at = static_cast<size_t>(D0.row_begin[b]) + l;
+        D0.off_col[at] = oc;
+        D0.off_row[at] = orw;
+        oc += __builtin_popcountll(D0.mask_col[at]);
+        orw += __builtin_popcountll(D0.mask_row[at]);
+      }
+      wo += oc;  // == orw
+    }
     D0.w_by_col.assign(static_cast<size_t>(wo), 0.0);
     D0.w_by_row.assign(static_cast<size_t>(wo), 0.0);
+    // groups (the rotation rows of a pose) in adjacent lanes of one block: lets the kernel fuse row-unit work
+    P.groups_whole = group != nullptr;
+    if (group)
+      for (int v = 0; v + 1 < m && P.groups_whole; ++v)
+        if ((*group)[v] >= 0 && (*group)[v + 1] == (*group)[v] &&
+            !(stage[v] == stage[v + 1] && (stage[v] != 0 || (blk_id[v] == blk_id[v + 1] && loc[v + 1] == loc[v] + 1))))
+          P.groups_whole = false;
     D0.ext_ptr.assign(static_cast<size_t>(rb) + 1, 0);
     for (int v = 0; v < m; ++v)
       if (stage[v] == 0) {
@@ -258,10 +294,11 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       const double wv = w[v] / Lx[Lp[v]];
       w[v] = 0.0;
       if (dense) {
-        const int nb = D0.nrows[blk_id[j]], lj = loc[j], li = loc[v];
+        const int lj = loc[j], li = loc[v];
         const int64_t base = D0.w_off[blk_id[j]];
-        D0.w_by_col[base + static_cast<int64_t>(lj) * nb - static_cast<int64_t>(lj) * (lj - 1) / 2 + (li - lj)] = wv;
-        D0.w_by_row[base + static_cast<int64_t>(li) * (li + 1) / 2 + lj] = wv;
+        const size_t rb0 = static_cast<size_t>(D0.row_begin[blk_id[j]]);
+        D0.w_by_col[base + D0.off_col[rb0 + lj] + __builtin_popcountll(D0.mask_col[rb0 + lj] & ((1ull << li) - 1))] = wv;
+        D0.w_by_row[base + D0.off_row[rb0 + li] + __builtin_popcountll(D0.mask_row[rb0 + li] & ((1ull << lj) - 1))] = wv;
         ++P.nnzW;
       } else {
         B.add(row_of[v], wv);
@@ -341,10 +378,11 @@ void apply_blocks(const BlockOpHost &B, bool bwd, const double *src, double *dst
         for (int32_t k = B.ext_ptr[rb + l]; k < B.ext_ptr[rb + l + 1]; ++k) t[l] += B.ext_val[k] * src[B.ext_col[k]];
     }
     const double *W = (bwd ? B.w_by_row.data() : B.w_by_col.data()) + B.w_off[b];
-    int at = 0;
-    for (int q = 0; q < nb; ++q) {
-      for (int l = bwd ? 0 : q; l < (bwd ? q + 1 : nb); ++l) acc[l] += W[at + (bwd ? l : l - q)] * t[q];
-      at += bwd ? q + 1 : nb - q;
+    for (int q = 0; q < nb; ++q) {  // the kernel's loop: lane l takes entry off + popcount(mask below l)
+      const uint64_t mask = bwd ? B.mask_row[rb + q] : B.mask_col[rb + q];
+      const int32_t off = bwd ? B.off_row[rb + q] : B.off_col[rb + q];
+      for (int l = 0; l < nb; ++l)
+        if (mask >> l & 1) acc[l] += W[off + __builtin_popcountll(mask & ((1ull << l) - 1))] * t[q];
     }
     for (int l = 0; l < nb; ++l) dst[B.rows[rb + l]] = acc[l];
   }

@@ -9,40 +9,6 @@
 #include "synthetic.h"
 #include "trisolve.h"
 using cora::RowOpHost;
-static void apply(const RowOpHost &op, const std::vector<double> *src0, const std::vector<double> &src, std::vector<double> &dst) {
-  const int n = op.n8 + op.n64;
-  for (int r = 0; r < n; ++r) {
-    double s = src0 ? (*src0)[op.out_row[r]] : 0.0;
-    for (int k = op.begin[r]; k < op.end[r]; ++k) s += op.val[k] * src[op.col[k]];
-    dst[op.out_row[r]] = s;
-  }
-  for (size_t r = 0; r < op.long_out.size(); ++r) {
-    double s = src0 ? (*src0)[op.long_out[r]] : 0.0;
-    for (int ch = op.long_chunk_ptr[r]; ch < op.long_chunk_ptr[r + 1]; ++ch)
-      for (int k = op.chunk_begin[ch]; k < op.chunk_end[ch]; ++k) s += op.val[k] * src[op.col[k]];
-    dst[op.long_out[r]] = s;
-  }
-}
-static void apply_blocks(const cora::BlockOpHost &B, bool bwd, const std::vector<double> &src, std::vector<double> &dst) {
-  for (size_t b = 0; b < B.nrows.size(); ++b) {
-    const int nb = B.nrows[b], rb = B.row_begin[b];
-    std::vector<double> t(nb), acc(nb, 0.0);
-    for (int l = 0; l < nb; ++l) {
-      t[l] = src[B.rows[rb + l]];
-      if (bwd)
-        for (int k = B.ext_ptr[rb + l]; k < B.ext_ptr[rb + l + 1]; ++k) t[l] += B.ext_val[k] * src[B.ext_col[k]];
-    }
-    const double *W = (bwd ? B.w_by_row.data() : B.w_by_col.data()) + B.w_off[b];
-    int at = 0;
-    for (int q = 0; q < nb; ++q) {
-      for (int l = 0; l < nb; ++l) {
-        if (bwd ? l <= q : l >= q) acc[l] += W[at + (bwd ? l : l - q)] * t[q];
-      }
-      at += bwd ? q + 1 : nb - q;
-    }
-    for (int l = 0; l < nb; ++l) dst[B.rows[rb + l]] = acc[l];
-  }
-}
 static void stat(const char *name, const RowOpHost &op) {
   std::printf("    %-6s rows8 %7d rows64 %6d long %3zu chunks %5zu entries %9zu\n", name, op.n8, op.n64, op.long_out.size(),
               op.chunk_begin.size(), op.col.size());
@@ -68,7 +34,7 @@ int main(int argc, char **argv) {
     const auto &S = plan.stages[k];
     std::printf("  stage %zu: rows %d blocks %d\n", k, S.rows, S.blocks);
     if (S.dense) {
-      std::printf("    dense: %zu blocks, %zu packed entries, %zu ext entries\n", S.blocks_op.nrows.size(), S.blocks_op.w_by_col.size(), S.blocks_op.ext_col.size());
+      std::printf("    dense: %zu blocks, %zu stored entries, %zu ext entries\n", S.blocks_op.nrows.size(), S.blocks_op.w_by_col.size(), S.blocks_op.ext_col.size());
       continue;
     }
     if (k > 0) stat("fwd_a", S.fwd_a);
@@ -77,23 +43,9 @@ int main(int argc, char **argv) {
     stat("bwd_b", S.bwd_b);
   }
   // emulate
-  std::vector<double> rhs(N, 0.0), out(N, 7.0), t(N, 0.0), t2v(N, 0.0);
+  std::vector<double> rhs(N, 0.0), out(N, 7.0);
   for (int i = 0; i < m; ++i) rhs[i] = std::sin(0.37 * i) + 0.1;
-  const int K = static_cast<int>(plan.stages.size());
-  for (int k = 0; k < K; ++k) {
-    const auto &S = plan.stages[k];
-    if (S.dense) { apply_blocks(S.blocks_op, false, rhs, out); continue; }
-    const std::vector<double> *tk = &rhs;
-    if (k > 0) { apply(S.fwd_a, &rhs, out, t); tk = &t; }
-    apply(S.fwd_b, nullptr, *tk, k == K - 1 ? t2v : out);
-  }
-  for (int k = K - 1; k >= 0; --k) {
-    const auto &S = plan.stages[k];
-    if (S.dense) { apply_blocks(S.blocks_op, true, out, out); continue; }
-    const std::vector<double> *tk = &t2v;
-    if (k + 1 < K) { apply(S.bwd_a, &out, out, t); tk = &t; }
-    apply(S.bwd_b, nullptr, *tk, out);
-  }
+  cora::tri_plan_solve_host(plan, N, rhs.data(), out.data());
   CORA::Matrix B(m, 1);
   for (int i = 0; i < m; ++i) B(i, 0) = rhs[i];
   F.solveInPlace(B);
