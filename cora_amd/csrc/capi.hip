@@ -51,12 +51,14 @@ struct cora_ctx {
   struct DevStage {
     RowOpDev fwd_a{}, fwd_b{}, bwd_a{}, bwd_b{};
     BlockOpDev blocks{};
-    bool has_fwd_a = false, has_bwd_a = false, dense = false;
+    SubOpDev sub{};
+    bool has_fwd_a = false, has_bwd_a = false, dense = false, is_sub = false;
   };
   struct DevFactor {
     TriPlan plan;  // host copy is dropped after upload (only the counts are kept)
     std::vector<DevStage> stages;
     std::vector<void *> allocs;
+    int aux_rows = 0;  // two-stage plans: rows appended to the work vector
     bool ready = false;
   };
   DevFactor precond_f, implicit_f;
@@ -130,8 +132,8 @@ size_t vec_bytes(const cora_ctx *c, int ld) {
   return static_cast<size_t>(c->F.L.rows) * ld * sizeof(double);
 }
 
-int get_scratch(cora_ctx *c, int slot, int ld, double **out) {
-  const size_t need = vec_bytes(c, ld);
+int get_scratch(cora_ctx *c, int slot, int ld, double **out, int64_t extra_rows = 0) {
+  const size_t need = vec_bytes(c, ld) + static_cast<size_t>(extra_rows) * ld * sizeof(double);
   if (c->scratch_bytes[slot] < need) {
     if (c->scratch[slot]) (void)hipFree(c->scratch[slot]);
     c->scratch[slot] = nullptr;
@@ -622,15 +624,17 @@ int cora_precond_setup(cora_ctx *c, int kind) {
 
 // Builds the level schedule of a factor and uploads it.  row_of[i] = internal row of permuted variable i.
 static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int32_t *Lp, const int32_t *Li,
-                          const double *Lx, const std::vector<int32_t> &row_of, int32_t zero_row) {
+                          const double *Lx, const std::vector<int32_t> &row_of, int32_t zero_row,
+                          const std::vector<int32_t> *group = nullptr) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (void *p : f.allocs)
     if (p) (void)hipFree(p);
   f.allocs.clear();
   f.stages.clear();
   f.ready = false;
+  f.aux_rows = 0;
   try {
-    build_tri_plan(m, Lp, Li, Lx, row_of, zero_row, f.plan);
+    build_tri_plan(m, Lp, Li, Lx, row_of, zero_row, f.plan, group, static_cast<int32_t>(c->F.L.rows));
   } catch (const std::exception &e) {
     return fail(c, CORA_ERR_ARG, e.what());
   }
@@ -682,6 +686,63 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
     D.has_fwd_a = k > 0;
     D.has_bwd_a = k + 1 < K;
     D.dense = S.dense;
+    if (S.sub) {
+      SubBlockOpHost &H = S.sub_op;
+      D.is_sub = true;
+      std::vector<SubDesc> desc(H.nrows.size());
+      for (size_t b = 0; b < desc.size(); ++b) {
+        SubDesc &d = desc[b];
+        d.row_begin = H.row_begin[b];
+        d.nrows = H.nrows[b];
+        d.f_ent_begin = H.f_ent_begin[b];
+        d.f_nent = H.f_nent[b];
+        d.b_ent_begin = H.b_ent_begin[b];
+        d.b_nent = H.b_nent[b];
+        d.f_lev_begin = H.f_lev_begin[b];
+        d.f_nlev = H.f_lev_begin[b + 1] - H.f_lev_begin[b] - 1;
+        d.b_lev_begin = H.b_lev_begin[b];
+        d.b_nlev = H.b_lev_begin[b + 1] - H.b_lev_begin[b] - 1;
+        d.tgt_begin = H.tgt_begin[b];
+        d.ntgt = H.tgt_begin[b + 1] - H.tgt_begin[b];
+      }
+      SubOpDev &Q = D.sub;
+      Q.nblocks = static_cast<int>(desc.size());
+      Q.ntop = static_cast<int>(f.plan.top_rows.size());
+      Q.max_rows = H.max_rows;
+      Q.max_ent = H.max_ent;
+      Q.max_lev = H.max_lev;
+      Q.aux_base = f.plan.aux_base;
+      // the entry batches of the ext / aux gathers read (and drop) entries past a row's end
+      H.e_col.resize(H.e_col.size() + 8, 0);
+      H.e_val.resize(H.e_val.size() + 8, 0.0);
+      HIP_TRY(c, up(&Q.desc, desc));
+      HIP_TRY(c, up(&Q.fwd.rows, H.rows));
+      H.f_hdr.resize(H.f_hdr.size() + 8, 0);  // the kernel reads one header ahead
+      H.b_hdr.resize(H.b_hdr.size() + 8, 0);
+      HIP_TRY(c, up(&Q.fwd.hdr, H.f_hdr));
+      HIP_TRY(c, up(&Q.fwd.idx, H.f_idx));
+      HIP_TRY(c, up(&Q.fwd.val, H.f_val));
+      HIP_TRY(c, up(&Q.bwd.rows, H.b_rows));
+      HIP_TRY(c, up(&Q.bwd.hdr, H.b_hdr));
+      HIP_TRY(c, up(&Q.bwd.idx, H.b_idx));
+      HIP_TRY(c, up(&Q.bwd.val, H.b_val));
+      HIP_TRY(c, up(&Q.e_ptr, H.e_ptr));
+      HIP_TRY(c, up(&Q.e_col, H.e_col));
+      HIP_TRY(c, up(&Q.e_val, H.e_val));
+      HIP_TRY(c, up(&Q.tgt_slot, H.tgt_slot));
+      HIP_TRY(c, up(&Q.c_ptr, H.c_ptr));
+      HIP_TRY(c, up(&Q.c_idx, H.c_idx));
+      HIP_TRY(c, up(&Q.c_val, H.c_val));
+      HIP_TRY(c, up(&Q.top_rows, f.plan.top_rows));
+      f.aux_rows = H.n_aux;
+      H = SubBlockOpHost();
+      continue;
+    }
+    if (k == 1 && f.stages[0].is_sub) {  // the last stage of a two-stage plan: only its two explicit-inverse products
+      HIP_TRY(c, up_op(D.fwd_b, S.fwd_b));
+      HIP_TRY(c, up_op(D.bwd_b, S.bwd_b));
+      continue;
+    }
     if (D.has_fwd_a) HIP_TRY(c, up_op(D.fwd_a, S.fwd_a));
     if (S.dense) {
       BlockOpHost &H = S.blocks_op;
@@ -736,8 +797,16 @@ static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, const doubl
   if (K == 0) return CORA_OK;
   double *t, *t2;
   int rc;
-  if ((rc = get_scratch(c, 6, ld, &t))) return rc;
+  if ((rc = get_scratch(c, 6, ld, &t, f.aux_rows))) return rc;
   if ((rc = get_scratch(c, 7, ld, &t2))) return rc;
+  if (f.stages[0].is_sub) {  // two-stage plan: substitution blocks around one explicit inverse (trisolve.h)
+    const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
+    HIP_TRY(c, launch_subblock(S0.sub, ld, false, rhs, t, out, c->stream));  // y_0 -> out, couplings + rhs_1 -> t
+    HIP_TRY(c, launch_rowop(S1.fwd_b, ld, nullptr, t, t2, c->stream));       // y_1 = W_1 t_1
+    HIP_TRY(c, launch_rowop(S1.bwd_b, ld, nullptr, t2, t, c->stream));       // x_1 = W_1^T y_1 -> t
+    HIP_TRY(c, launch_subblock(S0.sub, ld, true, out, t, out, c->stream));   // x_0, and x_1 -> out
+    return CORA_OK;
+  }
   for (int k = 0; k < K; ++k) {  // L y = rhs
     const cora_ctx::DevStage &S = f.stages[k];
     if (S.dense) {  // stage 0, never the last one
@@ -787,7 +856,12 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
   if (m == N - 1)
     for (int64_t i = 0; i < N; ++i)
       if (!seen[i]) zero_row = c->F.api2int[i];
-  return install_factor(c, c->precond_f, m, Lp, Li, Lx, row_of, zero_row);
+  // the d rotation rows of a pose stay in one block of the solve plan (row-unit work can then be fused into it)
+  std::vector<int32_t> group(static_cast<size_t>(m), -1);
+  const int64_t dn = static_cast<int64_t>(c->F.L.d) * c->F.L.n;
+  for (int i = 0; i < m; ++i)
+    if (perm[i] < dn) group[i] = perm[i] / c->F.L.d;
+  return install_factor(c, c->precond_f, m, Lp, Li, Lx, row_of, zero_row, &group);
 }
 
 // dOut = [ (Q + lambda I)[0:m]^-1 V[0:m] ; 0 ]
@@ -1358,7 +1432,7 @@ int cora_debug_factor_solve_host(int m, const int32_t *Lp, const int32_t *Li, co
     std::vector<int32_t> row_of(static_cast<size_t>(m));
     for (int i = 0; i < m; ++i) row_of[i] = i;
     TriPlan P;
-    build_tri_plan(m, Lp, Li, Lx, row_of, m, P);  // row m plays the pinned variable
+    build_tri_plan(m, Lp, Li, Lx, row_of, m, P, nullptr, m + 1);  // row m plays the pinned variable
     std::vector<double> rhs(static_cast<size_t>(m) + 1), out(static_cast<size_t>(m) + 1);
     for (int cc = 0; cc < k; ++cc) {
       std::copy(B + static_cast<size_t>(cc) * m, B + static_cast<size_t>(cc + 1) * m, rhs.begin());
@@ -1372,7 +1446,8 @@ int cora_debug_factor_solve_host(int m, const int32_t *Lp, const int32_t *Li, co
       stats[0] = static_cast<int64_t>(P.stages.size());
       stats[1] = P.nnzW;
       stats[2] = P.nnzL;
-      stats[3] = (!P.stages.empty() && P.stages[0].dense) ? static_cast<int64_t>(P.stages[0].blocks_op.nrows.size()) : 0;
+      stats[3] = P.stages.empty() ? 0 : (P.stages[0].dense ? static_cast<int64_t>(P.stages[0].blocks_op.nrows.size())
+                                                        : (P.stages[0].sub ? static_cast<int64_t>(P.stages[0].sub_op.nrows.size()) : 0));
     }
   } catch (const std::exception &e) {
     return fail(nullptr, CORA_ERR_ARG, e.what());

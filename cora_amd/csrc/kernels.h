@@ -78,7 +78,6 @@ struct RowOpDev {  // device copy of a RowOpHost (trisolve.h)
   const int32_t *chunk_row;  // long-row ordinal of every chunk
   double *partial;     // [nchunks][kMaxLD]
   unsigned *tickets;   // [nlong], zero between launches
-  int ablate;          // lab switch (CORA_ABLATE)
 };
 // Device copy of a BlockOpHost (trisolve.h), packed so that everything wave-uniform is one scalar load:
 // a 16-byte descriptor per block and a 16-byte record per block row (its internal row for the lane that
@@ -92,8 +91,36 @@ struct BlockOpDev {
   const int32_t *ext_ptr, *ext_col;
   const double *ext_val;
   int nblocks;
-  int ablate;  // lab switch (CORA_ABLATE)
 };
+// Device copy of a SubBlockOpHost (trisolve.h): stage 0 as workgroup blocks solved by substitution in LDS.
+struct SubDesc {  // 48 bytes per block
+  int32_t row_begin, nrows;
+  int32_t f_ent_begin, f_nent, b_ent_begin, b_nent;
+  int32_t f_lev_begin, f_nlev, b_lev_begin, b_nlev;
+  int32_t tgt_begin, ntgt;
+};
+struct SubSweep {  // one direction of the solve; rows are numbered by level within the block
+  const int32_t *rows;      // [row_begin + k]: internal row
+  const int32_t *hdr;       // [4 * (lev_begin + l)]: {first row, lanes per task g, entries per lane npl, first entry} of level l
+  const uint16_t *idx;      // local row a block entry multiplies (rows padded to g * npl entries, stored lane by lane)
+  const double *val;        // coefficient
+};
+struct SubOpDev {
+  const SubDesc *desc;
+  SubSweep fwd, bwd;
+  const int32_t *e_ptr, *e_col;  // backward: per row, couplings to the last stage
+  const double *e_val;
+  const int32_t *tgt_slot, *c_ptr;  // forward: aux rows written for the last stage
+  const uint16_t *c_idx;
+  const double *c_val;
+  const int32_t *top_rows;  // rows of the last stage + the pinned row
+  int nblocks, ntop, max_rows, max_ent, max_lev, aux_base;
+};
+// forward : y[block rows] = L_bb^-1 rhs[block rows] -> y;  work[aux rows] = couplings to the last stage;  work[top rows] = rhs[top rows]
+// backward: x[block rows] = L_bb^-T (y[block rows] - L[top, rows]^T work[top rows]) -> x (may be y);  x[top rows] = work[top rows]
+hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const double *rhs_or_y, double *work, double *out,
+                           hipStream_t st);
+
 // forward: dst[rows] = W src[rows];  backward: dst[rows] = W^T (src[rows] - L[later, rows]^T src[later])
 hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st);
 // dst[out_row] = (src0 ? src0[out_row] : 0) + sum_k val_k * src[col_k] for every row of the product

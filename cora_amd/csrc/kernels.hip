@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 
 #include "cora_internal.h"
@@ -924,11 +926,6 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
                                                const double *__restrict__ src, double *__restrict__ dst) {
   const int nb8 = (op.n8 + 31) >> 5, nb64 = (op.n64 + 3) >> 2;
   const int b = static_cast<int>(blockIdx.x);
-  if (op.ablate) {
-    if ((op.ablate & 8) && b < nb8) return;
-    if ((op.ablate & 16) && b >= nb8 && b < nb8 + nb64) return;
-    if ((op.ablate & 32) && b >= nb8 + nb64) return;
-  }
   double acc[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
@@ -1112,8 +1109,7 @@ __global__ __launch_bounds__(256) void k_blockop(BlockOpDev B, const double *src
   i32x16 ra = *reinterpret_cast<const i32x16 *>(meta), rc = *reinterpret_cast<const i32x16 *>(meta + 4);
   double wa[8], wb[8];
   issue(ra, rc, wa);
-  const int nbx = (B.ablate & 1) ? 0 : ((B.ablate & 2) ? (nb < 8 ? nb : 8) : nb);
-  for (int q0 = 0; q0 < nbx; q0 += 16) {
+  for (int q0 = 0; q0 < nb; q0 += 16) {
     const i32x16 sa = *reinterpret_cast<const i32x16 *>(meta + q0 + 8), sc = *reinterpret_cast<const i32x16 *>(meta + q0 + 12);
     issue(sa, sc, wb);  // past the block's end on its last round: the arrays are padded, the result is unused
     products(ra, rc, wa, q0);
@@ -1123,8 +1119,227 @@ __global__ __launch_bounds__(256) void k_blockop(BlockOpDev B, const double *src
     issue(ra, rc, wa);
     products(sa, sc, wb, q0 + 8);
   }
-  if (mine && !(B.ablate & 4)) store_row<LD>(dst + row * LD, acc);
-  if ((B.ablate & 4) && acc[0] == 1.2345e-300) dst[0] = acc[1];
+  if (mine) store_row<LD>(dst + row * LD, acc);
+}
+
+
+// ---------------------------------------------------------------------------
+// Stage 0 as workgroup blocks solved by substitution in LDS (trisolve.h, SubBlockOpHost).  One workgroup of
+// kSubThreads per block: the block's part of L (values + 16-bit local indices), its level tables and its
+// right-hand sides are copied into LDS, then the triangular solve runs level by level -- the tasks of a level
+// are (row, right-hand-side column) pairs, g lanes per task for long rows -- with one workgroup barrier per
+// level.  The workgroups after the blocks move the rows of the last stage between the vectors.
+// ---------------------------------------------------------------------------
+#ifndef CORA_SUB_THREADS
+#define CORA_SUB_THREADS 1024
+#endif
+constexpr int kSubThreads = CORA_SUB_THREADS;
+
+struct SubLds {  // carve-up of the dynamic LDS segment (every offset a multiple of 16); T comes first (LDS offset 0)
+  double *T, *val;
+  int32_t *hdr;
+  uint16_t *idx;
+};
+__host__ __device__ inline size_t sub_align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
+__host__ __device__ inline size_t sub_lds_bytes(int max_rows, int max_ent, int max_lev, int ld) {
+  return sub_align16(static_cast<size_t>(max_rows) * ld * 8) + sub_align16(static_cast<size_t>(max_ent + 8) * 8) +
+         sub_align16(static_cast<size_t>(max_lev + 1) * 16) + sub_align16(static_cast<size_t>(max_ent + 8) * 2);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of g lanes (g a power of two, wave-uniform); every lane of the group gets the total.
+// Neighbours first: quad permutes, then the half-row / row mirrors, then shuffles across rows of 16.
+__device__ __forceinline__ double group_sum(double x, int g) {
+  if (g >= 2) x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+  if (g >= 4) x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+  if (g >= 8) x += dpp_f64<0x141>(x);   // row_half_mirror
+  if (g >= 16) x += dpp_f64<0x140>(x);  // row_mirror
+  if (g >= 32) x += __shfl_xor(x, 16, 64);
+  if (g >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// A level: every task (row, column of the right-hand side; g lanes) forms  sum_e val_e T[idx_e]  from the tile as
+// the previous levels left it, THEN (barrier) the rows of the level are written, then (barrier) the next level
+// starts: the rows of a supernode read each other's right-hand sides.  One to four passes of the workgroup cover
+// a level (the plan bounds rows x g of a level by 160: x 24 columns <= 4 x 1024 lanes).
+//
+// The level loop is bound by VALU issue (eight wavefronts per SIMD, a wave64 instruction takes the SIMD 2-4
+// cycles: ~150 vector instructions per wavefront and level were ~2300 cycles per level whatever the memory side
+// did), so everything wave-uniform is kept on the scalar unit -- level headers come through the scalar cache one
+// level ahead, wavefronts without a task only see two barriers -- and the inner loop is stripped to the
+// essentials: rows of a level are padded to one width and stored lane by lane (a lane's npl entries sit at
+// consecutive addresses, no predicates), local row indices become byte offsets into the tile when they are
+// copied to LDS, and a task gets as few lanes as its row length allows.
+template <int LD> struct SubPasses { static constexpr int value = LD <= 6 ? 1 : (LD <= 12 ? 2 : 4); };
+
+template <int LD, bool BWD>
+__global__ __launch_bounds__(kSubThreads, kSubThreads / 128) void k_subblock(SubOpDev S, const double *src, double *work, double *dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int b = static_cast<int>(blockIdx.x);
+  if (b >= S.nblocks) {  // rows of the last stage: forward rhs -> work, backward work -> x
+    const int t = (b - S.nblocks) * kSubThreads + tid;
+    if (t < S.ntop) {
+      const size_t row = static_cast<size_t>(S.top_rows[t]);
+      double x[LD];
+      load_row<LD>((BWD ? work : src) + row * LD, x);
+      store_row<LD>((BWD ? dst : work) + row * LD, x);
+    }
+    return;
+  }
+  const SubSweep &Q = BWD ? S.bwd : S.fwd;
+  const SubDesc bd = S.desc[b];
+  const int nb = bd.nrows, rb = bd.row_begin;
+  const int nent = BWD ? bd.b_nent : bd.f_nent, nlev = BWD ? bd.b_nlev : bd.f_nlev;
+  const int ent0 = BWD ? bd.b_ent_begin : bd.f_ent_begin, lev0 = BWD ? bd.b_lev_begin : bd.f_lev_begin;
+  SubLds M;
+  {
+    char *p = smem;
+    M.T = reinterpret_cast<double *>(p);      p += sub_align16(static_cast<size_t>(S.max_rows) * LD * 8);
+    M.val = reinterpret_cast<double *>(p);    p += sub_align16(static_cast<size_t>(S.max_ent + 8) * 8);
+    M.hdr = reinterpret_cast<int32_t *>(p);   p += sub_align16(static_cast<size_t>(S.max_lev + 1) * 16);
+    M.idx = reinterpret_cast<uint16_t *>(p);
+  }
+  // ---- prologue: block data -> LDS; right-hand sides -> T (backward: minus the coupling to the last stage, whose
+  // solution sits in `work`).  Loads are issued in batches ahead of the LDS stores.
+  {
+    const double *__restrict__ gv = Q.val + ent0;
+    const uint16_t *__restrict__ gi = Q.idx + ent0;
+    for (int kb = tid; kb < nent; kb += 8 * kSubThreads) {
+      double ev[8];
+      uint16_t ei[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u * kSubThreads;
+        const int kk = k < nent ? k : kb;
+        ev[u] = gv[kk];
+        ei[u] = gi[kk];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u * kSubThreads;
+        if (k < nent) {
+          M.val[k] = ev[u];
+          M.idx[k] = static_cast<uint16_t>(LD <= 16 ? ei[u] * (LD * 8) : ei[u] * LD);  // local row -> offset of its row in the tile
+        }
+      }
+    }
+  }
+  for (int t = tid; t < nb; t += kSubThreads) {
+    const int row = Q.rows[rb + t];
+    double x0[LD];
+    load_row<LD>(src + static_cast<size_t>(row) * LD, x0);
+    if (BWD) {  // couplings to the last stage, four rows in flight (register budget)
+      const int ek0 = S.e_ptr[rb + t], ek1 = S.e_ptr[rb + t + 1];
+      for (int kb = ek0; kb < ek1; kb += 4) {
+        int ec[4];
+        double evv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = kb + u < ek1;
+          const int kk = ok ? kb + u : kb;
+          ec[u] = S.e_col[kk];
+          const double v = S.e_val[kk];
+          evv[u] = ok ? v : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          double xr[LD];
+          load_row<LD>(work + static_cast<size_t>(ec[u]) * LD, xr);
+#pragma unroll
+          for (int j = 0; j < LD; ++j) x0[j] = fma(evv[u], xr[j], x0[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < LD; ++j) M.T[t * LD + j] = x0[j];
+  }
+  __syncthreads();
+  // ---- the triangular solve, level by level
+  constexpr int kPasses = SubPasses<LD>::value;  // rows x lanes of a level <= 160 (plan): x LD <= kPasses x 1024
+  constexpr bool kByteIdx = LD <= 16;            // 512 rows x LD x 8 bytes fit 16 bits
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid);
+  const int32_t *__restrict__ gh = Q.hdr + 4 * lev0;  // wave-uniform reads: scalar loads
+  int r0 = gh[0], g = gh[1], npl = gh[2], e0 = gh[3], r1 = gh[4];
+  for (int l = 0; l < nlev; ++l) {
+    const int n_g = gh[4 * l + 5], n_npl = gh[4 * l + 6], n_e0 = gh[4 * l + 7], n_r1 = gh[4 * l + 8];  // next header
+    const int gs = 31 - __builtin_clz(g), ntask = (r1 - r0) * LD, nlane = ntask << gs;
+    double res[kPasses];
+    int at[kPasses];
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      at[ps] = -1;
+      res[ps] = 0.0;
+      if (ps * kSubThreads + wave_base < nlane) {  // wavefront-uniform: the others go straight to the barriers
+        const int id = ps * kSubThreads + tid, task = id >> gs, part = id & (g - 1);
+        const bool live = task < ntask;
+        const int rr = live ? task / LD : 0, col = live ? task - rr * LD : 0;
+        const int k0 = e0 + __mul24((rr << gs) + part, npl);  // the lane's npl consecutive entries
+        const double *__restrict__ pv = M.val + k0;
+        const uint16_t *__restrict__ pi = M.idx + k0;
+        const char *__restrict__ tcol = reinterpret_cast<const char *>(M.T + col);
+        double s0 = 0.0;
+#pragma unroll 2
+        for (int u = 0; u < npl; ++u) {  // wave-uniform trip count (unroll 4: 24.7k -> 32.3k cycles for the levels of a block)
+          const double t = kByteIdx ? *reinterpret_cast<const double *>(tcol + pi[u])
+                                    : *reinterpret_cast<const double *>(tcol + (static_cast<int>(pi[u]) << 3));
+          s0 = fma(pv[u], t, s0);
+        }
+        res[ps] = group_sum(s0, g);
+        if (live && part == 0) at[ps] = (r0 + rr) * LD + col;
+      }
+    }
+    __syncthreads();  // every row of the level has read the tile ...
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps)
+      if (at[ps] >= 0) M.T[at[ps]] = res[ps];
+    __syncthreads();  // ... before any of them is written
+    r0 = r1;
+    g = n_g;
+    npl = n_npl;
+    e0 = n_e0;
+    r1 = n_r1;
+  }
+  // ---- results
+  for (int t = tid; t < nb; t += kSubThreads) {
+    double x[LD];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) x[j] = M.T[t * LD + j];
+    store_row<LD>(dst + static_cast<size_t>(Q.rows[rb + t]) * LD, x);
+  }
+  if (!BWD) {  // couplings to the last stage: aux row of target g = -sum_v L_gv y_v, 16 lanes per (target, column)
+    const int ntask = bd.ntgt * LD;
+    for (int base = 0; base < (ntask << 4); base += kSubThreads) {
+      const int id = base + tid, task = id >> 4, part = id & 15;
+      const bool live = task < ntask;
+      const int tg = bd.tgt_begin + (live ? task / LD : 0), col = live ? task % LD : 0;
+      const int c0 = S.c_ptr[tg] + part, c1 = live ? S.c_ptr[tg + 1] : 0;
+      double sum = 0.0;
+      for (int kb = c0; kb < c1; kb += 8 * 16) {
+        int ci[8];
+        double cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = kb + u * 16;
+          const bool ok = k < c1;
+          const int kk = ok ? k : kb;
+          ci[u] = S.c_idx[kk];
+          const double v = S.c_val[kk];
+          cv[u] = ok ? v : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum = fma(cv[u], M.T[ci[u] * LD + col], sum);
+      }
+      sum = group_sum(sum, 16);
+      if (live && part == 0) work[(static_cast<size_t>(S.aux_base) + S.tgt_slot[tg]) * LD + col] = sum;
+    }
+  }
 }
 
 __global__ void k_zero_row(double *x, size_t row, int ld) {
@@ -1312,20 +1527,14 @@ hipError_t launch_download(int64_t N, int k, int ld, const double *src, const in
 namespace cora {
 
 template <int LD>
-static hipError_t rowop_ld(const RowOpDev &op_in, const double *src0, const double *src, double *dst, hipStream_t st) {
-  RowOpDev op = op_in;
-  static const int ablate = std::getenv("CORA_ABLATE") ? std::atoi(std::getenv("CORA_ABLATE")) : 0;
-  op.ablate = ablate;
+static hipError_t rowop_ld(const RowOpDev &op, const double *src0, const double *src, double *dst, hipStream_t st) {
   const int grid = ((op.n8 + 31) >> 5) + ((op.n64 + 3) >> 2) + ((op.nchunks + 3) >> 2);
   if (grid > 0) hipLaunchKernelGGL((k_rowop<LD>), dim3(grid), dim3(256), 0, st, op, src0, src, dst);
   return hipGetLastError();
 }
 
 template <int LD>
-static hipError_t blockop_ld(const BlockOpDev &B_in, bool backward, const double *src, double *dst, hipStream_t st) {
-  BlockOpDev B = B_in;
-  static const int ablate = std::getenv("CORA_ABLATE") ? std::atoi(std::getenv("CORA_ABLATE")) : 0;
-  B.ablate = ablate;
+static hipError_t blockop_ld(const BlockOpDev &B, bool backward, const double *src, double *dst, hipStream_t st) {
   const int grid = (B.nblocks + 3) >> 2;
   if (grid <= 0) return hipSuccess;
   if (backward) hipLaunchKernelGGL((k_blockop<LD, true>), dim3(grid), dim3(256), 0, st, B, src, dst);
@@ -1345,6 +1554,39 @@ hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const do
                         hipStream_t st) {
 #define CASE(L) \
   if (ld == L) return rowop_ld<L>(op, src0, src, dst, st);
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+
+template <int LD>
+static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *src, double *work, double *dst, hipStream_t st) {
+  const int grid = S.nblocks + (S.ntop + kSubThreads - 1) / kSubThreads;
+  if (grid <= 0) return hipSuccess;
+  const size_t lds = sub_lds_bytes(S.max_rows, S.max_ent, S.max_lev, LD);
+  if (4 * (S.max_lev + 1) > kSubThreads || static_cast<int64_t>(S.max_rows) * LD > 65535) return hipErrorInvalidValue;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {  // dynamic LDS above the default 64 KB limit
+    const void *fns[2] = {reinterpret_cast<const void *>(k_subblock<LD, false>),
+                          reinterpret_cast<const void *>(k_subblock<LD, true>)};
+    for (const void *f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    attr_set = true;
+  }
+  const dim3 g(grid), t(kSubThreads);
+  if (backward) hipLaunchKernelGGL((k_subblock<LD, true>), g, t, lds, st, S, src, work, dst);
+  else hipLaunchKernelGGL((k_subblock<LD, false>), g, t, lds, st, S, src, work, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const double *rhs_or_y, double *work, double *out,
+                           hipStream_t st) {
+#define CASE(L) \
+  if (ld == L) return subblock_ld<L>(S, backward, rhs_or_y, work, out, st);
   CORA_LD_CASES(CASE)
 #undef CASE
   return hipErrorInvalidValue;

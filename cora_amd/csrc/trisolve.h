@@ -60,10 +60,55 @@ struct BlockOpHost {
   std::vector<double> ext_val;
 };
 
+// Stage 0 as WORKGROUP blocks solved by substitution (two-stage plans; the form used whenever what is left
+// above the blocks is small enough for one explicit inverse).  A block is a subtree of the elimination tree
+// of up to kSubRows rows whose part of L fits the LDS next to the block's right-hand sides; the workgroup
+// copies both into LDS and runs the triangular solve level by level (rows of one level are independent;
+// a level's tasks are (row, column of the right-hand side) pairs, long rows get several lanes per task).
+// Reading L instead of an explicit inverse keeps the traffic at ~7 entries per row whatever the block size,
+// so blocks can be large and the separator system above them tiny: two launches for all of it.
+//   forward : T = rhs[rows];  level by level  T_i = sum_e val_e T[idx_e]  (a supernode -- a pose -- per level: the
+//             inverse of its small dense diagonal block is folded into its rows, see trisolve_build.cpp);  y[rows] = T;
+//             for every later-stage row g coupled to the block: aux[slot_g] = -sum_v L_gv y_v
+//             (the later stage reads rhs_g + the aux rows of the blocks next to it: no gather product,
+//             no split rows for the landmarks)
+//   backward: T = y[rows] - L[later, rows]^T x[later];  level by level from the root, same form;  x[rows] = T
+// Local row index = position in forward level order; the backward sweep has its own numbering (backward level order).
+struct SubBlockOpHost {
+  // per block
+  std::vector<int32_t> row_begin, nrows;          // local rows of block b: [row_begin, row_begin + nrows)
+  std::vector<int32_t> f_ent_begin, b_ent_begin;  // first in-block entry of the block (forward / backward arrays)
+  std::vector<int32_t> f_nent, b_nent;            // ... and their number (padding included)
+  std::vector<int32_t> f_lev_begin, b_lev_begin;  // first level header of the block in *_hdr; one extra entry
+  std::vector<int32_t> tgt_begin;                 // first coupled later-stage row (target) of the block; one extra entry
+  // per local row (global position row_begin + li)
+  std::vector<int32_t> rows;                      // internal row
+  // the backward sweep numbers the block's rows by backward level (position k, stored at row_begin + k)
+  std::vector<int32_t> b_rows;                    // internal row of backward position k
+  std::vector<int32_t> e_ptr, e_col;              // ext: per backward position, (row in the later stage's vector, -L) pairs
+  std::vector<double> e_val;
+  // per level: {first row of the level (block-relative), lanes per task g (power of two <= 64), entries per lane
+  // npl (<= 8), first entry (block-relative)}; every row of the level holds exactly g * npl entries (null padded);
+  // nlev + 1 headers per block, the last one closes the row range
+  std::vector<int32_t> f_hdr, b_hdr;
+  // in-block entries
+  std::vector<uint16_t> f_idx, b_idx;             // local column (forward) / backward position of the row (backward)
+  std::vector<double> f_val, b_val;               // -L_ij
+  // forward contributions
+  std::vector<int32_t> tgt_slot;                  // aux row written by the target
+  std::vector<int32_t> c_ptr;                     // entries of the target (one extra entry at the end)
+  std::vector<uint16_t> c_idx;                    // local row v
+  std::vector<double> c_val;                      // -L_gv
+  int32_t n_aux = 0;                              // aux rows in total
+  int32_t max_rows = 0, max_ent = 0, max_lev = 0; // largest block (LDS sizing); max_lev counts headers
+};
+
 struct TriStage {
   RowOpHost fwd_a, fwd_b, bwd_a, bwd_b;  // fwd_a is empty for the first stage, bwd_a for the last
   bool dense = false;                    // stage 0 only: `blocks_op` replaces fwd_b, bwd_a and bwd_b
   BlockOpHost blocks_op;
+  bool sub = false;                      // stage 0 only: `sub_op` replaces them, and the next stage's fwd_a too
+  SubBlockOpHost sub_op;
   int32_t rows = 0, blocks = 0;
 };
 
@@ -74,15 +119,19 @@ struct TriPlan {
   int64_t nnzL = 0, nnzW = 0;  // entries of L and of the explicit block inverses
   int height = 0;              // number of stages
   bool groups_whole = false;   // see build_tri_plan
+  int32_t aux_base = 0;        // sub plans: aux row a of the forward sweep lives at row aux_base + a of the work vector
+  std::vector<int32_t> top_rows;  // sub plans: internal rows of the last stage (+ the pinned row)
 };
 
 // group (optional, size m): variables with the same id >= 0 (the d rotation rows of a pose) are kept in
 // one block; plan.groups_whole tells whether they also sit in adjacent lanes / consecutive positions.
+// aux_base >= 0 allows the two-stage workgroup-block form (SubBlockOpHost): the caller's work vectors then
+// have aux_base + plan.stages[0].sub_op.n_aux rows.
 // row_of[i]: internal row of permuted variable i (= api2int[perm[i]]).  zero_row >= 0: an internal
 // row outside the factor that every solve must set to zero (the pinned variable).
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &plan,
-                    const std::vector<int32_t> *group = nullptr);
+                    const std::vector<int32_t> *group = nullptr, int32_t aux_base = -1);
 
 
 // Test hook: runs the plan's products on the host in launch order (rhs, out: `rows` doubles, one

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <stdexcept>
+#include <utility>
 
 namespace cora {
 
@@ -20,6 +21,11 @@ constexpr int kShortRow = 64;        // entries: <= this -> 8 lanes per row
 constexpr int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
 constexpr int kChunk = 512;
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
+constexpr int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
+constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
+constexpr int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
+constexpr int kLaneEntries = 16;      // entries one lane of a task walks through
+constexpr int kLevelLanes = 160;     // rows x lanes per task of one level: x 24 columns <= 4 passes of 1024 threads
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
 
 struct RowList {  // rows of one product before they are sorted into length classes
@@ -70,7 +76,7 @@ void finalize(const RowList &R, RowOpHost &op) {
 
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P,
-                    const std::vector<int32_t> *group) {
+                    const std::vector<int32_t> *group, int32_t aux_base) {
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
   P = TriPlan();
   P.m = m;
@@ -111,7 +117,56 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   int nstage = 0;
   int64_t remaining = first_border, cap = kFirstCap;
   std::vector<int32_t> depth(m, 0);
-  while (remaining + (m - first_border) > kTopCap && cap < 4LL * m) {
+  auto inverse_nnz_of_rest = [&]() {  // entries of the explicit inverse of everything not taken yet
+    int64_t inv_nnz = 0;
+    for (int v = m - 1; v >= 0; --v)
+      if (stage[v] < 0) {
+        depth[v] = 1 + (parent[v] >= 0 && stage[parent[v]] < 0 ? depth[parent[v]] : 0);
+        inv_nnz += depth[v];
+      }
+    return inv_nnz;
+  };
+  // ---- two-stage form: workgroup blocks solved by substitution + ONE explicit inverse of what is left
+  bool sub0 = false;
+  {
+    const char *e = std::getenv("CORA_TRI_SUB");
+    const bool want = aux_base >= 0 && !(e && std::atoi(e) == 0);
+    if (want && remaining + (m - first_border) > kTopCap && inverse_nnz_of_rest() > kTopInverseNnz) {
+      std::vector<int64_t> esz(m, 0);
+      for (int v = 0; v < first_border; ++v) { sz[v] = 1; esz[v] = Lp[v + 1] - Lp[v] - 1; }
+      for (int v = 0; v < first_border; ++v) {
+        const int p = parent[v];
+        if (p >= 0 && p < first_border) { sz[p] += sz[v]; esz[p] += esz[v]; }
+      }
+      int64_t taken = 0;
+      int nblocks = 0;
+      for (int v = first_border - 1; v >= 0; --v) {
+        const int p = parent[v];
+        if (p >= 0 && p < first_border && stage[p] == 0) {
+          stage[v] = 0;
+          blk[v] = blk[p];
+          ++taken;
+        } else if (sz[v] <= kSubRows && esz[v] <= kSubEnt && (sz[v] >= kMinBlock || p < 0 || p >= first_border) &&
+                   !(group && p >= 0 && (*group)[v] >= 0 && (*group)[v] == (*group)[p])) {
+          stage[v] = 0;
+          blk[v] = v;
+          ++nblocks;
+          ++taken;
+        }
+      }
+      if (taken > 0 && inverse_nnz_of_rest() <= kTopInverseNnz) {
+        sub0 = true;
+        nstage = 1;
+        remaining -= taken;
+        P.stages.resize(1);
+        P.stages[0].blocks = nblocks;
+      } else {
+        std::fill(stage.begin(), stage.end(), -1);
+        std::fill(blk.begin(), blk.end(), -1);
+      }
+    }
+  }
+  while (!sub0 && remaining + (m - first_border) > kTopCap && cap < 4LL * m) {
     // entries of the explicit inverse of everything not taken yet = sum over its rows of the number of
     // remaining ancestors (the inverse of a Cholesky factor is non-zero exactly along tree paths)
     int64_t inv_nnz = 0;
@@ -165,7 +220,12 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   // what is left, so stage[j] <= stage[i]
   // ---- stage 0 in dense form when there is more than one stage and every block fits a wavefront
   std::vector<int32_t> loc(static_cast<size_t>(m), 0), blk_id(static_cast<size_t>(m), -1);
-  bool dense0 = K > 1;
+  bool dense0 = K > 1 && !sub0;
+  if (sub0) {
+    P.stages[0].sub = true;
+    P.aux_base = aux_base;
+    P.groups_whole = group != nullptr;  // a group is never cut, and substitution blocks have no lane layout to respect
+  }
   {
     std::vector<int32_t> bsz(static_cast<size_t>(m) + 1, 0);
     for (int v = 0; v < m; ++v)
@@ -255,8 +315,252 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
           }
       }
   }
+  // ---- stage 0 as workgroup blocks solved by substitution (trisolve.h, SubBlockOpHost)
+  std::vector<std::vector<int32_t>> aux_of(sub0 ? static_cast<size_t>(m) : 0);  // later-stage variable -> its aux rows
+  if (sub0) {
+    SubBlockOpHost &S0 = P.stages[0].sub_op;
+    // blocks in order of their roots, members ascending (= elimination order)
+    std::vector<int32_t> id_of_root(static_cast<size_t>(m), -1);
+    std::vector<std::vector<int32_t>> members;
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0 && blk[v] == v) {
+        id_of_root[v] = static_cast<int32_t>(members.size());
+        members.emplace_back();
+      }
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 0) members[id_of_root[blk[v]]].push_back(v);
+    std::vector<int32_t> flev(static_cast<size_t>(m), 0), blev(static_cast<size_t>(m), 0), li_of(static_cast<size_t>(m), -1);
+    // lanes per task: the kernel is bound by instruction issue, so as few lanes (wavefronts) as the row lengths
+    // allow -- up to kLaneEntries entries per lane
+    auto lanes_for = [](int max_len) {
+      int g = 1;
+      while (g < 64 && (max_len + g - 1) / g > kLaneEntries) g <<= 1;
+      return g;
+    };
+    S0.e_ptr.push_back(0);
+    S0.c_ptr.push_back(0);
+    for (size_t b = 0; b < members.size(); ++b) {
+      const std::vector<int32_t> &mem = members[b];
+      const int nb = static_cast<int>(mem.size());
+      const int32_t root = mem.back();
+      auto inside = [&](int u) { return stage[u] == 0 && blk[u] == root; };
+      // ---- supernodes: runs of consecutive variables chained in the elimination tree (a pose: its rotation rows
+      // and its translation), at most kSnCap rows.  A supernode is solved in ONE level with the explicit inverse W
+      // of its small dense diagonal block folded into its rows:
+      //   forward : y_i = sum_{q<=i} W_iq t_q - sum_j (sum_{q<=i} W_iq L_qj) y_j       (j: descendants in the block)
+      //   backward: x_i = sum_{q>=i} W_qi t_q - sum_k (sum_{q>=i} W_qi L_kq) x_k       (k: ancestors in the block)
+      // so every row is a plain list of (local row, coefficient) pairs over the block's tile -- siblings still hold
+      // their right-hand side when a level reads them (read, barrier, write) -- and a block has ~10 levels, not ~32.
+      std::vector<int32_t> sn_begin;  // positions in `mem`
+      for (int t = 0; t < nb; ++t) {
+        const int32_t v = mem[t];
+        const bool chained = t > 0 && mem[t - 1] == v - 1 && parent[v - 1] == v &&
+                             t - sn_begin.back() < kSnCap;
+        if (!chained) sn_begin.push_back(t);
+      }
+      sn_begin.push_back(nb);
+      const int nsn = static_cast<int>(sn_begin.size()) - 1;
+      std::vector<int32_t> sn_id(static_cast<size_t>(nb));
+      for (int sidx = 0; sidx < nsn; ++sidx)
+        for (int t = sn_begin[sidx]; t < sn_begin[sidx + 1]; ++t) sn_id[t] = sidx;
+      using Ent = std::pair<int32_t, double>;  // (variable, coefficient)
+      std::vector<std::vector<Ent>> frow(static_cast<size_t>(nb)), brow(static_cast<size_t>(nb));
+      auto add_to = [](std::vector<Ent> &row, int32_t var, double val) {
+        for (Ent &e : row)
+          if (e.first == var) { e.second += val; return; }
+        row.push_back({var, val});
+      };
+      std::vector<std::vector<double>> Wsn(static_cast<size_t>(nsn));
+      int nfl = 0, nbl = 0;
+      for (int sidx = 0; sidx < nsn; ++sidx) {
+        const int t0 = sn_begin[sidx], sz = sn_begin[sidx + 1] - t0;
+        const int32_t v0 = mem[t0];
+        // dense diagonal block and its inverse (row-major sz x sz, lower triangular)
+        std::vector<double> Ld(static_cast<size_t>(sz) * sz, 0.0), &W = Wsn[sidx];
+        for (int i = 0; i < sz; ++i) {
+          Ld[i * sz + i] = Lx[Lp[v0 + i]];
+          for (int32_t q = rptr[v0 + i]; q < rptr[v0 + i + 1]; ++q)
+            if (rcol[q] >= v0) Ld[i * sz + (rcol[q] - v0)] = rval[q];
+        }
+        W.assign(static_cast<size_t>(sz) * sz, 0.0);
+        for (int c = 0; c < sz; ++c)
+          for (int i = c; i < sz; ++i) {
+            double sacc = i == c ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) sacc -= Ld[i * sz + k] * W[k * sz + c];
+            W[i * sz + c] = sacc / Ld[i * sz + i];
+          }
+        int lev = 0;
+        for (int i = 0; i < sz; ++i) {
+          std::vector<Ent> &row = frow[t0 + i];
+          for (int q = 0; q <= i; ++q) {
+            row.push_back({v0 + q, W[i * sz + q]});
+            for (int32_t e = rptr[v0 + q]; e < rptr[v0 + q + 1]; ++e)
+              if (rcol[e] < v0 && inside(rcol[e])) {
+                add_to(row, rcol[e], -W[i * sz + q] * rval[e]);
+                lev = std::max(lev, flev[rcol[e]] + 1);
+              }
+          }
+        }
+        for (int i = 0; i < sz; ++i) flev[v0 + i] = lev;
+        nfl = std::max(nfl, lev + 1);
+      }
+      for (int sidx = nsn - 1; sidx >= 0; --sidx) {
+        const int t0 = sn_begin[sidx], sz = sn_begin[sidx + 1] - t0;
+        const int32_t v0 = mem[t0], vend = v0 + sz;
+        const std::vector<double> &W = Wsn[sidx];
+        int lev = 0;
+        for (int i = 0; i < sz; ++i) {
+          std::vector<Ent> &row = brow[t0 + i];
+          for (int q = i; q < sz; ++q) {
+            row.push_back({v0 + q, W[q * sz + i]});
+            for (int32_t e = Lp[v0 + q] + 1; e < Lp[v0 + q + 1]; ++e)
+              if (Li[e] >= vend && inside(Li[e])) {
+                add_to(row, Li[e], -W[q * sz + i] * Lx[e]);
+                lev = std::max(lev, blev[Li[e]] + 1);
+              }
+          }
+        }
+        for (int i = 0; i < sz; ++i) blev[v0 + i] = lev;
+        nbl = std::max(nbl, lev + 1);
+      }
+      // positions of `mem` in forward / backward level order; inside a level the supernodes (kept whole) are sorted by
+      // their longest row, so that rows of similar length share a chunk of the level (chunks are padded to one width)
+      std::vector<int32_t> ford(static_cast<size_t>(nb)), bord(static_cast<size_t>(nb));
+      {
+        std::vector<int32_t> fmax(static_cast<size_t>(nsn), 0), bmax(static_cast<size_t>(nsn), 0), so(static_cast<size_t>(nsn));
+        for (int t = 0; t < nb; ++t) {
+          fmax[sn_id[t]] = std::max<int32_t>(fmax[sn_id[t]], static_cast<int32_t>(frow[t].size()));
+          bmax[sn_id[t]] = std::max<int32_t>(bmax[sn_id[t]], static_cast<int32_t>(brow[t].size()));
+        }
+        auto order_by = [&](const std::vector<int32_t> &lev, const std::vector<int32_t> &mx, std::vector<int32_t> &out) {
+          for (int i = 0; i < nsn; ++i) so[i] = i;
+          std::stable_sort(so.begin(), so.end(), [&](int32_t x, int32_t y) {
+            const int lx = lev[mem[sn_begin[x]]], ly = lev[mem[sn_begin[y]]];
+            return lx != ly ? lx < ly : mx[x] > mx[y];
+          });
+          int at = 0;
+          for (int32_t i : so)
+            for (int t = sn_begin[i]; t < sn_begin[i + 1]; ++t) out[at++] = t;
+        };
+        order_by(flev, fmax, ford);
+        order_by(blev, bmax, bord);
+      }
+      std::vector<int32_t> bpos_of(static_cast<size_t>(nb));  // backward position of mem position
+      for (int t = 0; t < nb; ++t) {
+        li_of[mem[ford[t]]] = t;
+        bpos_of[bord[t]] = t;
+      }
+      std::vector<int32_t> mempos_of_var;  // variable -> position in mem (variables of a block are looked up by search)
+      auto mem_pos = [&](int32_t var) { return static_cast<int32_t>(std::lower_bound(mem.begin(), mem.end(), var) - mem.begin()); };
+      S0.row_begin.push_back(static_cast<int32_t>(S0.rows.size()));
+      S0.nrows.push_back(nb);
+      S0.f_ent_begin.push_back(static_cast<int32_t>(S0.f_idx.size()));
+      S0.b_ent_begin.push_back(static_cast<int32_t>(S0.b_idx.size()));
+      S0.f_lev_begin.push_back(0);  // set below
+      S0.b_lev_begin.push_back(0);
+      S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
+      // Emits one sweep: rows in `order` (positions of mem), their entries translated to the sweep's local numbering.
+      // A level is cut into chunks (levels of their own for the kernel) of rows x lanes per task <= kLevelLanes, never
+      // inside a supernode; every row of a chunk is padded with null entries to the chunk's width g * npl (npl <=
+      // kLaneEntries per lane), so a lane finds its entries by arithmetic and the kernel's inner loop has no predicates.
+      // Header of chunk c: {first row, g, npl, first entry}; one more header closes the list.
+      auto emit = [&](const std::vector<int32_t> &order, const std::vector<int32_t> &lev_of_var,
+                      std::vector<std::vector<Ent>> &rows_ent, bool backward, std::vector<uint16_t> &idx,
+                      std::vector<double> &val, std::vector<int32_t> &hdr, int32_t ent0) {
+        for (int k = 0; k < nb; ++k) {
+          std::vector<Ent> &row = rows_ent[order[k]];
+          std::sort(row.begin(), row.end(), [](const Ent &x, const Ent &y) { return x.first < y.first; });
+        }
+        int t = 0;
+        while (t < nb) {
+          const int lev = lev_of_var[mem[order[t]]];
+          int t1 = t;
+          while (t1 < nb && lev_of_var[mem[order[t1]]] == lev) ++t1;
+          for (int c0 = t; c0 < t1;) {
+            int max_len = 1;
+            for (int q = c0; q < t1 && sn_id[order[q]] == sn_id[order[c0]]; ++q)
+              max_len = std::max<int>(max_len, static_cast<int>(rows_ent[order[q]].size()));
+            const int g = lanes_for(max_len), npl = (max_len + g - 1) / g, w = g * npl;
+            const int cap_rows = std::max(kSnCap, kLevelLanes / g);
+            int c1 = c0;
+            while (c1 < t1 && c1 - c0 < cap_rows) {  // whole supernodes while they fit the width and are not much shorter
+              int q = c1, sn_len = 0;
+              while (q < t1 && sn_id[order[q]] == sn_id[order[c1]]) sn_len = std::max<int>(sn_len, static_cast<int>(rows_ent[order[q++]].size()));
+              if (c1 > c0 && (q - c0 > cap_rows || sn_len > w || (2 * sn_len <= w && c1 - c0 >= 16))) break;
+              c1 = q;
+            }
+            hdr.insert(hdr.end(), {c0, g, npl, static_cast<int32_t>(idx.size()) - ent0});
+            for (int k = c0; k < c1; ++k) {
+              // lane p of the task takes entries p, p + g, ...: stored lane by lane (slot p * npl + u holds entry p + u * g)
+              const std::vector<Ent> &row = rows_ent[order[k]];
+              for (int p = 0; p < g; ++p)
+                for (int u = 0; u < npl; ++u) {
+                  const int e = p + u * g;
+                  const bool real = e < static_cast<int>(row.size());
+                  idx.push_back(real ? static_cast<uint16_t>(backward ? bpos_of[mem_pos(row[e].first)] : li_of[row[e].first]) : uint16_t(0));
+                  val.push_back(real ? row[e].second : 0.0);
+                }
+            }
+            c0 = c1;
+          }
+          t = t1;
+        }
+        hdr.insert(hdr.end(), {nb, 1, 0, static_cast<int32_t>(idx.size()) - ent0});
+      };
+      const int32_t fe0 = static_cast<int32_t>(S0.f_idx.size()), be0 = static_cast<int32_t>(S0.b_idx.size());
+      S0.f_lev_begin.back() = static_cast<int32_t>(S0.f_hdr.size() / 4);
+      S0.b_lev_begin.back() = static_cast<int32_t>(S0.b_hdr.size() / 4);
+      emit(ford, flev, frow, false, S0.f_idx, S0.f_val, S0.f_hdr, fe0);
+      emit(bord, blev, brow, true, S0.b_idx, S0.b_val, S0.b_hdr, be0);
+      S0.f_nent.push_back(static_cast<int32_t>(S0.f_idx.size()) - fe0);
+      S0.b_nent.push_back(static_cast<int32_t>(S0.b_idx.size()) - be0);
+      S0.max_lev = std::max<int32_t>(S0.max_lev, std::max<int32_t>(static_cast<int32_t>(S0.f_hdr.size() / 4) - S0.f_lev_begin.back(),
+                                                                    static_cast<int32_t>(S0.b_hdr.size() / 4) - S0.b_lev_begin.back()));
+      for (int k = 0; k < nb; ++k) {
+        S0.rows.push_back(row_of[mem[ford[k]]]);
+        const int32_t v = mem[bord[k]];
+        S0.b_rows.push_back(row_of[v]);
+        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q)
+          if (!inside(Li[q])) {
+            S0.e_col.push_back(row_of[Li[q]]);
+            S0.e_val.push_back(-Lx[q]);
+          }
+        S0.e_ptr.push_back(static_cast<int32_t>(S0.e_col.size()));
+      }
+      (void)nfl;
+      (void)nbl;
+      (void)mempos_of_var;
+      // forward contributions: one target per later-stage row coupled to the block, entries by local row
+      std::vector<std::pair<int32_t, std::pair<int32_t, double>>> trip;  // (target variable, (local row, -L))
+      for (int32_t v : mem)
+        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q)
+          if (!inside(Li[q])) trip.push_back({Li[q], {li_of[v], -Lx[q]}});
+      std::sort(trip.begin(), trip.end(), [](const auto &a, const auto &c) {
+        return a.first != c.first ? a.first < c.first : a.second.first < c.second.first;
+      });
+      for (size_t t = 0; t < trip.size(); ++t) {
+        if (t == 0 || trip[t].first != trip[t - 1].first) {
+          if (t > 0) S0.c_ptr.push_back(static_cast<int32_t>(S0.c_idx.size()));
+          aux_of[trip[t].first].push_back(S0.n_aux);
+          S0.tgt_slot.push_back(S0.n_aux++);
+        }
+        S0.c_idx.push_back(static_cast<uint16_t>(trip[t].second.first));
+        S0.c_val.push_back(trip[t].second.second);
+      }
+      if (!trip.empty()) S0.c_ptr.push_back(static_cast<int32_t>(S0.c_idx.size()));
+      S0.max_rows = std::max(S0.max_rows, nb);
+      S0.max_ent = std::max<int32_t>(S0.max_ent, std::max<int32_t>(static_cast<int32_t>(S0.f_idx.size()) - fe0,
+                                                                    static_cast<int32_t>(S0.b_idx.size()) - be0));
+    }
+    S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
+    S0.f_lev_begin.push_back(static_cast<int32_t>(S0.f_hdr.size() / 4));
+    S0.b_lev_begin.push_back(static_cast<int32_t>(S0.b_hdr.size() / 4));
+    for (int v = 0; v < m; ++v)
+      if (stage[v] == 1) P.top_rows.push_back(row_of[v]);
+    if (zero_row >= 0) P.top_rows.push_back(zero_row);
+  }
   // ---- "a" products: the couplings between stages
-  for (int k = 0; k < K; ++k) {
+  for (int k = 0; k < K && !sub0; ++k) {
     RowList fa, ba;
     for (int i = 0; i < m; ++i) {
       if (stage[i] != k) continue;
@@ -286,6 +590,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   std::vector<RowList> bb(static_cast<size_t>(K));
   for (int j = 0; j < m; ++j) {
     const int k = stage[j], b = blk[j];
+    if (k == 0 && sub0) continue;
     const bool dense = k == 0 && dense0;
     RowList &B = bb[k];
     if (!dense) B.begin_row(row_of[j]);  // backward "b": x_j = sum_i W_ij t_i  (column j of W)
@@ -319,7 +624,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     bb[K - 1].end_row();
   }
   for (int k = 0; k < K; ++k) {
-    if (k == 0 && dense0) continue;
+    if (k == 0 && (dense0 || sub0)) continue;
     finalize(bb[k], P.stages[k].bwd_b);
     bb[k] = RowList();
     // forward "b": y_i = sum_j W_ij t_j  (row i of W): bucket the triplets by row
@@ -339,7 +644,12 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     for (int i = 0; i < m; ++i) {
       if (stage[i] != k) continue;
       F.begin_row(row_of[i]);
-      for (int32_t q = cnt[i]; q < cnt[i + 1]; ++q) F.add(row_of[cc[q]], vv[q]);
+      for (int32_t q = cnt[i]; q < cnt[i + 1]; ++q) {
+        F.add(row_of[cc[q]], vv[q]);
+        // two-stage form: t_j = rhs_j + the aux rows the stage-0 blocks next to j wrote (row order: fixed)
+        if (sub0)
+          for (int32_t a : aux_of[cc[q]]) F.add(aux_base + a, vv[q]);
+      }
       F.end_row();
     }
     finalize(F, P.stages[k].fwd_b);
@@ -387,10 +697,82 @@ void apply_blocks(const BlockOpHost &B, bool bwd, const double *src, double *dst
     for (int l = 0; l < nb; ++l) dst[B.rows[rb + l]] = acc[l];
   }
 }
+
+// the substitution blocks, in the kernel's order of operations (levels, tasks, partial sums of the lanes of a task
+// added pairwise: neighbours first)
+double lane_tree_sum(double *part, int g) {
+  for (int off = 1; off < g; off <<= 1)
+    for (int p = 0; p + off < g; p += 2 * off) part[p] += part[p + off];
+  return part[0];
+}
+void sub_levels(const int32_t *hdr, int nlev, const uint16_t *idx, const double *val, std::vector<double> &T) {
+  std::vector<double> res;
+  for (int l = 0; l < nlev; ++l) {
+    const int r0 = hdr[4 * l], g = hdr[4 * l + 1], npl = hdr[4 * l + 2], e0 = hdr[4 * l + 3], r1 = hdr[4 * l + 4];
+    res.assign(static_cast<size_t>(r1 - r0), 0.0);
+    for (int r = r0; r < r1; ++r) {  // every row of the level reads the tile before any of them writes it
+      double part[64];
+      for (int p = 0; p < g; ++p) {
+        part[p] = 0.0;
+        for (int u = 0; u < npl; ++u) {
+          const int k = e0 + (r - r0) * g * npl + p * npl + u;
+          part[p] += val[k] * T[idx[k]];
+        }
+      }
+      res[r - r0] = lane_tree_sum(part, g);
+    }
+    for (int r = r0; r < r1; ++r) T[r] = res[r - r0];
+  }
+}
+void apply_sub_forward(const SubBlockOpHost &S, const double *rhs, double *y, double *aux) {
+  std::vector<double> T;
+  for (size_t b = 0; b < S.nrows.size(); ++b) {
+    const int nb = S.nrows[b], rb = S.row_begin[b];
+    T.assign(nb, 0.0);
+    for (int l = 0; l < nb; ++l) T[l] = rhs[S.rows[rb + l]];
+    sub_levels(&S.f_hdr[4 * S.f_lev_begin[b]], S.f_lev_begin[b + 1] - S.f_lev_begin[b] - 1, &S.f_idx[S.f_ent_begin[b]],
+               &S.f_val[S.f_ent_begin[b]], T);
+    for (int l = 0; l < nb; ++l) y[S.rows[rb + l]] = T[l];
+    for (int32_t t = S.tgt_begin[b]; t < S.tgt_begin[b + 1]; ++t) {
+      double part[16];
+      for (int p = 0; p < 16; ++p) {
+        part[p] = 0.0;
+        for (int32_t k = S.c_ptr[t] + p; k < S.c_ptr[t + 1]; k += 16) part[p] += S.c_val[k] * T[S.c_idx[k]];
+      }
+      aux[S.tgt_slot[t]] = lane_tree_sum(part, 16);
+    }
+  }
+}
+void apply_sub_backward(const SubBlockOpHost &S, const double *y, const double *xlater, double *x) {
+  std::vector<double> T;
+  for (size_t b = 0; b < S.nrows.size(); ++b) {
+    const int nb = S.nrows[b], rb = S.row_begin[b];
+    T.assign(nb, 0.0);
+    for (int l = 0; l < nb; ++l) {
+      double t = y[S.b_rows[rb + l]];
+      for (int32_t k = S.e_ptr[rb + l]; k < S.e_ptr[rb + l + 1]; ++k) t += S.e_val[k] * xlater[S.e_col[k]];
+      T[l] = t;
+    }
+    sub_levels(&S.b_hdr[4 * S.b_lev_begin[b]], S.b_lev_begin[b + 1] - S.b_lev_begin[b] - 1, &S.b_idx[S.b_ent_begin[b]],
+               &S.b_val[S.b_ent_begin[b]], T);
+    for (int l = 0; l < nb; ++l) x[S.b_rows[rb + l]] = T[l];
+  }
+}
 }  // namespace
 
 void tri_plan_solve_host(const TriPlan &P, int64_t rows, const double *rhs, double *out) {
   const int K = static_cast<int>(P.stages.size());
+  if (K == 2 && P.stages[0].sub) {  // factor_solve_sub's sequence
+    const SubBlockOpHost &S = P.stages[0].sub_op;
+    std::vector<double> work(static_cast<size_t>(P.aux_base) + S.n_aux, 0.0), t2(static_cast<size_t>(rows), 0.0);
+    apply_sub_forward(S, rhs, out, work.data() + P.aux_base);
+    for (int32_t r : P.top_rows) work[r] = rhs[r];
+    apply_rowop(P.stages[1].fwd_b, nullptr, work.data(), t2.data());
+    apply_rowop(P.stages[1].bwd_b, nullptr, t2.data(), work.data());
+    apply_sub_backward(S, out, work.data(), out);
+    for (int32_t r : P.top_rows) out[r] = work[r];
+    return;
+  }
   std::vector<double> t(static_cast<size_t>(rows), 0.0), t2(static_cast<size_t>(rows), 0.0);
   for (int k = 0; k < K; ++k) {
     const TriStage &S = P.stages[k];

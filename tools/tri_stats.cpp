@@ -26,13 +26,29 @@ int main(int argc, char **argv) {
   auto t1 = std::chrono::steady_clock::now();
   std::vector<int32_t> row_of(perm.begin(), perm.end());  // internal row = original row here
   cora::TriPlan plan;
-  cora::build_tri_plan(m, F.Lp.data(), F.Li.data(), F.Lx.data(), row_of, N - 1, plan);
+  cora::build_tri_plan(m, F.Lp.data(), F.Li.data(), F.Lx.data(), row_of, N - 1, plan, nullptr, N);
   auto t2 = std::chrono::steady_clock::now();
   std::printf("factor %.3f s, plan %.3f s, nnz(L) %ld nnz(W) %ld stages %zu\n", std::chrono::duration<double>(t1 - t0).count(),
               std::chrono::duration<double>(t2 - t1).count(), (long)plan.nnzL, (long)plan.nnzW, plan.stages.size());
   for (size_t k = 0; k < plan.stages.size(); ++k) {
     const auto &S = plan.stages[k];
     std::printf("  stage %zu: rows %d blocks %d\n", k, S.rows, S.blocks);
+    if (S.sub) {
+      const auto &B = S.sub_op;
+      std::printf("    sub: %zu blocks (max %d rows, %d entries, %d headers), fwd entries %zu, bwd entries %zu, ext %zu, targets %zu (aux rows %d), headers fwd %zu bwd %zu\n",
+                  B.nrows.size(), B.max_rows, B.max_ent, B.max_lev, B.f_idx.size(), B.b_idx.size(), B.e_col.size(), B.tgt_slot.size(), B.n_aux,
+                  B.f_hdr.size() / 4, B.b_hdr.size() / 4);
+      for (size_t b : {size_t(0), B.nrows.size() / 2}) {
+        for (int dir = 0; dir < 2; ++dir) {
+          const auto &H = dir ? B.b_hdr : B.f_hdr;
+          const auto &LB = dir ? B.b_lev_begin : B.f_lev_begin;
+          std::printf("    block %zu %s levels (rows x g x npl):", b, dir ? "bwd" : "fwd");
+          for (int l = LB[b]; l + 1 < LB[b + 1]; ++l) std::printf(" %dx%dx%d", H[4 * (l + 1)] - H[4 * l], H[4 * l + 1], H[4 * l + 2]);
+          std::printf("\n");
+        }
+      }
+      continue;
+    }
     if (S.dense) {
       std::printf("    dense: %zu blocks, %zu stored entries, %zu ext entries\n", S.blocks_op.nrows.size(), S.blocks_op.w_by_col.size(), S.blocks_op.ext_col.size());
       continue;
@@ -44,6 +60,7 @@ int main(int argc, char **argv) {
   }
   // emulate
   std::vector<double> rhs(N, 0.0), out(N, 7.0);
+  rhs[N - 1] = 3.0;
   for (int i = 0; i < m; ++i) rhs[i] = std::sin(0.37 * i) + 0.1;
   cora::tri_plan_solve_host(plan, N, rhs.data(), out.data());
   CORA::Matrix B(m, 1);
