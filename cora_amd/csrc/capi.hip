@@ -1111,6 +1111,20 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   // neutralised by the state); on large ones an iteration is worth 20 waits and running ahead would waste it.
   const int batch = n > 1000000 ? 1 : 4;
   int enqueued = 0;
+  // Fused iteration (explicit formulation, one shard, row strides up to 12): six passes instead of nine --
+  //   Hp = H p | kappa = <p, Hp> | r += alpha Hp with <r, r> | Cholesky solve | v = Proj_Y(x) with <r, v> |
+  //   s += alpha p, p = -v + beta p
+  // The scalar steps run in the last block of the pass that finishes the inner product they need.
+  const bool chol = c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY;
+  const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
+  const bool fused = !c->implicit && c->ld <= 12 && n % 2 == 0 && (off * sizeof(double)) % 16 == 0 &&
+                     !std::getenv("CORA_NO_FUSE");
+  if (fused) {
+    const RowArgs R = row_args(c);
+    const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+    if ((rc = ensure_red(c, std::max<size_t>(4 * 512, static_cast<size_t>((units + 255) / 256) + 8)))) return rc;
+    D.partial = c->d_red;
+  }
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
     for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
@@ -1123,6 +1137,23 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
       D.seq_out = nullptr;
       D.seq = 0;
       HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
+      if (fused) {
+        D.mode = DOTS_STPCG_RR;
+        HIP_TRY(c, launch_stpcg_residual(D, n, dHp + off, dR + off, c->stream));
+        const double *x = dR, *scale = nullptr;
+        if (chol) {
+          if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;
+          x = dV;
+        } else if (c->precond == CORA_PRECOND_JACOBI) {
+          scale = c->d_diag_inv;
+        }
+        D.mode = DOTS_STPCG_RV;
+        D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+        D.seq = seq = ++c->dot_seq;
+        HIP_TRY(c, launch_tangent_project_dot(row_args(c), D, c->ld, c->d_Y, x, scale, dR, dV, c->stream));
+        HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
+        continue;
+      }
       HIP_TRY(c, launch_stpcg_update(n, c->d_stpcg, dP, dHp, dS, dR, c->stream));
       if ((rc = cora_precondition_projected_dev(c, dR, dV))) return rc;
       D.count = 2;

@@ -52,7 +52,7 @@ struct StpcgState {
   double kappa, rr, step_M_norm;
   int iters, status, max_iters, pad;
 };
-enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2 };
+enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4 };
 
 struct DotArgs {
   const double *a[4];
@@ -147,6 +147,14 @@ hipError_t launch_axpy2(int64_t n, double a1, const double *x1, double *y1, doub
 hipError_t launch_stpcg_update(int64_t n, const StpcgState *S, const double *p, const double *Hp, double *s,
                                double *r, hipStream_t st);
 hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *v, double *p, hipStream_t st);
+// the fused passes of the device-resident STPCG iteration (cora_stpcg_dev):
+//   r += coef_r Hp with <r, r> (DOTS_STPCG_RR)  |  out = Proj_Y(V) with <r, out> (DOTS_STPCG_RV)  |
+//   s += coef_s p, then p = coef_v v + coef_beta p
+hipError_t launch_stpcg_residual(const DotArgs &D, int64_t n, const double *Hp, double *r, hipStream_t st);
+hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D, int ld, const double *Y, const double *V,
+                                      const double *scale, const double *r, double *out, hipStream_t st);
+hipError_t launch_stpcg_step_direction(int64_t n, const StpcgState *S, const double *v, double *p, double *s,
+                                       hipStream_t st);
 hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const double *x, double *y,
                              hipStream_t st);
 hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st);

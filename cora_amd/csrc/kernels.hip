@@ -633,6 +633,52 @@ __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const 
     y[i] = scale[i / ld] * x[i];
 }
 
+// Scalar recurrences of the device-resident Steihaug-Toint PCG (StpcgState, kernels.h), run by ONE thread of the
+// kernel that finished the inner product they need.
+__device__ __forceinline__ void stpcg_after_kappa(StpcgState &S, double kappa) {  // after Hp = H p:  kappa = <p, Hp>
+  if (S.status == 0 && S.iters >= S.max_iters) S.status = 3;
+  if (S.status != 0) {
+    S.coef_s = 0.0;
+    S.coef_r = 0.0;
+    return;
+  }
+  S.iters++;
+  S.kappa = kappa;
+  const double alpha = S.r_v / kappa;
+  const double sigma_next = S.sigma_M2 + 2 * alpha * S.s_Mp + alpha * alpha * S.p_M2;
+  if (!(kappa > 0.0) || sigma_next >= S.Delta2) {  // negative curvature / leaves the trust region
+    S.coef_s = (-S.s_Mp + sqrt(S.s_Mp * S.s_Mp + S.p_M2 * (S.Delta2 - S.sigma_M2))) / S.p_M2;
+    S.coef_r = 0.0;
+    S.status = 2;
+    S.step_M_norm = sqrt(S.Delta2);
+  } else {
+    S.alpha = alpha;
+    S.coef_s = alpha;
+    S.coef_r = alpha;
+    S.sigma_M2 = sigma_next;
+    S.step_M_norm = sqrt(sigma_next);
+  }
+}
+__device__ __forceinline__ void stpcg_after_rr(StpcgState &S, double rr) {  // after r += alpha Hp:  <r, r>
+  if (S.status == 0) {
+    S.rr = rr;
+    if (sqrt(rr) <= S.target) S.status = 1;
+  }
+}
+__device__ __forceinline__ void stpcg_after_rv(StpcgState &S, double rv) {  // after v = P r:  <r, v>
+  if (S.status != 0) {
+    S.coef_v = 0.0;
+    S.coef_beta = 1.0;
+    return;
+  }
+  const double beta = rv / S.r_v;
+  S.r_v = rv;
+  S.coef_v = -1.0;
+  S.coef_beta = beta;
+  S.s_Mp = beta * (S.s_Mp + S.alpha * S.p_M2);
+  S.p_M2 = S.r_v + beta * beta * S.p_M2;
+}
+
 // Tail of the inner-product kernels: every block publishes its partial sums write-through, takes a
 // ticket, and the last block to arrive adds all partials in block order (deterministic) and writes the
 // results to D.out -- pinned host memory, so the caller only has to wait for the stream.  Same
@@ -664,55 +710,107 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
     if (threadIdx.x == 0) D.out[j] = t;
     if (threadIdx.x == 0) sm[4 + j] = t;
   }
-  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA) {  // after Hp = H p:  kappa = <p, Hp>
-    StpcgState &S = *D.st;
-    if (S.status == 0 && S.iters >= S.max_iters) S.status = 3;
-    if (S.status != 0) {
-      S.coef_s = 0.0;
-      S.coef_r = 0.0;
-    } else {
-      const double kappa = sm[4];
-      S.iters++;
-      S.kappa = kappa;
-      const double alpha = S.r_v / kappa;
-      const double sigma_next = S.sigma_M2 + 2 * alpha * S.s_Mp + alpha * alpha * S.p_M2;
-      if (!(kappa > 0.0) || sigma_next >= S.Delta2) {  // negative curvature / leaves the trust region
-        S.coef_s = (-S.s_Mp + sqrt(S.s_Mp * S.s_Mp + S.p_M2 * (S.Delta2 - S.sigma_M2))) / S.p_M2;
-        S.coef_r = 0.0;
-        S.status = 2;
-        S.step_M_norm = sqrt(S.Delta2);
-      } else {
-        S.alpha = alpha;
-        S.coef_s = alpha;
-        S.coef_r = alpha;
-        S.sigma_M2 = sigma_next;
-        S.step_M_norm = sqrt(sigma_next);
-      }
-    }
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA) stpcg_after_kappa(*D.st, sm[4]);
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RR) stpcg_after_rr(*D.st, sm[4]);
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RV) {
+    stpcg_after_rv(*D.st, sm[4]);
+    *D.st_host = *D.st;  // pinned mirror for the host's (infrequent) look
   }
-  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_BETA) {  // after v = P r:  <r, r>, <r, v>
-    StpcgState &S = *D.st;
-    if (S.status == 0) {
-      S.rr = sm[4];
-      if (sqrt(sm[4]) <= S.target) S.status = 1;
-    }
-    if (S.status != 0) {
-      S.coef_v = 0.0;
-      S.coef_beta = 1.0;
-    } else {
-      const double beta = sm[5] / S.r_v;
-      S.r_v = sm[5];
-      S.coef_v = -1.0;
-      S.coef_beta = beta;
-      S.s_Mp = beta * (S.s_Mp + S.alpha * S.p_M2);
-      S.p_M2 = S.r_v + beta * beta * S.p_M2;
-    }
-    *D.st_host = S;  // pinned mirror for the host's (infrequent) look
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_BETA) {
+    stpcg_after_rr(*D.st, sm[4]);
+    stpcg_after_rv(*D.st, sm[5]);
+    *D.st_host = *D.st;
   }
   if (threadIdx.x == 0 && D.seq_out) {  // results first, then the sequence number the host spins on
     __threadfence_system();
     __hip_atomic_store(D.seq_out, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// r += coef_r Hp with <r, r> of the result in the same pass (the scalar step that follows it runs in the last block)
+__global__ __launch_bounds__(256) void k_stpcg_residual(DotArgs D, const double2 *__restrict__ Hp, double2 *__restrict__ r) {
+  __shared__ double sm[8];
+  const double cr = D.st->coef_r;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    double2 rv = r[i];
+    if (cr != 0.0) {
+      const double2 h = Hp[i];
+      rv.x = fma(cr, h.x, rv.x);
+      rv.y = fma(cr, h.y, rv.y);
+      r[i] = rv;
+    }
+    acc[0] = fma(rv.x, rv.x, fma(rv.y, rv.y, acc[0]));
+  }
+  dots_finish(D, acc, sm);
+}
+
+// s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
+__global__ __launch_bounds__(256) void k_stpcg_step_direction(int64_t n2, const StpcgState *__restrict__ S,
+                                                              const double2 *__restrict__ v, double2 *__restrict__ p,
+                                                              double2 *__restrict__ s) {
+  const double cs = S->coef_s, cv = S->coef_v, cb = S->coef_beta;
+  if (cs == 0.0 && cv == 0.0 && cb == 1.0) return;  // solve already finished: enqueued ahead of the host's check
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const double2 pv = p[i], vv = v[i];
+    double2 sv = s[i];
+    sv.x = fma(cs, pv.x, sv.x);
+    sv.y = fma(cs, pv.y, sv.y);
+    s[i] = sv;
+    p[i] = make_double2(fma(cv, vv.x, cb * pv.x), fma(cv, vv.y, cb * pv.y));
+  }
+}
+
+// v = Proj_Y(x) by row unit with <r, v> in the same pass (the preconditioned residual of an STPCG iteration: the
+// scalar step that follows <r, v> runs in the last block)
+template <int LD, int D>
+__global__ __launch_bounds__(256) void k_tangent_project_dot(const RowArgs R, DotArgs Dt, const double *__restrict__ Y,
+                                                             const double *V, const double *__restrict__ scale,
+                                                             const double *__restrict__ r, double *out) {
+  __shared__ double sm[8];
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const Unit un = unit_of(R, u);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (un.kind == 0) {
+    double y[D][LD], v[D][LD];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(Y + (un.row + a) * LD, y[a]);
+      load_row<LD>(V + (un.row + a) * LD, v[a]);
+      if (scale) {
+        const double sc = scale[un.row + a - R.base];
+#pragma unroll
+        for (int c = 0; c < LD; ++c) v[a][c] *= sc;
+      }
+    }
+    stiefel_project_thread<LD, D>(y, v);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(r + (un.row + a) * LD, y[a]);  // y is dead: reuse its registers for the residual rows
+      acc[0] += dot_row<LD>(y[a], v[a]);
+      store_row<LD>(out + (un.row + a) * LD, v[a]);
+    }
+  } else if (un.kind == 1 || un.kind == 2) {
+    double y[LD], v[LD];
+    load_row<LD>(V + un.row * LD, v);
+    if (scale) {
+      const double sc = scale[un.row - R.base];
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[c] *= sc;
+    }
+    if (un.kind == 1) {
+      load_row<LD>(Y + un.row * LD, y);
+      const double ip = dot_row<LD>(y, v);
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[c] = fma(-ip, y[c], v[c]);
+    }
+    load_row<LD>(r + un.row * LD, y);
+    acc[0] = dot_row<LD>(y, v);
+    store_row<LD>(out + un.row * LD, v);
+  }
+  dots_finish(Dt, acc, sm);
 }
 
 // scalar variant for odd lengths / 8-byte aligned shards
@@ -1471,6 +1569,48 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_stpcg_direction, dim3(grid_for(n)), dim3(256), 0, st, n, S, v, p);
   return hipGetLastError();
+}
+
+// D: mode / st / st_host / partial / ticket / seq fields set by the caller; n doubles, even, 16-byte aligned
+hipError_t launch_stpcg_residual(const DotArgs &D_in, int64_t n, const double *Hp, double *r, hipStream_t st) {
+  if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
+  DotArgs D = D_in;
+  D.count = 1;
+  D.n2 = n / 2;
+  hipLaunchKernelGGL(k_stpcg_residual, dim3(grid_for(n / 2, 256, 256)), dim3(256), 0, st, D, reinterpret_cast<const double2 *>(Hp),
+                     reinterpret_cast<double2 *>(r));
+  return hipGetLastError();
+}
+
+hipError_t launch_stpcg_step_direction(int64_t n, const StpcgState *S, const double *v, double *p, double *s,
+                                       hipStream_t st) {
+  if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(v) % 16 || reinterpret_cast<uintptr_t>(p) % 16 ||
+      reinterpret_cast<uintptr_t>(s) % 16)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_stpcg_step_direction, dim3(grid_for(n / 2)), dim3(256), 0, st, n / 2, S,
+                     reinterpret_cast<const double2 *>(v), reinterpret_cast<double2 *>(p), reinterpret_cast<double2 *>(s));
+  return hipGetLastError();
+}
+
+// out = Proj_Y(V) and <r, out>; the partial array of D needs one slot per 256 row units
+hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D_in, int ld, const double *Y, const double *V,
+                                      const double *scale, const double *r, double *out, hipStream_t st) {
+  const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+  const int grid = static_cast<int>((units + 255) / 256);
+  if (grid == 0) return hipErrorInvalidValue;
+  DotArgs D = D_in;
+  D.count = 1;
+#define CASE(L)                                                                                          \
+  if (ld == L) {                                                                                         \
+    if (R.d == 2) hipLaunchKernelGGL((k_tangent_project_dot<L, 2>), dim3(grid), dim3(256), 0, st, R, D,  \
+                                     Y, V, scale, r, out);                                               \
+    else hipLaunchKernelGGL((k_tangent_project_dot<L, 3>), dim3(grid), dim3(256), 0, st, R, D, Y, V,     \
+                            scale, r, out);                                                              \
+    return hipGetLastError();                                                                            \
+  }
+  CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
+#undef CASE
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const double *x, double *y,
