@@ -321,6 +321,15 @@ class Context:
                                         C.c_void_p(p), C.c_void_p(hp), C.byref(it), C.byref(sm)))
         return it.value, sm.value
 
+    def profile_stpcg(self, on=True):
+        self._chk(self.L.cora_debug_profile_stpcg(self.h, int(on)))
+
+    def stpcg_hvp_us(self):
+        """(mean microseconds, count) of the Hessian-vector products of the last stpcg_dev call (profile_stpcg on)."""
+        us, cnt = C.c_double(), C.c_int()
+        self._chk(self.L.cora_debug_stpcg_hvp_us(self.h, C.byref(us), C.byref(cnt)))
+        return us.value, cnt.value
+
     def dot_dev(self, a, b, k):
         v = C.c_double()
         self._chk(self.L.cora_dot_dev(self.h, C.c_void_p(a), C.c_void_p(b), int(k), C.byref(v)))

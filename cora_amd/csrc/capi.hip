@@ -83,6 +83,12 @@ struct cora_ctx {
   int *d_flag = nullptr;
   int *h_flag = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // measurement hook (cora_debug_profile_stpcg): event pairs around the Hessian-vector product of every
+  // device-resident STPCG iteration
+  bool prof_stpcg = false;
+  std::vector<hipEvent_t> prof_events;
+  double prof_hvp_us = 0.0;
+  int prof_hvp_count = 0;
   std::vector<void *> user_allocs;
   std::string err;
 };
@@ -403,6 +409,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -1128,7 +1135,10 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
     for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
+      const bool prof = c->prof_stpcg && 2 * static_cast<size_t>(enqueued) + 1 < c->prof_events.size();
+      if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
       if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
+      if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
       int nblocks = 0;
       D.count = 1;
       D.a[0] = dP;
@@ -1172,8 +1182,38 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   // an iteration that starts at the limit only records the status: flush it so that the mirror is final
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(&H, c->d_stpcg, sizeof(StpcgState), hipMemcpyDeviceToHost));
+  if (c->prof_stpcg) {  // products of iterations that really ran (enqueued-ahead ones after the stop are neutral but timed)
+    double tot = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < H.iters && 2 * static_cast<size_t>(i) + 1 < c->prof_events.size(); ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]) == hipSuccess) {
+        tot += ms * 1e3;
+        ++cnt;
+      }
+    }
+    c->prof_hvp_us = cnt ? tot / cnt : 0.0;
+    c->prof_hvp_count = cnt;
+  }
   *iters = H.iters;
   *step_M_norm = H.step_M_norm;
+  return CORA_OK;
+}
+
+int cora_debug_profile_stpcg(cora_ctx *c, int on) {
+  NEED_DEVICE(c);
+  c->prof_stpcg = on != 0;
+  if (on && c->prof_events.empty()) {
+    c->prof_events.resize(2 * 256, nullptr);
+    for (hipEvent_t &e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
+  }
+  return CORA_OK;
+}
+
+int cora_debug_stpcg_hvp_us(cora_ctx *c, double *mean_us, int *count) {
+  if (!c || !mean_us || !count) return CORA_ERR_ARG;
+  *mean_us = c->prof_hvp_us;
+  *count = c->prof_hvp_count;
   return CORA_OK;
 }
 

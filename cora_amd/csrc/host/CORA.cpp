@@ -1,5 +1,7 @@
 #include "CORA.h"
 
+#include <stdexcept>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -18,6 +20,11 @@ Scalar thresholdVal(Scalar v, Scalar lo, Scalar hi) { return v < lo ? lo : (v > 
 
 CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank, bool verbose, bool log_iterates,
                      bool show_iterates, CoraSolveInfo *info, const TNTParams *params_override) {
+  // resident device vectors carry at most 24 columns and saddleEscape lifts to rank + 1: say so before the
+  // staircase starts rather than in the middle of it (the reference has no such cap; it never needs one either --
+  // the staircase certifies at rank <= d + a few)
+  if (max_relaxation_rank > 23 || x0.cols() > 24)
+    throw std::invalid_argument("solveCORA: this build supports relaxation ranks up to 24 (max_relaxation_rank <= 23)");
   if (problem.getFormulation() == Formulation::Explicit) {
     checkMatrixShape("solveCora::Explicit", problem.getDataMatrixSize(), x0.cols(), x0.rows(), x0.cols());
   } else {  // src/CORA.cpp:33-40

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "../../../include/cora_hip.h"
+#include "dense.h"
 #include "sparse_cholesky.h"
 
 namespace CORA {
@@ -700,6 +701,16 @@ void Problem::checkVariablesAreValid(const Matrix &Y) const {
           throw std::runtime_error("Pose is not a valid rotation matrix");
         }
       }
+    if (p == dim_) {  // det(R) = +1 at rank d (src/CORA_problem.cpp:1212-1217)
+      Matrix R(dim_, dim_);
+      for (Index a = 0; a < dim_; ++a)
+        for (Index b = 0; b < dim_; ++b) R(a, b) = Y(i * dim_ + a, b);
+      const Scalar det = determinant(R);
+      if (std::abs(det - 1) > 1e-6) {
+        std::cout << "Pose " << i << " has determinant " << det << std::endl;
+        throw std::runtime_error("Pose does not have determinant 1");
+      }
+    }
   }
   for (Index j = 0; j < numRangeMeasurements(); ++j) {
     Scalar s = 0;
@@ -763,7 +774,9 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   // certificate operator below uses the same Lambda), S assembled on the host for the Cholesky test
   const SparseMatrix S = get_certificate_matrix(Y);
   cora_ctx *c = ctx_.get();
-  const Index num_eigvecs = std::min<Index>(std::max<Index>(static_cast<Index>(nx), p + 2), N);
+  // device vectors carry at most 24 columns (kMaxLD): the block is clamped there (the reference has no cap; p + 2 only
+  // exceeds it at ranks solveCORA rejects up front)
+  const Index num_eigvecs = std::min<Index>(std::min<Index>(std::max<Index>(static_cast<Index>(nx), p + 2), N), 24);
   if (N < p) throw std::invalid_argument("The number of rows of S must be greater than or equal to the number of columns of Y");
   Matrix X0 = Matrix::Random(N, num_eigvecs, 0xC0FFEEull);
   if (eigvec_bootstrap.rows() == N)

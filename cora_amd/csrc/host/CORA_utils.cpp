@@ -109,11 +109,34 @@ Matrix projectToSOd(const Matrix &M) {
   Vector ev;
   Matrix V;
   symmetricEigen(M.transpose() * M, ev, V);  // ascending: smallest singular value first
+  // columns of U from the largest singular value down; a column whose singular value vanishes (rank-deficient
+  // block) is completed by Gram-Schmidt against the columns already there, like the full U of the reference's
+  // JacobiSVD, so the result is orthogonal in every case
   Matrix U(d, d);
-  for (Index k = 0; k < d; ++k) {
+  const Scalar smax = std::sqrt(std::max(ev(d - 1), 0.0));
+  for (Index k = d - 1; k >= 0; --k) {
     const Matrix uk = M * V.col(k);
     const Scalar s = std::sqrt(std::max(ev(k), 0.0));
-    for (Index i = 0; i < d; ++i) U(i, k) = s > 0 ? uk(i) / s : 0.0;
+    if (s > 1e-12 * std::max(smax, Scalar(1e-300))) {
+      for (Index i = 0; i < d; ++i) U(i, k) = uk(i) / s;
+      continue;
+    }
+    Scalar best = -1;
+    for (Index e = 0; e < d; ++e) {  // the unit vector that keeps the largest remainder
+      Vector w(d, 1);
+      for (Index i = 0; i < d; ++i) w(i) = i == e ? 1.0 : 0.0;
+      for (Index j = k + 1; j < d; ++j) {
+        Scalar dot = 0;
+        for (Index i = 0; i < d; ++i) dot += w(i) * U(i, j);
+        for (Index i = 0; i < d; ++i) w(i) -= dot * U(i, j);
+      }
+      Scalar nrm = 0;
+      for (Index i = 0; i < d; ++i) nrm += w(i) * w(i);
+      if (nrm > best) {
+        best = nrm;
+        for (Index i = 0; i < d; ++i) U(i, k) = w(i) / std::sqrt(nrm);
+      }
+    }
   }
   if (determinant(U) * determinant(V) < 0)
     for (Index i = 0; i < d; ++i) U(i, 0) = -U(i, 0);  // the column of the SMALLEST singular value

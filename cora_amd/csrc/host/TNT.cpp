@@ -143,10 +143,13 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
   const double *grad = cora_point_rgrad_dev(c);
   auto gradient_norms = [&](double &gn, double &pgn) {
     D.chk(cora_precondition_projected_dev(c, grad, Pg), "precon");
+    // ||P g||, the measure saddleEscape uses (src/CORA.cpp:149 there, CORA.cpp here), so that a point the
+    // escape accepted (pgn > tolerance) is not stopped by the first test of the next TNT call; <g, P g> is
+    // only the STPCG recurrences' business
     double o[2];
-    D.dots2(grad, grad, grad, Pg, o);
+    D.dots2(grad, grad, Pg, Pg, o);
     gn = std::sqrt(o[0]);
-    pgn = std::sqrt(std::max(o[1], 0.0));
+    pgn = std::sqrt(o[1]);
   };
   double grad_norm, pgrad_norm;
   gradient_norms(grad_norm, pgrad_norm);

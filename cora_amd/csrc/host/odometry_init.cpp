@@ -87,6 +87,28 @@ Matrix getOdomInitialization(const Problem &problem, uint64_t seed) {
     nrm = std::sqrt(nrm);
     for (Index i = 0; i < p; ++i) Qm(i, j) /= nrm;
   }
+  // det +1 (the reference flips the last column): with p = d a reflection would start every rotation block in
+  // the other component of O(d), which the solver cannot leave
+  {
+    Matrix A = Qm;  // sign of det by Gaussian elimination with partial pivoting
+    int sign = 1;
+    for (Index k = 0; k < p; ++k) {
+      Index piv = k;
+      for (Index i = k + 1; i < p; ++i)
+        if (std::fabs(A(i, k)) > std::fabs(A(piv, k))) piv = i;
+      if (piv != k) {
+        for (Index j = 0; j < p; ++j) std::swap(A(k, j), A(piv, j));
+        sign = -sign;
+      }
+      if (A(k, k) < 0) sign = -sign;
+      for (Index i = k + 1; i < p; ++i) {
+        const double f = A(i, k) / A(k, k);
+        for (Index j = k; j < p; ++j) A(i, j) -= f * A(k, j);
+      }
+    }
+    if (sign < 0)
+      for (Index i = 0; i < p; ++i) Qm(i, p - 1) = -Qm(i, p - 1);
+  }
   return x0 * Qm;
 }
 

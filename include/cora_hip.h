@@ -293,6 +293,12 @@ int cora_sync(cora_ctx *ctx);
 /* Test hook: executes the handle's device FORMAT (slices + long rows) on the
  * host, to validate the format conversion where no GPU exists.  Never used by
  * any compute entry point. */
+/* Measurement hook (bench.py): HIP event pairs around the Hessian-vector product of every iteration of
+ * cora_stpcg_dev, i.e. the product as it runs INSIDE the solver loop, with the preconditioner's traffic between
+ * two of them (the back-to-back figure keeps Q in the Infinity Cache). */
+int cora_debug_profile_stpcg(cora_ctx *ctx, int on);
+int cora_debug_stpcg_hvp_us(cora_ctx *ctx, double *mean_us, int *count);
+
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
                                 int k, double *out, int ldo);
 

@@ -80,7 +80,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, **kw):
     grad = orc.tangent_proj(dm, x, G)
     P = precon_at(x)
     gn = math.sqrt(orc.inner(grad, grad))
-    pgn = math.sqrt(max(orc.inner(grad, P(grad)), 0.0))
+    pgn = math.sqrt(orc.inner(P(grad), P(grad)))  # ||P g||: the measure saddleEscape uses (src/CORA.cpp:149)
     Delta = prm["Delta0"]
     hist = []
     status = "iteration_limit"
@@ -114,7 +114,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, **kw):
             grad = orc.tangent_proj(dm, x, G)
             P = precon_at(x)
             gn = math.sqrt(orc.inner(grad, grad))
-            pgn = math.sqrt(max(orc.inner(grad, P(grad)), 0.0))
+            pgn = math.sqrt(orc.inner(P(grad), P(grad)))  # ||P g||: the measure saddleEscape uses (src/CORA.cpp:149)
         if math.isnan(rho) or rho < prm["eta1"]:
             Delta = prm["alpha1"] * hM
         elif rho > prm["eta2"] and hM >= 0.99 * Delta:
