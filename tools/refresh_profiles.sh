@@ -2,10 +2,10 @@
 # Regenerates the rocprofv3 evidence under gpurun_out/ (copy the summaries into profiles/ afterwards).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-rm -rf gpurun_out/r01_stats gpurun_out/pmc_bench3
-mkdir -p gpurun_out/r01_stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01_stats -o bench -- python bench.py --steps 1000 --warmup 100 --cpu-seconds 2 > gpurun_out/r01_stats/bench.log 2>&1
-echo "stats rc=$?"; tail -1 gpurun_out/r01_stats/bench.log | cut -c1-300
-bash tools/pmc_passes.sh gpurun_out/pmc_bench3 "k_spmm|k_blockop|k_rowop" tools/pmc_hbm.txt -- python bench.py --steps 50 --warmup 5 --cpu-seconds 0.5
-python tools/pmc_summary.py gpurun_out/pmc_bench3 > gpurun_out/pmc_bench3/summary.txt; cat gpurun_out/pmc_bench3/summary.txt
-find gpurun_out/r01_stats -name "*kernel_stats.csv" | head; find gpurun_out/r01_stats -name "*.csv" -size +2M -delete
+rm -rf gpurun_out/r02_stats gpurun_out/r02_pmc
+mkdir -p gpurun_out/r02_stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_stats -o bench -- python bench.py --steps 1000 --warmup 100 --cpu-seconds 2 > gpurun_out/r02_stats/bench.log 2>&1
+echo "stats rc=$?"; tail -1 gpurun_out/r02_stats/bench.log | cut -c1-300
+bash tools/pmc_passes.sh gpurun_out/r02_pmc "k_spmm|k_subblock|k_rowop" tools/pmc_hbm.txt -- python bench.py --steps 50 --warmup 5 --cpu-seconds 0.5
+python tools/pmc_summary.py gpurun_out/r02_pmc > gpurun_out/r02_pmc/summary.txt; cat gpurun_out/r02_pmc/summary.txt
+find gpurun_out/r02_stats -name "*kernel_stats.csv" | head; find gpurun_out/r02_stats -name "*.csv" -size +2M -delete
