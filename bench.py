@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--poses", type=int, default=100000)
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank p")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--op", choices=["hvp", "cert"], default="hvp",
+                    help="hvp: Riemannian Hessian-vector product (the headline metric); cert: certificate operator "
+                         "(Q - Lambda) X with --rank columns (BASELINE config 5, use --rank 10)")
     args = ap.parse_args()
 
     import torch
@@ -184,37 +187,29 @@ def main():
     y = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
     x = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
     out = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
+    # N > 1: the handle is collective -- cora_amd.dist.TorchComm installs the three injected steps (cora_set_comm):
+    # before every product the rows of the operand that another rank's part of Q reads are packed
+    # (cora_pack_rows_dev), moved by ONE RCCL all-gather and scattered (cora_scatter_rows_dev)
+    comm = None
+    if world > 1:
+        from cora_amd.dist import TorchComm
+        comm = TorchComm(ctx, device=dev)
     ctx.upload(Yh, y.data_ptr())
-    ctx.project_to_manifold_dev(y.data_ptr(), y.data_ptr())
-    if dist is not None:  # every rank projected only its own rows
-        dist.all_gather_into_tensor(y, y[rank * shard * ld:(rank + 1) * shard * ld].clone())
-    ctx.set_point_dev(y.data_ptr())
+    ctx.project_to_manifold_dev(y.data_ptr(), y.data_ptr())   # row-local: every rank projects its own rows
+    ctx.set_point_dev(y.data_ptr())                           # collective: exchanges Y, reduces the cost
     ctx.upload(Vh, x.data_ptr())
     ctx.tangent_space_projection_dev(x.data_ptr(), x.data_ptr())
-    from cora_amd.dist import RowShardedOperator
-    # N > 1: only the rows of Ydot that another rank's part of Q reads are exchanged (one RCCL all-gather of
-    # the packed rows per product); CORA_BENCH_EXCHANGE=shards all-gathers whole shards instead
-    need = None
-    if world > 1 and os.environ.get("CORA_BENCH_EXCHANGE", "rows") == "rows":
-        need = ctx.remote_rows()
-    local = lambda fx, fo: ctx.hvp_dev(fx.data_ptr(), fo.data_ptr())
-    try:
-        op = RowShardedOperator(rows, shard, ld, rank, world, dev, local, needed_rows=need)
-    except Exception as e:  # planning the row exchange failed on this stack: whole-shard all-gathers still work
-        if rank == 0:
-            print("row exchange unavailable (%r); falling back to whole-shard all-gathers" % (e,), file=sys.stderr)
-        op = RowShardedOperator(rows, shard, ld, rank, world, dev, local, needed_rows=None)
-    x_shard = x[rank * shard * ld:(rank + 1) * shard * ld].clone()  # this rank's rows of Ydot
-
-    if world > 1:
-        op.operand_shard().copy_(x_shard)  # the operand lives in the exchange buffer, as in a resident solver
+    k_op = p
+    if args.op == "cert":   # BASELINE config 5: the certificate operator (Q - Lambda) X, k columns
+        xk = torch.zeros(rows * ctx.L.cora_ld_for(k_op), dtype=torch.float64, device=dev)
+        ok = torch.zeros_like(xk)
+        ctx.upload(rng.uniform(-1, 1, (dm["N"], k_op)), xk.data_ptr())
 
     def step():
-        # N > 1: pack + all-gather + scatter of the rows other ranks read, then the fused local kernel
-        if world > 1:
-            op.apply_resident()
+        if args.op == "cert":
+            ctx.certificate_product_dev(xk.data_ptr(), k_op, ok.data_ptr())
         else:
-            op.apply(x_shard)
+            ctx.hvp_dev(x.data_ptr(), out.data_ptr())
 
     def fence():
         torch.cuda.synchronize()
@@ -237,15 +232,25 @@ def main():
         elapsed = float(t.item())
 
     # ---- roofline: the kernel alone, HIP events on the stream it runs on ------
-    x = op.full_x if world > 1 else x_shard  # fully gathered Ydot
+    # (N > 1: the exchange is part of the step, so the kernel alone is timed on a handle-local product: the operand's
+    # remote rows are current after the timed region above)
+    ex_fn = None
+    if world > 1:
+        ex_fn = comm.exchange
+        comm.exchange = lambda ptr, ld_: None
     for _ in range(20):
-        ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+        step()
     ctx.sync()
     reps = 500
     ctx.timer_start()
     for _ in range(reps):
-        ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+        step()
     kernel_us = ctx.timer_stop_ms() * 1e3 / reps
+    if world > 1:
+        comm.exchange = ex_fn
+    if args.op == "cert":
+        b_spmm, _ = algorithmic_bytes(dm["d"], dm["n"], dm["r"], dm["N"], dm["nnz"], k_op)
+        b_hvp = b_spmm + (dm["n"] * dm["d"] ** 2 + dm["r"]) * 8   # + the Lambda blocks
     stats = ctx.format_stats()
     local_frac = stats["local_nnz"] / max(dm["nnz"], 1)
     achieved = b_hvp * local_frac / kernel_us / 1e3  # GB/s, this rank's share of the bytes
@@ -260,7 +265,7 @@ def main():
     # ---- the same kernel with its working set forced out of the 256 MiB Infinity Cache: five independent copies
     # of the problem (Q + point + operand + result, ~150 MB each) visited round-robin on one stream
     hbm_us = None
-    if world == 1:
+    if world == 1 and args.op == "hvp":
         others = []
         for _ in range(4):
             c2 = capi.Context(dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"], rowptr, colidx, vals, device=local_rank)
@@ -282,22 +287,20 @@ def main():
         hbm_us = ctx.timer_stop_ms() * 1e3 / (rounds * len(ring))
         del ring, others
 
-    # N > 1: gather one product and keep it for the parity check on rank 0
+    # N > 1: one product gathered on every rank (download is collective) for the parity check on rank 0
     gathered = None
     if dist is not None:
-        y_shard = op.apply(x_shard).clone()
-        gathered = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, y_shard)
-        full_ydot = torch.zeros(rows * ld, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(full_ydot, x_shard)
+        ctx.hvp_dev(x.data_ptr(), out.data_ptr())
+        gathered = ctx.download(out.data_ptr(), p)
         torch.cuda.synchronize()
 
     result = None
     if rank == 0:
         result = {
-            "metric": "riemannian_hessian_vector_products_per_sec",
+            "metric": "riemannian_hessian_vector_products_per_sec" if args.op == "hvp" else
+                      "certificate_operator_products_per_sec",
             "value": args.steps / elapsed,
-            "unit": "Hvp/s",
+            "unit": "Hvp/s" if args.op == "hvp" else "products/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -309,18 +312,21 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic SE(3) odometry chain, %d poses + %d landmarks + %d range edges (seed 42); "
-                            "Hvp = Proj_Y((Q - Lambda) Ydot) at relaxation rank p=%d; N=%d, nnz(Q)=%d"
-                            % (dm["n"], dm["l"], dm["r"], p, dm["N"], dm["nnz"]),
+                            "%s at relaxation rank p=%d; N=%d, nnz(Q)=%d"
+                            % (dm["n"], dm["l"], dm["r"],
+                               "Hvp = Proj_Y((Q - Lambda) Ydot)" if args.op == "hvp" else
+                               "certificate operator (Q - Lambda) X, %d columns" % k_op, p, dm["N"], dm["nnz"]),
                 "parallelism": "1 GPU" if world == 1 else
-                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + RCCL all-gather of %s"
-                               % (world, "the %d rows of Ydot (of %d) that other ranks read" % (op.exchanged_rows, rows)
-                                  if op.rows_mode else "Ydot (whole shards)"),
+                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + one RCCL all-gather of the %d rows "
+                               "of the operand (of %d) that other ranks read, packed and scattered by the library's own "
+                               "kernels" % (world, comm.exchanged_rows, rows),
                 "algorithmic_bytes_per_hvp": b_hvp,
                 "algorithmic_bytes_per_spmm": b_spmm,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "cora::k_spmm<%d, 3, 2> (LD=%d, d=3, EPI_HVP)" % (ld, ld),
+                "kernel": "cora::k_spmm<%d, 3, %d> (LD=%d, d=3, %s)" % (ld, 2 if args.op == "hvp" else 1, ld,
+                                                                        "EPI_HVP" if args.op == "hvp" else "EPI_S"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -342,19 +348,30 @@ def main():
                 "frac": b_hvp / hbm_us / 1e3 / HBM_PEAK_GBS,
                 "how": "five independent copies of the problem visited round-robin (working set ~750 MB)",
             }
-        if world > 1:
+        if world > 1 and args.op == "hvp":
             # parity of the sharded product against the CPU oracle on the same operands
             from oracle import oracle as orc
             Qo = orc.CSR(rowptr, colidx, vals, dm["N"])
             dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
-            m = ctx.row_map().astype(np.int64)
-            full = gathered.cpu().numpy().reshape(rows, ld)
-            got = full[m][:, :p]
-            Yc = y.cpu().numpy().reshape(rows, ld)[m][:, :p]
-            Vc = full_ydot.cpu().numpy().reshape(rows, ld)[m][:, :p]
+            Yc = orc.project_manifold(dims, Yh)
+            Vc = orc.tangent_proj(dims, Yc, Vh)
             ref = orc.hvp(Qo, dims, Yc, orc.egrad(Qo, Yc), Vc)
+            result["parity_max_rel_err_vs_cpu"] = float(np.abs(gathered - ref).max() / np.abs(ref).max())
+        if world == 1 and args.op == "cert":
+            from oracle import oracle as orc
+            Qo = orc.CSR(rowptr, colidx, vals, dm["N"])
+            dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+            Yc = ctx.download(y.data_ptr(), p)
+            Xc = ctx.download(xk.data_ptr(), k_op)
+            Lst, lob = orc.lambda_blocks(Qo, dims, Yc)
+            t0c = time.perf_counter()
+            ref = orc.S_apply(Qo, dims, Lst, lob, Xc)
+            t_cpu = time.perf_counter() - t0c
+            got = ctx.download(ok.data_ptr(), k_op)
             result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
-        if world == 1:
+            result["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "products/s", "cores": 1, "kind": "port",
+                                      "sample": "1 product of the same workload with oracle/cora_oracle.c (single thread)"}
+        if world == 1 and args.op == "hvp":
             cores = os.cpu_count()
             hv_s, reps_cpu, (Yc, Vc, ref) = cpu_baseline(rowptr, colidx, vals, dm, p, args.cpu_seconds)
             # parity of the timed GPU path against the CPU result on the same inputs

@@ -19,6 +19,12 @@ STATUS = {0: "CORA_OK", 1: "CORA_ERR_SHAPE", 2: "CORA_ERR_NOT_READY", 3: "CORA_E
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_CHOLESKY, PRECOND_REGULARIZED_CHOLESKY = 0, 1, 2, 3
 
 
+# callback types of cora_set_comm (user pointer, device / host pointer as an integer, count)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
 class CoraError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("%s: %s" % (STATUS.get(code, str(code)), msg))
@@ -170,6 +176,34 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.cora_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- multi-GPU building blocks (include/cora_hip.h, cora_set_comm)
+    @property
+    def rank(self):
+        return self.L.cora_rank(self.h)
+
+    @property
+    def world(self):
+        return self.L.cora_world(self.h)
+
+    def set_comm(self, exchange, allreduce, allgather):
+        """ctypes callbacks (EXCHANGE_FN / ALLREDUCE_FN / ALLGATHER_FN); the caller keeps them alive."""
+        self._chk(self.L.cora_set_comm(self.h, exchange, allreduce, allgather, None))
+
+    def pack_rows_dev(self, x, ld, rows_ptr, n, packed):
+        self._chk(self.L.cora_pack_rows_dev(self.h, C.c_void_p(x), int(ld), C.c_void_p(rows_ptr), C.c_int64(n),
+                                            C.c_void_p(packed)))
+
+    def scatter_rows_dev(self, packed, ld, rows_ptr, n, x):
+        self._chk(self.L.cora_scatter_rows_dev(self.h, C.c_void_p(packed), int(ld), C.c_void_p(rows_ptr), C.c_int64(n),
+                                               C.c_void_p(x)))
+
+    def copy_rows_dev(self, src, ld, rows_ptr, n, dst):
+        self._chk(self.L.cora_copy_rows_dev(self.h, C.c_void_p(src), int(ld), C.c_void_p(rows_ptr), C.c_int64(n),
+                                            C.c_void_p(dst)))
+
+    def copy_shard_dev(self, src, ld, shard, dst):
+        self._chk(self.L.cora_copy_shard_dev(self.h, C.c_void_p(src), int(ld), int(shard), C.c_void_p(dst)))
 
     # ---- host-pointer operator API (mirrors CORA::Problem)
     def _out(self, k):

@@ -85,6 +85,11 @@ struct cora_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // measurement hook (cora_debug_profile_stpcg): event pairs around the Hessian-vector product of every
   // device-resident STPCG iteration
+  // injected communication of a partitioned handle (cora_set_comm)
+  cora_exchange_fn comm_exchange = nullptr;
+  cora_allreduce_fn comm_allreduce = nullptr;
+  cora_allgather_fn comm_allgather = nullptr;
+  void *comm_user = nullptr;
   bool prof_stpcg = false;
   std::vector<hipEvent_t> prof_events;
   double prof_hvp_us = 0.0;
@@ -148,6 +153,25 @@ int get_scratch(cora_ctx *c, int slot, int ld, double **out, int64_t extra_rows 
     c->scratch_bytes[slot] = need;
   }
   *out = c->scratch[slot];
+  return CORA_OK;
+}
+
+// collective steps of a partitioned handle; no-ops on a single-GPU one
+// (a partitioned handle WITHOUT communication keeps the round-1 contract: the caller keeps the rows the products
+// read current and adds up the per-rank partial results itself)
+int comm_exchange(cora_ctx *c, const double *dX, int ld) {
+  if (c->F.L.world == 1 || !c->comm_exchange) return CORA_OK;
+  if (c->comm_exchange(c->comm_user, const_cast<double *>(dX), ld)) return fail(c, CORA_ERR_HIP, "exchange callback failed");
+  return CORA_OK;
+}
+int comm_allreduce(cora_ctx *c, double *vals, int n) {
+  if (c->F.L.world == 1 || !c->comm_allreduce) return CORA_OK;
+  if (c->comm_allreduce(c->comm_user, vals, n)) return fail(c, CORA_ERR_HIP, "all-reduce callback failed");
+  return CORA_OK;
+}
+int comm_allgather(cora_ctx *c, const double *dX, int ld) {
+  if (c->F.L.world == 1 || !c->comm_allgather) return CORA_OK;
+  if (c->comm_allgather(c->comm_user, const_cast<double *>(dX), ld)) return fail(c, CORA_ERR_HIP, "all-gather callback failed");
   return CORA_OK;
 }
 
@@ -234,6 +258,10 @@ int download_impl(cora_ctx *c, const double *dptr, int k, double *host, int ldh)
     HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), need));
     c->stage_bytes = need;
   }
+  {
+    const int rc = comm_allgather(c, dptr, ld);
+    if (rc) return rc;
+  }
   HIP_TRY(c, launch_download(N, k, ld, dptr, c->d_api2int, c->d_stage, c->stream));
   HIP_TRY(c, hipMemcpy2DAsync(host, static_cast<size_t>(ldh) * sizeof(double), c->d_stage, N * sizeof(double),
                               N * sizeof(double), k, hipMemcpyDeviceToHost, c->stream));
@@ -258,6 +286,7 @@ int point_finish(cora_ctx *c) {
   } else {
     c->f = 0.0;
   }
+  if ((rc = comm_allreduce(c, &c->f, 1))) return rc;
   c->have_point = true;
   return CORA_OK;
 }
@@ -597,6 +626,10 @@ int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *d
   NEED_DEVICE(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
+  {
+    const int rc = comm_exchange(c, dX, ld_for(k));
+    if (rc) return rc;
+  }
   const SpmmArgs A = spmm_args(c, dX, dOut);
   HIP_TRY(c, launch_spmm(A, ld_for(k), c->F.L.d, EPI_S, c->stream));
   return CORA_OK;
@@ -919,6 +952,10 @@ static int implicit_product(cora_ctx *c, const double *dX, int ld, int epi, doub
 // one product in the active formulation
 static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut) {
   if (c->implicit) return implicit_product(c, dX, ld, epi, dOut);
+  {
+    const int rc = comm_exchange(c, dX, ld);
+    if (rc) return rc;
+  }
   const SpmmArgs A = spmm_args(c, dX, dOut);
   HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
   return CORA_OK;
@@ -1067,7 +1104,7 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
   HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
   if ((rc = wait_dots(c, D.seq))) return rc;
   for (int j = 0; j < count; ++j) out[j] = c->h_scalars[j];
-  return CORA_OK;
+  return comm_allreduce(c, out, count);
 }
 
 // Steihaug-Toint truncated PCG for  min <g,s> + 1/2 <s,Hs>,  ||s||_M <= Delta, entirely on the device
@@ -1200,6 +1237,49 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   return CORA_OK;
 }
 
+int cora_set_comm(cora_ctx *c, cora_exchange_fn exchange, cora_allreduce_fn allreduce, cora_allgather_fn allgather,
+                  void *user) {
+  if (!c) return CORA_ERR_ARG;
+  c->comm_exchange = exchange;
+  c->comm_allreduce = allreduce;
+  c->comm_allgather = allgather;
+  c->comm_user = user;
+  return CORA_OK;
+}
+
+int cora_rank(const cora_ctx *c) { return c ? c->F.L.rank : 0; }
+int cora_world(const cora_ctx *c) { return c ? c->F.L.world : 0; }
+
+int cora_pack_rows_dev(cora_ctx *c, const double *dX, int ld, const int32_t *d_rows, int64_t n, double *dPacked) {
+  NEED_DEVICE(c);
+  if (!dX || !d_rows || !dPacked || ld <= 0 || n < 0) return fail(c, CORA_ERR_ARG, "bad arguments");
+  HIP_TRY(c, launch_move_rows(0, n, ld, d_rows, dX, dPacked, c->stream));
+  return CORA_OK;
+}
+
+int cora_scatter_rows_dev(cora_ctx *c, const double *dPacked, int ld, const int32_t *d_rows, int64_t n, double *dX) {
+  NEED_DEVICE(c);
+  if (!dX || !d_rows || !dPacked || ld <= 0 || n < 0) return fail(c, CORA_ERR_ARG, "bad arguments");
+  HIP_TRY(c, launch_move_rows(1, n, ld, d_rows, dPacked, dX, c->stream));
+  return CORA_OK;
+}
+
+int cora_copy_rows_dev(cora_ctx *c, const double *dSrc, int ld, const int32_t *d_rows, int64_t n, double *dDst) {
+  NEED_DEVICE(c);
+  if (!dSrc || !d_rows || !dDst || ld <= 0 || n < 0) return fail(c, CORA_ERR_ARG, "bad arguments");
+  HIP_TRY(c, launch_move_rows(2, n, ld, d_rows, dSrc, dDst, c->stream));
+  return CORA_OK;
+}
+
+int cora_copy_shard_dev(cora_ctx *c, const double *dSrc, int ld, int shard, double *dDst) {
+  NEED_DEVICE(c);
+  if (!dSrc || !dDst || ld <= 0 || shard < 0 || shard >= c->F.L.world) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const size_t off = static_cast<size_t>(shard) * c->F.L.shard_rows * ld;
+  HIP_TRY(c, hipMemcpyAsync(dDst + off, dSrc + off, static_cast<size_t>(c->F.L.shard_rows) * ld * sizeof(double),
+                            hipMemcpyDeviceToDevice, c->stream));
+  return CORA_OK;
+}
+
 int cora_debug_profile_stpcg(cora_ctx *c, int on) {
   NEED_DEVICE(c);
   c->prof_stpcg = on != 0;
@@ -1241,7 +1321,7 @@ int cora_dot_dev(cora_ctx *c, const double *dA, const double *dB, int k, double 
   HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
   if ((rc = wait_dots(c, D.seq))) return rc;
   *out = c->h_scalars[0];
-  return CORA_OK;
+  return comm_allreduce(c, out, 1);
 }
 
 int cora_gram_dev(cora_ctx *c, const double *dA, int ka, const double *dB, int kb, double *G) {
@@ -1257,7 +1337,7 @@ int cora_gram_dev(cora_ctx *c, const double *dA, int ka, const double *dB, int k
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int a = 0; a < ka; ++a)  // device result is row-major ka x kb
     for (int b = 0; b < kb; ++b) G[static_cast<size_t>(b) * ka + a] = tmp[static_cast<size_t>(a) * kb + b];
-  return CORA_OK;
+  return comm_allreduce(c, G, nel);
 }
 
 int cora_combine_dev(cora_ctx *c, int n, const double *const *dX, const int *k, const double *const *C, int kout,

@@ -287,13 +287,14 @@ void Problem::ensureContext() const {
   checkUpToDate();
   if (!ctx_) {
     cora_ctx *c = nullptr;
-    const int rc = cora_ctx_create(device_, dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
-                                   data_matrix_.outerIndexPtr(), data_matrix_.innerIndexPtr(),
-                                   data_matrix_.valuePtr(), &c);
+    const int rc = cora_ctx_create_part(device_, dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
+                                        data_matrix_.outerIndexPtr(), data_matrix_.innerIndexPtr(),
+                                        data_matrix_.valuePtr(), part_rank_, part_world_, &c);
     if (rc != CORA_OK)
       throw std::runtime_error(std::string("CORA::Problem: cannot create the device problem: ") +
                                cora_last_error(nullptr));
     ctx_ = std::shared_ptr<cora_ctx>(c, [](cora_ctx *p) { cora_ctx_destroy(p); });
+    if (part_world_ > 1) cora_set_comm(c, comm_exchange_, comm_allreduce_, comm_allgather_, comm_user_);
     implicit_ready_ = false;
   }
   if (formulation_ == Formulation::Implicit && !implicit_ready_) fillImplicitFormulationMatrices();
@@ -601,7 +602,19 @@ Matrix Problem::getTranslationExplicitSolution(const Matrix &Y) const {
 
 Matrix Problem::getRandomInitialGuess(uint64_t seed) const {  // src/CORA_problem.cpp:1023-1028
   checkUpToDate();
-  return projectToManifold(Matrix::Random(getExpectedVariableSize(), relaxation_rank_, seed));
+  Matrix Y = projectToManifold(Matrix::Random(getExpectedVariableSize(), relaxation_rank_, seed));
+  // At rank d the polar factors are in O(d); a block of determinant -1 can neither be left by the solver nor
+  // passes checkVariablesAreValid (:1212-1217).  Among the points the reference's sampler can return, take one
+  // with every block in SO(d): flip the last row of the reflected blocks.
+  if (relaxation_rank_ == dim_)
+    for (Index i = 0; i < numPoses(); ++i) {
+      Matrix R(dim_, dim_);
+      for (Index a = 0; a < dim_; ++a)
+        for (Index b = 0; b < dim_; ++b) R(a, b) = Y(i * dim_ + a, b);
+      if (determinant(R) < 0)
+        for (Index b = 0; b < dim_; ++b) Y(i * dim_ + dim_ - 1, b) = -Y(i * dim_ + dim_ - 1, b);
+    }
+  return Y;
 }
 
 // ---- certification pieces: src/CORA_problem.cpp:1105-1166 --------------------

@@ -18,6 +18,12 @@
 #include "Symbol.h"
 
 struct cora_ctx;
+// the injected communication steps of a partitioned handle (include/cora_hip.h, cora_set_comm)
+extern "C" {
+typedef int (*cora_exchange_fn)(void *user, double *dX, int ld);
+typedef int (*cora_allreduce_fn)(void *user, double *vals, int n);
+typedef int (*cora_allgather_fn)(void *user, double *dX, int ld);
+}
 
 namespace CORA {
 
@@ -59,6 +65,11 @@ class Problem {
   bool has_priors_ = false;
   bool problem_data_up_to_date_ = false;
   int device_ = 0;
+  int part_rank_ = 0, part_world_ = 1;
+  cora_exchange_fn comm_exchange_ = nullptr;
+  cora_allreduce_fn comm_allreduce_ = nullptr;
+  cora_allgather_fn comm_allgather_ = nullptr;
+  void *comm_user_ = nullptr;
   mutable std::shared_ptr<cora_ctx> ctx_;
   mutable bool precond_ready_ = false;
   mutable bool implicit_ready_ = false;  // chol(Q33[0:nt-1]) installed on the handle
@@ -150,6 +161,23 @@ class Problem {
   }
   void setFormulation(Formulation f) { formulation_ = f; }
   void setDevice(int device) { device_ = device; }
+  // Multi-GPU (one process per GPU): this process owns partition `rank` of `world` of the rows of Q (pose-aligned,
+  // nnz-balanced, include/cora_hip.h cora_ctx_create_part) and reaches the others through the three injected steps
+  // of cora_set_comm.  Every operator of this class, TNT, LOBPCG and solveCORA then run unchanged, all ranks calling
+  // the same sequence; the exact-Cholesky preconditioners and the host factorisation of the certificate do not
+  // shard (use Jacobi).  Call before the first operator.
+  void setPartition(int rank, int world, cora_exchange_fn exchange, cora_allreduce_fn allreduce,
+                    cora_allgather_fn allgather, void *user) {
+    part_rank_ = rank;
+    part_world_ = world;
+    comm_exchange_ = exchange;
+    comm_allreduce_ = allreduce;
+    comm_allgather_ = allgather;
+    comm_user_ = user;
+    ctx_.reset();
+    precond_ready_ = false;
+  }
+  int partitionWorld() const { return part_world_; }
 
   Scalar evaluateObjective(const Matrix &Y) const;
   Matrix Euclidean_gradient(const Matrix &Y) const;

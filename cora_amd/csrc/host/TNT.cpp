@@ -65,7 +65,7 @@ struct Dev {
 int STPCG(Dev &D, const double *grad, double Delta, const TNTParams &prm, double *s, double *r, double *v,
           double *pk, double *Hp, double &step_M_norm) {
   cora_ctx *c = D.c;
-  if (prm.device_stpcg) {
+  if (prm.device_stpcg && cora_world(c) == 1) {  // partitioned handles: the host-driven loop below (collective calls)
     int iters = 0;
     D.chk(cora_stpcg_dev(c, grad, Delta, prm.kappa_fgr, prm.theta, prm.max_TPCG_iterations, s, r, v, pk, Hp, &iters,
                          &step_M_norm),

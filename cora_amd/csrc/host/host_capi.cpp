@@ -208,6 +208,10 @@ int cora_problem_variable_size(cora_problem *p, int64_t *rows) {
 int cora_problem_set_device(cora_problem *p, int device) {
   return guarded([&] { p->problem.setDevice(device); });
 }
+int cora_problem_set_partition(cora_problem *p, int rank, int world, cora_exchange_fn exchange,
+                               cora_allreduce_fn allreduce, cora_allgather_fn allgather, void *user) {
+  return guarded([&] { p->problem.setPartition(rank, world, exchange, allreduce, allgather, user); });
+}
 
 int cora_problem_op(cora_problem *p, const char *op, int cols, const double *A, const double *B,
                     const double *C, double *out) {

@@ -161,6 +161,9 @@ hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st);
 hipError_t launch_reduce_partials(const double *partial, int nblocks, int count, double *out,
                                   hipStream_t st);
 hipError_t launch_has_nan(int64_t n, const double *x, int *flag, hipStream_t st);
+// mode 0: dst[k] = src[rows[k]];  1: dst[rows[k]] = src[k];  2: dst[rows[k]] = src[rows[k]]  (rows of ld doubles)
+hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, const double *src, double *dst,
+                            hipStream_t st);
 hipError_t launch_upload(int64_t N, int k, int ld, const double *src, const int32_t *api2int,
                          double *dst, hipStream_t st);
 hipError_t launch_download(int64_t N, int k, int ld, const double *src, const int32_t *api2int,

@@ -870,6 +870,21 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
   }
 }
 
+// Row moves of the multi-GPU exchange: mode 0 pack (out[k] = x[rows[k]]), 1 scatter (x[rows[k]] = in[k]),
+// 2 copy (dst[rows[k]] = src[rows[k]]); one thread per double.
+__global__ __launch_bounds__(256) void k_move_rows(int mode, int64_t n, int ld, const int32_t *__restrict__ rows,
+                                                   const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t tot = n * ld;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < tot;
+       t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t k = t / ld, j = t - k * ld;
+    const int64_t at = static_cast<int64_t>(rows[k]) * ld + j;
+    if (mode == 0) dst[t] = src[at];
+    else if (mode == 1) dst[at] = src[t];
+    else dst[at] = src[at];
+  }
+}
+
 // NaN guard of Problem::precondition (:898-901): flag != 0 if any NaN.
 __global__ __launch_bounds__(256) void k_has_nan(int64_t n, const double *__restrict__ x, int *flag) {
   int bad = 0;
@@ -1639,6 +1654,13 @@ hipError_t launch_dots(const DotArgs &D_in, int *nblocks, hipStream_t st) {
 hipError_t launch_reduce_partials(const double *partial, int nblocks, int count, double *out,
                                   hipStream_t st) {
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, nblocks, count, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, const double *src, double *dst,
+                            hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * ld)), dim3(256), 0, st, mode, n, ld, rows, src, dst);
   return hipGetLastError();
 }
 

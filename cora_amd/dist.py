@@ -118,3 +118,200 @@ class RowShardedOperator:
         if self.world > 1:
             dist.all_reduce(s, group=self.group)
         return float(s.item())
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Injected communication of a partitioned handle (include/cora_hip.h, cora_set_comm).  With one of these
+# installed every resident entry point of the C ABI -- and the C++ host above it: TNT, LOBPCG, solveCORA -- is
+# collective: all ranks call the same sequence.
+# ----------------------------------------------------------------------------------------------------------
+import ctypes as _C
+import threading as _threading
+
+import numpy as _np
+
+
+class _CommBase:
+    """Callback plumbing shared by the communicators: ctypes trampolines that never let an exception cross the
+    C boundary (a failed step returns 1 and the library reports CORA_ERR_HIP)."""
+
+    def _install(self, ctx):
+        from . import capi
+        self.ctx = ctx
+        self.error = None
+
+        def guard(f):
+            def g(*a):
+                try:
+                    f(*a)
+                    return 0
+                except BaseException as e:  # noqa: BLE001 -- reported through the status code
+                    self.error = e
+                    return 1
+            return g
+
+        self._cb = (capi.EXCHANGE_FN(guard(lambda user, ptr, ld: self.exchange(int(ptr), int(ld)))),
+                    capi.ALLREDUCE_FN(guard(lambda user, vals, n: self.allreduce(vals, int(n)))),
+                    capi.ALLGATHER_FN(guard(lambda user, ptr, ld: self.allgather(int(ptr), int(ld)))))
+        return self._cb
+
+
+def _plan_exports(need_lists, rank, shard_rows):
+    """need_lists[r]: rows rank r reads outside its shard.  Returns, for `rank`, the rows of its shard that any
+    other rank reads (ascending)."""
+    lo = rank * shard_rows
+    wanted = [l for r, l in enumerate(need_lists) if r != rank and len(l)]
+    if not wanted:
+        return _np.zeros(0, dtype=_np.int64)
+    w = _np.concatenate(wanted)
+    return _np.unique(w[(w >= lo) & (w < lo + shard_rows)])
+
+
+class TorchComm(_CommBase):
+    """One rank per process, torch.distributed underneath (backend "nccl" = RCCL over xGMI; "gloo" on CPU for the
+    tests).  The exchange moves only the rows somebody reads: pack (cora_pack_rows_dev) -> ONE all-gather of the
+    packed rows -> scatter (cora_scatter_rows_dev); every rank pads its export list to the longest one with its own
+    first row.  `device` None = the vectors live in host memory (handles without a device: format tests)."""
+
+    def __init__(self, ctx, group=None, device=None):
+        self.group, self.device = group, device
+        self.rank, self.world = ctx.rank, ctx.world
+        self.rows, self.shard = ctx.rows, ctx.shard_rows
+        dev = device if device is not None else torch.device("cpu")
+        self.dev = dev
+        need = torch.as_tensor(ctx.remote_rows(), dtype=torch.int64)
+        # every rank learns every need-list
+        cnt = torch.tensor([need.numel()], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(counts, cnt, group=group)
+        n_max = max(1, max(int(c.item()) for c in counts))
+        padded = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
+        padded[:need.numel()] = need.to(dev)
+        lists = [torch.empty_like(padded) for _ in range(self.world)]
+        dist.all_gather(lists, padded, group=group)
+        need_lists = [l[l >= 0].cpu().numpy() for l in lists]
+        mine = _plan_exports(need_lists, self.rank, self.shard)
+        e_max = max(1, max(len(_plan_exports(need_lists, r, self.shard)) for r in range(self.world)))
+        export = _np.full(e_max, self.rank * self.shard, dtype=_np.int32)
+        export[:len(mine)] = mine
+        all_exports = _np.concatenate([
+            _np.concatenate([_plan_exports(need_lists, r, self.shard).astype(_np.int32),
+                             _np.full(e_max - len(_plan_exports(need_lists, r, self.shard)), r * self.shard, _np.int32)])
+            for r in range(self.world)])
+        self.e_max = e_max
+        self.export_idx = torch.from_numpy(export).to(dev)
+        self.recv_idx = torch.from_numpy(all_exports).to(dev)
+        self.exchanged_rows = self.world * e_max
+        self._buf = {}
+        if device is not None and device.type == "cuda":
+            ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)  # collectives and kernels on one stream
+        self._install(ctx)
+        ctx.set_comm(*self._cb)
+
+    def _buffers(self, ld):
+        if ld not in self._buf:
+            self._buf[ld] = (torch.zeros(self.e_max * ld, dtype=torch.float64, device=self.dev),
+                             torch.zeros(self.world * self.e_max * ld, dtype=torch.float64, device=self.dev),
+                             torch.zeros(self.rows * ld, dtype=torch.float64, device=self.dev))
+        return self._buf[ld]
+
+    def _host_view(self, ptr, ld):
+        return torch.from_numpy(_np.ctypeslib.as_array((_C.c_double * (self.rows * ld)).from_address(ptr))).view(self.rows, ld)
+
+    def exchange(self, ptr, ld):
+        send, recv, _ = self._buffers(ld)
+        if self.dev.type == "cuda":
+            self.ctx.pack_rows_dev(ptr, ld, self.export_idx.data_ptr(), self.e_max, send.data_ptr())
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.ctx.scatter_rows_dev(recv.data_ptr(), ld, self.recv_idx.data_ptr(), self.world * self.e_max, ptr)
+        else:
+            x = self._host_view(ptr, ld)
+            torch.index_select(x, 0, self.export_idx.long(), out=send.view(-1, ld))
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            x.index_copy_(0, self.recv_idx.long(), recv.view(-1, ld))
+
+    def allreduce(self, vals, n):
+        t = torch.tensor([vals[i] for i in range(n)], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, group=self.group)
+        out = t.cpu().tolist()
+        for i in range(n):
+            vals[i] = out[i]
+
+    def allgather(self, ptr, ld):
+        _, _, full = self._buffers(ld)
+        n = self.shard * ld
+        if self.dev.type == "cuda":
+            self.ctx.copy_shard_dev(ptr, ld, self.rank, full.data_ptr())
+            dist.all_gather_into_tensor(full, full[self.rank * n:(self.rank + 1) * n].clone(), group=self.group)
+            for r in range(self.world):
+                if r != self.rank:
+                    self.ctx.copy_shard_dev(full.data_ptr(), ld, r, ptr)
+        else:
+            x = self._host_view(ptr, ld).view(-1)
+            dist.all_gather_into_tensor(full, x[self.rank * n:(self.rank + 1) * n].clone(), group=self.group)
+            x.copy_(full)
+
+
+class ThreadGroup:
+    """Meeting point of `world` ThreadComm ranks that live in one process and share one GPU (tests: every
+    partition of a big graph on a single device)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = _threading.Barrier(world)
+        self.ptrs = [0] * world
+        self.vals = [None] * world
+        self.needs = [None] * world
+
+
+class ThreadComm(_CommBase):
+    """Rank `ctx.rank` of a ThreadGroup.  Same contract as TorchComm; the transport is device-to-device row copies
+    (cora_copy_rows_dev / cora_copy_shard_dev) between the ranks' vectors, the reductions add in rank order."""
+
+    def __init__(self, ctx, group):
+        import torch as _torch
+        self.g = group
+        self.rank, self.world = ctx.rank, ctx.world
+        need = ctx.remote_rows()
+        shard = ctx.shard_rows
+        self.by_owner = []
+        for r in range(self.world):
+            rows = need[(need >= r * shard) & (need < (r + 1) * shard)].astype(_np.int32)
+            self.by_owner.append(_torch.from_numpy(rows).cuda() if len(rows) else None)
+        self.exchanged_rows = int(len(need))
+        self._install(ctx)
+        ctx.set_comm(*self._cb)
+
+    def _meet(self):
+        self.g.barrier.wait(timeout=600)
+
+    def exchange(self, ptr, ld):
+        self.ctx.sync()
+        self.g.ptrs[self.rank] = ptr
+        self._meet()
+        for r, rows in enumerate(self.by_owner):
+            if rows is not None and r != self.rank:
+                self.ctx.copy_rows_dev(self.g.ptrs[r], ld, rows.data_ptr(), rows.numel(), ptr)
+        self.ctx.sync()
+        self._meet()
+
+    def allreduce(self, vals, n):
+        self.g.vals[self.rank] = [vals[i] for i in range(n)]
+        self._meet()
+        tot = [0.0] * n
+        for r in range(self.world):
+            for i in range(n):
+                tot[i] += self.g.vals[r][i]
+        self._meet()
+        for i in range(n):
+            vals[i] = tot[i]
+
+    def allgather(self, ptr, ld):
+        self.ctx.sync()
+        self.g.ptrs[self.rank] = ptr
+        self._meet()
+        for r in range(self.world):
+            if r != self.rank:
+                self.ctx.copy_shard_dev(self.g.ptrs[r], ld, r, ptr)
+        self.ctx.sync()
+        self._meet()

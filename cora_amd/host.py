@@ -156,6 +156,18 @@ class Problem:
     def set_device(self, dev):
         self._chk(self.L.cora_problem_set_device(self.h, int(dev)))
 
+    def set_partition(self, rank, world, make_comm):
+        """Problem::setPartition: this process (or thread) owns partition `rank` of `world` of the rows of Q.
+        `make_comm(ctx)` builds the communicator (cora_amd.dist.TorchComm / ThreadComm) once the partitioned handle
+        exists; it installs its callbacks on the handle itself.  Collective: every rank calls it."""
+        from . import capi
+        none = (capi.EXCHANGE_FN(), capi.ALLREDUCE_FN(), capi.ALLGATHER_FN())
+        self._chk(self.L.cora_problem_set_partition(self.h, int(rank), int(world), none[0], none[1], none[2], None))
+        dm = self.dims()
+        ctx = capi.Context.from_handle(self.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+        self._comm = make_comm(ctx)
+        return self._comm
+
     def op(self, name, A=None, B=None, C_=None):
         dm = self.dims()
         N, p = self.variable_size(), dm["rank"]

@@ -293,6 +293,36 @@ int cora_sync(cora_ctx *ctx);
 /* Test hook: executes the handle's device FORMAT (slices + long rows) on the
  * host, to validate the format conversion where no GPU exists.  Never used by
  * any compute entry point. */
+/* ------------------------------------------------ multi-GPU: injected communication
+ *
+ * A partitioned handle (cora_ctx_create_part, world > 1) owns the rows of its shard; every resident vector still
+ * has cora_rows() rows, of which only the shard is kept current.  The library links no collective library: the
+ * three steps that need other ranks are callbacks (RCCL through torch.distributed in bench.py, gloo or threads in
+ * the tests).  With them installed every entry point of the resident API is collective -- all ranks call the same
+ * sequence -- and the C++ host above (TNT, LOBPCG, solveCORA) runs unchanged, one process per GPU:
+ *   exchange : make the rows of dX that this rank's part of Q reads (cora_remote_rows) current; called before
+ *              every product (src/CORA_problem.cpp:742-746 and its callers), on the handle's stream
+ *   allreduce: sum n host doubles over the ranks in place (inner products src/CORA.cpp:119-122, the cost
+ *              src/CORA_problem.cpp:759-762, Gram matrices of LOBPCG); must return the SAME bits on every rank
+ *   allgather: make every row of dX current on every rank (before a download)
+ * Without callbacks a partitioned handle leaves both to the caller (operands current where read, results are
+ * per-rank partial sums).  Each returns 0 on success.  Work they enqueue must be ordered after the work already on the handle's stream
+ * (they may synchronise it) and complete, or be ordered on that stream, when they return. */
+typedef int (*cora_exchange_fn)(void *user, double *dX, int ld);
+typedef int (*cora_allreduce_fn)(void *user, double *vals, int n);
+typedef int (*cora_allgather_fn)(void *user, double *dX, int ld);
+int cora_set_comm(cora_ctx *ctx, cora_exchange_fn exchange, cora_allreduce_fn allreduce, cora_allgather_fn allgather,
+                  void *user);
+/* Building blocks of an exchange, on the handle's stream: dPacked[k] = dX[rows[k]], dX[rows[k]] = dPacked[k],
+ * dDst[rows[k]] = dSrc[rows[k]] (rows: device array of n internal rows; ld = row stride in doubles). */
+int cora_pack_rows_dev(cora_ctx *ctx, const double *dX, int ld, const int32_t *d_rows, int64_t n, double *dPacked);
+int cora_scatter_rows_dev(cora_ctx *ctx, const double *dPacked, int ld, const int32_t *d_rows, int64_t n, double *dX);
+int cora_copy_rows_dev(cora_ctx *ctx, const double *dSrc, int ld, const int32_t *d_rows, int64_t n, double *dDst);
+/* dDst[rows of shard `shard`] = dSrc[the same rows] (one contiguous block of cora_shard_rows() rows) */
+int cora_copy_shard_dev(cora_ctx *ctx, const double *dSrc, int ld, int shard, double *dDst);
+int cora_rank(const cora_ctx *ctx);
+int cora_world(const cora_ctx *ctx);
+
 /* Measurement hook (bench.py): HIP event pairs around the Hessian-vector product of every iteration of
  * cora_stpcg_dev, i.e. the product as it runs INSIDE the solver loop, with the preconditioner's traffic between
  * two of them (the back-to-back figure keeps Q in the Infinity Cache). */

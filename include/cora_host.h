@@ -12,6 +12,8 @@
 
 #include <stdint.h>
 
+#include "cora_hip.h" /* cora_exchange_fn, cora_allreduce_fn, cora_allgather_fn */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -62,6 +64,10 @@ int cora_problem_matrix(cora_problem *p, const char *name, int64_t *rows, int64_
 int cora_problem_set_rank(cora_problem *p, int rank);
 int cora_problem_set_preconditioner(cora_problem *p, int kind);
 int cora_problem_set_device(cora_problem *p, int device);
+/* Problem::setPartition (this build's multi-GPU entry, cora_amd/csrc/host/CORA_problem.h): the process owns
+ * partition `rank` of `world` and communicates through the callbacks of cora_set_comm (include/cora_hip.h). */
+int cora_problem_set_partition(cora_problem *p, int rank, int world, cora_exchange_fn exchange,
+                               cora_allreduce_fn allreduce, cora_allgather_fn allgather, void *user);
 /* Problem::setFormulation (include/CORA/CORA_problem.h:338): implicit != 0 selects
  * Formulation::Implicit, where the variable is the leading d*n + r rows (rotations and ranges)
  * and the translations are eliminated analytically (src/CORA_problem.cpp:714-753). */

@@ -95,3 +95,119 @@ def test_two_rank_gloo_exchange(rows_mode):
         assert derr < 1e-12, (rank, derr)
         if rows_mode:
             assert exchanged < rows // 2   # only the halo and the landmark couplings travel
+
+
+# ---- the injected communication of partitioned handles (cora_amd.dist.TorchComm) under gloo, world 2 and 4 ----------
+def _stpcg(apply_H, apply_P, dot, g, Delta, max_iters):
+    """Steihaug-Toint PCG (the loop of cora_amd/csrc/host/TNT.cpp, STPCG) on whatever vectors / inner product the
+    caller supplies: the sharded run passes collective operators, the reference run plain numpy ones."""
+    s = np.zeros_like(g)
+    r = g.copy()
+    v = apply_P(r)
+    p = -v
+    r_v = dot(r, v)
+    sigma2, s_Mp, p_M2 = 0.0, 0.0, r_v
+    for it in range(max_iters):
+        Hp = apply_H(p)
+        kappa = dot(p, Hp)
+        alpha = r_v / kappa
+        sig_next = sigma2 + 2 * alpha * s_Mp + alpha * alpha * p_M2
+        if not (kappa > 0) or sig_next >= Delta * Delta:
+            tau = (-s_Mp + np.sqrt(s_Mp * s_Mp + p_M2 * (Delta * Delta - sigma2))) / p_M2
+            return s + tau * p, it + 1
+        s = s + alpha * p
+        r = r + alpha * Hp
+        v = apply_P(r)
+        rv_new = dot(r, v)
+        beta = rv_new / r_v
+        r_v = rv_new
+        s_Mp = beta * (s_Mp + alpha * p_M2)
+        p_M2 = r_v + beta * beta * p_M2
+        sigma2 = sig_next
+        p = -v + beta * p
+    return s, max_iters
+
+
+def _comm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from cora_amd import capi, host
+    from cora_amd.dist import TorchComm
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        P = host.Problem.synthetic(dim=3, n_poses=400, n_landmarks=4, n_ranges=200, n_loops=6, seed=13)
+        P.update()
+        dm = P.dims()
+        _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+        ctx = capi.Context(dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"], rowptr, colidx, vals, device=-1,
+                           rank=rank, world=world)
+        comm = TorchComm(ctx)           # host memory: the handle has no device, the vectors below are numpy
+        k = 3
+        ld = capi.load().cora_ld_for(k)
+        m = ctx.row_map().astype(np.int64)
+        rows, shard = ctx.rows, ctx.shard_rows
+        mine = (m >= rank * shard) & (m < (rank + 1) * shard)      # API rows this rank owns
+        import scipy.sparse as sp
+        Qs = sp.csr_matrix((vals, colidx, rowptr), shape=(dm["N"], dm["N"]))
+        dinv = 1.0 / (Qs.diagonal() + 1.0)
+        buf = np.zeros((rows, ld))                                 # a resident vector in the internal layout
+
+        def apply_H(X):                                            # (Q + I) X on the owned rows; others garbage
+            buf[:] = np.nan                                        # rows nobody sends must not be read
+            buf[m[mine], :k] = X[mine]
+            comm.exchange(buf.ctypes.data, ld)                     # the callback the library would call
+            Xfull = np.where(np.isnan(buf[m][:, :k]), 0.0, buf[m][:, :k])
+            out = ctx.debug_format_spmm_host(np.asfortranarray(Xfull))
+            res = np.full_like(X, np.nan)
+            res[mine] = out[mine] + X[mine]
+            return res
+
+        def apply_P(R):
+            return R * dinv[:, None]
+
+        def dot(A, B):
+            v = (C.c_double * 1)(float((A[mine] * B[mine]).sum()))
+            comm.allreduce(v, 1)
+            return v[0]
+
+        import ctypes as C
+        rng = np.random.default_rng(4)
+        g = rng.standard_normal((dm["N"], k))
+        g_sh = np.where(mine[:, None], g, np.nan)                  # each rank only holds its rows
+        res = {}
+        for Delta, iters in ((1e30, 12), (0.05, 40)):
+            s, its = _stpcg(apply_H, apply_P, dot, g_sh, Delta, iters)
+            buf[:] = 0.0
+            buf[m[mine], :k] = s[mine]
+            comm.allgather(buf.ctypes.data, ld)                    # every row current on every rank
+            res[Delta] = (buf[m][:, :k].copy(), its)
+        # the single-process reference: same loop, plain numpy
+        H1 = lambda X: Qs @ X + X
+        d1 = lambda A, B: float((A * B).sum())
+        errs = []
+        for Delta, iters in ((1e30, 12), (0.05, 40)):
+            s1, its1 = _stpcg(H1, apply_P, d1, g, Delta, iters)
+            assert its1 == res[Delta][1]
+            errs.append(float(np.abs(res[Delta][0] - s1).max() / np.abs(s1).max()))
+        q.put((rank, max(errs), comm.exchanged_rows, rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_stpcg_through_torchcomm_matches_single_process(world):
+    """Exchange (pack / one all-gather / scatter of the rows somebody reads), all-reduce and all-gather of
+    cora_amd.dist.TorchComm -- the callbacks cora_set_comm installs -- drive a full Steihaug-Toint PCG solve on a
+    graph cut into `world` row partitions; the step equals the single-process solve to 1e-10."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, exchanged, rows in res:
+        assert err < 1e-10, (rank, err)
+        assert exchanged < rows // 2

@@ -81,8 +81,12 @@ def test_solve_implicit_plaza2():
     P.update()
     P.set_formulation(True)
     dm = P.dims()
+    # rank d + 1: at rank d a random point has rotation blocks of determinant -1, which the solver cannot leave and
+    # which checkVariablesAreValid rejects (src/CORA_problem.cpp:1212-1217, reached through
+    # getTranslationExplicitSolution :1194 when the implicit run certifies)
+    P.set_rank(dm["d"] + 1)
     x0 = P.op("getRandomInitialGuess")
-    assert x0.shape == (dm["d"] * dm["n"] + dm["r"], dm["d"])
+    assert x0.shape == (dm["d"] * dm["n"] + dm["r"], dm["d"] + 1)
     res = P.solve(x0, max_rank=10, max_seconds=60)
     assert abs(res["f"] - 734.328) < 2e-3
     full = P.op("alignEstimateToOrigin", res["x"])

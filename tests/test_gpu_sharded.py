@@ -1,0 +1,130 @@
+"""The sharded solver on ONE GPU: every partition of the graph is a rank of a cora_amd.dist.ThreadGroup (one
+thread and one partitioned handle each; the exchange is device-to-device row copies).  With the communication
+injected (include/cora_hip.h, cora_set_comm) the C ABI's resident entry points are collective and the C++ host
+-- operators, TNT, the certificate operator -- runs unchanged on every rank.  Checked against the single-handle
+run and the CPU oracle.  Reference call sites that run sharded this way: src/CORA.cpp:139-140 (TNT with the
+closures of :52-92,119-122), src/CORA_utils.cpp:83 (the certificate operator)."""
+import threading
+
+import numpy as np
+import pytest
+
+from cora_amd import capi, host
+from cora_amd.dist import ThreadComm, ThreadGroup
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(world, body):
+    group = ThreadGroup(world)
+    out, err = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            out[r] = body(r, group)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+            group.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def _problem(n, p, seed=11, loops=4):
+    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=5, n_ranges=n // 2, n_loops=loops, seed=seed,
+                               precond=capi.PRECOND_JACOBI)
+    P.update()
+    P.set_rank(p)
+    return P
+
+
+@pytest.mark.parametrize("world,n", [(2, 900), (4, 3000)])
+def test_sharded_operators_and_tnt_match_single_handle(world, n):
+    p = 4
+    P1 = _problem(n, p)
+    dm = P1.dims()
+    _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    rng = np.random.default_rng(5)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dm["N"], p)))
+    V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, (dm["N"], p)))
+    G = orc.egrad(Q, Y)
+    ref_hvp = orc.hvp(Q, dims, Y, G, V)
+    single = P1.tnt(Y, max_iterations=6, host_stpcg=True)
+
+    def body(r, group):
+        P = _problem(n, p)
+        comm = P.set_partition(r, world, lambda ctx: ThreadComm(ctx, group))
+        assert 0 < comm.exchanged_rows < dm["N"]
+        f = P.op("evaluateObjective", Y)
+        H = P.op("Riemannian_Hessian_vector_product", Y, P.op("Euclidean_gradient", Y), V)
+        res = P.tnt(Y, max_iterations=6)   # partitioned handles take the host-driven STPCG (collective calls)
+        return f, H, res
+
+    outs = _run_ranks(world, body)
+    for f, H, res in outs:
+        assert abs(f - orc.cost(Q, Y)) < 1e-11 * abs(f)
+        assert np.abs(H - ref_hvp).max() < 1e-10 * np.abs(ref_hvp).max()
+        assert res["iterations"] == single["iterations"] and res["hvps"] == single["hvps"]
+        assert abs(res["f"] - single["f"]) < 1e-10 * abs(single["f"])
+        assert np.abs(res["x"] - single["x"]).max() < 1e-8
+    # every rank returns the same bits (the reductions add in rank order on every rank)
+    for f, H, res in outs[1:]:
+        assert f == outs[0][0] and np.array_equal(res["x"], outs[0][2]["x"])
+
+
+def test_eight_partitions_of_the_headline_graph():
+    """BASELINE config 4 / 5 on one GPU: the 10^5-pose graph cut into 8 row partitions, the Hessian-vector
+    product at rank 5 and the certificate operator (Q - Lambda) X with 10 columns against the CPU oracle."""
+    world, n, p = 8, 100000, 5
+    P1 = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42, precond=capi.PRECOND_JACOBI)
+    P1.update()
+    dm = P1.dims()
+    _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    rng = np.random.default_rng(7)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dm["N"], p)))
+    V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, (dm["N"], p)))
+    X10 = rng.uniform(-1, 1, (dm["N"], 10))
+    G = orc.egrad(Q, Y)
+    ref_hvp = orc.hvp(Q, dims, Y, G, V)
+    Lst, lob = orc.lambda_blocks(Q, dims, Y)
+    ref_S = orc.S_apply(Q, dims, Lst, lob, X10)
+    del P1
+
+    def body(r, group):
+        P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42, precond=capi.PRECOND_JACOBI)
+        P.update()
+        P.set_rank(p)
+        comm = P.set_partition(r, world, lambda ctx: ThreadComm(ctx, group))
+        ctx = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+        y, x, o = ctx.dev_alloc(p), ctx.dev_alloc(p), ctx.dev_alloc(p)
+        x10, o10 = ctx.dev_alloc(10), ctx.dev_alloc(10)
+        ctx.upload(Y, y)
+        ctx.set_point_dev(y)
+        ctx.upload(V, x)
+        ctx.hvp_dev(x, o)
+        H = ctx.download(o, p)
+        ctx.upload(X10, x10)
+        ctx.certificate_product_dev(x10, 10, o10)
+        S = ctx.download(o10, 10)
+        return comm.exchanged_rows, ctx.rows, H, S
+
+    outs = _run_ranks(world, body)
+    for exch, rows, H, S in outs:
+        assert exch < rows // 3
+        assert np.abs(H - ref_hvp).max() < 1e-10 * np.abs(ref_hvp).max()
+        assert np.abs(S - ref_S).max() < 1e-10 * np.abs(ref_S).max()
