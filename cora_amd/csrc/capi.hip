@@ -61,7 +61,7 @@ struct cora_ctx {
     int aux_rows = 0;  // two-stage plans: rows appended to the work vector
     bool ready = false;
   };
-  DevFactor precond_f, implicit_f;
+  DevFactor precond_f, implicit_f, aux_f;  // aux_f: the caller's own factor (cora_aux_set_cholesky)
   bool implicit = false;  // Formulation::Implicit active
 
   bool have_point = false;
@@ -430,7 +430,7 @@ void cora_ctx_destroy(cora_ctx *c) {
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (void *p : c->user_allocs)
       if (p) (void)hipFree(p);
-    for (auto *f : {&c->precond_f, &c->implicit_f})
+    for (auto *f : {&c->precond_f, &c->implicit_f, &c->aux_f})
       for (void *p : f->allocs)
         if (p) (void)hipFree(p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -976,6 +976,29 @@ int cora_implicit_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int3
     row_of[i] = c->F.api2int[tb + perm[i]];
   }
   return install_factor(c, c->implicit_f, m, Lp, Li, Lx, row_of, -1);
+}
+
+int cora_aux_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
+                          const int32_t *perm) {
+  NEED_DEVICE(c);
+  const int64_t N = c->F.L.N;
+  if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "triangular solves do not shard");
+  if (!Lp || !Li || !Lx || !perm || m != N) return fail(c, CORA_ERR_ARG, "factor must have N rows");
+  std::vector<int32_t> row_of(static_cast<size_t>(m));
+  std::vector<char> seen(static_cast<size_t>(N), 0);
+  for (int i = 0; i < m; ++i) {
+    if (perm[i] < 0 || perm[i] >= N || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
+    seen[perm[i]] = 1;
+    row_of[i] = c->F.api2int[perm[i]];
+  }
+  return install_factor(c, c->aux_f, m, Lp, Li, Lx, row_of, -1);
+}
+
+int cora_aux_solve_dev(cora_ctx *c, const double *dB, int k, double *dX) {
+  NEED_DEVICE(c);
+  if (!c->aux_f.ready) return fail(c, CORA_ERR_NOT_READY, "no factor installed (cora_aux_set_cholesky)");
+  if (!dB || !dX || k <= 0 || k > kMaxLD || dB == dX) return fail(c, CORA_ERR_ARG, "bad arguments");
+  return factor_solve(c, c->aux_f, ld_for(k), dB, dX);
 }
 
 int cora_set_formulation(cora_ctx *c, int implicit) {

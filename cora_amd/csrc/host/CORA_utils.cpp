@@ -13,7 +13,8 @@ namespace CORA {
 CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X0, size_t max_iters,
                               const std::vector<int32_t> &perm_in, cora_ctx *ctx,
                               const std::optional<DeviceOperator> &S_op,
-                              const std::optional<DeviceOperator> &precond) {
+                              const std::optional<DeviceOperator> &precond, Scalar max_fill_factor, Scalar drop_tol,
+                              const FastVerificationLab *lab) {
   const Index n = S.rows();
   CertResults results;
   results.theta = 0;
@@ -75,20 +76,30 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
                           stopfun);
   size_t iters = r.num_iters;
   if (!(r.Theta(0) - eta < -eta / 2)) {
-    // STEP 3 (:129-167): the "hard" case.  The reference builds an ILDL preconditioner here
-    // (libs/Preconditioners, absent).  Instead the block is seeded with the direction of
-    // non-positive curvature that the failed factorisation of step 1 yields for free
-    // (z' M z = d_k <= 0, i.e. z' S z <= -eta): Rayleigh-Ritz can only improve on it, so the
-    // stopping rule x' S x < -eta/2 is always reachable; `precond` (e.g. the regularised-Cholesky
-    // solve) is used when the caller has one.
+    // STEP 3 (:129-167): the "hard" case -- a negative eigenvalue of small magnitude.  Preconditioner T: incomplete
+    // L D L^T of M = S + eta I (max_fill_factor, drop_tol; libs/Preconditioners is absent, see incompleteLDLT) applied
+    // with the positive-definite modification |D| (ILDL::solve(x, true), :152), on the device through the staged
+    // triangular solves.  A caller-supplied `precond` takes its place.  The block is also seeded with the direction
+    // of non-positive curvature the failed factorisation of step 1 yields for free (z' M z = d_k <= 0): Rayleigh-Ritz
+    // can only improve on it.
+    if (lab) lab->reached_step3 = true;
+    std::optional<DeviceOperator> T = precond;
+    if (!T && (!lab || lab->use_ildl)) {
+      const CholeskyFactor I = incompleteLDLT(S, static_cast<int>(n), eta, perm, max_fill_factor, drop_tol);
+      if (cora_aux_set_cholesky(c, static_cast<int>(n), I.Lp.data(), I.Li.data(), I.Lx.data(), I.perm.data()) != CORA_OK)
+        throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(c));
+      T = [c](const double *dX, int k, double *dOut) {
+        if (cora_aux_solve_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
+      };
+    }
     Matrix X0s = X0;
-    if (!F.negative_direction.empty()) {
+    if (!F.negative_direction.empty() && (!lab || lab->seed_negative_direction)) {
       const Index m0 = X0.cols() < 24 ? X0.cols() + 1 : X0.cols();
       X0s = Matrix(n, m0);
       X0s.setBlock(0, 0, X0.block(0, 0, n, std::min<Index>(X0.cols(), m0 - 1)));
       for (Index i = 0; i < n; ++i) X0s(i, m0 - 1) = F.negative_direction[static_cast<size_t>(i)];
     }
-    r = LOBPCG(c, Mop, precond, X0s, 1, static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters), 0.0, stopfun);
+    r = LOBPCG(c, Mop, T, X0s, 1, static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters), 0.0, stopfun);
     iters += r.num_iters;
   }
   results.x = r.X.col(0);

@@ -20,14 +20,22 @@ namespace CORA {
  * The operator S*X runs on the GPU: `op` when given (the problem's own handle,
  * certificate operator at its current point), else a temporary handle built from S.
  * `perm` (new -> old) is the fill-reducing order for step 1 (natural order if empty).
- * Deviation: the reference switches to ILDL-preconditioned LOBPCG after 1 % of the
- * iterations (:140-167, libs/Preconditioners absent); here `precond` (optional, e.g. the
- * regularised-Cholesky solve) is used for all iterations.
+ * After 1 % of the iterations without a direction of curvature < -eta/2 the reference switches to
+ * ILDL-preconditioned LOBPCG (:140-167); so does this: incomplete L D L^T of S + eta I with max_fill_factor /
+ * drop_tol (sparse_cholesky.h, incompleteLDLT), applied on the device; `precond`, when given, replaces it.
  */
+/** Test switches of step 3 (tests/test_gpu_certification.py): run it without the seed from the failed factorisation
+ * and / or without the ILDL preconditioner, and learn whether it ran. */
+struct FastVerificationLab {
+  bool seed_negative_direction = true, use_ildl = true;
+  mutable bool reached_step3 = false;
+};
+
 CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X0, size_t max_iters = 1000,
                               const std::vector<int32_t> &perm = {}, cora_ctx *ctx = nullptr,
                               const std::optional<DeviceOperator> &S_op = std::nullopt,
-                              const std::optional<DeviceOperator> &precond = std::nullopt);
+                              const std::optional<DeviceOperator> &precond = std::nullopt,
+                              Scalar max_fill_factor = 3, Scalar drop_tol = 1e-3, const FastVerificationLab *lab = nullptr);
 
 inline CertResults fast_verification(const SparseMatrix &S, Scalar eta, size_t nx, size_t max_iters = 1000) {
   return fast_verification(S, eta, Matrix::Random(S.rows(), static_cast<Index>(nx)), max_iters);

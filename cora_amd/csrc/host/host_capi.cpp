@@ -290,6 +290,28 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
   });
 }
 
+int cora_host_fast_verification_lab(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                    double eta, const double *X0, int nx, int max_iters, const double opts[4],
+                                    double out[4], double *x) {
+  return guarded([&] {
+    SparseMatrix S(n, n);
+    S.outer.assign(rowptr, rowptr + n + 1);
+    S.inner.assign(colidx, colidx + rowptr[n]);
+    S.values.assign(vals, vals + rowptr[n]);
+    const Matrix X = X0 ? wrap(X0, n, nx) : Matrix::Random(n, nx, 99);
+    FastVerificationLab lab;
+    lab.seed_negative_direction = opts[2] != 0.0;
+    lab.use_ildl = opts[3] != 0.0;
+    const CertResults c = fast_verification(S, eta, X, static_cast<size_t>(max_iters), {}, nullptr, std::nullopt,
+                                            std::nullopt, opts[0], opts[1], &lab);
+    out[0] = c.is_certified ? 1.0 : 0.0;
+    out[1] = c.theta;
+    out[2] = static_cast<double>(c.num_iters);
+    out[3] = lab.reached_step3 ? 1.0 : 0.0;
+    if (x) std::memcpy(x, c.x.data(), sizeof(double) * static_cast<size_t>(c.x.size()));
+  });
+}
+
 int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                 double eta, const double *X0, int nx, int max_iters, double out[3], double *x) {
   return guarded([&] {

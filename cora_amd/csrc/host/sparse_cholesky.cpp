@@ -1,5 +1,6 @@
 #include "sparse_cholesky.h"
 
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <numeric>
@@ -190,6 +191,127 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
     F.Li[w] = k;
     F.Lx[w] = std::sqrt(dk);
   }
+  return F;
+}
+
+CholeskyFactor incompleteLDLT(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
+                              double max_fill_factor, double drop_tol, int *negative_pivots) {
+  CholeskyFactor F;
+  const int n = m;
+  F.n = n;
+  if (static_cast<int>(perm.size()) != n) throw std::invalid_argument("incompleteLDLT: bad permutation size");
+  F.perm = perm;
+  F.iperm.assign(static_cast<size_t>(A.rows()), -1);
+  for (int i = 0; i < n; ++i) F.iperm[perm[i]] = i;
+  // columns of L (unit diagonal implied while eliminating) as growing lists; `first[j]`: position in column j of its
+  // first entry with row >= the current column; `list[k]`: columns j < k with an entry in row k (linked)
+  std::vector<std::vector<int32_t>> Lrow(static_cast<size_t>(n));
+  std::vector<std::vector<double>> Lval(static_cast<size_t>(n));
+  std::vector<double> d(static_cast<size_t>(n), 0.0);
+  std::vector<int32_t> first(static_cast<size_t>(n), 0), next_in_row(static_cast<size_t>(n), -1), head(static_cast<size_t>(n), -1);
+  std::vector<double> w(static_cast<size_t>(n), 0.0);
+  std::vector<char> mark(static_cast<size_t>(n), 0);
+  std::vector<int32_t> pattern;
+  int neg = 0;
+  for (int k = 0; k < n; ++k) {
+    // w = (A + shift I)[k:, k] in the permuted order
+    pattern.clear();
+    const int old = perm[k];
+    int a_cnt = 0;
+    double dk = shift;
+    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+      const int i = F.iperm[A.inner[q]];
+      if (i < 0) continue;
+      ++a_cnt;
+      if (i == k) dk += A.values[q];
+      else if (i > k) {
+        if (!mark[i]) { mark[i] = 1; pattern.push_back(i); }
+        w[i] += A.values[q];
+      }
+    }
+    // minus the contributions of the columns j < k with L_kj != 0
+    for (int j = head[k]; j >= 0;) {
+      const int nj = next_in_row[j];
+      const std::vector<int32_t> &rj = Lrow[j];
+      const std::vector<double> &vj = Lval[j];
+      const int32_t f = first[j];  // rj[f] == k
+      const double lkj_d = vj[f] * d[j];
+      dk -= vj[f] * lkj_d;
+      for (size_t t = static_cast<size_t>(f) + 1; t < rj.size(); ++t) {
+        const int i = rj[t];
+        if (!mark[i]) { mark[i] = 1; pattern.push_back(i); }
+        w[i] -= vj[t] * lkj_d;
+      }
+      // column j moves on to its next row
+      first[j] = f + 1;
+      if (static_cast<size_t>(f) + 1 < rj.size()) {
+        const int r2 = rj[f + 1];
+        next_in_row[j] = head[r2];
+        head[r2] = j;
+      }
+      j = nj;
+    }
+    double col1 = std::fabs(dk);
+    for (int32_t i : pattern) col1 += std::fabs(w[i]);
+    if (std::fabs(dk) < 1e-10 * col1 || dk == 0.0) dk = (dk < 0 ? -1.0 : 1.0) * std::max(1e-10 * col1, 1e-300);
+    if (dk < 0) ++neg;
+    d[k] = dk;
+    // dropping: small entries, then all but the largest `keep`
+    const double tol = drop_tol * col1;
+    std::vector<std::pair<double, int32_t>> ent;
+    ent.reserve(pattern.size());
+    for (int32_t i : pattern) {
+      const double l = w[i] / dk;
+      if (std::fabs(w[i]) > tol) ent.push_back({std::fabs(l), i});
+      w[i] = l;  // keep the scaled value for the survivors below
+    }
+    const size_t keep = static_cast<size_t>(std::ceil(max_fill_factor * std::max(a_cnt, 1)));
+    if (ent.size() > keep) {
+      std::nth_element(ent.begin(), ent.begin() + static_cast<std::ptrdiff_t>(keep), ent.end(),
+                       [](const auto &x, const auto &y) { return x.first > y.first; });
+      ent.resize(keep);
+    }
+    std::sort(ent.begin(), ent.end(), [](const auto &x, const auto &y) { return x.second < y.second; });
+    std::vector<int32_t> &rk = Lrow[k];
+    std::vector<double> &vk = Lval[k];
+    rk.reserve(ent.size());
+    vk.reserve(ent.size());
+    for (const auto &e : ent) {
+      rk.push_back(e.second);
+      vk.push_back(w[e.second]);
+    }
+    for (int32_t i : pattern) { w[i] = 0.0; mark[i] = 0; }
+    first[k] = 0;
+    if (!rk.empty()) {
+      next_in_row[k] = head[rk[0]];
+      head[rk[0]] = k;
+    }
+  }
+  if (negative_pivots) *negative_pivots = neg;
+  // Cholesky form of L |D| L^T: column k = sqrt|d_k| * [1; L[k+1:, k]]
+  F.Lp.assign(static_cast<size_t>(n) + 1, 0);
+  int64_t tot = 0;
+  for (int k = 0; k < n; ++k) {
+    F.Lp[k] = static_cast<int32_t>(tot);
+    tot += 1 + static_cast<int64_t>(Lrow[k].size());
+    if (tot > 2000000000LL) throw std::runtime_error("incompleteLDLT: factor too large for int32 indexing");
+  }
+  F.Lp[n] = static_cast<int32_t>(tot);
+  F.Li.resize(static_cast<size_t>(tot));
+  F.Lx.resize(static_cast<size_t>(tot));
+  F.parent.assign(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k) {
+    const double sk = std::sqrt(std::fabs(d[k]));
+    int32_t at = F.Lp[k];
+    F.Li[at] = k;
+    F.Lx[at++] = sk;
+    for (size_t t = 0; t < Lrow[k].size(); ++t) {
+      F.Li[at] = Lrow[k][t];
+      F.Lx[at++] = Lval[k][t] * sk;
+    }
+    if (!Lrow[k].empty()) F.parent[k] = Lrow[k][0];
+  }
+  F.ok = true;
   return F;
 }
 

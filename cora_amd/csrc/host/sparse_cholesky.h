@@ -47,4 +47,16 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
  * both triangles) plus shift * I, in the order perm (new -> old). */
 CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm);
 
+/** Incomplete L D L^T of the symmetric (possibly INDEFINITE) matrix A[0:m, 0:m] + shift * I in the order perm --
+ * the stand-in for Preconditioners::ILDL (libs/Preconditioners, un-vendored submodule; reference call
+ * src/CORA_utils.cpp:140-156 with ILDLOpts{max_fill_factor, drop_tol}).  Left-looking (Crout) elimination with
+ * 1x1 pivots: column k keeps its entries above drop_tol * ||column||_1, at most max_fill_factor * (entries of
+ * column k of A) of them; a pivot smaller than 1e-10 * ||column|| is moved away from zero.  What comes back is the
+ * factor of the POSITIVE-DEFINITE modification the reference applies (ILDL::solve(x, pos_def_mod = true): |D| in
+ * place of D), in Cholesky form:  Lx holds  L |D|^(1/2)  (CSC, diagonal first), so that
+ * (L |D| L^T)^-1 = (Lx Lx^T)^-1 is applied by the same triangular solves as a Cholesky factor.  `negative_pivots`
+ * counts the d_k < 0 (the inertia estimate). */
+CholeskyFactor incompleteLDLT(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
+                              double max_fill_factor, double drop_tol, int *negative_pivots = nullptr);
+
 }  // namespace CORA

@@ -110,6 +110,24 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         rval[fill[Li[q]]++] = Lx[q];
       }
   }
+  // ---- elimination tree of the factor's own pattern (Liu's algorithm with path compression).  For a complete
+  // Cholesky factor this is "parent = first sub-diagonal row of the column"; an INCOMPLETE factor (dropped entries)
+  // only keeps the property the stages below rely on -- L_ij != 0 implies that i is an ancestor of j -- with the
+  // tree of its actual pattern.
+  {
+    std::fill(parent.begin(), parent.end(), -1);
+    std::vector<int32_t> anc(static_cast<size_t>(m), -1);
+    for (int i = 0; i < m; ++i)
+      for (int32_t q = rptr[i]; q < rptr[i + 1]; ++q) {
+        int j = rcol[q];
+        while (j != -1 && j < i) {
+          const int nxt = anc[j];
+          anc[j] = i;
+          if (nxt == -1) parent[j] = i;
+          j = nxt;
+        }
+      }
+  }
   // ---- stages: repeatedly peel the maximal subtrees of the remaining forest that fit the cap
   int first_border = m;  // trailing run of long rows: forced into the last stage
   while (first_border > 0 && rcount[first_border - 1] > kBorderRowNnz) --first_border;

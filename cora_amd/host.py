@@ -302,8 +302,9 @@ def block_cholesky_solve(A, block_sizes, B):
     return X
 
 
-def fast_verification(S, eta, X0=None, nx=1, max_iters=1000):
-    """CORA::fast_verification on an arbitrary symmetric scipy sparse matrix."""
+def fast_verification(S, eta, X0=None, nx=1, max_iters=1000, lab=None):
+    """CORA::fast_verification on an arbitrary symmetric scipy sparse matrix.  lab = dict(max_fill_factor, drop_tol,
+    seed, ildl) exposes the knobs of step 3 (tests) and adds `step3` to the result."""
     import scipy.sparse as sp
     L = _lib()
     S = sp.csr_matrix(S)
@@ -319,9 +320,20 @@ def fast_verification(S, eta, X0=None, nx=1, max_iters=1000):
         X0 = np.asfortranarray(np.asarray(X0, dtype=np.float64).reshape(n, -1))
         nx = X0.shape[1]
         xp = X0.ctypes.data_as(_dp)
-    rc = L.cora_host_fast_verification(n, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), va.ctypes.data_as(_dp),
-                                       C.c_double(eta), xp, int(nx), int(max_iters), out.ctypes.data_as(_dp),
-                                       x.ctypes.data_as(_dp))
+    if lab is not None:
+        out = np.zeros(4)
+        opts = np.array([lab.get("max_fill_factor", 3.0), lab.get("drop_tol", 1e-3), float(lab.get("seed", True)),
+                         float(lab.get("ildl", True))])
+        rc = L.cora_host_fast_verification_lab(n, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), va.ctypes.data_as(_dp),
+                                               C.c_double(eta), xp, int(nx), int(max_iters), opts.ctypes.data_as(_dp),
+                                               out.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    else:
+        rc = L.cora_host_fast_verification(n, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), va.ctypes.data_as(_dp),
+                                           C.c_double(eta), xp, int(nx), int(max_iters), out.ctypes.data_as(_dp),
+                                           x.ctypes.data_as(_dp))
     if rc:
         raise HostError(L.cora_host_last_error().decode())
-    return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
+    res = dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
+    if lab is not None:
+        res["step3"] = bool(out[3])
+    return res

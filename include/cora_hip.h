@@ -293,6 +293,14 @@ int cora_sync(cora_ctx *ctx);
 /* Test hook: executes the handle's device FORMAT (slices + long rows) on the
  * host, to validate the format conversion where no GPU exists.  Never used by
  * any compute entry point. */
+/* A factor of the caller's own for the handle's vectors: (L L^T)^-1 with L (CSC, diagonal first) the Cholesky-form
+ * factor of P A P^T, N rows, perm new -> old in API row order.  It may be INCOMPLETE (dropped entries).  Used by
+ * fast_verification for the preconditioner of src/CORA_utils.cpp:140-156 (ILDL with pos_def_mod: L |D|^(1/2)).
+ * cora_aux_solve_dev: dX = (P^T L L^T P)^-1 dB on k-column resident vectors, dB != dX. */
+int cora_aux_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
+                          const int32_t *perm);
+int cora_aux_solve_dev(cora_ctx *ctx, const double *dB, int k, double *dX);
+
 /* ------------------------------------------------ multi-GPU: injected communication
  *
  * A partitioned handle (cora_ctx_create_part, world > 1) owns the rows of its shard; every resident vector still

@@ -114,6 +114,13 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
 int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                 double eta, const double *X0, int nx, int max_iters, double out[3], double *x);
 
+/* The same with the knobs of step 3 (src/CORA_utils.cpp:129-167) exposed for the tests: opts = {max_fill_factor,
+ * drop_tol, seed the block with the failed factorisation's direction (0/1), use the ILDL preconditioner (0/1)};
+ * out[3] = 1 when step 3 ran. */
+int cora_host_fast_verification_lab(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                    double eta, const double *X0, int nx, int max_iters, const double opts[4],
+                                    double out[4], double *x);
+
 /* solveCORA (src/CORA.cpp:26-243) from x0 (N x rank): Riemannian staircase up to max_rank, final
  * projection to rank d and refinement.  x_out: N x d.  opts[0..4] as in cora_problem_tnt (may be NULL).
  * stats: [0] f, [1] |grad|, [2] certified, [3] eta, [4] theta, [5] final rank, [6] staircase levels,

@@ -88,3 +88,34 @@ def test_certification_sign_matches_oracle(d, n, p):
             assert abs(res["theta"] - x @ Sd @ x) < 1e-8 * max(1.0, abs(res["theta"]))
             assert res["theta"] < -eta / 2
             assert res["theta"] >= lam_min - 1e-8 * abs(lam_min)
+
+
+def test_ildl_preconditioned_lobpcg_branch():
+    """Step 3 of fast_verification (src/CORA_utils.cpp:129-167): a matrix whose negative eigenvalue is tiny and whose
+    spectrum is crowded near it -- a long weighted path Laplacian shifted down -- is out of reach of the 1 % of
+    unpreconditioned iterations, so the ILDL-preconditioned branch has to find the direction.  Checked against the
+    dense eigen-decomposition; the same run without the preconditioner does not get there."""
+    n = 4000
+    rng = np.random.default_rng(1)
+    w = rng.uniform(0.5, 2.0, n - 1)
+    Lp = sp.diags([np.r_[w, 0] + np.r_[0, w], -w, -w], [0, 1, -1]).tocsr()
+    lam = np.linalg.eigvalsh(Lp.toarray())
+    S = (Lp - (lam[1] * 0.5) * sp.eye(n)).tocsr()        # lambda_min(S) = -lam[1]/2 < 0, tiny; second one positive
+    lmin = -0.5 * lam[1]
+    eta = 1e-3 * abs(lmin)
+    x0 = rng.standard_normal((n, 2))
+    got = host.fast_verification(S, eta, X0=x0, max_iters=400, lab=dict(seed=False, ildl=True))
+    assert not got["is_certified"] and got["step3"]
+    assert got["theta"] < -eta / 2                        # the stopping rule of the reference
+    assert got["theta"] >= lmin - 1e-12 * max(1.0, abs(lmin))
+    assert abs(got["theta"] - got["x"] @ (S @ got["x"])) < 1e-12
+    assert 4 <= got["iters"] < 100                        # 1 % unpreconditioned = 4 iterations, then a few more
+    # the only direction of negative curvature is the constant vector; the iteration stops as soon as the curvature
+    # passes -eta/2 (the reference's rule), so the estimate is dominated by it without having converged to it
+    v = np.full(n, 1.0 / np.sqrt(n))
+    assert abs(v @ got["x"]) > 0.5
+    plain = host.fast_verification(S, eta, X0=x0, max_iters=400, lab=dict(seed=False, ildl=False))
+    assert plain["step3"] and plain["iters"] > 2 * got["iters"]
+    # with the seed of the failed factorisation (the default) the direction is there at once
+    seeded = host.fast_verification(S, eta, X0=x0, max_iters=400, lab=dict())
+    assert not seeded["is_certified"] and seeded["theta"] < -eta / 2 and seeded["theta"] >= lmin - 1e-12

@@ -82,3 +82,25 @@ def test_rejects_malformed_factor():
     rc = lib.cora_debug_factor_solve_host(2, Lp.ctypes.data_as(_ip), Li.ctypes.data_as(_ip), Lx.ctypes.data_as(_dp), 1,
                                           B.ctypes.data_as(_dp), X.ctypes.data_as(_dp), None)
     assert rc != 0 and b"diagonal first" in lib.cora_last_error(None)
+
+
+def test_incomplete_factor_goes_through_the_staged_plan():
+    """An INCOMPLETE factor (entries dropped, as the ILDL preconditioner of fast_verification produces) no longer has
+    the elimination tree of a complete one; the plan takes the tree of the factor's own pattern.  The staged
+    products must apply (L L^T)^-1 of exactly the factor that was given."""
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(8)
+    n = 2600
+    A = _spd(n, "random", rng)
+    Ls = _factor_csc(A).tolil()
+    L = Ls.tocoo()
+    keep = (L.row == L.col) | (np.abs(L.data) > 0.02) | (rng.uniform(size=L.nnz) < 0.3)
+    Li = sp.csc_matrix((L.data[keep], (L.row[keep], L.col[keep])), shape=(n, n))
+    Li.sort_indices()
+    assert Li.nnz < 0.8 * L.nnz
+    B = rng.uniform(-1, 1, (n, 2))
+    X, st = _solve(Li, B)
+    Y = spl.spsolve_triangular(Li.tocsr(), B, lower=True)
+    ref = spl.spsolve_triangular(Li.T.tocsr(), Y, lower=False)
+    assert np.abs(X - ref).max() < 1e-10 * np.abs(ref).max()
+    assert st["nnzL"] == Li.nnz
