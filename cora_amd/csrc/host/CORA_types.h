@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <iostream>  // the reference's headers bring it in (examples/main.cpp uses std::cout without including it)
 #include <cstdint>
 #include <random>
 #include <stdexcept>

@@ -1,0 +1,5 @@
+// <CORA/CORA_types.h> of the reference (MarineRoboticsGroup/cora, include/CORA/CORA_types.h): Scalar, Matrix, SparseMatrix, CertResults, enums.
+// Forwarding header: code written against the reference's include layout compiles against this build with
+// -I<repo>/include and links libcora_hip.so.
+#pragma once
+#include "../../cora_amd/csrc/host/CORA_types.h"

@@ -1,0 +1,5 @@
+// <CORA/ObliqueManifold.h> of the reference (MarineRoboticsGroup/cora, include/CORA/ObliqueManifold.h): ObliqueManifold.
+// Forwarding header: code written against the reference's include layout compiles against this build with
+// -I<repo>/include and links libcora_hip.so.
+#pragma once
+#include "../../cora_amd/csrc/host/Manifolds.h"

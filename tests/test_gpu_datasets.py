@@ -95,3 +95,20 @@ def test_solve_implicit_plaza2():
     assert abs(orc.cost(Q, full) - res["f"]) < 1e-6 * res["f"]
     print("\nplaza2 implicit: f=%.6f certified=%s levels=%d hvps=%d %.2fs" % (res["f"], res["certified"], res["levels"],
                                                                             res["hvps"], res["seconds"]))
+
+
+def test_reference_call_sequence_binary_solves_plaza2(tmp_path):
+    """The reference's examples/main.cpp call sequence (tests/drop_in/reference_call_sequence.cpp, written against
+    <CORA/...>), compiled against include/ and libcora_hip.so, run on the reference's own Plaza2 file."""
+    import subprocess
+    from cora_amd import build as _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _build.build()
+    exe = str(tmp_path / "seq")
+    subprocess.run([_build.HIPCC, "-O1", "-std=c++17", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "drop_in", "reference_call_sequence.cpp"), "-L" + os.path.dirname(lib),
+                    "-lcora_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True, timeout=600)
+    r = subprocess.run([exe, os.path.join(DATA, "plaza2.pyfg")], stdout=subprocess.PIPE, text=True, timeout=300, check=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("cost ")][-1].split()
+    assert abs(float(line[1]) - 734.328) < 2e-3      # run_utils/parse_data.py:40 of the reference
+    assert int(line[3]) == 4091 * 3 + 1807 + 4091 + 4
