@@ -122,6 +122,16 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
     ex["preconditioner_apply_us"] = h.timer_stop_ms() * 1e3 / 50
     for q in v:
         h.dev_free(q)
+    # end to end at this size: the full staircase (solveCORA, rank 3 upwards, certification by factorisation) from
+    # the generator's ground truth -- where a front end would leave the problem; what the host does per level
+    # (numeric LL^T + solve plan of the preconditioner, LL^T of the certificate) is inside these seconds
+    t0 = time.perf_counter()
+    P.set_rank(dm["d"])
+    res = P.solve(P.op("projectToManifold", x_gt), max_rank=7, max_seconds=120)
+    ex["staircase_from_ground_truth"] = {
+        "seconds": time.perf_counter() - t0, "solver_seconds": res["seconds"], "hessian_vector_products": res["hvps"],
+        "levels": res["levels"], "f": res["f"], "grad_norm": res["grad_norm"], "certified": bool(res["certified"]),
+        "theta": res["theta"], "eta": res["eta"], "chi_square_sized_optimum": dm["r"] / 2}
     return ex
 
 

@@ -83,24 +83,36 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
     // of non-positive curvature the failed factorisation of step 1 yields for free (z' M z = d_k <= 0): Rayleigh-Ritz
     // can only improve on it.
     if (lab) lab->reached_step3 = true;
-    std::optional<DeviceOperator> T = precond;
-    if (!T && (!lab || lab->use_ildl)) {
-      const CholeskyFactor I = incompleteLDLT(S, static_cast<int>(n), eta, perm, max_fill_factor, drop_tol);
-      if (cora_aux_set_cholesky(c, static_cast<int>(n), I.Lp.data(), I.Li.data(), I.Lx.data(), I.perm.data()) != CORA_OK)
-        throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(c));
-      T = [c](const double *dX, int k, double *dOut) {
-        if (cora_aux_solve_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
-      };
-    }
+    const size_t budget3 = static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters);
+    const bool seeded = !F.negative_direction.empty() && (!lab || lab->seed_negative_direction);
     Matrix X0s = X0;
-    if (!F.negative_direction.empty() && (!lab || lab->seed_negative_direction)) {
+    if (seeded) {
       const Index m0 = X0.cols() < 24 ? X0.cols() + 1 : X0.cols();
       X0s = Matrix(n, m0);
       X0s.setBlock(0, 0, X0.block(0, 0, n, std::min<Index>(X0.cols(), m0 - 1)));
       for (Index i = 0; i < n; ++i) X0s(i, m0 - 1) = F.negative_direction[static_cast<size_t>(i)];
     }
-    r = LOBPCG(c, Mop, T, X0s, 1, static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters), 0.0, stopfun);
-    iters += r.num_iters;
+    bool done = false;
+    if (seeded && !precond) {
+      // with the seed in the block the first Rayleigh-Ritz step already meets the stopping rule: a few plain
+      // iterations, and the factorisation below is only paid for when they do not
+      r = LOBPCG(c, Mop, std::nullopt, X0s, 1, std::min<size_t>(budget3, 3), 0.0, stopfun);
+      iters += r.num_iters;
+      done = r.Theta(0) - eta < -eta / 2;
+    }
+    if (!done) {
+      std::optional<DeviceOperator> T = precond;
+      if (!T && (!lab || lab->use_ildl)) {
+        const CholeskyFactor I = incompleteLDLT(S, static_cast<int>(n), eta, perm, max_fill_factor, drop_tol);
+        if (cora_aux_set_cholesky(c, static_cast<int>(n), I.Lp.data(), I.Li.data(), I.Lx.data(), I.perm.data()) != CORA_OK)
+          throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(c));
+        T = [c](const double *dX, int k, double *dOut) {
+          if (cora_aux_solve_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
+        };
+      }
+      r = LOBPCG(c, Mop, T, X0s, 1, budget3, 0.0, stopfun);
+      iters += r.num_iters;
+    }
   }
   results.x = r.X.col(0);
   // curvature along x, recomputed from S like the reference (:124-127)
@@ -120,34 +132,44 @@ Matrix projectToSOd(const Matrix &M) {
   Vector ev;
   Matrix V;
   symmetricEigen(M.transpose() * M, ev, V);  // ascending: smallest singular value first
-  // columns of U from the largest singular value down; a column whose singular value vanishes (rank-deficient
-  // block) is completed by Gram-Schmidt against the columns already there, like the full U of the reference's
-  // JacobiSVD, so the result is orthogonal in every case
+  // Columns of U from the largest singular value down: u_k = M v_k, orthogonalised against the columns already there
+  // and normalised (dividing by sqrt(eigenvalue) alone loses the small singular directions: the eigenvalues of M^T M
+  // carry an absolute error of eps * sigma_max^2).  A column that vanishes (rank-deficient block) is completed with
+  // the unit vector that keeps the largest remainder -- like the full U of the reference's JacobiSVD, the result is
+  // orthogonal in every case.
   Matrix U(d, d);
-  const Scalar smax = std::sqrt(std::max(ev(d - 1), 0.0));
+  Scalar smax = 0;
   for (Index k = d - 1; k >= 0; --k) {
-    const Matrix uk = M * V.col(k);
-    const Scalar s = std::sqrt(std::max(ev(k), 0.0));
-    if (s > 1e-12 * std::max(smax, Scalar(1e-300))) {
-      for (Index i = 0; i < d; ++i) U(i, k) = uk(i) / s;
-      continue;
-    }
-    Scalar best = -1;
-    for (Index e = 0; e < d; ++e) {  // the unit vector that keeps the largest remainder
-      Vector w(d, 1);
-      for (Index i = 0; i < d; ++i) w(i) = i == e ? 1.0 : 0.0;
-      for (Index j = k + 1; j < d; ++j) {
-        Scalar dot = 0;
-        for (Index i = 0; i < d; ++i) dot += w(i) * U(i, j);
-        for (Index i = 0; i < d; ++i) w(i) -= dot * U(i, j);
-      }
+    Vector w = M * V.col(k);
+    auto orth = [&](Vector &x) {
+      for (int pass = 0; pass < 2; ++pass)
+        for (Index j = k + 1; j < d; ++j) {
+          Scalar dot = 0;
+          for (Index i = 0; i < d; ++i) dot += x(i) * U(i, j);
+          for (Index i = 0; i < d; ++i) x(i) -= dot * U(i, j);
+        }
       Scalar nrm = 0;
-      for (Index i = 0; i < d; ++i) nrm += w(i) * w(i);
-      if (nrm > best) {
-        best = nrm;
-        for (Index i = 0; i < d; ++i) U(i, k) = w(i) / std::sqrt(nrm);
+      for (Index i = 0; i < d; ++i) nrm += x(i) * x(i);
+      return std::sqrt(nrm);
+    };
+    Scalar nrm = orth(w);
+    if (k == d - 1) smax = nrm;
+    if (!(nrm > 1e-10 * std::max(smax, Scalar(1e-300)))) {
+      Scalar best = -1;
+      Vector wb(d, 1);
+      for (Index e = 0; e < d; ++e) {
+        Vector x(d, 1);
+        for (Index i = 0; i < d; ++i) x(i) = i == e ? 1.0 : 0.0;
+        const Scalar ne = orth(x);
+        if (ne > best) {
+          best = ne;
+          wb = x;
+        }
       }
+      w = wb;
+      nrm = best;
     }
+    for (Index i = 0; i < d; ++i) U(i, k) = w(i) / nrm;
   }
   if (determinant(U) * determinant(V) < 0)
     for (Index i = 0; i < d; ++i) U(i, 0) = -U(i, 0);  // the column of the SMALLEST singular value

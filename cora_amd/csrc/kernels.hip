@@ -978,19 +978,26 @@ __global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, Com
   __syncthreads();
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; r < rows;
        r += static_cast<int64_t>(gridDim.x) * 256) {
-    double o[24];
-    for (int j = 0; j < A.kout; ++j) o[j] = 0.0;
+    // the output row stays in registers: every loop over its kMaxLD slots is unrolled with a (wave-uniform)
+    // predicate, never indexed dynamically (which put it in scratch: 208 bytes per lane)
+    double o[kMaxLD];
+#pragma unroll
+    for (int j = 0; j < kMaxLD; ++j) o[j] = 0.0;
     for (int b = 0; b < A.nblocks; ++b) {
       const double *xr = A.x[b] + (row0 + r) * A.ldx[b];
       const double *C = sc + A.coff[b];
       for (int i = 0; i < A.kx[b]; ++i) {
         const double v = xr[i];
-        for (int j = 0; j < A.kout; ++j) o[j] = fma(v, C[i * A.kout + j], o[j]);
+        const double *Ci = C + i * A.kout;
+#pragma unroll
+        for (int j = 0; j < kMaxLD; ++j)
+          if (j < A.kout) o[j] = fma(v, Ci[j], o[j]);
       }
     }
     double *orow = out + (row0 + r) * A.ldo;
-    for (int j = 0; j < A.kout; ++j) orow[j] = o[j];
-    for (int j = A.kout; j < A.ldo; ++j) orow[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMaxLD; ++j)
+      if (j < A.ldo) orow[j] = j < A.kout ? o[j] : 0.0;
   }
 }
 

@@ -24,7 +24,7 @@ constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use 
 constexpr int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
 constexpr int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
-constexpr int kLaneEntries = 16;      // entries one lane of a task walks through
+int kLaneEntries = 16;      // entries one lane of a task walks through
 constexpr int kLevelLanes = 160;     // rows x lanes per task of one level: x 24 columns <= 4 passes of 1024 threads
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
 
@@ -78,6 +78,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P,
                     const std::vector<int32_t> *group, int32_t aux_base) {
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
+  if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::max(1, std::atoi(e));
   P = TriPlan();
   P.m = m;
   P.zero_row = zero_row;

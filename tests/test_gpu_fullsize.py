@@ -177,3 +177,33 @@ def test_certification_of_the_noiseless_ground_truth():
     S.sort_indices()
     ok = orc.Cholesky(orc.CSR.from_scipy(S), perm=_pose_major_order(Q, dims)).ok
     assert ok and res["is_certified"]
+
+
+def test_full_staircase_on_the_headline_graph():
+    """End to end at BASELINE config 4's size: solveCORA (staircase from rank 3, RegularizedCholesky preconditioner,
+    certification by factorisation) on the 10^5-pose graph, started where a front end would leave it (the generator's
+    ground truth; from dead-reckoned odometry the drift over 10^5 poses exhausts the reference's TNT limits, see
+    profiles/r02_datasets.md).  The noise is unit variance in the whitened residuals, so the optimum sits near
+    #ranges / 2; the returned point is checked against the oracle."""
+    n = 100_000
+    P, X_gt = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42,
+                                     precond=capi.PRECOND_REGULARIZED_CHOLESKY, ground_truth=True)
+    P.update()
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    x0 = P.op("projectToManifold", X_gt)
+    f0 = orc.cost(Q, x0)
+    res = P.solve(x0, max_rank=7, max_seconds=300)
+    X = res["x"]
+    assert X.shape == (dims.N, 3)
+    assert np.abs(X - orc.project_manifold(dims, X)).max() < 1e-9
+    # f = 1/2 <X, QX> cancels ten digits here: translations reach 5e3 m, |Q| |X|^2 ~ 1e14 against f ~ 2.5e4, so two
+    # summation orders agree to ~1e-2 absolute
+    assert abs(orc.cost(Q, X) - res["f"]) < 1e-5 * res["f"]
+    assert res["f"] < f0 and 0.5 * (n // 2) / 2 < res["f"] < 2.0 * (n // 2) / 2
+    assert res["levels"] >= 1 and res["final_rank"] == 3
+    print("\n10^5-pose staircase: f0=%.1f -> f=%.4f |g|=%.2e certified=%s theta=%.3e eta=%.3e levels=%d hvps=%d %.2fs"
+          % (f0, res["f"], res["grad_norm"], res["certified"], res["theta"], res["eta"], res["levels"], res["hvps"],
+             res["seconds"]))
