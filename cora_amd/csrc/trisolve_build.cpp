@@ -1,8 +1,12 @@
 #include "trisolve.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 #include <utility>
 
 namespace cora {
@@ -79,6 +83,13 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
                     const std::vector<int32_t> *group, int32_t aux_base) {
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
   if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::max(1, std::atoi(e));
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  [tri plan] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   P = TriPlan();
   P.m = m;
   P.zero_row = zero_row;
@@ -111,6 +122,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         rval[fill[Li[q]]++] = Lx[q];
       }
   }
+  tick("rows of L");
   // ---- elimination tree of the factor's own pattern (Liu's algorithm with path compression).  For a complete
   // Cholesky factor this is "parent = first sub-diagonal row of the column"; an INCOMPLETE factor (dropped entries)
   // only keeps the property the stages below rely on -- L_ij != 0 implies that i is an ancestor of j -- with the
@@ -129,6 +141,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         }
       }
   }
+  tick("elimination tree");
   // ---- stages: repeatedly peel the maximal subtrees of the remaining forest that fit the cap
   int first_border = m;  // trailing run of long rows: forced into the last stage
   while (first_border > 0 && rcount[first_border - 1] > kBorderRowNnz) --first_border;
@@ -334,10 +347,11 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
           }
       }
   }
+  tick("stages");
   // ---- stage 0 as workgroup blocks solved by substitution (trisolve.h, SubBlockOpHost)
   std::vector<std::vector<int32_t>> aux_of(sub0 ? static_cast<size_t>(m) : 0);  // later-stage variable -> its aux rows
   if (sub0) {
-    SubBlockOpHost &S0 = P.stages[0].sub_op;
+    SubBlockOpHost &SG = P.stages[0].sub_op;
     // blocks in order of their roots, members ascending (= elimination order)
     std::vector<int32_t> id_of_root(static_cast<size_t>(m), -1);
     std::vector<std::vector<int32_t>> members;
@@ -356,9 +370,18 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       while (g < 64 && (max_len + g - 1) / g > kLaneEntries) g <<= 1;
       return g;
     };
-    S0.e_ptr.push_back(0);
-    S0.c_ptr.push_back(0);
-    for (size_t b = 0; b < members.size(); ++b) {
+    // Blocks are independent: each one is built into a piece of its own (offsets relative to the piece), several
+    // threads at a time, and the pieces are appended in block order afterwards.
+    struct Piece {
+      SubBlockOpHost S;
+      std::vector<int32_t> tgt_var;  // later-stage variable of every target
+      bool groups_ok = true;
+    };
+    std::vector<Piece> pieces(members.size());
+    auto build_block = [&](size_t b) {
+      SubBlockOpHost &S0 = pieces[b].S;
+      std::vector<int32_t> &tgt_var = pieces[b].tgt_var;
+      bool &groups_ok = pieces[b].groups_ok;
       const std::vector<int32_t> &mem = members[b];
       const int nb = static_cast<int>(mem.size());
       const int32_t root = mem.back();
@@ -560,7 +583,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       for (size_t t = 0; t < trip.size(); ++t) {
         if (t == 0 || trip[t].first != trip[t - 1].first) {
           if (t > 0) S0.c_ptr.push_back(static_cast<int32_t>(S0.c_idx.size()));
-          aux_of[trip[t].first].push_back(S0.n_aux);
+          tgt_var.push_back(trip[t].first);
           S0.tgt_slot.push_back(S0.n_aux++);
         }
         S0.c_idx.push_back(static_cast<uint16_t>(trip[t].second.first));
@@ -570,6 +593,68 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       S0.max_rows = std::max(S0.max_rows, nb);
       S0.max_ent = std::max<int32_t>(S0.max_ent, std::max<int32_t>(static_cast<int32_t>(S0.f_idx.size()) - fe0,
                                                                     static_cast<int32_t>(S0.b_idx.size()) - be0));
+    };
+    {
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      size_t nth = std::min<size_t>(std::min<size_t>(hw, 16), std::max<size_t>(members.size() / 8, 1));
+      if (const char *e = std::getenv("CORA_TRI_THREADS")) nth = std::max(1, std::atoi(e));
+      std::vector<std::thread> pool;
+      std::vector<std::exception_ptr> errs(nth);
+      for (size_t t = 0; t < nth; ++t)
+        pool.emplace_back([&, t] {
+          try {
+            for (size_t b = t; b < members.size(); b += nth) build_block(b);
+          } catch (...) {
+            errs[t] = std::current_exception();
+          }
+        });
+      for (std::thread &th : pool) th.join();
+      for (const std::exception_ptr &e : errs)
+        if (e) std::rethrow_exception(e);
+    }
+    tick("blocks (threads)");
+    SubBlockOpHost &S0 = SG;
+    S0.e_ptr.push_back(0);
+    S0.c_ptr.push_back(0);
+    auto append = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    for (size_t b = 0; b < pieces.size(); ++b) {
+      SubBlockOpHost &Pc = pieces[b].S;
+      if (!pieces[b].groups_ok) P.groups_whole = false;
+      const int32_t row0 = static_cast<int32_t>(S0.rows.size()), fe = static_cast<int32_t>(S0.f_idx.size()),
+                    be = static_cast<int32_t>(S0.b_idx.size()), fl = static_cast<int32_t>(S0.f_hdr.size() / 4),
+                    bl = static_cast<int32_t>(S0.b_hdr.size() / 4), tg = static_cast<int32_t>(S0.tgt_slot.size()),
+                    e0 = static_cast<int32_t>(S0.e_col.size()), c0 = static_cast<int32_t>(S0.c_idx.size());
+      S0.row_begin.push_back(row0);
+      S0.nrows.push_back(Pc.nrows[0]);
+      S0.f_ent_begin.push_back(fe);
+      S0.b_ent_begin.push_back(be);
+      S0.f_nent.push_back(Pc.f_nent[0]);
+      S0.b_nent.push_back(Pc.b_nent[0]);
+      S0.f_lev_begin.push_back(fl);
+      S0.b_lev_begin.push_back(bl);
+      S0.tgt_begin.push_back(tg);
+      append(S0.rows, Pc.rows);
+      append(S0.b_rows, Pc.b_rows);
+      for (int32_t v : Pc.e_ptr) S0.e_ptr.push_back(e0 + v);
+      append(S0.e_col, Pc.e_col);
+      append(S0.e_val, Pc.e_val);
+      append(S0.f_hdr, Pc.f_hdr);
+      append(S0.b_hdr, Pc.b_hdr);
+      append(S0.f_idx, Pc.f_idx);
+      append(S0.b_idx, Pc.b_idx);
+      append(S0.f_val, Pc.f_val);
+      append(S0.b_val, Pc.b_val);
+      for (size_t t = 0; t < Pc.tgt_slot.size(); ++t) {
+        aux_of[pieces[b].tgt_var[t]].push_back(S0.n_aux);
+        S0.tgt_slot.push_back(S0.n_aux++);
+      }
+      for (int32_t v : Pc.c_ptr) S0.c_ptr.push_back(c0 + v);
+      append(S0.c_idx, Pc.c_idx);
+      append(S0.c_val, Pc.c_val);
+      S0.max_rows = std::max(S0.max_rows, Pc.max_rows);
+      S0.max_ent = std::max(S0.max_ent, Pc.max_ent);
+      S0.max_lev = std::max(S0.max_lev, Pc.max_lev);
+      pieces[b] = Piece();
     }
     S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
     S0.f_lev_begin.push_back(static_cast<int32_t>(S0.f_hdr.size() / 4));
@@ -578,6 +663,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       if (stage[v] == 1) P.top_rows.push_back(row_of[v]);
     if (zero_row >= 0) P.top_rows.push_back(zero_row);
   }
+  tick("merge / dense blocks");
   // ---- "a" products: the couplings between stages
   for (int k = 0; k < K && !sub0; ++k) {
     RowList fa, ba;
@@ -601,6 +687,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     if (k > 0) finalize(fa, P.stages[k].fwd_a);
     if (k < K - 1 && !(k == 0 && dense0)) finalize(ba, P.stages[k].bwd_a);
   }
+  tick("a products");
   // ---- "b" products: explicit inverse of every diagonal block.  Column j of W = L_bb^-1 solves
   // L_bb w = e_j and is non-zero only on the path from j to the root of its block.
   std::vector<double> w(static_cast<size_t>(m), 0.0);
@@ -676,6 +763,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     wt_col[k] = std::vector<int32_t>();
     wt_val[k] = std::vector<double>();
   }
+  tick("b products");
 }
 
 
