@@ -147,12 +147,6 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
     // escape accepted (pgn > tolerance) is not stopped by the first test of the next TNT call; <g, P g> is
     // only the STPCG recurrences' business
     double o[2];
-    if (std::getenv("CORA_PGN_OLD")) {
-      D.dots2(grad, grad, grad, Pg, o);
-      gn = std::sqrt(o[0]);
-      pgn = std::sqrt(std::max(o[1], 0.0));
-      return;
-    }
     D.dots2(grad, grad, Pg, Pg, o);
     gn = std::sqrt(o[0]);
     pgn = std::sqrt(o[1]);
