@@ -751,6 +751,8 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       Q.max_rows = H.max_rows;
       Q.max_ent = H.max_ent;
       Q.max_lev = H.max_lev;
+      Q.max_level_lanes = H.max_level_lanes;
+      Q.max_npl = H.max_npl;
       Q.aux_base = f.plan.aux_base;
       // the entry batches of the ext / aux gathers read (and drop) entries past a row's end
       H.e_col.resize(H.e_col.size() + 8, 0);
@@ -758,6 +760,10 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       HIP_TRY(c, up(&Q.desc, desc));
       HIP_TRY(c, up(&Q.fwd.rows, H.rows));
       H.f_hdr.resize(H.f_hdr.size() + 8, 0);  // the kernel reads one header ahead
+      H.f_idx.resize(H.f_idx.size() + 8, 0);  // ... and an entry past a block without entries
+      H.f_val.resize(H.f_val.size() + 8, 0.0);
+      H.b_idx.resize(H.b_idx.size() + 8, 0);
+      H.b_val.resize(H.b_val.size() + 8, 0.0);
       H.b_hdr.resize(H.b_hdr.size() + 8, 0);
       HIP_TRY(c, up(&Q.fwd.hdr, H.f_hdr));
       HIP_TRY(c, up(&Q.fwd.idx, H.f_idx));

@@ -101,8 +101,9 @@ struct SubDesc {  // 48 bytes per block
 };
 struct SubSweep {  // one direction of the solve; rows are numbered by level within the block
   const int32_t *rows;      // [row_begin + k]: internal row
-  const int32_t *hdr;       // [4 * (lev_begin + l)]: {first row, lanes per task g, entries per lane npl, first entry} of level l
-  const uint16_t *idx;      // local row a block entry multiplies (rows padded to g * npl entries, stored lane by lane)
+  const int32_t *hdr;       // [4 * (lev_begin + l)]: {first row, lanes per row g | entries per lane npl << 8, first coefficient (block-relative), first index (absolute)} of level l
+  const uint16_t *idx;      // local row a block entry multiplies: per level [lane = row * g + part][4 or 8]
+  // val: per level [slot u < npl][lane]
   const double *val;        // coefficient
 };
 struct SubOpDev {
@@ -115,6 +116,7 @@ struct SubOpDev {
   const double *c_val;
   const int32_t *top_rows;  // rows of the last stage + the pinned row
   int nblocks, ntop, max_rows, max_ent, max_lev, aux_base;
+  int max_level_lanes, max_npl;  // widest level (rows x lanes per row) and most entries per lane of the plan
 };
 // forward : y[block rows] = L_bb^-1 rhs[block rows] -> y;  work[aux rows] = couplings to the last stage;  work[top rows] = rhs[top rows]
 // backward: x[block rows] = L_bb^-T (y[block rows] - L[top, rows]^T work[top rows]) -> x (may be y);  x[top rows] = work[top rows]

@@ -1244,27 +1244,23 @@ __global__ __launch_bounds__(256) void k_blockop(BlockOpDev B, const double *src
 
 
 // ---------------------------------------------------------------------------
-// Stage 0 as workgroup blocks solved by substitution in LDS (trisolve.h, SubBlockOpHost).  One workgroup of
-// kSubThreads per block: the block's part of L (values + 16-bit local indices), its level tables and its
-// right-hand sides are copied into LDS, then the triangular solve runs level by level -- the tasks of a level
-// are (row, right-hand-side column) pairs, g lanes per task for long rows -- with one workgroup barrier per
-// level.  The workgroups after the blocks move the rows of the last stage between the vectors.
+// Stage 0 as workgroup blocks solved by substitution (trisolve.h, SubBlockOpHost).  One workgroup of kSubThreads
+// per block; only the block's right-hand sides sit in LDS (the tile T, rows x LD).  The block's part of L is
+// STREAMED: the coefficients of a level are stored [entry slot u][lane] (coalesced), its local row indices
+// [lane][4 or 8]; every lane fetches its <= kSubNpl entries of level l + 1 into registers while level l is
+// computed (two register sets, ping-pong), so the HBM latency of the stream
+// hides behind the LDS work of the level before, and four workgroups per CU -- the whole of a 10^5-pose problem
+// resident at once -- keep the memory side busy without phases.  (The first version copied the block's entries into
+// LDS before the first level: 75 KB per block, two blocks per CU, every block of a round streaming at the same
+// time and computing at the same time: 20 us of row I/O + 8 us of stream + 17 us of levels, added up.)
+//
+// A level: lane (row, part) forms  sum_e val_e T[idx_e]  over its entries for ALL columns (columns in chunks of
+// <= 6 accumulators), the g lanes of a row are summed with DPP, THEN (barrier) the rows of the level are written,
+// then (barrier) the next level starts: the rows of a supernode read each other's right-hand sides.  Everything
+// wave-uniform (level headers) stays on the scalar unit; wavefronts without a row only see the two barriers.
 // ---------------------------------------------------------------------------
-#ifndef CORA_SUB_THREADS
-#define CORA_SUB_THREADS 1024
-#endif
-constexpr int kSubThreads = CORA_SUB_THREADS;
-
-struct SubLds {  // carve-up of the dynamic LDS segment (every offset a multiple of 16); T comes first (LDS offset 0)
-  double *T, *val;
-  int32_t *hdr;
-  uint16_t *idx;
-};
-__host__ __device__ inline size_t sub_align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
-__host__ __device__ inline size_t sub_lds_bytes(int max_rows, int max_ent, int max_lev, int ld) {
-  return sub_align16(static_cast<size_t>(max_rows) * ld * 8) + sub_align16(static_cast<size_t>(max_ent + 8) * 8) +
-         sub_align16(static_cast<size_t>(max_lev + 1) * 16) + sub_align16(static_cast<size_t>(max_ent + 8) * 2);
-}
+constexpr int kSubThreads = 256;  // >= rows x lanes per row of a level (plan: kLevelLanes)
+constexpr int kSubNpl = 8;        // >= entries per lane of a level (plan: kLaneEntries)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
@@ -1284,23 +1280,23 @@ __device__ __forceinline__ double group_sum(double x, int g) {
   return x;
 }
 
-// A level: every task (row, column of the right-hand side; g lanes) forms  sum_e val_e T[idx_e]  from the tile as
-// the previous levels left it, THEN (barrier) the rows of the level are written, then (barrier) the next level
-// starts: the rows of a supernode read each other's right-hand sides.  One to four passes of the workgroup cover
-// a level (the plan bounds rows x g of a level by 160: x 24 columns <= 4 x 1024 lanes).
-//
-// The level loop is bound by VALU issue (eight wavefronts per SIMD, a wave64 instruction takes the SIMD 2-4
-// cycles: ~150 vector instructions per wavefront and level were ~2300 cycles per level whatever the memory side
-// did), so everything wave-uniform is kept on the scalar unit -- level headers come through the scalar cache one
-// level ahead, wavefronts without a task only see two barriers -- and the inner loop is stripped to the
-// essentials: rows of a level are padded to one width and stored lane by lane (a lane's npl entries sit at
-// consecutive addresses, no predicates), local row indices become byte offsets into the tile when they are
-// copied to LDS, and a task gets as few lanes as its row length allows.
-template <int LD> struct SubPasses { static constexpr int value = LD <= 6 ? 1 : (LD <= 12 ? 2 : 4); };
+struct SubRegs {  // a lane's entries of one level: coefficients and (two per dword) local row indices
+  double v[kSubNpl];
+  uint32_t i[kSubNpl / 2];
+};
+// Pins a register set: the compiler waits HERE for whatever load still writes it (before the next level's loads are
+// issued), and treats the values as opaque afterwards.
+__device__ __forceinline__ void sub_touch(SubRegs &R) {
+#pragma unroll
+  for (int u = 0; u < kSubNpl; ++u) asm volatile("" : "+v"(R.v[u]));
+#pragma unroll
+  for (int u = 0; u < kSubNpl / 2; ++u) asm volatile("" : "+v"(R.i[u]));
+}
 
 template <int LD, bool BWD>
-__global__ __launch_bounds__(kSubThreads, kSubThreads / 128) void k_subblock(SubOpDev S, const double *src, double *work, double *dst) {
+__global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const double *src, double *work, double *dst) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *T = reinterpret_cast<double *>(smem);
   const int tid = threadIdx.x;
   const int b = static_cast<int>(blockIdx.x);
   if (b >= S.nblocks) {  // rows of the last stage: forward rhs -> work, backward work -> x
@@ -1316,46 +1312,59 @@ __global__ __launch_bounds__(kSubThreads, kSubThreads / 128) void k_subblock(Sub
   const SubSweep &Q = BWD ? S.bwd : S.fwd;
   const SubDesc bd = S.desc[b];
   const int nb = bd.nrows, rb = bd.row_begin;
-  const int nent = BWD ? bd.b_nent : bd.f_nent, nlev = BWD ? bd.b_nlev : bd.f_nlev;
-  const int ent0 = BWD ? bd.b_ent_begin : bd.f_ent_begin, lev0 = BWD ? bd.b_lev_begin : bd.f_lev_begin;
-  SubLds M;
-  {
-    char *p = smem;
-    M.T = reinterpret_cast<double *>(p);      p += sub_align16(static_cast<size_t>(S.max_rows) * LD * 8);
-    M.val = reinterpret_cast<double *>(p);    p += sub_align16(static_cast<size_t>(S.max_ent + 8) * 8);
-    M.hdr = reinterpret_cast<int32_t *>(p);   p += sub_align16(static_cast<size_t>(S.max_lev + 1) * 16);
-    M.idx = reinterpret_cast<uint16_t *>(p);
-  }
-  // ---- prologue: block data -> LDS; right-hand sides -> T (backward: minus the coupling to the last stage, whose
-  // solution sits in `work`).  Loads are issued in batches ahead of the LDS stores.
-  {
-    const double *__restrict__ gv = Q.val + ent0;
-    const uint16_t *__restrict__ gi = Q.idx + ent0;
-    for (int kb = tid; kb < nent; kb += 8 * kSubThreads) {
-      double ev[8];
-      uint16_t ei[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = kb + u * kSubThreads;
-        const int kk = k < nent ? k : kb;
-        ev[u] = gv[kk];
-        ei[u] = gi[kk];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = kb + u * kSubThreads;
-        if (k < nent) {
-          M.val[k] = ev[u];
-          M.idx[k] = static_cast<uint16_t>(LD <= 16 ? ei[u] * (LD * 8) : ei[u] * LD);  // local row -> offset of its row in the tile
-        }
-      }
+  const int nlev = BWD ? bd.b_nlev : bd.f_nlev;
+  const double *__restrict__ gv = Q.val + (BWD ? bd.b_ent_begin : bd.f_ent_begin);
+  const uint16_t *__restrict__ gi = Q.idx;
+  const int4 *__restrict__ gh = reinterpret_cast<const int4 *>(Q.hdr) + (BWD ? bd.b_lev_begin : bd.f_lev_begin);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid);
+  // level headers {first row, g | npl << 8 | rows << 12, first coefficient, first index}: staged in LDS behind the tile
+  // (the loop below orders its loads with scheduling barriers, after which the compiler no longer reads global memory
+  // through the scalar cache) and handed from level to level in scalar registers
+  int4 *hl = reinterpret_cast<int4 *>(smem + ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)));
+  if (tid <= nlev) hl[tid] = gh[tid];
+  auto header = [&](int l) {
+    const int4 h = hl[l < nlev ? l : nlev];  // the closing header has no rows
+    return make_int4(__builtin_amdgcn_readfirstlane(h.x), __builtin_amdgcn_readfirstlane(h.y),
+                     __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w));
+  };
+
+  // entries of a level -> registers: one load for the lane's indices, one per coefficient slot.  Wavefronts
+  // without a row of the level and slots past its width load nothing (the load unit's instruction rate is what
+  // bounds a level once the latency is hidden: 16 unconditional loads per lane and level were 1.7 us per level).
+  auto fetch = [&](const int4 h, SubRegs &R) {
+    const int g = h.y & 0xff, npl = (h.y >> 8) & 0xf, nlane = (h.y >> 12) * g;
+    if (wave_base >= nlane) return;
+    const int lane = tid < nlane ? tid : nlane - 1;
+    if (npl > 4) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(gi + h.w + lane * 8);
+      R.i[0] = q.x, R.i[1] = q.y, R.i[2] = q.z, R.i[3] = q.w;
+    } else {
+      const uint2 q = *reinterpret_cast<const uint2 *>(gi + h.w + lane * 4);
+      R.i[0] = q.x, R.i[1] = q.y;
     }
+    const double *__restrict__ pv = gv + h.z + lane;
+#pragma unroll
+    for (int u = 0; u < kSubNpl; ++u)
+      if (u < npl) R.v[u] = pv[u * nlane];
+  };
+  SubRegs RA, RB;
+#pragma unroll
+  for (int u = 0; u < kSubNpl; ++u) RA.v[u] = RB.v[u] = 0.0;
+#pragma unroll
+  for (int u = 0; u < kSubNpl / 2; ++u) RA.i[u] = RB.i[u] = 0;
+  {
+    const int4 h = gh[0];  // before anything is ordered: through the scalar cache
+    fetch(make_int4(__builtin_amdgcn_readfirstlane(h.x), __builtin_amdgcn_readfirstlane(h.y),
+                    __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w)), RA);
   }
+
+  // ---- prologue: right-hand sides -> T (backward: minus the coupling to the last stage, whose solution sits in
+  // `work`), four coupled rows in flight
   for (int t = tid; t < nb; t += kSubThreads) {
     const int row = Q.rows[rb + t];
     double x0[LD];
     load_row<LD>(src + static_cast<size_t>(row) * LD, x0);
-    if (BWD) {  // couplings to the last stage, four rows in flight (register budget)
+    if (BWD) {
       const int ek0 = S.e_ptr[rb + t], ek1 = S.e_ptr[rb + t + 1];
       for (int kb = ek0; kb < ek1; kb += 4) {
         int ec[4];
@@ -1378,74 +1387,84 @@ __global__ __launch_bounds__(kSubThreads, kSubThreads / 128) void k_subblock(Sub
       }
     }
 #pragma unroll
-    for (int j = 0; j < LD; ++j) M.T[t * LD + j] = x0[j];
+    for (int j = 0; j < LD; ++j) T[t * LD + j] = x0[j];
   }
   __syncthreads();
+
   // ---- the triangular solve, level by level
-  constexpr int kPasses = SubPasses<LD>::value;  // rows x lanes of a level <= 160 (plan): x LD <= kPasses x 1024
-  constexpr bool kByteIdx = LD <= 16;            // 512 rows x LD x 8 bytes fit 16 bits
-  const int wave_base = __builtin_amdgcn_readfirstlane(tid);
-  const int32_t *__restrict__ gh = Q.hdr + 4 * lev0;  // wave-uniform reads: scalar loads
-  int r0 = gh[0], g = gh[1], npl = gh[2], e0 = gh[3], r1 = gh[4];
-  for (int l = 0; l < nlev; ++l) {
-    const int n_g = gh[4 * l + 5], n_npl = gh[4 * l + 6], n_e0 = gh[4 * l + 7], n_r1 = gh[4 * l + 8];  // next header
-    const int gs = 31 - __builtin_clz(g), ntask = (r1 - r0) * LD, nlane = ntask << gs;
-    double res[kPasses];
-    int at[kPasses];
+  constexpr int CW = LD <= 6 ? LD : (LD % 6 == 0 ? 6 : (LD % 5 == 0 ? 5 : 4));  // accumulators per column chunk
+  auto level = [&](int l, const int4 h, const int4 hn, SubRegs &R, SubRegs &Rnext) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the level's entries have arrived ...
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(hn, Rnext);  // ... the next level's are on their way while this one is computed
+    __builtin_amdgcn_sched_barrier(0);
+    const int4 hnn = header(l + 2);
+    const int r0 = h.x, g = h.y & 0xff, npl = (h.y >> 8) & 0xf;
+    const int gs = 31 - __builtin_clz(g), nlane = (h.y >> 12) << gs;
+    const bool active = wave_base < nlane;  // wavefront-uniform: the others go straight to the barriers
+    double res[LD];
+    if (active) {
 #pragma unroll
-    for (int ps = 0; ps < kPasses; ++ps) {
-      at[ps] = -1;
-      res[ps] = 0.0;
-      if (ps * kSubThreads + wave_base < nlane) {  // wavefront-uniform: the others go straight to the barriers
-        const int id = ps * kSubThreads + tid, task = id >> gs, part = id & (g - 1);
-        const bool live = task < ntask;
-        const int rr = live ? task / LD : 0, col = live ? task - rr * LD : 0;
-        const int k0 = e0 + __mul24((rr << gs) + part, npl);  // the lane's npl consecutive entries
-        const double *__restrict__ pv = M.val + k0;
-        const uint16_t *__restrict__ pi = M.idx + k0;
-        const char *__restrict__ tcol = reinterpret_cast<const char *>(M.T + col);
-        double s0 = 0.0;
-#pragma unroll 2
-        for (int u = 0; u < npl; ++u) {  // wave-uniform trip count (unroll 4: 24.7k -> 32.3k cycles for the levels of a block)
-          const double t = kByteIdx ? *reinterpret_cast<const double *>(tcol + pi[u])
-                                    : *reinterpret_cast<const double *>(tcol + (static_cast<int>(pi[u]) << 3));
-          s0 = fma(pv[u], t, s0);
-        }
-        res[ps] = group_sum(s0, g);
-        if (live && part == 0) at[ps] = (r0 + rr) * LD + col;
+      for (int c0 = 0; c0 < LD; c0 += CW) {
+        double s[CW];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) s[j] = 0.0;
+#pragma unroll
+        for (int u = 0; u < kSubNpl; ++u)
+          if (u < npl) {  // wave-uniform
+            const uint32_t li = (u & 1) ? R.i[u >> 1] >> 16 : R.i[u >> 1] & 0xffffu;
+            const double *__restrict__ t = reinterpret_cast<const double *>(smem + __umul24(li, LD * 8)) + c0;
+#pragma unroll
+            for (int j = 0; j < CW; ++j)
+              if (c0 + j < LD) s[j] = fma(R.v[u], t[j], s[j]);
+          }
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+          if (c0 + j < LD) res[c0 + j] = group_sum(s[j], g);
       }
     }
     __syncthreads();  // every row of the level has read the tile ...
+    if (active && tid < nlane && (tid & (g - 1)) == 0) {
+      double *__restrict__ o = reinterpret_cast<double *>(smem + __mul24(r0 + (tid >> gs), LD * 8));
 #pragma unroll
-    for (int ps = 0; ps < kPasses; ++ps)
-      if (at[ps] >= 0) M.T[at[ps]] = res[ps];
+      for (int j = 0; j < LD; ++j) o[j] = res[j];
+    }
     __syncthreads();  // ... before any of them is written
-    r0 = r1;
-    g = n_g;
-    npl = n_npl;
-    e0 = n_e0;
-    r1 = n_r1;
+    return hnn;
+  };
+  {
+    int4 h0 = header(0), h1 = header(1);
+    for (int l = 0; l < nlev; l += 2) {
+      const int4 h2 = level(l, h0, h1, RA, RB);
+      if (l + 1 >= nlev) break;
+      const int4 h3 = level(l + 1, h1, h2, RB, RA);
+      h0 = h2;
+      h1 = h3;
+    }
   }
+
   // ---- results
   for (int t = tid; t < nb; t += kSubThreads) {
     double x[LD];
 #pragma unroll
-    for (int j = 0; j < LD; ++j) x[j] = M.T[t * LD + j];
+    for (int j = 0; j < LD; ++j) x[j] = T[t * LD + j];
     store_row<LD>(dst + static_cast<size_t>(Q.rows[rb + t]) * LD, x);
   }
-  if (!BWD) {  // couplings to the last stage: aux row of target g = -sum_v L_gv y_v, 16 lanes per (target, column)
-    const int ntask = bd.ntgt * LD;
-    for (int base = 0; base < (ntask << 4); base += kSubThreads) {
-      const int id = base + tid, task = id >> 4, part = id & 15;
-      const bool live = task < ntask;
-      const int tg = bd.tgt_begin + (live ? task / LD : 0), col = live ? task % LD : 0;
+  if (!BWD) {  // couplings to the last stage: aux row of target g = -sum_v L_gv y_v, 16 lanes per target
+    const int ntgt = bd.ntgt;
+    for (int base = 0; base < (ntgt << 4); base += kSubThreads) {
+      const int id = base + tid, tq = id >> 4, part = id & 15;
+      const bool live = tq < ntgt;
+      const int tg = bd.tgt_begin + (live ? tq : 0);
       const int c0 = S.c_ptr[tg] + part, c1 = live ? S.c_ptr[tg + 1] : 0;
-      double sum = 0.0;
-      for (int kb = c0; kb < c1; kb += 8 * 16) {
-        int ci[8];
-        double cv[8];
+      double sum[LD];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+      for (int j = 0; j < LD; ++j) sum[j] = 0.0;
+      for (int kb = c0; kb < c1; kb += 4 * 16) {
+        int ci[4];
+        double cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
           const int k = kb + u * 16;
           const bool ok = k < c1;
           const int kk = ok ? k : kb;
@@ -1454,10 +1473,15 @@ __global__ __launch_bounds__(kSubThreads, kSubThreads / 128) void k_subblock(Sub
           cv[u] = ok ? v : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sum = fma(cv[u], M.T[ci[u] * LD + col], sum);
+        for (int u = 0; u < 4; ++u) {
+          const double *__restrict__ t = T + ci[u] * LD;
+#pragma unroll
+          for (int j = 0; j < LD; ++j) sum[j] = fma(cv[u], t[j], sum[j]);
+        }
       }
-      sum = group_sum(sum, 16);
-      if (live && part == 0) work[(static_cast<size_t>(S.aux_base) + S.tgt_slot[tg]) * LD + col] = sum;
+#pragma unroll
+      for (int j = 0; j < LD; ++j) sum[j] = group_sum(sum[j], 16);
+      if (live && part == 0) store_row<LD>(work + (static_cast<size_t>(S.aux_base) + S.tgt_slot[tg]) * LD, sum);
     }
   }
 }
@@ -1733,19 +1757,8 @@ template <int LD>
 static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *src, double *work, double *dst, hipStream_t st) {
   const int grid = S.nblocks + (S.ntop + kSubThreads - 1) / kSubThreads;
   if (grid <= 0) return hipSuccess;
-  const size_t lds = sub_lds_bytes(S.max_rows, S.max_ent, S.max_lev, LD);
-  if (4 * (S.max_lev + 1) > kSubThreads || static_cast<int64_t>(S.max_rows) * LD > 65535) return hipErrorInvalidValue;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {  // dynamic LDS above the default 64 KB limit
-    const void *fns[2] = {reinterpret_cast<const void *>(k_subblock<LD, false>),
-                          reinterpret_cast<const void *>(k_subblock<LD, true>)};
-    for (const void *f : fns) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
-  }
+  const size_t lds = ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(S.max_lev + 2) * 16;
+  if (S.max_level_lanes > kSubThreads || S.max_npl > kSubNpl || S.max_lev + 1 > kSubThreads || lds > 64 * 1024) return hipErrorInvalidValue;
   const dim3 g(grid), t(kSubThreads);
   if (backward) hipLaunchKernelGGL((k_subblock<LD, true>), g, t, lds, st, S, src, work, dst);
   else hipLaunchKernelGGL((k_subblock<LD, false>), g, t, lds, st, S, src, work, dst);

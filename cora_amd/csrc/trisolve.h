@@ -101,6 +101,7 @@ struct SubBlockOpHost {
   std::vector<double> c_val;                      // -L_gv
   int32_t n_aux = 0;                              // aux rows in total
   int32_t max_rows = 0, max_ent = 0, max_lev = 0; // largest block (LDS sizing); max_lev counts headers
+  int32_t max_level_lanes = 0, max_npl = 0;       // widest level (rows x lanes per row), most entries per lane
 };
 
 struct TriStage {

@@ -28,8 +28,8 @@ constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use 
 constexpr int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
 constexpr int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
-int kLaneEntries = 16;      // entries one lane of a task walks through
-constexpr int kLevelLanes = 160;     // rows x lanes per task of one level: x 24 columns <= 4 passes of 1024 threads
+int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
+int kLevelLanes = 160;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
 
 struct RowList {  // rows of one product before they are sorted into length classes
@@ -82,7 +82,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P,
                     const std::vector<int32_t> *group, int32_t aux_base) {
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
-  if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::min(8, std::max(1, std::atoi(e)));
+  if (const char *e = std::getenv("CORA_TRI_LEVEL_LANES")) kLevelLanes = std::min(256, std::max(64, std::atoi(e)));
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
   auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
     if (!timing) return;
@@ -496,8 +497,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       auto mem_pos = [&](int32_t var) { return static_cast<int32_t>(std::lower_bound(mem.begin(), mem.end(), var) - mem.begin()); };
       S0.row_begin.push_back(static_cast<int32_t>(S0.rows.size()));
       S0.nrows.push_back(nb);
-      S0.f_ent_begin.push_back(static_cast<int32_t>(S0.f_idx.size()));
-      S0.b_ent_begin.push_back(static_cast<int32_t>(S0.b_idx.size()));
+      S0.f_ent_begin.push_back(static_cast<int32_t>(S0.f_val.size()));
+      S0.b_ent_begin.push_back(static_cast<int32_t>(S0.b_val.size()));
       S0.f_lev_begin.push_back(0);  // set below
       S0.b_lev_begin.push_back(0);
       S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
@@ -531,31 +532,45 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
               if (c1 > c0 && (q - c0 > cap_rows || sn_len > w || (2 * sn_len <= w && c1 - c0 >= 16))) break;
               c1 = q;
             }
-            hdr.insert(hdr.end(), {c0, g, npl, static_cast<int32_t>(idx.size()) - ent0});
+            // header {first row, g | npl << 8 | rows << 12, first coefficient (block-relative), first index (absolute in the idx array)}
+            hdr.insert(hdr.end(), {c0, g | (npl << 8) | ((c1 - c0) << 12), static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
+            // lane p of row k takes the row's entries p, p + g, ...  Coefficients of the level: slot-major,
+            // [u][lane = (k - c0) * g + p] (the kernel streams them, one coalesced load per slot); local row indices:
+            // lane-major, [lane][4 or 8] (one load per lane), the level padded to a multiple of 8 indices
+            S0.max_level_lanes = std::max<int32_t>(S0.max_level_lanes, (c1 - c0) * g);
+            S0.max_npl = std::max<int32_t>(S0.max_npl, npl);
+            const int istride = npl <= 4 ? 4 : 8;
+            for (int u = 0; u < npl; ++u)
+              for (int k = c0; k < c1; ++k) {
+                const std::vector<Ent> &row = rows_ent[order[k]];
+                for (int p = 0; p < g; ++p) {
+                  const int e = p + u * g;
+                  val.push_back(e < static_cast<int>(row.size()) ? row[e].second : 0.0);
+                }
+              }
             for (int k = c0; k < c1; ++k) {
-              // lane p of the task takes entries p, p + g, ...: stored lane by lane (slot p * npl + u holds entry p + u * g)
               const std::vector<Ent> &row = rows_ent[order[k]];
               for (int p = 0; p < g; ++p)
-                for (int u = 0; u < npl; ++u) {
+                for (int u = 0; u < istride; ++u) {
                   const int e = p + u * g;
-                  const bool real = e < static_cast<int>(row.size());
+                  const bool real = u < npl && e < static_cast<int>(row.size());
                   idx.push_back(real ? static_cast<uint16_t>(backward ? bpos_of[mem_pos(row[e].first)] : li_of[row[e].first]) : uint16_t(0));
-                  val.push_back(real ? row[e].second : 0.0);
                 }
             }
+            while (idx.size() % 8) idx.push_back(0);
             c0 = c1;
           }
           t = t1;
         }
-        hdr.insert(hdr.end(), {nb, 1, 0, static_cast<int32_t>(idx.size()) - ent0});
+        hdr.insert(hdr.end(), {nb, 1, static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
       };
-      const int32_t fe0 = static_cast<int32_t>(S0.f_idx.size()), be0 = static_cast<int32_t>(S0.b_idx.size());
+      const int32_t fe0 = static_cast<int32_t>(S0.f_val.size()), be0 = static_cast<int32_t>(S0.b_val.size());
       S0.f_lev_begin.back() = static_cast<int32_t>(S0.f_hdr.size() / 4);
       S0.b_lev_begin.back() = static_cast<int32_t>(S0.b_hdr.size() / 4);
       emit(ford, flev, frow, false, S0.f_idx, S0.f_val, S0.f_hdr, fe0);
       emit(bord, blev, brow, true, S0.b_idx, S0.b_val, S0.b_hdr, be0);
-      S0.f_nent.push_back(static_cast<int32_t>(S0.f_idx.size()) - fe0);
-      S0.b_nent.push_back(static_cast<int32_t>(S0.b_idx.size()) - be0);
+      S0.f_nent.push_back(static_cast<int32_t>(S0.f_val.size()) - fe0);
+      S0.b_nent.push_back(static_cast<int32_t>(S0.b_val.size()) - be0);
       S0.max_lev = std::max<int32_t>(S0.max_lev, std::max<int32_t>(static_cast<int32_t>(S0.f_hdr.size() / 4) - S0.f_lev_begin.back(),
                                                                     static_cast<int32_t>(S0.b_hdr.size() / 4) - S0.b_lev_begin.back()));
       for (int k = 0; k < nb; ++k) {
@@ -620,8 +635,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     for (size_t b = 0; b < pieces.size(); ++b) {
       SubBlockOpHost &Pc = pieces[b].S;
       if (!pieces[b].groups_ok) P.groups_whole = false;
-      const int32_t row0 = static_cast<int32_t>(S0.rows.size()), fe = static_cast<int32_t>(S0.f_idx.size()),
-                    be = static_cast<int32_t>(S0.b_idx.size()), fl = static_cast<int32_t>(S0.f_hdr.size() / 4),
+      const int32_t row0 = static_cast<int32_t>(S0.rows.size()), fe = static_cast<int32_t>(S0.f_val.size()),
+                    be = static_cast<int32_t>(S0.b_val.size()), fl = static_cast<int32_t>(S0.f_hdr.size() / 4),
                     bl = static_cast<int32_t>(S0.b_hdr.size() / 4), tg = static_cast<int32_t>(S0.tgt_slot.size()),
                     e0 = static_cast<int32_t>(S0.e_col.size()), c0 = static_cast<int32_t>(S0.c_idx.size());
       S0.row_begin.push_back(row0);
@@ -638,6 +653,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       for (int32_t v : Pc.e_ptr) S0.e_ptr.push_back(e0 + v);
       append(S0.e_col, Pc.e_col);
       append(S0.e_val, Pc.e_val);
+      for (size_t q = 3; q < Pc.f_hdr.size(); q += 4) Pc.f_hdr[q] += static_cast<int32_t>(S0.f_idx.size());  // indices: absolute
+      for (size_t q = 3; q < Pc.b_hdr.size(); q += 4) Pc.b_hdr[q] += static_cast<int32_t>(S0.b_idx.size());
       append(S0.f_hdr, Pc.f_hdr);
       append(S0.b_hdr, Pc.b_hdr);
       append(S0.f_idx, Pc.f_idx);
@@ -654,6 +671,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       S0.max_rows = std::max(S0.max_rows, Pc.max_rows);
       S0.max_ent = std::max(S0.max_ent, Pc.max_ent);
       S0.max_lev = std::max(S0.max_lev, Pc.max_lev);
+      S0.max_level_lanes = std::max(S0.max_level_lanes, Pc.max_level_lanes);
+      S0.max_npl = std::max(S0.max_npl, Pc.max_npl);
       pieces[b] = Piece();
     }
     S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
@@ -815,16 +834,16 @@ double lane_tree_sum(double *part, int g) {
 void sub_levels(const int32_t *hdr, int nlev, const uint16_t *idx, const double *val, std::vector<double> &T) {
   std::vector<double> res;
   for (int l = 0; l < nlev; ++l) {
-    const int r0 = hdr[4 * l], g = hdr[4 * l + 1], npl = hdr[4 * l + 2], e0 = hdr[4 * l + 3], r1 = hdr[4 * l + 4];
+    const int r0 = hdr[4 * l], g = hdr[4 * l + 1] & 0xff, npl = (hdr[4 * l + 1] >> 8) & 0xf, e0 = hdr[4 * l + 2], i0 = hdr[4 * l + 3],
+              r1 = r0 + (hdr[4 * l + 1] >> 12);
+    const int nlane = (r1 - r0) * g, istride = npl <= 4 ? 4 : 8;
     res.assign(static_cast<size_t>(r1 - r0), 0.0);
     for (int r = r0; r < r1; ++r) {  // every row of the level reads the tile before any of them writes it
       double part[64];
       for (int p = 0; p < g; ++p) {
+        const int lane = (r - r0) * g + p;
         part[p] = 0.0;
-        for (int u = 0; u < npl; ++u) {
-          const int k = e0 + (r - r0) * g * npl + p * npl + u;
-          part[p] += val[k] * T[idx[k]];
-        }
+        for (int u = 0; u < npl; ++u) part[p] += val[e0 + u * nlane + lane] * T[idx[i0 + lane * istride + u]];
       }
       res[r - r0] = lane_tree_sum(part, g);
     }
@@ -837,7 +856,7 @@ void apply_sub_forward(const SubBlockOpHost &S, const double *rhs, double *y, do
     const int nb = S.nrows[b], rb = S.row_begin[b];
     T.assign(nb, 0.0);
     for (int l = 0; l < nb; ++l) T[l] = rhs[S.rows[rb + l]];
-    sub_levels(&S.f_hdr[4 * S.f_lev_begin[b]], S.f_lev_begin[b + 1] - S.f_lev_begin[b] - 1, &S.f_idx[S.f_ent_begin[b]],
+    sub_levels(&S.f_hdr[4 * S.f_lev_begin[b]], S.f_lev_begin[b + 1] - S.f_lev_begin[b] - 1, S.f_idx.data(),
                &S.f_val[S.f_ent_begin[b]], T);
     for (int l = 0; l < nb; ++l) y[S.rows[rb + l]] = T[l];
     for (int32_t t = S.tgt_begin[b]; t < S.tgt_begin[b + 1]; ++t) {
@@ -860,7 +879,7 @@ void apply_sub_backward(const SubBlockOpHost &S, const double *y, const double *
       for (int32_t k = S.e_ptr[rb + l]; k < S.e_ptr[rb + l + 1]; ++k) t += S.e_val[k] * xlater[S.e_col[k]];
       T[l] = t;
     }
-    sub_levels(&S.b_hdr[4 * S.b_lev_begin[b]], S.b_lev_begin[b + 1] - S.b_lev_begin[b] - 1, &S.b_idx[S.b_ent_begin[b]],
+    sub_levels(&S.b_hdr[4 * S.b_lev_begin[b]], S.b_lev_begin[b + 1] - S.b_lev_begin[b] - 1, S.b_idx.data(),
                &S.b_val[S.b_ent_begin[b]], T);
     for (int l = 0; l < nb; ++l) x[S.b_rows[rb + l]] = T[l];
   }

@@ -36,14 +36,14 @@ int main(int argc, char **argv) {
     if (S.sub) {
       const auto &B = S.sub_op;
       std::printf("    sub: %zu blocks (max %d rows, %d entries, %d headers), fwd entries %zu, bwd entries %zu, ext %zu, targets %zu (aux rows %d), headers fwd %zu bwd %zu\n",
-                  B.nrows.size(), B.max_rows, B.max_ent, B.max_lev, B.f_idx.size(), B.b_idx.size(), B.e_col.size(), B.tgt_slot.size(), B.n_aux,
+                  B.nrows.size(), B.max_rows, B.max_ent, B.max_lev, B.f_val.size(), B.b_val.size(), B.e_col.size(), B.tgt_slot.size(), B.n_aux,
                   B.f_hdr.size() / 4, B.b_hdr.size() / 4);
       for (size_t b : {size_t(0), B.nrows.size() / 2}) {
         for (int dir = 0; dir < 2; ++dir) {
           const auto &H = dir ? B.b_hdr : B.f_hdr;
           const auto &LB = dir ? B.b_lev_begin : B.f_lev_begin;
           std::printf("    block %zu %s levels (rows x g x npl):", b, dir ? "bwd" : "fwd");
-          for (int l = LB[b]; l + 1 < LB[b + 1]; ++l) std::printf(" %dx%dx%d", H[4 * (l + 1)] - H[4 * l], H[4 * l + 1], H[4 * l + 2]);
+          for (int l = LB[b]; l + 1 < LB[b + 1]; ++l) std::printf(" %dx%dx%d", H[4 * (l + 1)] - H[4 * l], H[4 * l + 1] & 0xff, (H[4 * l + 1] >> 8) & 0xf);
           std::printf("\n");
         }
       }
