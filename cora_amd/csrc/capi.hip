@@ -754,9 +754,6 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       Q.max_level_lanes = H.max_level_lanes;
       Q.max_npl = H.max_npl;
       Q.aux_base = f.plan.aux_base;
-      // the entry batches of the ext / aux gathers read (and drop) entries past a row's end
-      H.e_col.resize(H.e_col.size() + 8, 0);
-      H.e_val.resize(H.e_val.size() + 8, 0.0);
       HIP_TRY(c, up(&Q.desc, desc));
       HIP_TRY(c, up(&Q.fwd.rows, H.rows));
       H.f_hdr.resize(H.f_hdr.size() + 8, 0);  // the kernel reads one header ahead
@@ -772,9 +769,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       HIP_TRY(c, up(&Q.bwd.hdr, H.b_hdr));
       HIP_TRY(c, up(&Q.bwd.idx, H.b_idx));
       HIP_TRY(c, up(&Q.bwd.val, H.b_val));
-      HIP_TRY(c, up(&Q.e_ptr, H.e_ptr));
-      HIP_TRY(c, up(&Q.e_col, H.e_col));
-      HIP_TRY(c, up(&Q.e_val, H.e_val));
+      HIP_TRY(c, up(&Q.tgt_row, H.tgt_row));
       HIP_TRY(c, up(&Q.tgt_slot, H.tgt_slot));
       HIP_TRY(c, up(&Q.c_ptr, H.c_ptr));
       HIP_TRY(c, up(&Q.c_idx, H.c_idx));

@@ -109,8 +109,7 @@ struct SubSweep {  // one direction of the solve; rows are numbered by level wit
 struct SubOpDev {
   const SubDesc *desc;
   SubSweep fwd, bwd;
-  const int32_t *e_ptr, *e_col;  // backward: per row, couplings to the last stage
-  const double *e_val;
+  const int32_t *tgt_row;        // backward: rows of the last stage coupled to the block, staged behind the block's rows in the tile
   const int32_t *tgt_slot, *c_ptr;  // forward: aux rows written for the last stage
   const uint16_t *c_idx;
   const double *c_val;

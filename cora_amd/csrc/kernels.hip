@@ -1358,36 +1358,25 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
                     __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w)), RA);
   }
 
-  // ---- prologue: right-hand sides -> T (backward: minus the coupling to the last stage, whose solution sits in
-  // `work`), four coupled rows in flight
-  for (int t = tid; t < nb; t += kSubThreads) {
-    const int row = Q.rows[rb + t];
-    double x0[LD];
-    load_row<LD>(src + static_cast<size_t>(row) * LD, x0);
-    if (BWD) {
-      const int ek0 = S.e_ptr[rb + t], ek1 = S.e_ptr[rb + t + 1];
-      for (int kb = ek0; kb < ek1; kb += 4) {
-        int ec[4];
-        double evv[4];
+  // ---- prologue: right-hand sides -> T; backward: behind them the later stage's solution (it sits in `work`) at the
+  // rows coupled to the block, which the block's entries address as rows nb + k.  Two rows per lane in flight.
+  {
+    const int nfill = nb + (BWD ? bd.ntgt : 0);
+    auto row_ptr = [&](int t) -> const double * {
+      if (!BWD || t < nb) return src + static_cast<size_t>(Q.rows[rb + t]) * LD;
+      return work + static_cast<size_t>(S.tgt_row[bd.tgt_begin + (t - nb)]) * LD;
+    };
+    for (int t0 = tid; t0 < nfill; t0 += 2 * kSubThreads) {
+      const int t1 = t0 + kSubThreads < nfill ? t0 + kSubThreads : t0;
+      const double *p0 = row_ptr(t0), *p1 = row_ptr(t1);
+      double x0[LD], x1[LD];
+      load_row<LD>(p0, x0);
+      load_row<LD>(p1, x1);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool ok = kb + u < ek1;
-          const int kk = ok ? kb + u : kb;
-          ec[u] = S.e_col[kk];
-          const double v = S.e_val[kk];
-          evv[u] = ok ? v : 0.0;
-        }
+      for (int j = 0; j < LD; ++j) T[t0 * LD + j] = x0[j];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          double xr[LD];
-          load_row<LD>(work + static_cast<size_t>(ec[u]) * LD, xr);
-#pragma unroll
-          for (int j = 0; j < LD; ++j) x0[j] = fma(evv[u], xr[j], x0[j]);
-        }
-      }
+      for (int j = 0; j < LD; ++j) T[t1 * LD + j] = x1[j];
     }
-#pragma unroll
-    for (int j = 0; j < LD; ++j) T[t * LD + j] = x0[j];
   }
   __syncthreads();
 

@@ -85,8 +85,7 @@ struct SubBlockOpHost {
   std::vector<int32_t> rows;                      // internal row
   // the backward sweep numbers the block's rows by backward level (position k, stored at row_begin + k)
   std::vector<int32_t> b_rows;                    // internal row of backward position k
-  std::vector<int32_t> e_ptr, e_col;              // ext: per backward position, (row in the later stage's vector, -L) pairs
-  std::vector<double> e_val;
+  std::vector<int32_t> tgt_row;                   // per target: its row in the vectors (the backward sweep stages x[tgt_row] in tile row nrows + k)
   // per level: {first row of the level (block-relative), lanes per task g (power of two <= 64), entries per lane
   // npl (<= 8), first entry (block-relative)}; every row of the level holds exactly g * npl entries (null padded);
   // nlev + 1 headers per block, the last one closes the row range

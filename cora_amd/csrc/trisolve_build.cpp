@@ -29,7 +29,7 @@ constexpr int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows 
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
 constexpr int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
 int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
-int kLevelLanes = 160;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
+int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
 
 struct RowList {  // rows of one product before they are sorted into length classes
@@ -407,6 +407,15 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       for (int sidx = 0; sidx < nsn; ++sidx)
         for (int t = sn_begin[sidx]; t < sn_begin[sidx + 1]; ++t) sn_id[t] = sidx;
       using Ent = std::pair<int32_t, double>;  // (variable, coefficient)
+      // later-stage variables coupled to the block ("targets"), sorted; the backward sweep finds their solution in
+      // the rows nb + k of its tile (pseudo-variable m + k in the entry lists below)
+      for (int32_t v : mem)
+        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q)
+          if (!inside(Li[q])) tgt_var.push_back(Li[q]);
+      std::sort(tgt_var.begin(), tgt_var.end());
+      tgt_var.erase(std::unique(tgt_var.begin(), tgt_var.end()), tgt_var.end());
+      const int ntg = static_cast<int>(tgt_var.size());
+      auto tgt_of = [&](int32_t var) { return static_cast<int32_t>(std::lower_bound(tgt_var.begin(), tgt_var.end(), var) - tgt_var.begin()); };
       std::vector<std::vector<Ent>> frow(static_cast<size_t>(nb)), brow(static_cast<size_t>(nb));
       auto add_to = [](std::vector<Ent> &row, int32_t var, double val) {
         for (Ent &e : row)
@@ -460,6 +469,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
               if (Li[e] >= vend && inside(Li[e])) {
                 add_to(row, Li[e], -W[q * sz + i] * Lx[e]);
                 lev = std::max(lev, blev[Li[e]] + 1);
+              } else if (Li[e] >= vend) {  // coupling to the later stage: reads the staged row of the target
+                add_to(row, m + tgt_of(Li[e]), -W[q * sz + i] * Lx[e]);
               }
           }
         }
@@ -554,7 +565,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
                 for (int u = 0; u < istride; ++u) {
                   const int e = p + u * g;
                   const bool real = u < npl && e < static_cast<int>(row.size());
-                  idx.push_back(real ? static_cast<uint16_t>(backward ? bpos_of[mem_pos(row[e].first)] : li_of[row[e].first]) : uint16_t(0));
+                  idx.push_back(real ? static_cast<uint16_t>(row[e].first >= m ? nb + (row[e].first - m) : backward ? bpos_of[mem_pos(row[e].first)] : li_of[row[e].first]) : uint16_t(0));
                 }
             }
             while (idx.size() % 8) idx.push_back(0);
@@ -577,12 +588,6 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         S0.rows.push_back(row_of[mem[ford[k]]]);
         const int32_t v = mem[bord[k]];
         S0.b_rows.push_back(row_of[v]);
-        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q)
-          if (!inside(Li[q])) {
-            S0.e_col.push_back(row_of[Li[q]]);
-            S0.e_val.push_back(-Lx[q]);
-          }
-        S0.e_ptr.push_back(static_cast<int32_t>(S0.e_col.size()));
       }
       (void)nfl;
       (void)nbl;
@@ -598,14 +603,14 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       for (size_t t = 0; t < trip.size(); ++t) {
         if (t == 0 || trip[t].first != trip[t - 1].first) {
           if (t > 0) S0.c_ptr.push_back(static_cast<int32_t>(S0.c_idx.size()));
-          tgt_var.push_back(trip[t].first);
           S0.tgt_slot.push_back(S0.n_aux++);
+          S0.tgt_row.push_back(row_of[trip[t].first]);
         }
         S0.c_idx.push_back(static_cast<uint16_t>(trip[t].second.first));
         S0.c_val.push_back(trip[t].second.second);
       }
       if (!trip.empty()) S0.c_ptr.push_back(static_cast<int32_t>(S0.c_idx.size()));
-      S0.max_rows = std::max(S0.max_rows, nb);
+      S0.max_rows = std::max(S0.max_rows, nb + ntg);
       S0.max_ent = std::max<int32_t>(S0.max_ent, std::max<int32_t>(static_cast<int32_t>(S0.f_idx.size()) - fe0,
                                                                     static_cast<int32_t>(S0.b_idx.size()) - be0));
     };
@@ -629,7 +634,6 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     }
     tick("blocks (threads)");
     SubBlockOpHost &S0 = SG;
-    S0.e_ptr.push_back(0);
     S0.c_ptr.push_back(0);
     auto append = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
     for (size_t b = 0; b < pieces.size(); ++b) {
@@ -638,7 +642,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       const int32_t row0 = static_cast<int32_t>(S0.rows.size()), fe = static_cast<int32_t>(S0.f_val.size()),
                     be = static_cast<int32_t>(S0.b_val.size()), fl = static_cast<int32_t>(S0.f_hdr.size() / 4),
                     bl = static_cast<int32_t>(S0.b_hdr.size() / 4), tg = static_cast<int32_t>(S0.tgt_slot.size()),
-                    e0 = static_cast<int32_t>(S0.e_col.size()), c0 = static_cast<int32_t>(S0.c_idx.size());
+                    c0 = static_cast<int32_t>(S0.c_idx.size());
       S0.row_begin.push_back(row0);
       S0.nrows.push_back(Pc.nrows[0]);
       S0.f_ent_begin.push_back(fe);
@@ -650,9 +654,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       S0.tgt_begin.push_back(tg);
       append(S0.rows, Pc.rows);
       append(S0.b_rows, Pc.b_rows);
-      for (int32_t v : Pc.e_ptr) S0.e_ptr.push_back(e0 + v);
-      append(S0.e_col, Pc.e_col);
-      append(S0.e_val, Pc.e_val);
+      append(S0.tgt_row, Pc.tgt_row);
       for (size_t q = 3; q < Pc.f_hdr.size(); q += 4) Pc.f_hdr[q] += static_cast<int32_t>(S0.f_idx.size());  // indices: absolute
       for (size_t q = 3; q < Pc.b_hdr.size(); q += 4) Pc.b_hdr[q] += static_cast<int32_t>(S0.b_idx.size());
       append(S0.f_hdr, Pc.f_hdr);
@@ -872,13 +874,10 @@ void apply_sub_forward(const SubBlockOpHost &S, const double *rhs, double *y, do
 void apply_sub_backward(const SubBlockOpHost &S, const double *y, const double *xlater, double *x) {
   std::vector<double> T;
   for (size_t b = 0; b < S.nrows.size(); ++b) {
-    const int nb = S.nrows[b], rb = S.row_begin[b];
-    T.assign(nb, 0.0);
-    for (int l = 0; l < nb; ++l) {
-      double t = y[S.b_rows[rb + l]];
-      for (int32_t k = S.e_ptr[rb + l]; k < S.e_ptr[rb + l + 1]; ++k) t += S.e_val[k] * xlater[S.e_col[k]];
-      T[l] = t;
-    }
+    const int nb = S.nrows[b], rb = S.row_begin[b], ntg = S.tgt_begin[b + 1] - S.tgt_begin[b];
+    T.assign(nb + ntg, 0.0);
+    for (int l = 0; l < nb; ++l) T[l] = y[S.b_rows[rb + l]];
+    for (int k = 0; k < ntg; ++k) T[nb + k] = xlater[S.tgt_row[S.tgt_begin[b] + k]];  // the later stage's solution
     sub_levels(&S.b_hdr[4 * S.b_lev_begin[b]], S.b_lev_begin[b + 1] - S.b_lev_begin[b] - 1, S.b_idx.data(),
                &S.b_val[S.b_ent_begin[b]], T);
     for (int l = 0; l < nb; ++l) x[S.b_rows[rb + l]] = T[l];

@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     if (S.sub) {
       const auto &B = S.sub_op;
       std::printf("    sub: %zu blocks (max %d rows, %d entries, %d headers), fwd entries %zu, bwd entries %zu, ext %zu, targets %zu (aux rows %d), headers fwd %zu bwd %zu\n",
-                  B.nrows.size(), B.max_rows, B.max_ent, B.max_lev, B.f_val.size(), B.b_val.size(), B.e_col.size(), B.tgt_slot.size(), B.n_aux,
+                  B.nrows.size(), B.max_rows, B.max_ent, B.max_lev, B.f_val.size(), B.b_val.size(), B.tgt_row.size(), B.tgt_slot.size(), B.n_aux,
                   B.f_hdr.size() / 4, B.b_hdr.size() / 4);
       for (size_t b : {size_t(0), B.nrows.size() / 2}) {
         for (int dir = 0; dir < 2; ++dir) {
