@@ -358,6 +358,10 @@ class Context:
     def profile_stpcg(self, on=True):
         self._chk(self.L.cora_debug_profile_stpcg(self.h, int(on)))
 
+    def stpcg_path(self):
+        """Iteration form of the last stpcg_dev call: 0 unfused, 1 fused vector passes, 2 sweep-fused."""
+        return int(self.L.cora_debug_stpcg_path(self.h))
+
     def stpcg_hvp_us(self):
         """(mean microseconds, count) of the Hessian-vector products of the last stpcg_dev call (profile_stpcg on)."""
         us, cnt = C.c_double(), C.c_int()

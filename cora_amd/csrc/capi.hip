@@ -59,6 +59,8 @@ struct cora_ctx {
     std::vector<DevStage> stages;
     std::vector<void *> allocs;
     int aux_rows = 0;  // two-stage plans: rows appended to the work vector
+    bool fuse_ok = false;  // substitution blocks whose tiles hold every pose's rotation rows at consecutive positions:
+                           // the STPCG passes can be fused into the sweeps (SubFuse, kernels.h)
     bool ready = false;
   };
   DevFactor precond_f, implicit_f, aux_f;  // aux_f: the caller's own factor (cora_aux_set_cholesky)
@@ -94,6 +96,7 @@ struct cora_ctx {
   std::vector<hipEvent_t> prof_events;
   double prof_hvp_us = 0.0;
   int prof_hvp_count = 0;
+  int stpcg_path = 0;  // iteration form of the last cora_stpcg_dev: 0 unfused, 1 fused vector passes, 2 sweep-fused
   std::vector<void *> user_allocs;
   std::string err;
 };
@@ -673,6 +676,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
   f.stages.clear();
   f.ready = false;
   f.aux_rows = 0;
+  f.fuse_ok = false;
   try {
     build_tri_plan(m, Lp, Li, Lx, row_of, zero_row, f.plan, group, static_cast<int32_t>(c->F.L.rows));
   } catch (const std::exception &e) {
@@ -754,7 +758,6 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       Q.max_level_lanes = H.max_level_lanes;
       Q.max_npl = H.max_npl;
       Q.aux_base = f.plan.aux_base;
-      HIP_TRY(c, up(&Q.desc, desc));
       HIP_TRY(c, up(&Q.fwd.rows, H.rows));
       H.f_hdr.resize(H.f_hdr.size() + 8, 0);  // the kernel reads one header ahead
       H.f_idx.resize(H.f_idx.size() + 8, 0);  // ... and an entry past a block without entries
@@ -776,6 +779,63 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       HIP_TRY(c, up(&Q.c_val, H.c_val));
       HIP_TRY(c, up(&Q.top_rows, f.plan.top_rows));
       f.aux_rows = H.n_aux;
+      {
+        // memory-order I/O lists of both sweeps: {internal row, tile position} of every block row, sorted by row
+        auto io_of = [&](const std::vector<int32_t> &rows) {
+          std::vector<int2> io(rows.size());
+          std::vector<int32_t> ord;
+          for (size_t b = 0; b < desc.size(); ++b) {
+            const int32_t r0 = desc[b].row_begin, nb = desc[b].nrows;
+            ord.resize(static_cast<size_t>(nb));
+            for (int k = 0; k < nb; ++k) ord[k] = k;
+            std::sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return rows[r0 + x] < rows[r0 + y]; });
+            for (int k = 0; k < nb; ++k) io[static_cast<size_t>(r0) + k] = make_int2(rows[r0 + ord[k]], ord[k]);
+          }
+          io.push_back(make_int2(0, 0));  // a block without rows still forms an address
+          return io;
+        };
+        HIP_TRY(c, up(&Q.fwd.io, io_of(H.rows)));
+        HIP_TRY(c, up(&Q.bwd.io, io_of(H.b_rows)));
+        // fused projection in the backward sweep: the first rotation row of a pose finds the others right behind it
+        // in the tile, and a pose of the last stage has all its rows there.  Row units of a block: {tile position, row}
+        const Layout &L = c->F.L;
+        const int64_t rot0 = L.rot_base, rot1 = L.rot_base + static_cast<int64_t>(L.d) * L.nl_poses;
+        bool ok = group != nullptr && L.world == 1;
+        std::vector<int2> units;
+        for (size_t b = 0; b < desc.size(); ++b) {
+          const int32_t *rows = H.b_rows.data() + desc[b].row_begin;
+          const int nb = desc[b].nrows;
+          int64_t leaders = 0, rot_rows = 0;
+          desc[b].unit_begin = static_cast<int32_t>(units.size());
+          for (int k = 0; k < nb; ++k) {
+            if (rows[k] < rot0 || rows[k] >= rot1) {
+              units.push_back(make_int2(k, rows[k]));
+              continue;
+            }
+            ++rot_rows;
+            if ((rows[k] - rot0) % L.d != 0) continue;
+            ++leaders;
+            units.push_back(make_int2(k, rows[k]));
+            for (int a = 1; a < L.d && ok; ++a) ok = k + a < nb && rows[k + a] == rows[k] + a;
+          }
+          desc[b].nunits = static_cast<int32_t>(units.size()) - desc[b].unit_begin;
+          ok = ok && rot_rows == leaders * L.d;
+        }
+        units.push_back(make_int2(0, 0));
+        HIP_TRY(c, up(&Q.b_unit, units));
+        if (ok) {
+          std::vector<char> in_top(static_cast<size_t>(L.rows), 0);
+          for (int32_t r : f.plan.top_rows) in_top[r] = 1;
+          for (int32_t r : f.plan.top_rows)
+            if (r >= rot0 && r < rot1) {
+              const int64_t lead = r - (r - rot0) % L.d;
+              for (int a = 0; a < L.d && ok; ++a) ok = in_top[lead + a] != 0;
+            }
+        }
+        f.fuse_ok = ok;
+        if (std::getenv("CORA_TRI_TIMING")) std::fprintf(stderr, "  [tri plan] sweep fusion possible: %d\n", int(ok));
+      }
+      HIP_TRY(c, up(&Q.desc, desc));
       H = SubBlockOpHost();
       continue;
     }
@@ -1187,17 +1247,71 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
   const bool fused = !c->implicit && c->ld <= 12 && n % 2 == 0 && (off * sizeof(double)) % 16 == 0 &&
                      !std::getenv("CORA_NO_FUSE");
+  // Sweep-fused iteration (the above, with a two-stage Cholesky solve plan): five passes and a scalar step --
+  //   Hp = H p with the partials of kappa | kappa | forward sweep on r += alpha Hp with <r, r> | last stage (2 products) |
+  //   backward sweep with v = Proj_Y(x) and <r, v> | s += alpha p, p = -v + beta p
+  bool sweep_fused = false;
+  SubFuse FF, FB;
+  double *kappa_partial = nullptr;
+  int kappa_blocks = 0;
   if (fused) {
     const RowArgs R = row_args(c);
     const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
-    if ((rc = ensure_red(c, std::max<size_t>(4 * 512, static_cast<size_t>((units + 255) / 256) + 8)))) return rc;
+    size_t need = std::max<size_t>(4 * 512, static_cast<size_t>((units + 255) / 256) + 8);
+    const cora_ctx::DevFactor &f = c->precond_f;
+    sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 &&
+                  !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
+    if (sweep_fused) {
+      need = std::max<size_t>(need, static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8);
+      kappa_blocks = launch_spmm_blocks(spmm_args(c, dP, dHp));
+    }
+    if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks)))) return rc;
     D.partial = c->d_red;
+    kappa_partial = c->d_red + need;
+    if (sweep_fused) {
+      const Layout &L = c->F.L;
+      FF.dot = D;
+      FF.dot.count = 1;
+      FF.dot.mode = DOTS_STPCG_RR;
+      FF.dot.seq_out = nullptr;
+      FF.dot.seq = 0;
+      FF.Hp = dHp;
+      FF.r = dR;
+      FF.d = L.d;
+      FF.rot_base = L.rot_base;
+      FF.rng_base = L.rng_base;
+      FF.trn_base = L.trn_base;
+      FB = FF;
+      FB.dot.mode = DOTS_STPCG_RV;
+      FB.dot.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+      FB.Y = c->d_Y;
+    }
   }
+  c->stpcg_path = sweep_fused ? 2 : fused ? 1 : 0;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
     for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
       const bool prof = c->prof_stpcg && 2 * static_cast<size_t>(enqueued) + 1 < c->prof_events.size();
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
+      if (sweep_fused) {
+        SpmmArgs A = spmm_args(c, dP, dHp);
+        A.kappa_partial = kappa_partial;
+        HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP_K, c->stream));
+        if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
+        HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
+        cora_ctx::DevFactor &f = c->precond_f;
+        double *t, *t2;
+        if ((rc = get_scratch(c, 6, c->ld, &t, f.aux_rows))) return rc;
+        if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
+        const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
+        HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
+        HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream));
+        HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream));
+        FB.dot.seq = seq = ++c->dot_seq;
+        HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
+        HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
+        continue;
+      }
       if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
       int nblocks = 0;
@@ -1313,6 +1427,8 @@ int cora_debug_profile_stpcg(cora_ctx *c, int on) {
   }
   return CORA_OK;
 }
+
+int cora_debug_stpcg_path(const cora_ctx *c) { return c ? c->stpcg_path : -1; }
 
 int cora_debug_stpcg_hvp_us(cora_ctx *c, double *mean_us, int *count) {
   if (!c || !mean_us || !count) return CORA_ERR_ARG;

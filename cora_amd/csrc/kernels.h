@@ -10,7 +10,9 @@
 
 namespace cora {
 
-enum Epilogue : int { EPI_NONE = 0, EPI_S = 1, EPI_HVP = 2 };
+// EPI_HVP_K: EPI_HVP that also leaves per-block partial sums of <X, out> in SpmmArgs::kappa_partial (the curvature
+// kappa = <p, Hp> of an STPCG iteration without a pass of its own)
+enum Epilogue : int { EPI_NONE = 0, EPI_S = 1, EPI_HVP = 2, EPI_HVP_K = 3 };
 
 struct SpmmArgs {
   const SliceDesc *slices;
@@ -32,7 +34,10 @@ struct SpmmArgs {
   const double *Y;     // current point (epilogues)
   const double *lam_st;  // [local pose][d*d]
   const double *lam_ob;  // [local range]
+  double *kappa_partial = nullptr;  // EPI_HVP_K: [launch_spmm_blocks()] one partial sum per block
 };
+// number of blocks (= kappa partials) of a launch with these arguments
+inline int launch_spmm_blocks(const SpmmArgs &A) { return ((A.n_chunks + 7) & ~7) + 8 * ((A.n_slices + 7) / 8); }
 
 struct RowArgs {
   int d;
@@ -93,11 +98,12 @@ struct BlockOpDev {
   int nblocks;
 };
 // Device copy of a SubBlockOpHost (trisolve.h): stage 0 as workgroup blocks solved by substitution in LDS.
-struct SubDesc {  // 48 bytes per block
+struct SubDesc {  // 56 bytes per block
   int32_t row_begin, nrows;
   int32_t f_ent_begin, f_nent, b_ent_begin, b_nent;
   int32_t f_lev_begin, f_nlev, b_lev_begin, b_nlev;
   int32_t tgt_begin, ntgt;
+  int32_t unit_begin, nunits;  // backward, fused projection: the block's row units in SubOpDev::b_unit
 };
 struct SubSweep {  // one direction of the solve; rows are numbered by level within the block
   const int32_t *rows;      // [row_begin + k]: internal row
@@ -105,6 +111,9 @@ struct SubSweep {  // one direction of the solve; rows are numbered by level wit
   const uint16_t *idx;      // local row a block entry multiplies: per level [lane = row * g + part][4 or 8]
   // val: per level [slot u < npl][lane]
   const double *val;        // coefficient
+  // [row_begin + k]: {internal row, tile position} of the block's k-th row in MEMORY order: the tile is filled and
+  // written back element by element in that order (a block is a few runs of consecutive rows: coalesced)
+  const int2 *io;
 };
 struct SubOpDev {
   const SubDesc *desc;
@@ -114,9 +123,31 @@ struct SubOpDev {
   const uint16_t *c_idx;
   const double *c_val;
   const int32_t *top_rows;  // rows of the last stage + the pinned row
+  const int2 *b_unit;       // backward, fused projection: {tile position, internal row} of every row unit of a block (a pose's
+                            // first rotation row -- the others follow it in the tile --, a range row, a translation row)
   int nblocks, ntop, max_rows, max_ent, max_lev, aux_base;
   int max_level_lanes, max_npl;  // widest level (rows x lanes per row) and most entries per lane of the plan
 };
+// STPCG passes fused into the two sweeps (cora_stpcg_dev; one shard, explicit formulation):
+//   forward : the right-hand side IS the residual and is updated on the way in:  r += coef_r Hp  with <r, r>
+//             (dot.mode = DOTS_STPCG_RR); every row of the vector is a block row or a row of the last stage
+//   backward: the solution is projected on the way out:  v = Proj_Y(x)  with <r, v>  (DOTS_STPCG_RV); needs the d
+//             rotation rows of a pose at consecutive tile positions (checked when the factor is installed)
+// dot.partial holds one slot per block of the launch (launch_subblock_blocks).
+struct SubFuse {
+  DotArgs dot;
+  const double *Hp = nullptr;  // forward
+  double *r = nullptr;         // forward: the right-hand side (updated in place); backward: read for <r, v>
+  const double *Y = nullptr;   // backward: the current point
+  int d = 0;
+  int64_t rot_base = 0, rng_base = 0, trn_base = 0;  // internal rows: rotations | ranges | translations
+};
+inline int launch_subblock_blocks(const SubOpDev &S) { return S.nblocks + (S.ntop + 255) / 256; }
+hipError_t launch_subblock_fused(const SubOpDev &S, int ld, bool backward, const SubFuse &F, double *work, double *out,
+                                 hipStream_t st);
+// kappa = sum of the n per-block partials of an EPI_HVP_K product (fixed order), then the scalar step that follows it
+hipError_t launch_kappa_finish(const double *partial, int n, StpcgState *state, hipStream_t st);
+
 // forward : y[block rows] = L_bb^-1 rhs[block rows] -> y;  work[aux rows] = couplings to the last stage;  work[top rows] = rhs[top rows]
 // backward: x[block rows] = L_bb^-T (y[block rows] - L[top, rows]^T work[top rows]) -> x (may be y);  x[top rows] = work[top rows]
 hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const double *rhs_or_y, double *work, double *out,

@@ -122,8 +122,9 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm) {
 // Blocks [0, n_chunks) handle chunks of the long (landmark) rows instead.
 // ---------------------------------------------------------------------------
 // One wavefront per chunk of a long (landmark) row.
-template <int LD>
-__device__ __forceinline__ void long_chunk_wave(const SpmmArgs &A, int ci) {
+// Returns (EPI_HVP_K only, meaningful in the lanes j < LD of the wavefront that finishes the row) out[row][j] X[row][j].
+template <int LD, bool KAPPA>
+__device__ __forceinline__ double long_chunk_wave(const SpmmArgs &A, int ci) {
   const LongChunk ch = A.chunks[ci];
   const int lane = threadIdx.x;
   double acc[LD];
@@ -147,7 +148,7 @@ __device__ __forceinline__ void long_chunk_wave(const SpmmArgs &A, int ci) {
   double *orow = A.out + static_cast<size_t>(ch.row) * LD;
   if (ch.nchunks == 1) {
     if (lane < LD) orow[lane] = tot;
-    return;
+    return (KAPPA && lane < LD) ? tot * A.X[static_cast<size_t>(ch.row) * LD + lane] : 0.0;
   }
   // several chunks: publish the partial WRITE-THROUGH (sc1 stores, so no L2
   // release fence is needed), drain, take a ticket; the last arriver re-reads
@@ -182,7 +183,9 @@ __device__ __forceinline__ void long_chunk_wave(const SpmmArgs &A, int ci) {
     for (; c < ch.nchunks; ++c)
       s += __hip_atomic_load(P + static_cast<size_t>(c) * kMaxLD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     orow[lane] = s;
+    if (KAPPA) return s * A.X[static_cast<size_t>(ch.row) * LD + lane];
   }
+  return 0.0;
 }
 
 // V_i - sym(Y_i V_i^T) Y_i for one pose held entirely by this thread
@@ -207,7 +210,7 @@ __device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
 
 // Pose slice: lane = pose, d x LD accumulators, one X-row gather per d nonzeros.
 template <int LD, int D, int EPI>
-__device__ __forceinline__ void pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
+__device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
@@ -231,8 +234,10 @@ __device__ __forceinline__ void pose_slice(const SpmmArgs &A, const SliceDesc &s
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
   }
-  if (lane >= sd.nrows) return;
+  if (lane >= sd.nrows) return 0.0;
   const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(lane) * D;
+  constexpr bool kKeepX = EPI == EPI_HVP_K && D * LD <= 18;  // the pose's own rows of X stay in registers for <X, out>
+  double xs[kKeepX ? D : 1][LD];
   if (EPI != EPI_NONE) {
     const double *Lp = A.lam_st + static_cast<size_t>(sd.aux0 + lane) * (D * D);
 #pragma unroll
@@ -245,8 +250,12 @@ __device__ __forceinline__ void pose_slice(const SpmmArgs &A, const SliceDesc &s
 #pragma unroll
         for (int j = 0; j < LD; ++j) acc[a][j] = fma(-lam, x[j], acc[a][j]);
       }
+      if (kKeepX) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) xs[kKeepX ? b : 0][j] = x[j];
+      }
     }
-    if (EPI == EPI_HVP) {
+    if (EPI >= EPI_HVP) {
       double y[D][LD];
 #pragma unroll
       for (int b = 0; b < D; ++b) load_row<LD>(A.Y + (prow + b) * LD, y[b]);
@@ -255,39 +264,27 @@ __device__ __forceinline__ void pose_slice(const SpmmArgs &A, const SliceDesc &s
   }
 #pragma unroll
   for (int a = 0; a < D; ++a) store_row<LD>(A.out + (prow + a) * LD, acc[a]);
+  double kap = 0.0;
+  if (EPI == EPI_HVP_K) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      if (kKeepX) {
+        kap += dot_row<LD>(xs[kKeepX ? a : 0], acc[a]);
+      } else {
+        double x[LD];
+        load_row<LD>(X + (prow + a) * LD, x);
+        kap += dot_row<LD>(x, acc[a]);
+      }
+    }
+  }
+  return kap;
 }
 
-#ifndef CORA_SPMM_WAVES_PER_EU
-#define CORA_SPMM_WAVES_PER_EU 2
-#endif
-// The kernel is latency bound unless each wave keeps many loads in flight, so
-// let the register allocator spend registers (>= 2 waves / SIMD) instead of
-// squeezing for occupancy: measured 31.3 -> 20.4 us on the 10^5-pose graph.
+// One wavefront, one slice (lane = row, or lane = pose for the rotation rows).  Returns the lane's share of
+// <X, out> over the rows it wrote (EPI_HVP_K; 0 otherwise).
 template <int LD, int D, int EPI>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM_WAVES_PER_EU)))
-void k_spmm(const SpmmArgs A) {
-  // one wavefront per block: the dispatcher balances the (uneven) slices
-  if (static_cast<int>(blockIdx.x) < A.n_chunks) {
-    // chunk blocks, also one contiguous range of the (column-sorted) launch order per XCD
-    const int tc = static_cast<int>(blockIdx.x);
-    const int cper = A.n_chunks >> 3;  // n_chunks is a multiple of 8
-    const int pos = (tc & 7) * cper + (tc >> 3);
-    if (pos < A.n_real_chunks) long_chunk_wave<LD>(A, A.chunk_order[pos]);
-    return;
-  }
-  const int lane = threadIdx.x;
-  // Slice blocks: XCD x (= blockIdx % 8, observed dispatch order; speed only)
-  // walks its own contiguous eighth of the slice list, so neighbouring slices
-  // share one L2.  n_chunks is padded to a multiple of 8 by the launcher.
-  const int t = static_cast<int>(blockIdx.x) - A.n_chunks;
-  const int per_xcd = (A.n_slices + 7) >> 3;
-  const int s = (t & 7) * per_xcd + (t >> 3);
-  if ((t >> 3) >= per_xcd || s >= A.n_slices) return;
-  const SliceDesc sd = A.slices[s];
-  if (sd.type == kSliceStiefel) {
-    pose_slice<LD, D, EPI>(A, sd, lane);
-    return;
-  }
+__device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc sd, int lane) {
+  if (sd.type == kSliceStiefel) return pose_slice<LD, D, EPI>(A, sd, lane);
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
@@ -306,28 +303,72 @@ void k_spmm(const SpmmArgs A) {
     for (int j = 0; j < LD; ++j) acc[j] = fma(v, x[j], acc[j]);
   }
 
-  if (lane >= sd.nrows) return;
+  if (lane >= sd.nrows) return 0.0;
   if (sd.type == kSliceOblique) {
     const size_t row = static_cast<size_t>(sd.row0) + lane;
+    double kap = 0.0;
     if (EPI != EPI_NONE) {
       const double lam = A.lam_ob[sd.aux0 + lane];
       double x[LD];
       load_row<LD>(X + row * LD, x);
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
-      if (EPI == EPI_HVP) {
+      if (EPI >= EPI_HVP) {
         double y[LD];
         load_row<LD>(A.Y + row * LD, y);
         const double ip = dot_row<LD>(y, acc);
 #pragma unroll
         for (int j = 0; j < LD; ++j) acc[j] = fma(-ip, y[j], acc[j]);
       }
+      if (EPI == EPI_HVP_K) kap = dot_row<LD>(x, acc);
     }
     store_row<LD>(A.out + row * LD, acc);
+    return kap;
+  }
+  const size_t row = (sd.type == kSliceEuclidPerm) ? static_cast<size_t>(A.perm[sd.row0 + lane])
+                                                   : static_cast<size_t>(sd.row0) + lane;
+  store_row<LD>(A.out + row * LD, acc);
+  if (EPI == EPI_HVP_K) {
+    double x[LD];
+    load_row<LD>(X + row * LD, x);
+    return dot_row<LD>(x, acc);
+  }
+  return 0.0;
+}
+
+#ifndef CORA_SPMM_WAVES_PER_EU
+#define CORA_SPMM_WAVES_PER_EU 2
+#endif
+// The kernel is latency bound unless each wave keeps many loads in flight, so
+// let the register allocator spend registers (>= 2 waves / SIMD) instead of
+// squeezing for occupancy: measured 31.3 -> 20.4 us on the 10^5-pose graph.
+template <int LD, int D, int EPI>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM_WAVES_PER_EU)))
+void k_spmm(const SpmmArgs A) {
+  // one wavefront per block: the dispatcher balances the (uneven) slices.
+  // EPI_HVP_K: the wavefront also leaves sum <X[row], out[row]> over the rows it finished in
+  // kappa_partial[blockIdx.x] (every block writes its slot; k_kappa_finish adds them in block order).
+  constexpr bool KAPPA = EPI == EPI_HVP_K;
+  const int lane = threadIdx.x;
+  double kap = 0.0;
+  if (static_cast<int>(blockIdx.x) < A.n_chunks) {
+    // chunk blocks, also one contiguous range of the (column-sorted) launch order per XCD
+    const int tc = static_cast<int>(blockIdx.x);
+    const int cper = A.n_chunks >> 3;  // n_chunks is a multiple of 8
+    const int pos = (tc & 7) * cper + (tc >> 3);
+    if (pos < A.n_real_chunks) kap = long_chunk_wave<LD, KAPPA>(A, A.chunk_order[pos]);
   } else {
-    const size_t row = (sd.type == kSliceEuclidPerm) ? static_cast<size_t>(A.perm[sd.row0 + lane])
-                                                     : static_cast<size_t>(sd.row0) + lane;
-    store_row<LD>(A.out + row * LD, acc);
+    // Slice blocks: XCD x (= blockIdx % 8, observed dispatch order; speed only)
+    // walks its own contiguous eighth of the slice list, so neighbouring slices
+    // share one L2.  n_chunks is padded to a multiple of 8 by the launcher.
+    const int t = static_cast<int>(blockIdx.x) - A.n_chunks;
+    const int per_xcd = (A.n_slices + 7) >> 3;
+    const int s = (t & 7) * per_xcd + (t >> 3);
+    if ((t >> 3) < per_xcd && s < A.n_slices) kap = slice_wave<LD, D, EPI>(A, A.slices[s], lane);
+  }
+  if (KAPPA) {
+    kap = wave_sum(kap);
+    if (lane == 0) A.kappa_partial[blockIdx.x] = kap;
   }
 }
 
@@ -1280,6 +1321,21 @@ __device__ __forceinline__ double group_sum(double x, int g) {
   return x;
 }
 
+#ifndef CORA_SUB_NT
+#define CORA_SUB_NT 1
+#endif
+// The factor is read once per sweep: its loads are non-temporal (CORA_SUB_NT = 1), so that 130 MB of L per STPCG
+// iteration do not push Q and the vectors out of the 256 MB Infinity Cache.  Measured at 10^5 poses, p = 5: the
+// product inside the loop 31.8 -> 24.9 us (its back-to-back rate), the iteration 166 -> 153 us.
+template <typename T>
+__device__ __forceinline__ T factor_load(const T *p) {
+#if CORA_SUB_NT == 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 struct SubRegs {  // a lane's entries of one level: coefficients and (two per dword) local row indices
   double v[kSubNpl];
   uint32_t i[kSubNpl / 2];
@@ -1293,20 +1349,87 @@ __device__ __forceinline__ void sub_touch(SubRegs &R) {
   for (int u = 0; u < kSubNpl / 2; ++u) asm volatile("" : "+v"(R.i[u]));
 }
 
-template <int LD, bool BWD>
-__global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const double *src, double *work, double *dst) {
+// v = Proj_Y(x) for the row unit that starts at `row` (a pose's d rotation rows: only its first row does the work;
+// a range row; a translation row), v -> dst, returns <r, v> over the rows written.  row_of_x(a) -> the a-th row of x.
+// (Rows of the last stage in the fused backward sweep.)
+template <int LD, int D, typename RowOfX>
+__device__ __forceinline__ double project_unit_dot(const SubFuse &F, size_t row, RowOfX row_of_x, double *dst) {
+  double acc = 0.0;
+  if (row < static_cast<size_t>(F.rng_base)) {
+    if ((row - static_cast<size_t>(F.rot_base)) % D != 0) return 0.0;
+    double y[D][LD], v[D][LD];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(F.Y + (row + a) * LD, y[a]);
+      row_of_x(a, v[a]);
+    }
+    stiefel_project_thread<LD, D>(y, v);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(F.r + (row + a) * LD, y[a]);
+      acc += dot_row<LD>(y[a], v[a]);
+      store_row<LD>(dst + (row + a) * LD, v[a]);
+    }
+    return acc;
+  }
+  double y[LD], v[LD];
+  row_of_x(0, v);
+  if (row < static_cast<size_t>(F.trn_base)) {
+    load_row<LD>(F.Y + row * LD, y);
+    const double ip = dot_row<LD>(y, v);
+#pragma unroll
+    for (int c = 0; c < LD; ++c) v[c] = fma(-ip, y[c], v[c]);
+  }
+  load_row<LD>(F.r + row * LD, y);
+  acc = dot_row<LD>(y, v);
+  store_row<LD>(dst + row * LD, v);
+  return acc;
+}
+
+// FD: 0 plain solve; 1 (forward) residual update fused into the prologue; 2 / 3 (backward) tangent projection for
+// d = FD fused into the epilogue -- see SubFuse (kernels.h).
+//
+// Rows move between memory and the tile ELEMENT BY ELEMENT in memory order (SubSweep::io): a block is a few runs of
+// consecutive rows, so a wavefront's load is 512 contiguous bytes whatever the row stride, and all loads of a phase
+// are issued before the first one is consumed -- a phase costs two dependent latencies (index, value), not two per
+// row.  (A lane per row: 40-byte pieces, 5 x the line requests; with the fused passes written that way the forward
+// sweep took 50 us instead of 33.)
+template <int LD, bool BWD, int FD>
+__global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const double *src, double *work, double *dst,
+                                                              const SubFuse F) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double dot_sm[8];
   double *T = reinterpret_cast<double *>(smem);
   const int tid = threadIdx.x;
   const int b = static_cast<int>(blockIdx.x);
+  double dacc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double cr = (FD == 1) ? F.dot.st->coef_r : 0.0;
   if (b >= S.nblocks) {  // rows of the last stage: forward rhs -> work, backward work -> x
     const int t = (b - S.nblocks) * kSubThreads + tid;
     if (t < S.ntop) {
       const size_t row = static_cast<size_t>(S.top_rows[t]);
-      double x[LD];
-      load_row<LD>((BWD ? work : src) + row * LD, x);
-      store_row<LD>((BWD ? dst : work) + row * LD, x);
+      if (FD == 0) {
+        double x[LD];
+        load_row<LD>((BWD ? work : src) + row * LD, x);
+        store_row<LD>((BWD ? dst : work) + row * LD, x);
+      } else if (FD == 1) {  // r += coef_r Hp, <r, r>
+        double x[LD];
+        load_row<LD>(F.r + row * LD, x);
+        if (cr != 0.0) {
+          double h[LD];
+          load_row<LD>(F.Hp + row * LD, h);
+#pragma unroll
+          for (int j = 0; j < LD; ++j) x[j] = fma(cr, h[j], x[j]);
+          store_row<LD>(F.r + row * LD, x);
+        }
+        dacc[0] = dot_row<LD>(x, x);
+        store_row<LD>(work + row * LD, x);
+      } else {
+        constexpr int D = FD >= 2 ? FD : 2;
+        dacc[0] = project_unit_dot<LD, D>(F, row, [&](int a, double (&x)[LD]) { load_row<LD>(work + (row + a) * LD, x); }, dst);
+      }
     }
+    if (FD != 0) dots_finish(F.dot, dacc, dot_sm);
     return;
   }
   const SubSweep &Q = BWD ? S.bwd : S.fwd;
@@ -1335,17 +1458,19 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
     const int g = h.y & 0xff, npl = (h.y >> 8) & 0xf, nlane = (h.y >> 12) * g;
     if (wave_base >= nlane) return;
     const int lane = tid < nlane ? tid : nlane - 1;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if (npl > 4) {
-      const uint4 q = *reinterpret_cast<const uint4 *>(gi + h.w + lane * 8);
+      const u32x4 q = factor_load(reinterpret_cast<const u32x4 *>(gi + h.w + lane * 8));
       R.i[0] = q.x, R.i[1] = q.y, R.i[2] = q.z, R.i[3] = q.w;
     } else {
-      const uint2 q = *reinterpret_cast<const uint2 *>(gi + h.w + lane * 4);
+      const u32x2 q = factor_load(reinterpret_cast<const u32x2 *>(gi + h.w + lane * 4));
       R.i[0] = q.x, R.i[1] = q.y;
     }
     const double *__restrict__ pv = gv + h.z + lane;
 #pragma unroll
     for (int u = 0; u < kSubNpl; ++u)
-      if (u < npl) R.v[u] = pv[u * nlane];
+      if (u < npl) R.v[u] = factor_load(pv + u * nlane);
   };
   SubRegs RA, RB;
 #pragma unroll
@@ -1358,26 +1483,71 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
                     __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w)), RA);
   }
 
-  // ---- prologue: right-hand sides -> T; backward: behind them the later stage's solution (it sits in `work`) at the
-  // rows coupled to the block, which the block's entries address as rows nb + k.  Two rows per lane in flight.
+  // element e of the block = column e % LD of its (e / LD)-th row in memory order; kIoBatch elements per lane are in
+  // flight at a time (a block has <= 512 rows: ONE batch up to a row stride of 6)
+  const int2 *__restrict__ io = Q.io + rb;
+  const int ne = nb * LD;
+  constexpr int kIoBatch = 2 * LD <= 12 ? 2 * LD : 12;
+  struct IoAt { int g, t; bool ok; };  // offsets of an element in the vectors / in the tile
+  auto io_index = [&](int e0, IoAt (&at)[kIoBatch]) {
+    int2 rp[kIoBatch];
+    int col[kIoBatch];
+#pragma unroll
+    for (int u = 0; u < kIoBatch; ++u) {
+      const int e = e0 + u * kSubThreads;
+      at[u].ok = e < ne;
+      const int ee = at[u].ok ? e : ne - 1;
+      const int k = ee / LD;
+      col[u] = ee - k * LD;
+      rp[u] = io[k];
+    }
+#pragma unroll
+    for (int u = 0; u < kIoBatch; ++u) {
+      at[u].g = rp[u].x * LD + col[u];
+      at[u].t = rp[u].y * LD + col[u];
+    }
+  };
+
+  // ---- prologue: right-hand sides -> T (fused forward: r += coef_r Hp on the way, <r, r>); backward: behind them the
+  // later stage's solution (it sits in `work`) at the rows coupled to the block, which the block's entries address as
+  // rows nb + k
   {
-    const int nfill = nb + (BWD ? bd.ntgt : 0);
-    auto row_ptr = [&](int t) -> const double * {
-      if (!BWD || t < nb) return src + static_cast<size_t>(Q.rows[rb + t]) * LD;
-      return work + static_cast<size_t>(S.tgt_row[bd.tgt_begin + (t - nb)]) * LD;
-    };
-    for (int t0 = tid; t0 < nfill; t0 += 2 * kSubThreads) {
-      const int t1 = t0 + kSubThreads < nfill ? t0 + kSubThreads : t0;
-      const double *p0 = row_ptr(t0), *p1 = row_ptr(t1);
-      double x0[LD], x1[LD];
-      load_row<LD>(p0, x0);
-      load_row<LD>(p1, x1);
+    const int ntg = BWD ? bd.ntgt : 0;
+    int tgt_row = -1;
+    if (BWD && tid < ntg) tgt_row = S.tgt_row[bd.tgt_begin + tid];
+    for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
+      IoAt at[kIoBatch];
+      io_index(e0, at);
+      double x[kIoBatch], h[FD == 1 ? kIoBatch : 1];
 #pragma unroll
-      for (int j = 0; j < LD; ++j) T[t0 * LD + j] = x0[j];
+      for (int u = 0; u < kIoBatch; ++u) {
+        x[u] = (FD == 1 ? F.r : src)[at[u].g];
+        if (FD == 1) h[FD == 1 ? u : 0] = F.Hp[at[u].g];
+      }
 #pragma unroll
-      for (int j = 0; j < LD; ++j) T[t1 * LD + j] = x1[j];
+      for (int u = 0; u < kIoBatch; ++u) {
+        if (FD == 1) {
+          if (cr != 0.0) {
+            x[u] = fma(cr, h[FD == 1 ? u : 0], x[u]);
+            if (at[u].ok) F.r[at[u].g] = x[u];
+          }
+          if (at[u].ok) dacc[0] = fma(x[u], x[u], dacc[0]);
+        }
+        if (at[u].ok) T[at[u].t] = x[u];
+      }
+    }
+    if (BWD) {
+      for (int t = tid; t < ntg; t += kSubThreads) {
+        if (t != tid) tgt_row = S.tgt_row[bd.tgt_begin + t];
+        double x[LD];
+        load_row<LD>(work + static_cast<size_t>(tgt_row) * LD, x);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) T[(nb + t) * LD + j] = x[j];
+      }
     }
   }
+  // <r, r> is complete for this block: published now, so that the last block's scalar step overlaps the solve
+  if (FD == 1) dots_finish(F.dot, dacc, dot_sm);
   __syncthreads();
 
   // ---- the triangular solve, level by level
@@ -1433,11 +1603,59 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
   }
 
   // ---- results
-  for (int t = tid; t < nb; t += kSubThreads) {
-    double x[LD];
+  if (FD >= 2) {
+    // v = Proj_Y(x) in the tile, a lane per row unit (a pose's rotation rows sit at consecutive positions) ...
+    constexpr int D = FD >= 2 ? FD : 2;
+    const int2 *__restrict__ un = S.b_unit + bd.unit_begin;
+    for (int u = tid; u < bd.nunits; u += kSubThreads) {
+      const int2 pr = un[u];  // {tile position, internal row}
+      const size_t row = static_cast<size_t>(pr.y);
+      double *__restrict__ tv = T + pr.x * LD;
+      if (row < static_cast<size_t>(F.rng_base)) {
+        double y[D][LD], v[D][LD];
 #pragma unroll
-    for (int j = 0; j < LD; ++j) x[j] = T[t * LD + j];
-    store_row<LD>(dst + static_cast<size_t>(Q.rows[rb + t]) * LD, x);
+        for (int a = 0; a < D; ++a) load_row<LD>(F.Y + (row + a) * LD, y[a]);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int j = 0; j < LD; ++j) v[a][j] = tv[a * LD + j];
+        stiefel_project_thread<LD, D>(y, v);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int j = 0; j < LD; ++j) tv[a * LD + j] = v[a][j];
+      } else if (row < static_cast<size_t>(F.trn_base)) {
+        double y[LD], v[LD];
+        load_row<LD>(F.Y + row * LD, y);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) v[j] = tv[j];
+        const double ip = dot_row<LD>(y, v);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) tv[j] = fma(-ip, y[j], v[j]);
+      }
+    }
+    __syncthreads();
+  }
+  // ... and the tile -> dst in memory order (fused backward: with <r, v>)
+  for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
+    IoAt at[kIoBatch];
+    io_index(e0, at);
+    double rr[FD >= 2 ? kIoBatch : 1];
+    if (FD >= 2) {
+#pragma unroll
+      for (int u = 0; u < kIoBatch; ++u) rr[FD >= 2 ? u : 0] = F.r[at[u].g];
+    }
+#pragma unroll
+    for (int u = 0; u < kIoBatch; ++u)
+      if (at[u].ok) {
+        const double v = T[at[u].t];
+        dst[at[u].g] = v;
+        if (FD >= 2) dacc[0] = fma(rr[FD >= 2 ? u : 0], v, dacc[0]);
+      }
+  }
+  if (FD >= 2) {
+    dots_finish(F.dot, dacc, dot_sm);
+    return;
   }
   if (!BWD) {  // couplings to the last stage: aux row of target g = -sum_v L_gv y_v, 16 lanes per target
     const int ntgt = bd.ntgt;
@@ -1475,6 +1693,22 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
   }
 }
 
+// kappa = <p, Hp> from the per-block partials of an EPI_HVP_K product (one block, fixed order), then the scalar step
+__global__ __launch_bounds__(256) void k_kappa_finish(const double *__restrict__ partial, int n, StpcgState *st) {
+  __shared__ double sm[4];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < n; b += 1024) {
+    s0 += partial[b];
+    s1 += partial[b + 256];
+    s2 += partial[b + 512];
+    s3 += partial[b + 768];
+  }
+  for (; b < n; b += 256) s0 += partial[b];
+  const double t = block_sum_256((s0 + s1) + (s2 + s3), sm);
+  if (threadIdx.x == 0) stpcg_after_kappa(*st, t);
+}
+
 __global__ void k_zero_row(double *x, size_t row, int ld) {
   if (static_cast<int>(threadIdx.x) < ld) x[row * ld + threadIdx.x] = 0.0;
 }
@@ -1502,6 +1736,10 @@ static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) 
   switch (epi) {
     case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(64), 0, st, A); break;
     case EPI_S: hipLaunchKernelGGL((k_spmm<LD, D, EPI_S>), dim3(grid), dim3(64), 0, st, A); break;
+    case EPI_HVP_K:
+      if (!A.kappa_partial) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP_K>), dim3(grid), dim3(64), 0, st, A);
+      break;
     default: hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP>), dim3(grid), dim3(64), 0, st, A); break;
   }
   return hipGetLastError();
@@ -1743,17 +1981,42 @@ hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const do
 
 
 template <int LD>
-static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *src, double *work, double *dst, hipStream_t st) {
-  const int grid = S.nblocks + (S.ntop + kSubThreads - 1) / kSubThreads;
+static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *src, double *work, double *dst, hipStream_t st,
+                              const SubFuse *F = nullptr) {
+  const int grid = launch_subblock_blocks(S);
   if (grid <= 0) return hipSuccess;
   const size_t lds = ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(S.max_lev + 2) * 16;
   if (S.max_level_lanes > kSubThreads || S.max_npl > kSubNpl || S.max_lev + 1 > kSubThreads || lds > 64 * 1024) return hipErrorInvalidValue;
   const dim3 g(grid), t(kSubThreads);
-  if (backward) hipLaunchKernelGGL((k_subblock<LD, true>), g, t, lds, st, S, src, work, dst);
-  else hipLaunchKernelGGL((k_subblock<LD, false>), g, t, lds, st, S, src, work, dst);
+  if (F) {
+    if constexpr (LD <= 12) {
+      if (!backward) hipLaunchKernelGGL((k_subblock<LD, false, 1>), g, t, lds, st, S, src, work, dst, *F);
+      else if (F->d == 2) hipLaunchKernelGGL((k_subblock<LD, true, 2>), g, t, lds, st, S, src, work, dst, *F);
+      else if (F->d == 3) hipLaunchKernelGGL((k_subblock<LD, true, 3>), g, t, lds, st, S, src, work, dst, *F);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  const SubFuse none{};
+  if (backward) hipLaunchKernelGGL((k_subblock<LD, true, 0>), g, t, lds, st, S, src, work, dst, none);
+  else hipLaunchKernelGGL((k_subblock<LD, false, 0>), g, t, lds, st, S, src, work, dst, none);
   return hipGetLastError();
 }
-
+hipError_t launch_subblock_fused(const SubOpDev &S, int ld, bool backward, const SubFuse &F, double *work, double *out,
+                                 hipStream_t st) {
+  // forward: the right-hand side is F.r, y -> out;  backward: y is read from `out`, v -> out
+#define CASE(L) \
+  if (ld == L) return subblock_ld<L>(S, backward, backward ? out : F.r, work, out, st, &F);
+  CORA_LD_CASES(CASE)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+hipError_t launch_kappa_finish(const double *partial, int n, StpcgState *state, hipStream_t st) {
+  hipLaunchKernelGGL(k_kappa_finish, dim3(1), dim3(256), 0, st, partial, n, state);
+  return hipGetLastError();
+}
 hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const double *rhs_or_y, double *work, double *out,
                            hipStream_t st) {
 #define CASE(L) \

@@ -397,8 +397,19 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       std::vector<int32_t> sn_begin;  // positions in `mem`
       for (int t = 0; t < nb; ++t) {
         const int32_t v = mem[t];
-        const bool chained = t > 0 && mem[t - 1] == v - 1 && parent[v - 1] == v &&
-                             t - sn_begin.back() < kSnCap;
+        bool chained = t > 0 && mem[t - 1] == v - 1 && parent[v - 1] == v;
+        if (chained) {
+          // never cut inside a group (the d rotation rows of a pose share a supernode, hence sit at consecutive tile
+          // positions in both sweeps): a group that would not fit starts a supernode of its own
+          const int32_t gv = group ? (*group)[v] : -1;
+          if (gv >= 0 && (*group)[v - 1] == gv) {
+            chained = true;
+          } else {
+            int glen = 1;
+            while (gv >= 0 && t + glen < nb && mem[t + glen] == v + glen && (*group)[v + glen] == gv) ++glen;
+            chained = t - sn_begin.back() + glen <= kSnCap;
+          }
+        }
         if (!chained) sn_begin.push_back(t);
       }
       sn_begin.push_back(nb);

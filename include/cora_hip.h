@@ -336,6 +336,9 @@ int cora_world(const cora_ctx *ctx);
  * two of them (the back-to-back figure keeps Q in the Infinity Cache). */
 int cora_debug_profile_stpcg(cora_ctx *ctx, int on);
 int cora_debug_stpcg_hvp_us(cora_ctx *ctx, double *mean_us, int *count);
+/* Form of the iteration the last cora_stpcg_dev ran: 0 one pass per operation, 1 fused vector passes, 2 vector passes
+ * fused into the sweeps of the Cholesky solve (tests pin which form they compare). */
+int cora_debug_stpcg_path(const cora_ctx *ctx);
 
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
                                 int k, double *out, int ldo);

@@ -212,15 +212,17 @@ def test_precondition_in_place_and_out_of_place_agree():
         h.dev_free(q)
 
 
-@pytest.mark.parametrize("n,precond", [(30000, capi.PRECOND_REGULARIZED_CHOLESKY), (800, capi.PRECOND_REGULARIZED_CHOLESKY),
-                                        (800, capi.PRECOND_JACOBI)])
-def test_fused_stpcg_matches_unfused(n, precond):
+@pytest.mark.parametrize("d,n,precond", [(3, 30000, capi.PRECOND_REGULARIZED_CHOLESKY), (2, 40000, capi.PRECOND_REGULARIZED_CHOLESKY),
+                                          (3, 800, capi.PRECOND_REGULARIZED_CHOLESKY), (3, 800, capi.PRECOND_JACOBI)])
+@pytest.mark.parametrize("p", [5, 4])
+def test_fused_stpcg_matches_unfused(d, n, precond, p):
     """cora_stpcg_dev folds the residual update with <r, r>, the tangent projection with <r, v> and the step
-    with the new direction into three passes (six launches per iteration instead of nine).  Same iteration as the
-    unfused sequence (CORA_NO_FUSE=1): iteration count, M-norm of the step, step and residual agree."""
-    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=6, n_ranges=n // 2, seed=5, precond=precond)
+    with the new direction into three passes (six launches per iteration instead of nine), and -- with a two-stage
+    Cholesky solve plan -- the first two into the sweeps of the solve, kappa into the product's epilogue (seven
+    launches with the solve instead of ten).  Same iteration as the unfused sequence (CORA_NO_FUSE=1): iteration count,
+    M-norm of the step, step and residual agree."""
+    P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=6, n_ranges=n // 2, seed=5, precond=precond)
     P.update()
-    p = 5
     P.set_rank(p)
     P.precond_info()
     dm = P.dims()
@@ -233,20 +235,26 @@ def test_fused_stpcg_matches_unfused(n, precond):
     h.set_point_dev(y)
     grad = h.point_ptrs()[2]
     out = {}
-    for mode in ("fused", "unfused"):
-        if mode == "unfused":
-            os.environ["CORA_NO_FUSE"] = "1"
+    env = {"sweep": None, "fused": "CORA_NO_SWEEP_FUSE", "unfused": "CORA_NO_FUSE"}
+    for mode, var in env.items():
+        if var:
+            os.environ[var] = "1"
         try:
             for delta, iters in ((1e30, 7), (0.5, 40)):   # runs to the limit / stops on the trust-region boundary
                 done, step = h.stpcg_dev(grad, delta, s, r, v, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=iters)
-                out[(mode, delta)] = (done, step, h.download(s, p), h.download(r, p))
+                out[(mode, delta)] = (done, step, h.download(s, p), h.download(r, p), h.download(v, p), h.download(pk, p))
+            out[mode] = h.stpcg_path()
         finally:
-            os.environ.pop("CORA_NO_FUSE", None)
-    for delta in (1e30, 0.5):
-        a, b = out[("fused", delta)], out[("unfused", delta)]
-        assert a[0] == b[0] and a[0] > 0
-        assert abs(a[1] - b[1]) <= 1e-10 * abs(b[1])
-        assert np.abs(a[2] - b[2]).max() <= 1e-9 * np.abs(b[2]).max()
-        assert np.abs(a[3] - b[3]).max() <= 1e-9 * np.abs(b[3]).max()
+            if var:
+                os.environ.pop(var, None)
+    assert out["unfused"] == 0 and out["fused"] == 1
+    assert out["sweep"] == (2 if n >= 30000 else 1)  # the large plans are two-stage: the sweep-fused form really ran
+    for mode in ("sweep", "fused"):
+        for delta in (1e30, 0.5):
+            a, b = out[(mode, delta)], out[("unfused", delta)]
+            assert a[0] == b[0] and a[0] > 0
+            assert abs(a[1] - b[1]) <= 1e-10 * abs(b[1])
+            for k in (2, 3, 4, 5):
+                assert np.abs(a[k] - b[k]).max() <= 1e-9 * np.abs(b[k]).max(), (mode, delta, k)
     for q in vecs:
         h.dev_free(q)
