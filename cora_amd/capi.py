@@ -355,6 +355,16 @@ class Context:
                                         C.c_void_p(p), C.c_void_p(hp), C.byref(it), C.byref(sm)))
         return it.value, sm.value
 
+    def stpcg_warm_dev(self, grad, pg, g_g, g_pg, Delta, s, r, v, p, hp, kappa_fgr=0.1, theta=0.8, max_iters=80):
+        """stpcg_dev started from a known preconditioned gradient pg = P grad, <grad, grad> and <grad, pg>."""
+        it = C.c_int()
+        sm = C.c_double()
+        self._chk(self.L.cora_stpcg_warm_dev(self.h, C.c_void_p(grad), C.c_void_p(pg), C.c_double(g_g), C.c_double(g_pg),
+                                             C.c_double(Delta), C.c_double(kappa_fgr), C.c_double(theta), int(max_iters),
+                                             C.c_void_p(s), C.c_void_p(r), C.c_void_p(v), C.c_void_p(p), C.c_void_p(hp),
+                                             C.byref(it), C.byref(sm)))
+        return it.value, sm.value
+
     def profile_stpcg(self, on=True):
         self._chk(self.L.cora_debug_profile_stpcg(self.h, int(on)))
 

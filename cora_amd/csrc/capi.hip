@@ -1195,8 +1195,11 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
 // (the inner solver of Optimization::Riemannian::TNT, called from src/CORA.cpp:139-140).  The scalar
 // recurrences live in a StpcgState that the inner-product kernels update themselves, so the host only
 // enqueues iterations -- a few at a time -- and looks at the state's pinned mirror between batches.
-int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_fgr, double theta, int max_iters,
-                   double *dS, double *dR, double *dV, double *dP, double *dHp, int *iters, double *step_M_norm) {
+// dPg != nullptr: the caller already holds P g and the inner products <g, g>, <g, P g> (TNT computes them for its
+// stopping tests): the solve starts without a preconditioner apply and without a reduction of its own.
+static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double gg, double gPg, double Delta,
+                     double kappa_fgr, double theta, int max_iters, double *dS, double *dR, double *dV, double *dP,
+                     double *dHp, int *iters, double *step_M_norm) {
   NEED_DEVICE(c);
   NEED_RANK(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
@@ -1204,15 +1207,22 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
     return fail(c, CORA_ERR_ARG, "bad arguments");
   if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "the device-resident STPCG is single-GPU");
   int rc;
-  // s = 0, r = g, v = P r, p = -v
-  if ((rc = cora_axpby_dev(c, 0.0, dGrad, 0.0, dS))) return rc;
-  if ((rc = cora_axpby_dev(c, 1.0, dGrad, 0.0, dR))) return rc;
-  if ((rc = cora_precondition_projected_dev(c, dR, dV))) return rc;
-  if ((rc = cora_axpby_dev(c, -1.0, dV, 0.0, dP))) return rc;
   double rr_rv[2];
-  const double *A[2] = {dR, dR};
-  const double *B[2] = {dR, dV};
-  if ((rc = cora_dots_dev(c, 2, A, B, rr_rv))) return rc;
+  if (dPg) {  // s = 0, r = g, p = -P g in one pass
+    const size_t off0 = static_cast<size_t>(c->F.L.base) * c->ld;
+    HIP_TRY(c, launch_stpcg_init(c->F.L.local_rows * c->ld, dGrad + off0, dPg + off0, dS + off0, dR + off0, dP + off0,
+                                 c->stream));
+    rr_rv[0] = gg;
+    rr_rv[1] = gPg;
+  } else {  // s = 0, r = g, v = P r, p = -v
+    if ((rc = cora_axpby_dev(c, 0.0, dGrad, 0.0, dS))) return rc;
+    if ((rc = cora_axpby_dev(c, 1.0, dGrad, 0.0, dR))) return rc;
+    if ((rc = cora_precondition_projected_dev(c, dR, dV))) return rc;
+    if ((rc = cora_axpby_dev(c, -1.0, dV, 0.0, dP))) return rc;
+    const double *A[2] = {dR, dR};
+    const double *B[2] = {dR, dV};
+    if ((rc = cora_dots_dev(c, 2, A, B, rr_rv))) return rc;
+  }
   const double r0 = std::sqrt(rr_rv[0]);
   StpcgState &H = c->h_stpcg[1];  // staging copy for the upload; h_stpcg[0] is the mirror the kernels write
   H = StpcgState();
@@ -1259,7 +1269,7 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
     const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
     size_t need = std::max<size_t>(4 * 512, static_cast<size_t>((units + 255) / 256) + 8);
     const cora_ctx::DevFactor &f = c->precond_f;
-    sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 &&
+    sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
                   !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
     if (sweep_fused) {
       need = std::max<size_t>(need, static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8);
@@ -1373,6 +1383,18 @@ int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_
   *iters = H.iters;
   *step_M_norm = H.step_M_norm;
   return CORA_OK;
+}
+
+int cora_stpcg_dev(cora_ctx *c, const double *dGrad, double Delta, double kappa_fgr, double theta, int max_iters,
+                   double *dS, double *dR, double *dV, double *dP, double *dHp, int *iters, double *step_M_norm) {
+  return stpcg_run(c, dGrad, nullptr, 0.0, 0.0, Delta, kappa_fgr, theta, max_iters, dS, dR, dV, dP, dHp, iters, step_M_norm);
+}
+
+int cora_stpcg_warm_dev(cora_ctx *c, const double *dGrad, const double *dPg, double g_g, double g_Pg, double Delta,
+                        double kappa_fgr, double theta, int max_iters, double *dS, double *dR, double *dV, double *dP,
+                        double *dHp, int *iters, double *step_M_norm) {
+  if (!c || !dPg || dPg == dS || dPg == dR || dPg == dV || dPg == dP || dPg == dHp) return fail(c, CORA_ERR_ARG, "bad arguments");
+  return stpcg_run(c, dGrad, dPg, g_g, g_Pg, Delta, kappa_fgr, theta, max_iters, dS, dR, dV, dP, dHp, iters, step_M_norm);
 }
 
 int cora_set_comm(cora_ctx *c, cora_exchange_fn exchange, cora_allreduce_fn allreduce, cora_allgather_fn allgather,

@@ -62,14 +62,15 @@ struct Dev {
 
 // Steihaug-Toint truncated preconditioned CG for  min <g,s> + 1/2 <s,Hs>,  ||s||_M <= Delta.
 // Returns the number of Hessian-vector products; s is the update step.
-int STPCG(Dev &D, const double *grad, double Delta, const TNTParams &prm, double *s, double *r, double *v,
-          double *pk, double *Hp, double &step_M_norm) {
+// Pg, g_g, g_Pg: the preconditioned gradient and <g, g>, <g, P g> at this point (the outer loop has them).
+int STPCG(Dev &D, const double *grad, const double *Pg, double g_g, double g_Pg, double Delta, const TNTParams &prm,
+          double *s, double *r, double *v, double *pk, double *Hp, double &step_M_norm) {
   cora_ctx *c = D.c;
   if (prm.device_stpcg && cora_world(c) == 1) {  // partitioned handles: the host-driven loop below (collective calls)
     int iters = 0;
-    D.chk(cora_stpcg_dev(c, grad, Delta, prm.kappa_fgr, prm.theta, prm.max_TPCG_iterations, s, r, v, pk, Hp, &iters,
-                         &step_M_norm),
-          "cora_stpcg_dev");
+    D.chk(cora_stpcg_warm_dev(c, grad, Pg, g_g, g_Pg, Delta, prm.kappa_fgr, prm.theta, prm.max_TPCG_iterations, s, r, v,
+                              pk, Hp, &iters, &step_M_norm),
+          "cora_stpcg_warm_dev");
     return iters;
   }
   D.axpby(0.0, grad, 0.0, s);   // s = 0
@@ -141,15 +142,20 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
   double f;
   D.chk(cora_point_cost(c, &f), "cora_point_cost");
   const double *grad = cora_point_rgrad_dev(c);
+  double g_g = 0.0, g_Pg = 0.0;  // <g, g> and <g, P g>: where the inner solve starts
   auto gradient_norms = [&](double &gn, double &pgn) {
     D.chk(cora_precondition_projected_dev(c, grad, Pg), "precon");
     // ||P g||, the measure saddleEscape uses (src/CORA.cpp:149 there, CORA.cpp here), so that a point the
     // escape accepted (pgn > tolerance) is not stopped by the first test of the next TNT call; <g, P g> is
     // only the STPCG recurrences' business
-    double o[2];
-    D.dots2(grad, grad, Pg, Pg, o);
+    const double *A[3] = {grad, Pg, grad};
+    const double *B[3] = {grad, Pg, Pg};
+    double o[3];
+    D.chk(cora_dots_dev(c, 3, A, B, o), "cora_dots_dev");
     gn = std::sqrt(o[0]);
     pgn = std::sqrt(o[1]);
+    g_g = o[0];
+    g_Pg = o[2];
   };
   double grad_norm, pgrad_norm;
   gradient_norms(grad_norm, pgrad_norm);
@@ -170,7 +176,7 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
     if (elapsed() > prm.max_computation_time) { res.status = TNTStatus::ElapsedTime; break; }
 
     double h_M_norm = 0.0;
-    const int inner = STPCG(D, grad, Delta, prm, s, r, v, pk, Hp, h_M_norm);
+    const int inner = STPCG(D, grad, Pg, g_g, g_Pg, Delta, prm, s, r, v, pk, Hp, h_M_norm);
     res.hessian_vector_products += inner + 1;
     // model decrease  m(0) - m(h) = -<g,h> - 1/2 <h, H h>
     D.chk(cora_hvp_dev(c, s, Hp), "cora_hvp_dev");

@@ -787,6 +787,17 @@ __global__ __launch_bounds__(256) void k_stpcg_residual(DotArgs D, const double2
   dots_finish(D, acc, sm);
 }
 
+// start of a solve: s = 0, r = g, p = -Pg
+__global__ __launch_bounds__(256) void k_stpcg_init(int64_t n, const double *__restrict__ g, const double *__restrict__ Pg,
+                                                    double *__restrict__ s, double *__restrict__ r, double *__restrict__ p) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    s[i] = 0.0;
+    r[i] = g[i];
+    p[i] = -Pg[i];
+  }
+}
+
 // s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
 __global__ __launch_bounds__(256) void k_stpcg_step_direction(int64_t n2, const StpcgState *__restrict__ S,
                                                               const double2 *__restrict__ v, double2 *__restrict__ p,
@@ -1483,28 +1494,26 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
                     __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w)), RA);
   }
 
-  // element e of the block = column e % LD of its (e / LD)-th row in memory order; kIoBatch elements per lane are in
-  // flight at a time (a block has <= 512 rows: ONE batch up to a row stride of 6)
+  // element e of the block = column e % LD of its (e / LD)-th row in memory order.  Per pass a lane resolves kIoBatch
+  // elements (all index loads in flight together; a block has <= 512 rows: ONE pass up to a row stride of 6) and moves
+  // them in two halves (registers: the sweep must keep >= 5 workgroups per CU, or the 10^5-pose plan's 1 042 blocks
+  // no longer run at once)
   const int2 *__restrict__ io = Q.io + rb;
   const int ne = nb * LD;
-  constexpr int kIoBatch = 2 * LD <= 12 ? 2 * LD : 12;
-  struct IoAt { int g, t; bool ok; };  // offsets of an element in the vectors / in the tile
+  // (fused forward, two value streams: one pass of 2 LD elements per lane up to a row stride of 5 -- 45 us at 10^5 poses against
+  // 52 us in two passes of 6 --, two passes of LD above, where one pass spills)
+  constexpr int kIoBatch = (FD == 1 && LD > 5) ? (LD <= 8 ? LD : 8) : (2 * LD <= 12 ? 2 * LD : 12);
+  constexpr int kIoSub = (kIoBatch + 1) / 2;
+  struct IoAt { int g, t; };  // offsets of an element in the vectors / in the tile
   auto io_index = [&](int e0, IoAt (&at)[kIoBatch]) {
-    int2 rp[kIoBatch];
-    int col[kIoBatch];
 #pragma unroll
     for (int u = 0; u < kIoBatch; ++u) {
       const int e = e0 + u * kSubThreads;
-      at[u].ok = e < ne;
-      const int ee = at[u].ok ? e : ne - 1;
-      const int k = ee / LD;
-      col[u] = ee - k * LD;
-      rp[u] = io[k];
-    }
-#pragma unroll
-    for (int u = 0; u < kIoBatch; ++u) {
-      at[u].g = rp[u].x * LD + col[u];
-      at[u].t = rp[u].y * LD + col[u];
+      const int ee = e < ne ? e : ne - 1;
+      const int k = ee / LD, col = ee - k * LD;
+      const int2 rp = io[k];
+      at[u].g = rp.x * LD + col;
+      at[u].t = rp.y * LD + col;
     }
   };
 
@@ -1518,22 +1527,28 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
     for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
       IoAt at[kIoBatch];
       io_index(e0, at);
-      double x[kIoBatch], h[FD == 1 ? kIoBatch : 1];
 #pragma unroll
-      for (int u = 0; u < kIoBatch; ++u) {
-        x[u] = (FD == 1 ? F.r : src)[at[u].g];
-        if (FD == 1) h[FD == 1 ? u : 0] = F.Hp[at[u].g];
-      }
+      for (int half = 0; half < kIoBatch; half += kIoSub) {
+        double x[kIoSub], h[FD == 1 ? kIoSub : 1];
 #pragma unroll
-      for (int u = 0; u < kIoBatch; ++u) {
-        if (FD == 1) {
-          if (cr != 0.0) {
-            x[u] = fma(cr, h[FD == 1 ? u : 0], x[u]);
-            if (at[u].ok) F.r[at[u].g] = x[u];
-          }
-          if (at[u].ok) dacc[0] = fma(x[u], x[u], dacc[0]);
+        for (int u = 0; u < kIoSub; ++u) {
+          if (half + u >= kIoBatch) continue;
+          x[u] = (FD == 1 ? F.r : src)[at[half + u].g];
+          if (FD == 1) h[FD == 1 ? u : 0] = F.Hp[at[half + u].g];
         }
-        if (at[u].ok) T[at[u].t] = x[u];
+#pragma unroll
+        for (int u = 0; u < kIoSub; ++u) {
+          if (half + u >= kIoBatch) continue;
+          const bool ok = e0 + (half + u) * kSubThreads < ne;
+          if (FD == 1) {
+            if (cr != 0.0) {
+              x[u] = fma(cr, h[FD == 1 ? u : 0], x[u]);
+              if (ok) F.r[at[half + u].g] = x[u];
+            }
+            if (ok) dacc[0] = fma(x[u], x[u], dacc[0]);
+          }
+          if (ok) T[at[half + u].t] = x[u];
+        }
       }
     }
     if (BWD) {
@@ -1640,18 +1655,22 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
   for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
     IoAt at[kIoBatch];
     io_index(e0, at);
-    double rr[FD >= 2 ? kIoBatch : 1];
-    if (FD >= 2) {
 #pragma unroll
-      for (int u = 0; u < kIoBatch; ++u) rr[FD >= 2 ? u : 0] = F.r[at[u].g];
-    }
+    for (int half = 0; half < kIoBatch; half += kIoSub) {
+      double rr[FD >= 2 ? kIoSub : 1];
+      if (FD >= 2) {
 #pragma unroll
-    for (int u = 0; u < kIoBatch; ++u)
-      if (at[u].ok) {
-        const double v = T[at[u].t];
-        dst[at[u].g] = v;
-        if (FD >= 2) dacc[0] = fma(rr[FD >= 2 ? u : 0], v, dacc[0]);
+        for (int u = 0; u < kIoSub; ++u)
+          if (half + u < kIoBatch) rr[FD >= 2 ? u : 0] = F.r[at[half + u].g];
       }
+#pragma unroll
+      for (int u = 0; u < kIoSub; ++u)
+        if (half + u < kIoBatch && e0 + (half + u) * kSubThreads < ne) {
+          const double v = T[at[half + u].t];
+          dst[at[half + u].g] = v;
+          if (FD >= 2) dacc[0] = fma(rr[FD >= 2 ? u : 0], v, dacc[0]);
+        }
+    }
   }
   if (FD >= 2) {
     dots_finish(F.dot, dacc, dot_sm);
@@ -1855,6 +1874,11 @@ hipError_t launch_stpcg_residual(const DotArgs &D_in, int64_t n, const double *H
   return hipGetLastError();
 }
 
+hipError_t launch_stpcg_init(int64_t n, const double *g, const double *Pg, double *s, double *r, double *p, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stpcg_init, dim3(grid_for(n)), dim3(256), 0, st, n, g, Pg, s, r, p);
+  return hipGetLastError();
+}
 hipError_t launch_stpcg_step_direction(int64_t n, const StpcgState *S, const double *v, double *p, double *s,
                                        hipStream_t st) {
   if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(v) % 16 || reinterpret_cast<uintptr_t>(p) % 16 ||

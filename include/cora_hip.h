@@ -266,6 +266,13 @@ int cora_axpy2_dev(cora_ctx *ctx, double a1, const double *dX1, double *dY1, dou
 int cora_stpcg_dev(cora_ctx *ctx, const double *dGrad, double Delta, double kappa_fgr, double theta,
                    int max_iters, double *dS, double *dR, double *dV, double *dP, double *dHp, int *iters,
                    double *step_M_norm);
+/* The same solve started from a preconditioned gradient the caller already holds: dPg = M^-1 grad (projected, i.e.
+ * cora_precondition_projected_dev(grad)), g_g = <grad, grad>, g_Pg = <grad, dPg>.  The trust-region loop computes all
+ * three for its stopping tests at every accepted point, so the inner solve needs neither a preconditioner apply nor a
+ * reduction of its own to start.  dPg is read only. */
+int cora_stpcg_warm_dev(cora_ctx *ctx, const double *dGrad, const double *dPg, double g_g, double g_Pg, double Delta,
+                        double kappa_fgr, double theta, int max_iters, double *dS, double *dR, double *dV, double *dP,
+                        double *dHp, int *iters, double *step_M_norm);
 /* Same for vectors allocated with k columns (cora_dev_alloc(ctx, k, ..)). */
 int cora_axpby_cols_dev(cora_ctx *ctx, int k, double a, const double *dX, double b, double *dY);
 int cora_copy_dev(cora_ctx *ctx, const double *dX, int k, double *dY);

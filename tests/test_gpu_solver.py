@@ -247,6 +247,15 @@ def test_fused_stpcg_matches_unfused(d, n, precond, p):
         finally:
             if var:
                 os.environ.pop(var, None)
+    # the warm start (TNT hands over P g, <g, g>, <g, P g>) runs the same iteration as the cold one
+    pg = h.dev_alloc(p)
+    h.precondition_projected_dev(grad, pg)
+    g_g, g_pg = h.dot_dev(grad, grad, p), h.dot_dev(grad, pg, p)
+    done, step = h.stpcg_warm_dev(grad, pg, g_g, g_pg, 0.5, s, r, v, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=40)
+    cold = out[("sweep", 0.5)]
+    assert done == cold[0] and abs(step - cold[1]) <= 1e-12 * abs(cold[1])
+    assert np.abs(h.download(s, p) - cold[2]).max() <= 1e-10 * np.abs(cold[2]).max()
+    h.dev_free(pg)
     assert out["unfused"] == 0 and out["fused"] == 1
     assert out["sweep"] == (2 if n >= 30000 else 1)  # the large plans are two-stage: the sweep-fused form really ran
     for mode in ("sweep", "fused"):
