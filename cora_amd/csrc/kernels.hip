@@ -1462,6 +1462,9 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
                      __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w));
   };
 
+  // (Measured and dropped: entries of TWO levels ahead in a third register set.  The compiler only keeps loads in flight
+  // across a first use when their number is branch-free, i.e. nine loads per lane and level whatever the level's width:
+  // sweeps 45 -> 57 us fused, 33 -> 41 us plain -- the issue rate costs more than the latency hidden.)
   // entries of a level -> registers: one load for the lane's indices, one per coefficient slot.  Wavefronts
   // without a row of the level and slots past its width load nothing (the load unit's instruction rate is what
   // bounds a level once the latency is hidden: 16 unconditional loads per lane and level were 1.7 us per level).
