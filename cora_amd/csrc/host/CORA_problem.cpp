@@ -2,6 +2,9 @@
 // pass per problem), operators on the GPU through include/cora_hip.h.
 #include "CORA_problem.h"
 
+#include <chrono>
+#include <cstdio>
+
 #include <cmath>
 #include <iostream>
 
@@ -391,8 +394,15 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
     const int m = static_cast<int>(pin_last_translation_ ? N - 1 : N);
     int leaf = 4;  // poses per nested-dissection leaf: 8 / 4 / 2 give 5.6 / 4.4 / 4.3 M entries in the stage-0 block inverses at 10^5 poses
     if (const char *env = std::getenv("CORA_ND_LEAF")) leaf = std::max(1, std::atoi(env));
+    const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+    auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+      const auto now = std::chrono::steady_clock::now();
+      if (timing) std::fprintf(stderr, "  [precond] %-26s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+      t_prev = now;
+    };
     const auto perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
                                    data_matrix_, m, leaf);
+    tick("ordering");
     CholeskyFactor F;
     if (kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
       // lambda_reg = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 or CORA_REG_CHOLESKY_MAX_COND (:581-591)
@@ -406,7 +416,9 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
         std::cout << "Loaded CORA_REG_CHOLESKY_MAX_COND from environment variable: " << max_cond << std::endl;
       }
       precond_lambda_ = Dnorm / (max_cond - 1);
+      tick("spectral norm (device)");
       F = choleskyFactor(data_matrix_, m, precond_lambda_, perm);
+      tick("factorisation");
     } else {
       // documented semantics (include/CORA/CORA_preconditioners.h:28-44): independent factors of the
       // diagonal blocks (rotations | ranges | translations) of Q + 1e-3 I (:513-543).  The reference's
@@ -433,8 +445,10 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
       }
       precond_levels_ = h;
     }
+    tick("tree height");
     const int rc = cora_precond_set_cholesky(ctx_.get(), m, F.Lp.data(), F.Li.data(), F.Lx.data(), F.perm.data());
     if (rc != CORA_OK) throwLast(rc, "Problem::updatePreconditioner");
+    tick("solve plan + upload");
   }
   const int rc = cora_precond_setup(ctx_.get(), kind);
   if (rc != CORA_OK) throwLast(rc, "Problem::updatePreconditioner");

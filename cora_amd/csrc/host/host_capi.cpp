@@ -392,6 +392,32 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
   });
 }
 
+int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_poses, int64_t info[3], double *digest,
+                                double *negative_direction) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const SparseMatrix &Q = q.getDataMatrix();
+    const auto perm = coraOrdering(q.dim(), q.numPoses(), q.numRangeMeasurements(), q.numTranslationalStates(),
+                                   Q, m, leaf_poses > 0 ? leaf_poses : 16);
+    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
+    info[0] = F.ok ? 1 : 0;
+    info[1] = F.nnz();
+    info[2] = F.failed_column;
+    double d0 = 0.0, d1 = 0.0;  // order-dependent sums over the columns that are complete (all of them when ok)
+    const int upto = F.ok ? F.n : F.failed_column;
+    for (int j = 0; j < upto; ++j)
+      for (int32_t e = F.Lp[j]; e < F.Lp[j + 1]; ++e)
+        if (F.ok || F.Li[e] < upto) {
+          d0 += F.Lx[e] * static_cast<double>(1 + (e % 7));
+          d1 += static_cast<double>(F.Li[e] % 1009) * F.Lx[e];
+        }
+    digest[0] = d0;
+    digest[1] = d1;
+    if (negative_direction && !F.ok)
+      std::memcpy(negative_direction, F.negative_direction.data(), sizeof(double) * F.negative_direction.size());
+  });
+}
+
 int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int nblocks,
                                    const int32_t *block_sizes, int rhs_rows, int k, const double *B, double *X) {
   return guarded([&] {

@@ -1,5 +1,11 @@
 #include "sparse_cholesky.h"
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -64,6 +70,12 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
   const int n = m;
   F.n = n;
   if (static_cast<int>(perm.size()) != n) throw std::invalid_argument("choleskyFactor: bad permutation size");
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "    [cholesky] %-24s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   F.perm = perm;
   F.iperm.assign(static_cast<size_t>(A.rows()), -1);
   for (int i = 0; i < n; ++i) F.iperm[perm[i]] = i;
@@ -98,6 +110,7 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
     }
     if (!diag) { Ci[w] = k; Cx[w] = shift; ++w; }
   }
+  tick("permuted upper triangle");
   // elimination tree
   F.parent.assign(static_cast<size_t>(n), -1);
   std::vector<int32_t> anc(static_cast<size_t>(n), -1);
@@ -135,11 +148,20 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
   F.Lp[n] = static_cast<int32_t>(tot);
   F.Li.assign(static_cast<size_t>(tot), 0);
   F.Lx.assign(static_cast<size_t>(tot), 0.0);
-  std::vector<int32_t> next(F.Lp.begin(), F.Lp.end() - 1), stack(static_cast<size_t>(n));
-  std::vector<double> x(static_cast<size_t>(n), 0.0);
-  std::fill(flag.begin(), flag.end(), -1);
+  tick("symbolic");
+  std::vector<int32_t> next(F.Lp.begin(), F.Lp.end() - 1);
   F.ok = true;
-  for (int k = 0; k < n; ++k) {
+  struct Work {  // per-thread scratch of the up-looking row solve
+    std::vector<double> x;
+    std::vector<int32_t> flag, stack;
+    explicit Work(int n) : x(static_cast<size_t>(n), 0.0), flag(static_cast<size_t>(n), -1), stack(static_cast<size_t>(n)) {}
+  };
+  // Row k of L (up-looking: a sparse triangular solve over the columns of k's elimination-tree descendants).  Touches
+  // only columns of the subtree rooted at k, so disjoint subtrees can be factorised by different threads; the
+  // arithmetic of a row does not depend on who runs it, so the factor is the sequential one bit for bit.
+  auto process_row = [&](int k, Work &W) -> bool {
+    std::vector<double> &x = W.x;
+    std::vector<int32_t> &flag = W.flag, &stack = W.stack;
     int top = n;
     flag[k] = k;
     double dk = 0.0;
@@ -165,31 +187,98 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
       F.Li[w] = k;
       F.Lx[w] = lki;
     }
-    if (!(dk > 0.0)) {  // CHOLMOD's "not positive definite" (quick_return_if_not_posdef)
-      F.ok = false;
-      F.failed_column = k;
-      // direction of non-positive curvature from the failing pivot: solve L11^T y = l_k
-      std::vector<double> y(static_cast<size_t>(k) + 1, 0.0);
-      for (int j = 0; j < k; ++j)
-        for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
-          if (F.Li[q] == k) y[j] = F.Lx[q];  // l_k (row k of L)
-      for (int j = k - 1; j >= 0; --j) {
-        double s = y[j];
-        for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
-          if (F.Li[q] < k) s -= F.Lx[q] * y[F.Li[q]];
-        y[j] = s / F.Lx[F.Lp[j]];
-      }
-      F.negative_direction.assign(static_cast<size_t>(A.rows()), 0.0);
-      double nrm = 1.0;
-      for (int j = 0; j < k; ++j) nrm += y[j] * y[j];
-      nrm = std::sqrt(nrm);
-      for (int j = 0; j < k; ++j) F.negative_direction[perm[j]] = -y[j] / nrm;
-      F.negative_direction[perm[k]] = 1.0 / nrm;
-      return F;
-    }
+    if (!(dk > 0.0)) return false;  // CHOLMOD's "not positive definite" (quick_return_if_not_posdef)
     const int32_t w = next[k]++;
     F.Li[w] = k;
     F.Lx[w] = std::sqrt(dk);
+    return true;
+  };
+  int first_failure = n;  // sequential semantics: the smallest k whose pivot is not positive
+  unsigned nth = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *e = std::getenv("CORA_CHOL_THREADS")) nth = static_cast<unsigned>(std::max(1, std::atoi(e)));
+  if (n < 20000 || nth <= 1) {
+    Work W(n);
+    for (int k = 0; k < n; ++k)
+      if (!process_row(k, W)) { first_failure = k; break; }
+  } else {
+    // tasks: maximal elimination-tree subtrees whose share of the factor's entries is below 1 / (8 threads)
+    std::vector<int64_t> weight(cnt.begin(), cnt.end());
+    for (int v = 0; v < n; ++v)
+      if (F.parent[v] >= 0) weight[F.parent[v]] += weight[v];  // children come before parents
+    const int64_t target = std::max<int64_t>(tot / (8 * static_cast<int64_t>(nth)), 1);
+    std::vector<int32_t> task(static_cast<size_t>(n), -1);
+    std::vector<std::pair<int64_t, int32_t>> roots;  // (weight, root)
+    for (int v = n - 1; v >= 0; --v) {
+      const int p = F.parent[v];
+      if (p >= 0 && task[p] >= 0) task[v] = task[p];
+      else if (weight[v] <= target) {
+        task[v] = static_cast<int32_t>(roots.size());
+        roots.push_back({weight[v], v});
+      }
+    }
+    const int ntask = static_cast<int>(roots.size());
+    std::vector<int32_t> tptr(static_cast<size_t>(ntask) + 1, 0), trows(static_cast<size_t>(n));
+    for (int v = 0; v < n; ++v)
+      if (task[v] >= 0) tptr[task[v] + 1]++;
+    for (int t = 0; t < ntask; ++t) tptr[t + 1] += tptr[t];
+    {
+      std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+      for (int v = 0; v < n; ++v)
+        if (task[v] >= 0) trows[fill[task[v]]++] = v;  // ascending inside a task
+    }
+    std::vector<int32_t> order(static_cast<size_t>(ntask));
+    for (int t = 0; t < ntask; ++t) order[t] = t;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return roots[a].first > roots[b].first; });
+    std::atomic<int> next_task{0}, min_fail{n};
+    std::vector<std::thread> pool;
+    for (unsigned th = 0; th < nth; ++th)
+      pool.emplace_back([&] {
+        Work W(n);
+        for (;;) {
+          const int slot = next_task.fetch_add(1);
+          if (slot >= ntask) break;
+          const int t = order[slot];
+          for (int32_t q = tptr[t]; q < tptr[t + 1]; ++q) {
+            const int k = trows[q];
+            if (k >= min_fail.load(std::memory_order_relaxed)) break;  // rows past a failure are never looked at
+            if (!process_row(k, W)) {
+              int cur = min_fail.load();
+              while (k < cur && !min_fail.compare_exchange_weak(cur, k)) {}
+              break;
+            }
+          }
+        }
+      });
+    for (std::thread &th : pool) th.join();
+    tick("numeric: subtrees (threads)");
+    // what is left (separators above the tasks, landmark rows) in order; stops at the first failure, wherever it was
+    first_failure = min_fail.load();
+    Work W(n);
+    for (int k = 0; k < first_failure; ++k)
+      if (task[k] < 0 && !process_row(k, W)) { first_failure = k; break; }
+  }
+  tick("numeric: rest");
+  if (first_failure < n) {
+    const int k = first_failure;
+    F.ok = false;
+    F.failed_column = k;
+    // direction of non-positive curvature from the failing pivot: solve L11^T y = l_k
+    std::vector<double> y(static_cast<size_t>(k) + 1, 0.0);
+    for (int j = 0; j < k; ++j)
+      for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
+        if (F.Li[q] == k) y[j] = F.Lx[q];  // l_k (row k of L)
+    for (int j = k - 1; j >= 0; --j) {
+      double s = y[j];
+      for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
+        if (F.Li[q] < k) s -= F.Lx[q] * y[F.Li[q]];
+      y[j] = s / F.Lx[F.Lp[j]];
+    }
+    F.negative_direction.assign(static_cast<size_t>(A.rows()), 0.0);
+    double nrm = 1.0;
+    for (int j = 0; j < k; ++j) nrm += y[j] * y[j];
+    nrm = std::sqrt(nrm);
+    for (int j = 0; j < k; ++j) F.negative_direction[perm[j]] = -y[j] / nrm;
+    F.negative_direction[perm[k]] = 1.0 / nrm;
   }
   return F;
 }

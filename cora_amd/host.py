@@ -260,6 +260,17 @@ class Problem:
                                                      B.ctypes.data_as(_dp), B.shape[1], info))
         return B, dict(ok=bool(info[0]), nnz=int(info[1]), height=int(info[2]))
 
+    def cholesky_probe(self, m=None, shift=0.0, leaf_poses=16):
+        """Host factorisation of (Q + shift I)[0:m, 0:m]: ok, nnz, first failing column, digest of L, negative direction."""
+        dm = self.dims()
+        m = dm["N"] - 1 if m is None else m
+        info = (C.c_int64 * 3)()
+        digest = np.zeros(2)
+        neg = np.zeros(dm["N"])
+        self._chk(self.L.cora_problem_cholesky_probe(self.h, int(m), C.c_double(shift), int(leaf_poses), info,
+                                                     digest.ctypes.data_as(_dp), neg.ctypes.data_as(_dp)))
+        return dict(ok=bool(info[0]), nnz=int(info[1]), failed_column=int(info[2]), digest=digest, negative_direction=neg)
+
     def context_ptr(self):
         c = self.L.cora_problem_context(self.h)
         if not c:

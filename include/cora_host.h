@@ -137,6 +137,12 @@ int cora_problem_precond_info(cora_problem *p, double info[3]);
  * the elimination tree. */
 int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_poses, double *B, int k,
                                 int64_t info[3]);
+/* Test hook for the host factorisation itself: info = {ok, nnz(L), first failing column (permuted) or -1}, digest = two
+ * order-dependent sums over the finished columns of L (bit-equal runs give bit-equal digests), negative_direction
+ * (N doubles, optional) = the direction of non-positive curvature when the factorisation fails.  The subtree-parallel
+ * factorisation (CORA_CHOL_THREADS) must reproduce the one-thread result exactly. */
+int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_poses, int64_t info[3], double *digest,
+                                double *negative_direction);
 
 /* getBlockCholeskyFactorization + blockCholeskySolve (include/CORA/CORA_preconditioners.h:40-44) on the host:
  * A symmetric CSR n x n, block sizes summing to n, B rhs_rows x k column-major with rhs_rows = n or n + 1

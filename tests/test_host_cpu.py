@@ -234,3 +234,33 @@ def test_block_cholesky_free_functions():
         host.block_cholesky_solve(S, [2, 3], np.eye(9))
     with pytest.raises(host.HostError, match="right-hand side"):
         host.block_cholesky_solve(S, blocks, np.eye(11))
+
+
+@pytest.mark.parametrize("shift", [1e-3, 50.0, 0.0, -1.0, -200.0])
+def test_parallel_cholesky_is_the_sequential_one(shift):
+    """The host factorisation (CHOLMOD stand-in) hands disjoint elimination-tree subtrees to threads.  A row's
+    arithmetic does not depend on the thread, so the factor, the first failing pivot (the reference's PSD test,
+    src/CORA_utils.cpp:36-51) and the direction built from it must be those of the one-thread run, bit for bit."""
+    P = host.Problem.synthetic(dim=3, n_poses=6000, n_landmarks=5, n_ranges=3000, n_loops=3, seed=11)
+    P.update()
+    assert P.dims()["N"] > 20000  # above the size where threads are used
+    out = {}
+    for threads in ("1", "7"):
+        os.environ["CORA_CHOL_THREADS"] = threads
+        try:
+            out[threads] = P.cholesky_probe(shift=shift)
+        finally:
+            os.environ.pop("CORA_CHOL_THREADS", None)
+    a, b = out["1"], out["7"]
+    assert a["ok"] == b["ok"] == (shift > 0.0)  # Q itself is singular (the gauge), so is its leading block
+    assert a["nnz"] == b["nnz"] and a["failed_column"] == b["failed_column"]
+    assert np.array_equal(a["digest"], b["digest"])
+    assert np.array_equal(a["negative_direction"], b["negative_direction"])
+    if not a["ok"]:
+        z = a["negative_direction"]
+        _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+        import scipy.sparse as sp
+        N = P.dims()["N"]
+        Q = sp.csr_matrix((vals, colidx, rowptr), shape=(N, N))
+        assert abs(np.linalg.norm(z) - 1.0) < 1e-12 and z[-1] == 0.0
+        assert z @ (Q @ z) + shift * (z @ z) <= 1e-9  # non-positive curvature of (Q + shift I)[0:N-1]
