@@ -109,9 +109,12 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
     h.sync()
     ex["stpcg_iteration_us"] = (time.perf_counter() - t0) / max(done, 1) * 1e6
     ex["stpcg_iterations_timed"] = done
-    # the Hessian-vector product as it runs INSIDE that loop (HIP events around it in every iteration): ~300 MB of
-    # preconditioner traffic pass between two products, so Q does not wait in the Infinity Cache as it does
-    # between back-to-back launches
+    ex["stpcg_form"] = {0: "one pass per operation", 1: "fused vector passes (6 launches + the solve)",
+                        2: "vector passes fused into the sweeps of the Cholesky solve, kappa from the product's "
+                           "epilogue (7 launches per iteration)"}.get(h.stpcg_path(), "?")
+    # the Hessian-vector product as it runs INSIDE that loop (HIP events around it in every iteration).  Two sweeps
+    # over the factor (130 MB) pass between two products; their loads are non-temporal, so Q and the vectors stay in
+    # the Infinity Cache and the product runs close to its back-to-back rate (round 2 before that: 32.9 us)
     h.profile_stpcg(True)
     h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
     ex["hvp_in_stpcg_us"], ex["hvp_in_stpcg_samples"] = h.stpcg_hvp_us()

@@ -392,7 +392,9 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
   if (kind == CORA_PRECOND_BLOCK_CHOLESKY || kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
     const Index N = getDataMatrixSize();
     const int m = static_cast<int>(pin_last_translation_ ? N - 1 : N);
-    int leaf = 4;  // poses per nested-dissection leaf: 8 / 4 / 2 give 5.6 / 4.4 / 4.3 M entries in the stage-0 block inverses at 10^5 poses
+    // poses per nested-dissection leaf: 8 / 4 / 2 / 1 give an STPCG iteration of 158 / 157 / 152 / 152 us at 10^5 poses
+    // (fewer substitution levels per block; nnz(L) 4.99 / 4.82 / 4.82 / 4.8 M)
+    int leaf = 2;
     if (const char *env = std::getenv("CORA_ND_LEAF")) leaf = std::max(1, std::atoi(env));
     const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
     auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
