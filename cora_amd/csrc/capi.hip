@@ -1238,6 +1238,10 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   DotArgs D;
   for (int j = 0; j < 4; ++j) D.a[j] = D.b[j] = nullptr;
   D.n2 = n;
+  D.count = 1;
+  D.mode = DOTS_PLAIN;
+  D.seq_out = nullptr;
+  D.seq = 0;
   if ((rc = ensure_red(c, 4 * 512))) return rc;
   D.partial = c->d_red;
   D.ticket = c->d_ticket;
@@ -1271,10 +1275,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     const cora_ctx::DevFactor &f = c->precond_f;
     sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
                   !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
-    if (sweep_fused) {
-      need = std::max<size_t>(need, static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8);
-      kappa_blocks = launch_spmm_blocks(spmm_args(c, dP, dHp));
-    }
+    if (sweep_fused) need = std::max<size_t>(need, static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8);
+    kappa_blocks = launch_spmm_blocks(spmm_args(c, dP, dHp));
     if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks)))) return rc;
     D.partial = c->d_red;
     kappa_partial = c->d_red + need;
@@ -1297,29 +1299,54 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       FB.Y = c->d_Y;
     }
   }
+  // residual pass inside the forward sweep (144.0 us per iteration at 10^5 poses) or in one launch with the kappa step
+  // (147.5 us; what the other plans use)
+  const bool fwd_fuse_env = std::getenv("CORA_NO_FWD_FUSE") == nullptr;
   c->stpcg_path = sweep_fused ? 2 : fused ? 1 : 0;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
     for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
       const bool prof = c->prof_stpcg && 2 * static_cast<size_t>(enqueued) + 1 < c->prof_events.size();
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
-      if (sweep_fused) {
+      if (fused) {
+        // Hp = H p with the partials of kappa | kappa, alpha, r += alpha Hp with <r, r> | preconditioner | ...
         SpmmArgs A = spmm_args(c, dP, dHp);
         A.kappa_partial = kappa_partial;
         HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP_K, c->stream));
         if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
-        HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
-        cora_ctx::DevFactor &f = c->precond_f;
-        double *t, *t2;
-        if ((rc = get_scratch(c, 6, c->ld, &t, f.aux_rows))) return rc;
-        if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
-        const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
-        HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
-        HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream));
-        HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream));
-        FB.dot.seq = seq = ++c->dot_seq;
-        HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
+        const bool fwd_fuse = sweep_fused && fwd_fuse_env;
+        if (fwd_fuse) HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
+        else HIP_TRY(c, launch_kappa_residual(D, kappa_partial, kappa_blocks, n, dHp + off, dR + off, c->stream));
+        if (sweep_fused) {
+          cora_ctx::DevFactor &f = c->precond_f;
+          double *t, *t2;
+          if ((rc = get_scratch(c, 6, c->ld, &t, f.aux_rows))) return rc;
+          if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
+          const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
+          if (fwd_fuse) HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
+          else HIP_TRY(c, launch_subblock(S0.sub, c->ld, false, dR, t, dV, c->stream));
+          HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream));
+          HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream));
+          FB.dot.seq = seq = ++c->dot_seq;
+          HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
+          HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
+          continue;
+        }
+        const double *x = dR, *scale = nullptr;
+        if (chol) {
+          if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;
+          x = dV;
+        } else if (c->precond == CORA_PRECOND_JACOBI) {
+          scale = c->d_diag_inv;
+        }
+        D.mode = DOTS_STPCG_RV;
+        D.count = 1;
+        D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+        D.seq = seq = ++c->dot_seq;
+        HIP_TRY(c, launch_tangent_project_dot(row_args(c), D, c->ld, c->d_Y, x, scale, dR, dV, c->stream));
         HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
+        D.seq_out = nullptr;
+        D.seq = 0;
         continue;
       }
       if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
@@ -1332,23 +1359,6 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       D.seq_out = nullptr;
       D.seq = 0;
       HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
-      if (fused) {
-        D.mode = DOTS_STPCG_RR;
-        HIP_TRY(c, launch_stpcg_residual(D, n, dHp + off, dR + off, c->stream));
-        const double *x = dR, *scale = nullptr;
-        if (chol) {
-          if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;
-          x = dV;
-        } else if (c->precond == CORA_PRECOND_JACOBI) {
-          scale = c->d_diag_inv;
-        }
-        D.mode = DOTS_STPCG_RV;
-        D.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
-        D.seq = seq = ++c->dot_seq;
-        HIP_TRY(c, launch_tangent_project_dot(row_args(c), D, c->ld, c->d_Y, x, scale, dR, dV, c->stream));
-        HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
-        continue;
-      }
       HIP_TRY(c, launch_stpcg_update(n, c->d_stpcg, dP, dHp, dS, dR, c->stream));
       if ((rc = cora_precondition_projected_dev(c, dR, dV))) return rc;
       D.count = 2;

@@ -57,7 +57,7 @@ struct StpcgState {
   double kappa, rr, step_M_norm;
   int iters, status, max_iters, pad;
 };
-enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4 };
+enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4, DOTS_STPCG_KAPPA_RR = 5 };
 
 struct DotArgs {
   const double *a[4];
@@ -183,6 +183,9 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 //   r += coef_r Hp with <r, r> (DOTS_STPCG_RR)  |  out = Proj_Y(V) with <r, out> (DOTS_STPCG_RV)  |
 //   s += coef_s p, then p = coef_v v + coef_beta p
 hipError_t launch_stpcg_residual(const DotArgs &D, int64_t n, const double *Hp, double *r, hipStream_t st);
+// the same after an EPI_HVP_K product: kappa from its nk per-block partials, the scalar step, then the pass above -- one launch
+hipError_t launch_kappa_residual(const DotArgs &D, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
+                                 hipStream_t st);
 hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D, int ld, const double *Y, const double *V,
                                       const double *scale, const double *r, double *out, hipStream_t st);
 // s = 0, r = g, p = -Pg (start of a solve whose preconditioned gradient is known)

