@@ -378,6 +378,22 @@ class Context:
         self._chk(self.L.cora_debug_stpcg_hvp_us(self.h, C.byref(us), C.byref(cnt)))
         return us.value, cnt.value
 
+    def gram_dev(self, a, ka, b, kb):
+        """G = A^T B (ka x kb) of two resident blocks."""
+        G = np.zeros((ka, kb), order="F")
+        self._chk(self.L.cora_gram_dev(self.h, C.c_void_p(a), int(ka), C.c_void_p(b), int(kb),
+                                       G.ctypes.data_as(C.POINTER(C.c_double))))
+        return G
+
+    def combine_dev(self, xs, ks, Cs, kout, out):
+        """out = sum_i X_i C_i with host coefficient matrices C_i (k_i x kout)."""
+        n = len(xs)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(x) for x in xs])
+        kk = (C.c_int * n)(*[int(k) for k in ks])
+        mats = [np.asfortranarray(np.array(M, dtype=np.float64)) for M in Cs]
+        cp = (C.c_void_p * n)(*[M.ctypes.data_as(C.c_void_p) for M in mats])
+        self._chk(self.L.cora_combine_dev(self.h, n, ptrs, kk, cp, int(kout), C.c_void_p(out)))
+
     def dot_dev(self, a, b, k):
         v = C.c_double()
         self._chk(self.L.cora_dot_dev(self.h, C.c_void_p(a), C.c_void_p(b), int(k), C.byref(v)))

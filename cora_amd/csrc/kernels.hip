@@ -1021,43 +1021,77 @@ __global__ __launch_bounds__(256) void k_download(int64_t N, int k, int ld, cons
 __global__ __launch_bounds__(256) void k_gram(int64_t row0, int64_t rows, const double *__restrict__ A, int lda,
                                               int ka, const double *__restrict__ B, int ldb, int kb,
                                               double *__restrict__ partial) {
-  __shared__ double sa[32 * 24], sb[32 * 24];
-  const int nel = ka * kb;
-  double acc[3] = {0.0, 0.0, 0.0};
-  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-  const int64_t r_begin = static_cast<int64_t>(blockIdx.x) * per, r_end = min(rows, r_begin + per);
-  for (int64_t r = r_begin; r < r_end; r += 32) {
-    const int nr = static_cast<int>(min<int64_t>(32, r_end - r));
-    __syncthreads();
-    for (int t = threadIdx.x; t < nr * ka; t += 256) sa[t] = A[(row0 + r + t / ka) * lda + t % ka];
-    for (int t = threadIdx.x; t < nr * kb; t += 256) sb[t] = B[(row0 + r + t / kb) * ldb + t % kb];
-    __syncthreads();
+  // G = A^T B over the local rows is a GEMM with a long inner dimension (the rows) and a tiny output (ka x kb <= 24 x 24):
+  // v_mfma_f64_16x16x4_f64 with the rows as k.  A wavefront walks its share of the rows four at a time; lane l feeds
+  // A[row + l / 16][l % 16 (+ 16 per tile)] and B likewise -- one 8-byte load each, a wavefront covers four whole rows --
+  // and keeps a 16 x 16 accumulator tile (4 doubles per lane) for each of the <= 2 x 2 tiles.  The four wavefronts of a
+  // block are added through LDS in wave order, blocks by k_gram_reduce in block order: deterministic.
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  __shared__ double red[4][2][2][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int TA = (ka + 15) >> 4, TB = (kb + 15) >> 4;  // <= 2 each (kMaxLD = 24)
+  f64x4 acc[2][2];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int el = threadIdx.x + e * 256;
-      if (el < nel) {
-        const int ia = el / kb, ib = el - ia * kb;
-        double s = acc[e];
-        for (int q = 0; q < nr; ++q) s = fma(sa[q * ka + ia], sb[q * kb + ib], s);
-        acc[e] = s;
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * 4;
+  const int64_t per = ((rows + nwaves - 1) / nwaves + 3) & ~static_cast<int64_t>(3);
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int64_t r_begin = min(rows, w * per), r_end = min(rows, r_begin + per);
+  const int m = lane & 15, kq = lane >> 4;
+  constexpr int kUnroll = 8;
+  for (int64_t r = r_begin; r < r_end; r += 4 * kUnroll) {
+    double av[kUnroll][2], bv[kUnroll][2];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t row = r + 4 * u + kq;
+      const bool ok = row < r_end;
+      const size_t ra = static_cast<size_t>(row0 + (ok ? row : r_begin)) * lda, rb = static_cast<size_t>(row0 + (ok ? row : r_begin)) * ldb;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ca = m + 16 * t, cb = m + 16 * t;
+        av[u][t] = (t < TA && ok && ca < ka) ? A[ra + ca] : 0.0;
+        bv[u][t] = (t < TB && ok && cb < kb) ? B[rb + cb] : 0.0;
       }
     }
-  }
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    const int el = threadIdx.x + e * 256;
-    if (el < nel) partial[static_cast<size_t>(el) * gridDim.x + blockIdx.x] = acc[e];
+    for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          if (x < TA && y < TB) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][x], bv[u][y], acc[x][y], 0, 0, 0);
   }
+  // C/D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) red[wave][x][y][g * 64 + lane] = acc[x][y][g];
+  __syncthreads();
+  for (int x = 0; x < TA; ++x)
+    for (int y = 0; y < TB; ++y) {
+      const int t = threadIdx.x, g = t >> 6, l = t & 63;
+      const int i = 16 * x + (l >> 4) + 4 * g, j = 16 * y + (l & 15);
+      if (i < ka && j < kb) {
+        const double sum = ((red[0][x][y][t] + red[1][x][y][t]) + red[2][x][y][t]) + red[3][x][y][t];
+        partial[static_cast<size_t>(i * kb + j) * gridDim.x + blockIdx.x] = sum;
+      }
+    }
 }
 
-// out[el] = sum_b partial[el * nblocks + b], one thread per element (fixed order)
+// out[el] = sum over blocks of partial[el][block]: one block per element, fixed order
 __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ partial, int nblocks, int nel,
                                                      double *__restrict__ out) {
-  const int el = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double sm[4];
+  const int el = blockIdx.x;
   if (el >= nel) return;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[static_cast<size_t>(el) * nblocks + b];
-  out[el] = s;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[static_cast<size_t>(el) * nblocks + b];
+  const double t = block_sum_256(s, sm);
+  if (threadIdx.x == 0) out[el] = t;
 }
 
 struct CombineArgs {
@@ -1069,31 +1103,63 @@ struct CombineArgs {
 __global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, CombineArgs A,
                                                  const double *__restrict__ coef, int ncoef,
                                                  double *__restrict__ out) {
+  // Out = sum_b X_b C_b, 16 rows per wavefront and step, on v_mfma_f64_16x16x4_f64: the rows are the M dimension
+  // (lane l feeds X[row + l % 16][4 s + l / 16]), the coefficient matrices the B operand (from LDS, zero padded), the
+  // <= 2 column tiles of the output sit in 4 doubles per lane each: D[row = (l >> 4) + 4 reg][col = l & 15], so one
+  // store instruction writes four whole consecutive rows.
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
   extern __shared__ double sc[];
   for (int t = threadIdx.x; t < ncoef; t += 256) sc[t] = coef[t];
   __syncthreads();
-  for (int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; r < rows;
-       r += static_cast<int64_t>(gridDim.x) * 256) {
-    // the output row stays in registers: every loop over its kMaxLD slots is unrolled with a (wave-uniform)
-    // predicate, never indexed dynamically (which put it in scratch: 208 bytes per lane)
-    double o[kMaxLD];
-#pragma unroll
-    for (int j = 0; j < kMaxLD; ++j) o[j] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  const int TO = (A.kout + 15) >> 4;  // column tiles of the output (<= 2)
+  const int64_t groups = (rows + 15) >> 4, nw = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t gidx = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); gidx < groups; gidx += nw) {
+    const int64_t r = gidx << 4;
+    const bool rok = r + m < rows;
+    f64x4 acc[2] = {f64x4{0.0, 0.0, 0.0, 0.0}, f64x4{0.0, 0.0, 0.0, 0.0}};
     for (int b = 0; b < A.nblocks; ++b) {
-      const double *xr = A.x[b] + (row0 + r) * A.ldx[b];
-      const double *C = sc + A.coff[b];
-      for (int i = 0; i < A.kx[b]; ++i) {
-        const double v = xr[i];
-        const double *Ci = C + i * A.kout;
+      const double *__restrict__ xr = A.x[b] + static_cast<size_t>(row0 + (rok ? r + m : r)) * A.ldx[b];
+      const double *__restrict__ C = sc + A.coff[b];
+      const int kx = A.kx[b];
+      double xv[6];
 #pragma unroll
-        for (int j = 0; j < kMaxLD; ++j)
-          if (j < A.kout) o[j] = fma(v, Ci[j], o[j]);
+      for (int st = 0; st < 6; ++st) {
+        const int col = 4 * st + kq;
+        xv[st] = (4 * st < kx && rok && col < kx) ? xr[col] : 0.0;
       }
-    }
-    double *orow = out + (row0 + r) * A.ldo;
 #pragma unroll
-    for (int j = 0; j < kMaxLD; ++j)
-      if (j < A.ldo) orow[j] = j < A.kout ? o[j] : 0.0;
+      for (int st = 0; st < 6; ++st)
+        if (4 * st < kx) {  // wave-uniform
+          const int col = 4 * st + kq;
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+            if (y < TO) {
+              const int j = 16 * y + m;
+              const double cv = (col < kx && j < A.kout) ? C[col * A.kout + j] : 0.0;
+              acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[st], cv, acc[y], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+      if (y < TO) {
+        const int j = 16 * y + m;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t row = r + kq + 4 * g;
+          if (row < rows && j < A.ldo) out[static_cast<size_t>(row0 + row) * A.ldo + j] = j < A.kout ? acc[y][g] : 0.0;
+        }
+      }
+    if (A.ldo > 16 * TO) {  // padding columns beyond the last tile (row stride 20 / 24 with kout <= 16)
+      for (int j = 16 * TO + m; j < A.ldo; j += 16)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t row = r + kq + 4 * g;
+          if (row < rows) out[static_cast<size_t>(row0 + row) * A.ldo + j] = 0.0;
+        }
+    }
   }
 }
 
@@ -1468,6 +1534,9 @@ __device__ __forceinline__ double project_unit_dot(const SubFuse &F, size_t row,
   return acc;
 }
 
+#ifndef CORA_SUB_MIN_BLOCKS
+#define CORA_SUB_MIN_BLOCKS 4
+#endif
 // FD: 0 plain solve; 1 (forward) residual update fused into the prologue; 2 / 3 (backward) tangent projection for
 // d = FD fused into the epilogue -- see SubFuse (kernels.h).
 //
@@ -1477,7 +1546,7 @@ __device__ __forceinline__ double project_unit_dot(const SubFuse &F, size_t row,
 // row.  (A lane per row: 40-byte pieces, 5 x the line requests; with the fused passes written that way the forward
 // sweep took 50 us instead of 33.)
 template <int LD, bool BWD, int FD>
-__global__ __launch_bounds__(kSubThreads, 4) void k_subblock(SubOpDev S, const double *src, double *work, double *dst,
+__global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(SubOpDev S, const double *src, double *work, double *dst,
                                                               const SubFuse F) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double dot_sm[8];
@@ -2164,7 +2233,7 @@ hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, cons
                        double *partial, int nblocks, double *out, hipStream_t st) {
   hipLaunchKernelGGL(k_gram, dim3(nblocks), dim3(256), 0, st, row0, rows, A, ld_for(ka), ka, B, ld_for(kb), kb, partial);
   const int nel = ka * kb;
-  hipLaunchKernelGGL(k_gram_reduce, dim3((nel + 255) / 256), dim3(256), 0, st, partial, nblocks, nel, out);
+  hipLaunchKernelGGL(k_gram_reduce, dim3(nel), dim3(256), 0, st, partial, nblocks, nel, out);
   return hipGetLastError();
 }
 
@@ -2176,7 +2245,7 @@ hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double 
   A.nblocks = nblocks;
   A.kout = kout;
   A.ldo = ld_for(kout);
-  const int grid = static_cast<int>(std::min<int64_t>((rows + 255) / 256, 2048));
+  const int grid = static_cast<int>(std::min<int64_t>((rows + 63) / 64, 2048));  // 4 wavefronts x 16 rows per block and step
   hipLaunchKernelGGL(k_combine, dim3(std::max(grid, 1)), dim3(256), ncoef * sizeof(double), st, row0, rows, A, coef,
                      ncoef, out);
   return hipGetLastError();

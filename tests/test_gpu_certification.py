@@ -119,3 +119,36 @@ def test_ildl_preconditioned_lobpcg_branch():
     # with the seed of the failed factorisation (the default) the direction is there at once
     seeded = host.fast_verification(S, eta, X0=x0, max_iters=400, lab=dict())
     assert not seeded["is_certified"] and seeded["theta"] < -eta / 2 and seeded["theta"] >= lmin - 1e-12
+
+
+@pytest.mark.parametrize("ka,kb", [(10, 10), (1, 1), (3, 17), (16, 16), (17, 5), (24, 24), (20, 10)])
+def test_gram_and_combine_blocks(ka, kb):
+    """The Rayleigh-Ritz building blocks of LOBPCG (the reference takes the eigensolver from libs/Optimization,
+    src/CORA_utils.cpp:113-119): G = A^T B on the fp64 matrix cores (v_mfma_f64_16x16x4, rows as the inner dimension)
+    and Out = X C, against numpy on asymmetric random blocks; row count not a multiple of anything."""
+    P = host.Problem.synthetic(dim=3, n_poses=2311, n_landmarks=3, n_ranges=1157, seed=4)
+    P.update()
+    dm = P.dims()
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    rng = np.random.default_rng(ka * 100 + kb)
+    A = rng.uniform(-1, 1, (dm["N"], ka)) * np.linspace(0.5, 2.0, ka)
+    B = rng.uniform(-1, 1, (dm["N"], kb)) + 0.1 * np.arange(kb)
+    a, b, o = h.dev_alloc(ka), h.dev_alloc(kb), h.dev_alloc(kb)
+    h.upload(A, a)
+    h.upload(B, b)
+    G = h.gram_dev(a, ka, b, kb)
+    ref = A.T @ B
+    assert G.shape == ref.shape
+    assert np.abs(G - ref).max() <= 1e-12 * np.abs(A).T.dot(np.abs(B)).max()
+    Cm = rng.uniform(-1, 1, (ka, kb))
+    h.combine_dev([a], [ka], [Cm], kb, o)
+    out = h.download(o, kb)
+    assert np.abs(out - A @ Cm).max() <= 1e-13 * np.abs(A @ Cm).max() * ka
+    # two input blocks of different widths (the form of the LOBPCG updates: X C1 + W C2)
+    C1, C2 = rng.uniform(-1, 1, (ka, kb)), rng.uniform(-1, 1, (kb, kb))
+    h.combine_dev([a, b], [ka, kb], [C1, C2], kb, o)
+    out = h.download(o, kb)
+    ref2 = A @ C1 + B @ C2
+    assert np.abs(out - ref2).max() <= 1e-13 * np.abs(ref2).max() * (ka + kb)
+    for q in (a, b, o):
+        h.dev_free(q)
