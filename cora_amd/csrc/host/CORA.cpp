@@ -115,6 +115,9 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   }
   printIfVerbose(verbose, "Final solution is certified: " + std::to_string(cert.is_certified) + " with eta: " +
                               std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
+  printIfVerbose(verbose, "Time: TNT " + std::to_string(t_tnt) + " s, certification " + std::to_string(t_cert) +
+                              " s, saddle escape " + std::to_string(t_escape) + " s, Hessian-vector products " +
+                              std::to_string(hvps));
   if (info) {
     info->certified = cert.is_certified;
     info->eta = eta;

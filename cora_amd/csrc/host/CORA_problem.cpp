@@ -659,9 +659,53 @@ SparseMatrix Problem::compute_Lambda_from_Lambda_blocks(const LambdaBlocks &L, c
 
 SparseMatrix Problem::get_certificate_matrix(const Matrix &Y) const {
   const LambdaBlocks L = compute_Lambda_blocks(Y);
-  SparseMatrix Lambda = compute_Lambda_from_Lambda_blocks(L, getDataMatrixSize());
-  for (auto &v : Lambda.values) v = -v;
-  return data_matrix_.plus(Lambda);
+  // S = Q - Lambda.  Lambda lives on the d x d diagonal blocks of the rotation rows and on the diagonal of the range
+  // rows: every row of Q (sorted by column) is merged with its <= d entries of -Lambda in one pass, instead of
+  // assembling Lambda from 10^6 triplets and adding two general sparse matrices (0.29 -> 0.05 s at 10^5 poses, three
+  // times per staircase).  Entries of Lambda outside Q's pattern (the off-diagonals of a pose without translation
+  // measurements) are inserted.
+  const Index N = getDataMatrixSize(), rot = numPosesDim(), nr = numRangeMeasurements();
+  const SparseMatrix &Q = data_matrix_;
+  SparseMatrix S(N, N);
+  S.inner.reserve(Q.inner.size() + static_cast<size_t>(rot) * dim_ + nr);
+  S.values.reserve(Q.inner.size() + static_cast<size_t>(rot) * dim_ + nr);
+  for (Index row = 0; row < N; ++row) {
+    int32_t lc[3] = {0, 0, 0};
+    Scalar lv[3] = {0, 0, 0};
+    int nl = 0;
+    if (row < rot) {
+      const Index i = row / dim_, r = row % dim_;
+      for (Index c = 0; c < dim_; ++c) {
+        lc[nl] = static_cast<int32_t>(i * dim_ + c);
+        lv[nl++] = -L.first(r, i * dim_ + c);
+      }
+    } else if (row < rot + nr) {
+      lc[0] = static_cast<int32_t>(row);
+      lv[0] = -L.second(row - rot);
+      nl = 1;
+    }
+    int32_t q = Q.outer[static_cast<size_t>(row)];
+    const int32_t qe = Q.outer[static_cast<size_t>(row) + 1];
+    int k = 0;
+    while (q < qe || k < nl) {
+      if (k >= nl || (q < qe && Q.inner[q] < lc[k])) {
+        S.inner.push_back(Q.inner[q]);
+        S.values.push_back(Q.values[q]);
+        ++q;
+      } else if (q >= qe || lc[k] < Q.inner[q]) {
+        S.inner.push_back(lc[k]);
+        S.values.push_back(lv[k]);
+        ++k;
+      } else {
+        S.inner.push_back(lc[k]);
+        S.values.push_back(Q.values[q] + lv[k]);
+        ++q;
+        ++k;
+      }
+    }
+    S.outer[static_cast<size_t>(row) + 1] = static_cast<int32_t>(S.inner.size());
+  }
+  return S;
 }
 
 // ---- printProblem: src/CORA_problem.cpp:400-489 -------------------------------
@@ -783,6 +827,12 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
                                       size_t max_LOBPCG_iters) const {
   checkMatrixShape("Problem::certify_solution::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   const Index N = getDataMatrixSize(), p = Y.cols();
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "  [certify] %-26s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   // ratio of the extreme singular values of Y from the p x p Gram matrix (:1039-1049)
   {
     Vector ev;
@@ -801,7 +851,9 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   }
   // S = Q - Lambda(Y): Lambda on the device (also leaves Y as the handle's current point, so the
   // certificate operator below uses the same Lambda), S assembled on the host for the Cholesky test
+  tick("Gram of Y");
   const SparseMatrix S = get_certificate_matrix(Y);
+  tick("certificate matrix");
   cora_ctx *c = ctx_.get();
   // device vectors carry at most 24 columns (kMaxLD): the block is clamped there (the reference has no cap; p + 2 only
   // exceeds it at ranks solveCORA rejects up front)
@@ -815,7 +867,9 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   DeviceOperator Sop = [c](const double *dX, int k, double *dOut) {
     if (cora_certificate_product_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
   };
+  tick("start block + ordering");
   CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop);
+  tick("fast_verification");
   while (std::isnan(results.theta)) {  // :1076-1083
     std::cout << "NaN in theta -- result not certified" << std::endl;
     eta *= 2;

@@ -1,6 +1,9 @@
 #include "CORA_utils.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 
@@ -25,7 +28,14 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
     perm.resize(static_cast<size_t>(n));
     std::iota(perm.begin(), perm.end(), 0);
   }
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "    [verify] %-24s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   const CholeskyFactor F = choleskyFactor(S, static_cast<int>(n), eta, perm);
+  tick("Cholesky of S + eta I");
   const bool PSD = F.ok;
   results.is_certified = PSD;
   if (PSD) {
@@ -75,6 +85,7 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
   LOBPCGResult r = LOBPCG(c, Mop, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0,
                           stopfun);
   size_t iters = r.num_iters;
+  tick("LOBPCG, 1 % of the budget");
   if (!(r.Theta(0) - eta < -eta / 2)) {
     // STEP 3 (:129-167): the "hard" case -- a negative eigenvalue of small magnitude.  Preconditioner T: incomplete
     // L D L^T of M = S + eta I (max_fill_factor, drop_tol; libs/Preconditioners is absent, see incompleteLDLT) applied
@@ -98,6 +109,7 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
       // iterations, and the factorisation below is only paid for when they do not
       r = LOBPCG(c, Mop, std::nullopt, X0s, 1, std::min<size_t>(budget3, 3), 0.0, stopfun);
       iters += r.num_iters;
+      tick("LOBPCG, seeded");
       done = r.Theta(0) - eta < -eta / 2;
     }
     if (!done) {
