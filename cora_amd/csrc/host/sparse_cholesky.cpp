@@ -4,6 +4,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 #include <algorithm>
@@ -65,6 +68,144 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
   return perm;
 }
 
+
+namespace {
+
+// pattern-only part of a factorisation (see choleskyFactor)
+struct Symbolic {
+  uint64_t key = 0;
+  int n = 0;
+  size_t nnzA = 0;
+  std::vector<int32_t> Cp, Ci;  // upper triangle of P A P^T by columns
+  std::vector<int32_t> Cmap;    // entry -> position in A.values (-1: structurally missing diagonal, value 0)
+  std::vector<int32_t> Cdiag;   // position of the diagonal entry of every column
+  std::vector<int32_t> parent, cnt, Lp;
+  int64_t tot = 0;
+};
+
+uint64_t hashWords(uint64_t h, const int32_t *p, size_t count) {
+  uint64_t a = h ^ 0x9E3779B97F4A7C15ull, b = h + 0xC2B2AE3D27D4EB4Full, c = ~h, d = h * 0xD6E8FEB86659FD93ull + 1;
+  size_t i = 0;
+  for (; i + 8 <= count; i += 8) {
+    uint64_t w[4];
+    std::memcpy(w, p + i, 32);
+    a = (a ^ w[0]) * 0xFF51AFD7ED558CCDull; a ^= a >> 29;
+    b = (b ^ w[1]) * 0xC4CEB9FE1A85EC53ull; b ^= b >> 31;
+    c = (c ^ w[2]) * 0x9FB21C651E98DF25ull; c ^= c >> 30;
+    d = (d ^ w[3]) * 0xD6E8FEB86659FD93ull; d ^= d >> 32;
+  }
+  for (; i < count; ++i) { a = (a ^ static_cast<uint32_t>(p[i])) * 0xFF51AFD7ED558CCDull; a ^= a >> 29; }
+  uint64_t r = a;
+  r = (r ^ b) * 0xFF51AFD7ED558CCDull; r ^= r >> 32;
+  r = (r ^ c) * 0xC4CEB9FE1A85EC53ull; r ^= r >> 29;
+  r = (r ^ d) * 0x9FB21C651E98DF25ull; r ^= r >> 32;
+  return r;
+}
+
+std::mutex g_sym_mutex;
+std::shared_ptr<const Symbolic> g_sym[2];  // the two most recent patterns (preconditioner block, certificate matrix)
+
+std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const std::vector<int32_t> &perm,
+                                            const std::vector<int32_t> &iperm, bool *hit) {
+  *hit = false;
+  uint64_t key = hashWords(static_cast<uint64_t>(n) * 0x100000001B3ull + static_cast<uint64_t>(A.rows()), A.outer.data(), A.outer.size());
+  key = hashWords(key, A.inner.data(), A.inner.size());
+  key = hashWords(key, perm.data(), perm.size());
+  const bool use_cache = std::getenv("CORA_CHOL_NO_SYMBOLIC_CACHE") == nullptr;
+  if (use_cache) {
+    std::lock_guard<std::mutex> lock(g_sym_mutex);
+    for (int e = 0; e < 2; ++e)
+      if (g_sym[e] && g_sym[e]->key == key && g_sym[e]->n == n && g_sym[e]->nnzA == A.inner.size()) {
+        if (e == 1) std::swap(g_sym[0], g_sym[1]);
+        *hit = true;
+        return g_sym[0];
+      }
+  }
+  auto S = std::make_shared<Symbolic>();
+  S->key = key;
+  S->n = n;
+  S->nnzA = A.inner.size();
+  // upper triangle of P A P^T by columns == rows of A restricted to iperm <= k
+  std::vector<int32_t> &Cp = S->Cp, &Ci = S->Ci, &Cmap = S->Cmap;
+  Cp.assign(static_cast<size_t>(n) + 1, 0);
+  for (int k = 0; k < n; ++k) {
+    const int old = perm[k];
+    int cnt = 0;
+    bool diag = false;
+    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+      const int i = iperm[A.inner[q]];
+      if (i >= 0 && i <= k) { ++cnt; diag |= (i == k); }
+    }
+    if (!diag) ++cnt;  // room for the shift on a structurally missing diagonal
+    Cp[k + 1] = Cp[k] + cnt;
+  }
+  Ci.resize(static_cast<size_t>(Cp[n]));
+  Cmap.resize(static_cast<size_t>(Cp[n]));
+  S->Cdiag.assign(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k) {
+    const int old = perm[k];
+    int32_t w = Cp[k];
+    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+      const int i = iperm[A.inner[q]];
+      if (i >= 0 && i <= k) {
+        Ci[w] = i;
+        Cmap[w] = q;
+        // (a duplicated diagonal entry cannot occur: setFromTriplets sums duplicates)
+        if (i == k) S->Cdiag[k] = w;
+        ++w;
+      }
+    }
+    if (S->Cdiag[k] < 0) { Ci[w] = k; Cmap[w] = -1; S->Cdiag[k] = w; ++w; }
+  }
+  // elimination tree
+  std::vector<int32_t> &parent = S->parent;
+  parent.assign(static_cast<size_t>(n), -1);
+  std::vector<int32_t> anc(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k)
+    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+      int i = Ci[q];
+      while (i != -1 && i < k) {
+        const int nxt = anc[i];
+        anc[i] = k;
+        if (nxt == -1) parent[i] = k;
+        i = nxt;
+      }
+    }
+  // column counts (symbolic up-looking pass)
+  std::vector<int32_t> &cnt = S->cnt;
+  cnt.assign(static_cast<size_t>(n), 0);
+  std::vector<int32_t> flag(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k) {
+    flag[k] = k;
+    cnt[k]++;
+    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+      int i = Ci[q];
+      while (i != -1 && i < k && flag[i] != k) {
+        cnt[i]++;
+        flag[i] = k;
+        i = parent[i];
+      }
+    }
+  }
+  S->Lp.assign(static_cast<size_t>(n) + 1, 0);
+  int64_t tot = 0;
+  for (int k = 0; k < n; ++k) {
+    S->Lp[k] = static_cast<int32_t>(tot);
+    tot += cnt[k];
+    if (tot > 2000000000LL) throw std::runtime_error("choleskyFactor: factor too large for int32 indexing");
+  }
+  S->Lp[n] = static_cast<int32_t>(tot);
+  S->tot = tot;
+  if (use_cache) {
+    std::lock_guard<std::mutex> lock(g_sym_mutex);
+    g_sym[1] = g_sym[0];
+    g_sym[0] = S;
+  }
+  return S;
+}
+
+}  // namespace
+
 CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm) {
   CholeskyFactor F;
   const int n = m;
@@ -80,75 +221,27 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
   F.iperm.assign(static_cast<size_t>(A.rows()), -1);
   for (int i = 0; i < n; ++i) F.iperm[perm[i]] = i;
 
-  // upper triangle of P A P^T by columns == rows of A restricted to iperm <= k
-  std::vector<int32_t> Cp(static_cast<size_t>(n) + 1, 0);
-  for (int k = 0; k < n; ++k) {
-    const int old = perm[k];
-    int cnt = 0;
-    bool diag = false;
-    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
-      const int i = F.iperm[A.inner[q]];
-      if (i >= 0 && i <= k) { ++cnt; diag |= (i == k); }
-    }
-    if (!diag) ++cnt;  // room for the shift on a structurally missing diagonal
-    Cp[k + 1] = Cp[k] + cnt;
-  }
-  std::vector<int32_t> Ci(static_cast<size_t>(Cp[n]));
+  // Everything that depends only on the pattern of A and on the order -- the permuted upper triangle's structure, the
+  // elimination tree, the column counts -- is kept from one call to the next (`Symbolic`): the certificate matrix
+  // S + eta I is factorised up to three times per staircase on one pattern, like CHOLMOD's analyze / factorize split
+  // behind Eigen's analyzePattern.
+  bool sym_hit = false;
+  const std::shared_ptr<const Symbolic> sym = symbolicFor(A, n, perm, F.iperm, &sym_hit);
+  const std::vector<int32_t> &Cp = sym->Cp, &Ci = sym->Ci, &cnt = sym->cnt;
+  const int64_t tot = sym->tot;
   std::vector<double> Cx(static_cast<size_t>(Cp[n]));
-  for (int k = 0; k < n; ++k) {
-    const int old = perm[k];
-    int32_t w = Cp[k];
-    bool diag = false;
-    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
-      const int i = F.iperm[A.inner[q]];
-      if (i >= 0 && i <= k) {
-        Ci[w] = i;
-        Cx[w] = A.values[q] + (i == k ? shift : 0.0);
-        diag |= (i == k);
-        ++w;
-      }
-    }
-    if (!diag) { Ci[w] = k; Cx[w] = shift; ++w; }
+  {
+    const std::vector<int32_t> &Cmap = sym->Cmap;
+    const size_t nc = Cx.size();
+    for (size_t w = 0; w < nc; ++w) Cx[w] = Cmap[w] >= 0 ? A.values[Cmap[w]] : 0.0;
+    for (int k = 0; k < n; ++k) Cx[sym->Cdiag[k]] += shift;
   }
-  tick("permuted upper triangle");
-  // elimination tree
-  F.parent.assign(static_cast<size_t>(n), -1);
-  std::vector<int32_t> anc(static_cast<size_t>(n), -1);
-  for (int k = 0; k < n; ++k)
-    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
-      int i = Ci[q];
-      while (i != -1 && i < k) {
-        const int nxt = anc[i];
-        anc[i] = k;
-        if (nxt == -1) F.parent[i] = k;
-        i = nxt;
-      }
-    }
-  // column counts (symbolic up-looking pass)
-  std::vector<int32_t> cnt(static_cast<size_t>(n), 0), flag(static_cast<size_t>(n), -1);
-  for (int k = 0; k < n; ++k) {
-    flag[k] = k;
-    cnt[k]++;
-    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
-      int i = Ci[q];
-      while (i != -1 && i < k && flag[i] != k) {
-        cnt[i]++;
-        flag[i] = k;
-        i = F.parent[i];
-      }
-    }
-  }
-  F.Lp.assign(static_cast<size_t>(n) + 1, 0);
-  int64_t tot = 0;
-  for (int k = 0; k < n; ++k) {
-    F.Lp[k] = static_cast<int32_t>(tot);
-    tot += cnt[k];
-    if (tot > 2000000000LL) throw std::runtime_error("choleskyFactor: factor too large for int32 indexing");
-  }
-  F.Lp[n] = static_cast<int32_t>(tot);
+  tick(sym_hit ? "values into the cached pattern" : "permuted upper triangle + symbolic");
+  F.parent = sym->parent;
+  F.Lp = sym->Lp;
   F.Li.assign(static_cast<size_t>(tot), 0);
   F.Lx.assign(static_cast<size_t>(tot), 0.0);
-  tick("symbolic");
+  tick("factor storage");
   std::vector<int32_t> next(F.Lp.begin(), F.Lp.end() - 1);
   F.ok = true;
   struct Work {  // per-thread scratch of the up-looking row solve

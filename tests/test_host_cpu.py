@@ -264,3 +264,28 @@ def test_parallel_cholesky_is_the_sequential_one(shift):
         Q = sp.csr_matrix((vals, colidx, rowptr), shape=(N, N))
         assert abs(np.linalg.norm(z) - 1.0) < 1e-12 and z[-1] == 0.0
         assert z @ (Q @ z) + shift * (z @ z) <= 1e-9  # non-positive curvature of (Q + shift I)[0:N-1]
+
+
+def test_cholesky_symbolic_cache_changes_nothing():
+    """choleskyFactor keeps the pattern-only part of a factorisation (permuted structure, elimination tree, column
+    counts) between calls on the same pattern and order -- the certificate matrix S + eta I is factorised several times
+    per staircase (src/CORA_utils.cpp:36-51 behind src/CORA_problem.cpp:1030-1103).  Cached and uncached runs must give
+    the same factor bit for bit, also when another pattern (another block size m) was factorised in between."""
+    P = host.Problem.synthetic(dim=3, n_poses=3000, n_landmarks=4, n_ranges=1500, n_loops=2, seed=5)
+    P.update()
+    N = P.dims()["N"]
+    ref = {}
+    os.environ["CORA_CHOL_NO_SYMBOLIC_CACHE"] = "1"
+    try:
+        for m, shift in ((N - 1, 2.0), (N - 1, 7.5), (N, 3.0), (N - 1, -1.0)):
+            ref[(m, shift)] = P.cholesky_probe(m=m, shift=shift)
+    finally:
+        os.environ.pop("CORA_CHOL_NO_SYMBOLIC_CACHE", None)
+    for key in list(ref) + list(ref):  # second round: every pattern is served from the cache
+        m, shift = key
+        got = P.cholesky_probe(m=m, shift=shift)
+        want = ref[key]
+        assert got["ok"] == want["ok"] and got["nnz"] == want["nnz"] and got["failed_column"] == want["failed_column"]
+        assert np.array_equal(got["digest"], want["digest"])
+        assert np.array_equal(got["negative_direction"], want["negative_direction"])
+    assert ref[(N - 1, 2.0)]["ok"] and not ref[(N - 1, -1.0)]["ok"]
