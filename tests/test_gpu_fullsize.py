@@ -207,3 +207,34 @@ def test_full_staircase_on_the_headline_graph():
     print("\n10^5-pose staircase: f0=%.1f -> f=%.4f |g|=%.2e certified=%s theta=%.3e eta=%.3e levels=%d hvps=%d %.2fs"
           % (f0, res["f"], res["grad_norm"], res["certified"], res["theta"], res["eta"], res["levels"], res["hvps"],
              res["seconds"]))
+
+
+def test_million_pose_preconditioner_keeps_the_two_stage_plan():
+    """Ten times the headline size (10^6 poses, N = 4 500 010, nnz(L) ~ 48 M): everything is HBM-resident, and the top of
+    the elimination tree above the 10^4 substitution blocks (74 k rows) is too large for the cap that decides whether a
+    SMALL factor is applied as one explicit inverse.  The plan must still be the two-stage one of DESIGN.md 3a (the cap
+    scales with the factor) -- with the fixed cap it fell back to three explicit stages, 1.3 ms per apply instead of
+    0.9 -- and P (Q + lambda I) v = v must hold like at 10^5 poses (reference: blockCholeskySolve behind
+    src/CORA_problem.cpp:869-903)."""
+    import ctypes as C
+    P = host.Problem.synthetic(dim=3, n_poses=1_000_000, n_landmarks=10, n_ranges=500_000, seed=42,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    p = 5
+    P.set_rank(p)
+    dm = P.dims()
+    lam = P.precond_info()["lam"]
+    st = (C.c_int64 * 4)()
+    assert capi.load().cora_precond_stats(C.c_void_p(P.context_ptr()), st) == 0
+    stages, nnz_w, nnz_l, top_rows = st[0], st[1], st[2], st[3]
+    assert stages == 2 and nnz_w < nnz_l // 4 and top_rows < dm["N"] // 20
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    A = sp.csr_matrix((vals, colidx, rowptr), shape=(dm["N"], dm["N"]))
+    rng = np.random.default_rng(3)
+    V = rng.uniform(-1, 1, (dm["N"], p))
+    V[-1] = 0.0
+    W = A @ V + lam * V
+    W[-1] = 0.0
+    out = P.op("precondition", W)
+    assert np.all(out[-1] == 0.0)
+    assert np.abs(out[:-1] - V[:-1]).max() < 1e-6 * np.abs(V).max()
