@@ -52,7 +52,7 @@ struct cora_ctx {
     RowOpDev fwd_a{}, fwd_b{}, bwd_a{}, bwd_b{};
     BlockOpDev blocks{};
     SubOpDev sub{};
-    bool has_fwd_a = false, has_bwd_a = false, dense = false, is_sub = false;
+    bool has_fwd_a = false, has_bwd_a = false, dense = false, is_sub = false, aux_sum = false;
   };
   struct DevFactor {
     TriPlan plan;  // host copy is dropped after upload (only the counts are kept)
@@ -840,6 +840,8 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       continue;
     }
     if (k == 1 && f.stages[0].is_sub) {  // the last stage of a two-stage plan: only its two explicit-inverse products
+      D.aux_sum = !S.fwd_a.empty();      // (+ the sum of the aux rows as a product of its own on large plans)
+      if (D.aux_sum) HIP_TRY(c, up_op(D.fwd_a, S.fwd_a));
       HIP_TRY(c, up_op(D.fwd_b, S.fwd_b));
       HIP_TRY(c, up_op(D.bwd_b, S.bwd_b));
       continue;
@@ -903,7 +905,8 @@ static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, const doubl
   if (f.stages[0].is_sub) {  // two-stage plan: substitution blocks around one explicit inverse (trisolve.h)
     const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
     HIP_TRY(c, launch_subblock(S0.sub, ld, false, rhs, t, out, c->stream));  // y_0 -> out, couplings + rhs_1 -> t
-    HIP_TRY(c, launch_rowop(S1.fwd_b, ld, nullptr, t, t2, c->stream));       // y_1 = W_1 t_1
+    if (S1.aux_sum) HIP_TRY(c, launch_rowop(S1.fwd_a, ld, t, t, t, c->stream));  // t_1 += its aux rows (in place: a row is read and written by its own lanes only)
+    HIP_TRY(c, launch_rowop(S1.fwd_b, ld, nullptr, t, t2, c->stream));       // y_1 = W_1 t_1 (with the aux sums folded in otherwise)
     HIP_TRY(c, launch_rowop(S1.bwd_b, ld, nullptr, t2, t, c->stream));       // x_1 = W_1^T y_1 -> t
     HIP_TRY(c, launch_subblock(S0.sub, ld, true, out, t, out, c->stream));   // x_0, and x_1 -> out
     return CORA_OK;
@@ -1325,6 +1328,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
           if (fwd_fuse) HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
           else HIP_TRY(c, launch_subblock(S0.sub, c->ld, false, dR, t, dV, c->stream));
+          if (S1.aux_sum) HIP_TRY(c, launch_rowop(S1.fwd_a, c->ld, t, t, t, c->stream));
           HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream));
           HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream));
           FB.dot.seq = seq = ++c->dot_seq;

@@ -793,19 +793,42 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       cc[at] = wt_col[k][t];
       vv[at] = wt_val[k][t];
     }
+    // two-stage form: t_j = rhs_j + the aux rows the stage-0 blocks next to j wrote (row order: fixed).  Either the sum is
+    // folded into the product (every entry W_ij repeated once per aux row of j: one launch less, what small top stages
+    // want) or it is its own product in the slot of the unused "a" product (t_1 += sum of its aux rows, in place) --
+    // at 10^6 poses the folded product had 3.3 entries per entry of W and took 203 us against 33 us for W^T.
+    bool fold = true;
+    if (sub0) {
+      int64_t extra = 0;
+      for (size_t t = 0; t < nz; ++t) extra += static_cast<int64_t>(aux_of[wt_col[k][t]].size());
+      int64_t unfold_min = 2000000;  // extra entries that outweigh a launch AND the sum's own chain of latencies (measured: folded wins at 10^4 and 10^5 poses -- 7.7 vs 10.8 us, 13.6 vs 19.7 us --, loses at 10^6: 203 vs 99 us)
+      if (const char *e = std::getenv("CORA_TRI_UNFOLD_MIN")) unfold_min = std::atoll(e);
+      fold = extra < unfold_min;
+      if (timing) std::fprintf(stderr, "  [tri plan] top stage: %lld entries, %lld more with the aux sums folded in: %s\n",
+                               static_cast<long long>(nz), static_cast<long long>(extra), fold ? "folded" : "separate sum");
+    }
     RowList F;
     for (int i = 0; i < m; ++i) {
       if (stage[i] != k) continue;
       F.begin_row(row_of[i]);
       for (int32_t q = cnt[i]; q < cnt[i + 1]; ++q) {
         F.add(row_of[cc[q]], vv[q]);
-        // two-stage form: t_j = rhs_j + the aux rows the stage-0 blocks next to j wrote (row order: fixed)
-        if (sub0)
+        if (sub0 && fold)
           for (int32_t a : aux_of[cc[q]]) F.add(aux_base + a, vv[q]);
       }
       F.end_row();
     }
     finalize(F, P.stages[k].fwd_b);
+    if (sub0 && !fold) {
+      RowList A;
+      for (int i = 0; i < m; ++i) {
+        if (stage[i] != k || aux_of[i].empty()) continue;
+        A.begin_row(row_of[i]);
+        for (int32_t a : aux_of[i]) A.add(aux_base + a, 1.0);
+        A.end_row();
+      }
+      finalize(A, P.stages[k].fwd_a);
+    }
     wt_row[k] = std::vector<int32_t>();
     wt_col[k] = std::vector<int32_t>();
     wt_val[k] = std::vector<double>();
@@ -918,6 +941,7 @@ void tri_plan_solve_host(const TriPlan &P, int64_t rows, const double *rhs, doub
     std::vector<double> work(static_cast<size_t>(P.aux_base) + S.n_aux, 0.0), t2(static_cast<size_t>(rows), 0.0);
     apply_sub_forward(S, rhs, out, work.data() + P.aux_base);
     for (int32_t r : P.top_rows) work[r] = rhs[r];
+    if (!P.stages[1].fwd_a.empty()) apply_rowop(P.stages[1].fwd_a, work.data(), work.data(), work.data());  // aux sums, in place
     apply_rowop(P.stages[1].fwd_b, nullptr, work.data(), t2.data());
     apply_rowop(P.stages[1].bwd_b, nullptr, t2.data(), work.data());
     apply_sub_backward(S, out, work.data(), out);

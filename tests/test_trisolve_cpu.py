@@ -104,3 +104,22 @@ def test_incomplete_factor_goes_through_the_staged_plan():
     ref = spl.spsolve_triangular(Li.T.tocsr(), Y, lower=False)
     assert np.abs(X - ref).max() < 1e-10 * np.abs(ref).max()
     assert st["nnzL"] == Li.nnz
+
+
+@pytest.mark.parametrize("kind,n", [("chain", 3000), ("chain", 9000), ("arrow", 2500)])
+def test_two_stage_plan_with_the_aux_sums_as_their_own_product(kind, n, monkeypatch):
+    """Two-stage plans add the substitution blocks' couplings (aux rows) to the top stage's right-hand side either
+    inside the top product (entries repeated per aux row) or -- large top stages -- as a product of their own in the
+    slot of the unused "a" product.  Forced here (CORA_TRI_UNFOLD_MIN=0); both forms must solve the system."""
+    rng = np.random.default_rng(n + 1)
+    A = _spd(n, kind, rng)
+    Ls = _factor_csc(A)
+    B = rng.uniform(-1, 1, (n, 2))
+    ref = np.linalg.solve(A.toarray(), B)
+    monkeypatch.setenv("CORA_TRI_UNFOLD_MIN", "0")
+    X, st = _solve(Ls, B)
+    assert np.abs(X - ref).max() < 1e-11 * np.abs(ref).max()
+    monkeypatch.setenv("CORA_TRI_UNFOLD_MIN", "1000000000")
+    X2, st2 = _solve(Ls, B)
+    assert np.abs(X2 - ref).max() < 1e-11 * np.abs(ref).max()
+    assert st["stages"] == st2["stages"]
