@@ -245,6 +245,7 @@ void Problem::updateProblemData() {  // src/CORA_problem.cpp:500-510
   fillDataMatrix();
   ctx_.reset();  // the device copy of Q is rebuilt lazily
   precond_ready_ = false;
+  cert_perm_.clear();
   problem_data_up_to_date_ = true;
 }
 
@@ -862,8 +863,10 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   Matrix X0 = Matrix::Random(N, num_eigvecs, 0xC0FFEEull);
   if (eigvec_bootstrap.rows() == N)
     X0.setBlock(0, 0, eigvec_bootstrap.block(0, 0, N, std::min(eigvec_bootstrap.cols(), num_eigvecs)));
-  const auto perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_,
-                                 static_cast<int>(N));
+  if (static_cast<Index>(cert_perm_.size()) != N)
+    cert_perm_ = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_,
+                              static_cast<int>(N));
+  const std::vector<int32_t> &perm = cert_perm_;
   DeviceOperator Sop = [c](const double *dX, int k, double *dOut) {
     if (cora_certificate_product_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
   };

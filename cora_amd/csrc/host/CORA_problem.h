@@ -76,6 +76,7 @@ class Problem {
   mutable Scalar precond_lambda_ = 0;   // regularisation actually used
   mutable long precond_nnz_ = 0;         // nnz(L)
   mutable int precond_levels_ = 0;       // height of the elimination tree
+  mutable std::vector<int32_t> cert_perm_;  // elimination order of the full certificate matrix (pattern-only: kept per data matrix)
 
   void checkUpToDate() const;
   void addOriginPose();

@@ -58,13 +58,24 @@ LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<De
 
   // X <- orthonormal basis of span(X0): X0 V D^-1/2
   {
+    // (columns scaled to unit length first: the start block mixes columns of very different size -- at 10^6 poses the
+    // iterate's translation rows give columns of norm 1e8 next to a unit seed vector, and the Gram matrix's small
+    // eigenvalue drowned in the rounding of the large ones)
+    Matrix G = B.gram(t1, t1);
+    std::vector<double> dsc(static_cast<size_t>(m));
+    for (int j = 0; j < m; ++j) {
+      if (!(G(j, j) > 0.0)) throw std::runtime_error("LOBPCG: initial block is rank deficient");
+      dsc[j] = 1.0 / std::sqrt(G(j, j));
+    }
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) G(i, j) *= dsc[i] * dsc[j];
     Vector ev;
     Matrix V;
-    symmetricEigen(B.gram(t1, t1), ev, V);
+    symmetricEigen(G, ev, V);
     Matrix C(m, m);
     for (int j = 0; j < m; ++j) {
       if (!(ev(j) > 1e-14 * ev(m - 1))) throw std::runtime_error("LOBPCG: initial block is rank deficient");
-      for (int i = 0; i < m; ++i) C(i, j) = V(i, j) / std::sqrt(ev(j));
+      for (int i = 0; i < m; ++i) C(i, j) = dsc[i] * V(i, j) / std::sqrt(ev(j));
     }
     B.combine({t1}, {C}, X);
   }
@@ -106,13 +117,18 @@ LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<De
       Matrix XtW = B.gram(X, W);
       for (Index i = 0; i < XtW.size(); ++i) XtW.data()[i] = -XtW.data()[i];
       B.combine({W, X}, {I, XtW}, t1);
+      Matrix G = B.gram(t1, t1);  // columns scaled to unit length, as above (a vanished column stays out)
+      std::vector<double> dsc(static_cast<size_t>(m));
+      for (int j = 0; j < m; ++j) dsc[j] = G(j, j) > 0.0 ? 1.0 / std::sqrt(G(j, j)) : 0.0;
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) G(i, j) *= dsc[i] * dsc[j];
       Vector ev;
       Matrix V;
-      symmetricEigen(B.gram(t1, t1), ev, V);
+      symmetricEigen(G, ev, V);
       Matrix C(m, m);
       const double top = std::max(ev(m - 1), 1e-300);
       for (int j = 0; j < m; ++j)
-        for (int i = 0; i < m; ++i) C(i, j) = ev(j) > 1e-20 * top ? V(i, j) / std::sqrt(ev(j)) : 0.0;
+        for (int i = 0; i < m; ++i) C(i, j) = ev(j) > 1e-20 * top ? dsc[i] * V(i, j) / std::sqrt(ev(j)) : 0.0;
       B.combine({t1}, {C}, W);
     }
     A(W, m, AW);

@@ -152,3 +152,24 @@ def test_gram_and_combine_blocks(ka, kb):
     assert np.abs(out - ref2).max() <= 1e-13 * np.abs(ref2).max() * (ka + kb)
     for q in (a, b, o):
         h.dev_free(q)
+
+
+def test_start_block_with_columns_of_very_different_size():
+    """The eigensolver orthonormalises its start block through the block's Gram matrix.  At 10^6 poses the block holds
+    columns of the iterate (translation rows: norm 1e8) next to the unit-length seed of the failed factorisation, and
+    the unscaled Gram matrix lost the small column in the rounding of the large ones ("initial block is rank
+    deficient" in the middle of a staircase).  Columns are scaled to unit length first; the same situation in small:
+    the path Laplacian of test_ildl_preconditioned_lobpcg_branch, one start column blown up by 1e9."""
+    n = 4000
+    rng = np.random.default_rng(1)
+    w = rng.uniform(0.5, 2.0, n - 1)
+    Lp = sp.diags([np.r_[w, 0] + np.r_[0, w], -w, -w], [0, 1, -1]).tocsr()
+    lam = np.linalg.eigvalsh(Lp.toarray())
+    S = (Lp - (lam[1] * 0.5) * sp.eye(n)).tocsr()
+    lmin = -0.5 * lam[1]
+    eta = 1e-3 * abs(lmin)
+    x0 = rng.standard_normal((n, 2))
+    x0[:, 0] *= 1e9
+    got = host.fast_verification(S, eta, X0=x0, max_iters=400, lab=dict())
+    assert not got["is_certified"] and got["theta"] < -eta / 2 and got["theta"] >= lmin - 1e-12
+    assert abs(np.linalg.norm(got["x"]) - 1.0) < 1e-9
