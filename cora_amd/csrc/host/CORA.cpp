@@ -6,7 +6,10 @@
 #include <chrono>
 #include <cmath>
 #include <iostream>
+#include <string>
+#include <vector>
 
+#include "../../../include/cora_hip.h"
 #include "dense.h"
 
 namespace CORA {
@@ -144,27 +147,77 @@ Matrix saddleEscape(const Problem &problem, const Matrix &Y, Scalar theta, const
                              "saddle escape");
   Matrix Y_aug(Y.rows(), static_cast<Index>(r));
   Y_aug.setBlock(0, 0, Y);
-  const Scalar FY = problem.evaluateObjective(Y_aug);
   Matrix Ydot(Y.rows(), static_cast<Index>(r));
   for (Index i = 0; i < Y.rows(); ++i) Ydot(i, static_cast<Index>(r) - 1) = v(i);
+
+  // The line search runs on resident vectors: the saddle point and the direction are uploaded once, every trial point
+  // is a retraction, an objective and (only when the objective decreased -- the acceptance test is a conjunction) the
+  // two gradient norms on the device; one download at the end.  Through the host-matrix interface every trial point
+  // cost four round trips of an N x r matrix (0.2 s per trial at 10^6 poses).
+  cora_ctx *c = problem.context();
+  problem.ensurePreconditionerReady();
+  const int p = static_cast<int>(r);
+  struct Dev {
+    cora_ctx *c;
+    std::vector<double *> owned;
+    ~Dev() {
+      for (double *q : owned) cora_dev_free(c, q);
+    }
+    void chk(int rc, const char *what) const {
+      if (rc != CORA_OK) throw std::runtime_error(std::string("saddleEscape: ") + what + ": " + cora_last_error(c));
+    }
+    double *alloc(int k) {
+      double *q = nullptr;
+      chk(cora_dev_alloc(c, k, &q), "cora_dev_alloc");
+      owned.push_back(q);
+      return q;
+    }
+  } D{c, {}};
+  double *dY = D.alloc(p), *dV = D.alloc(p), *dT = D.alloc(p), *dPg = D.alloc(p);
+  Matrix tmp_y, tmp_v;
+  const Matrix &Yl = problem.lifted(Y_aug, tmp_y);  // implicit formulation: [Y; 0] on the device
+  const Matrix &Vl = problem.lifted(Ydot, tmp_v);
+  const int N = static_cast<int>(Yl.rows());
+  D.chk(cora_upload(c, Yl.data(), N, p, dY), "cora_upload");
+  D.chk(cora_upload(c, Vl.data(), N, p, dV), "cora_upload");
+  D.chk(cora_set_point_dev(c, dY), "cora_set_point_dev");
+  double FY = 0.0;
+  D.chk(cora_point_cost(c, &FY), "cora_point_cost");
+  auto download = [&](const double *d) {
+    Matrix m(N, p);
+    D.chk(cora_download(c, d, p, m.data(), N), "cora_download");
+    return problem.lowered(std::move(m));
+  };
 
   const Scalar alpha_min = 1e-6;
   Scalar alpha = std::max(16 * alpha_min, 100 * gradient_tolerance / std::fabs(theta));
   std::vector<double> alphas, fvals;
   while (alpha >= alpha_min) {
-    const Matrix Ytest = problem.retract(Y_aug, Ydot * alpha);
-    const Scalar FYtest = problem.evaluateObjective(Ytest);
-    const Matrix grad = problem.Riemannian_gradient(Ytest);
-    const Scalar gn = grad.norm();
-    const Scalar pgn = problem.tangent_space_projection(Ytest, problem.precondition(grad)).norm();
+    D.chk(cora_retract_dev(c, dV, alpha, dT), "cora_retract_dev");  // R_Y(alpha Ydot), Y the current point
+    double FYtest = 0.0;
+    D.chk(cora_objective_dev(c, dT, &FYtest), "cora_objective_dev");
     alphas.push_back(alpha);
     fvals.push_back(FYtest);
-    if (FYtest < FY && gn > gradient_tolerance && pgn > preconditioned_gradient_tolerance) return Ytest;
+    if (FYtest < FY) {
+      D.chk(cora_set_point_dev(c, dT), "cora_set_point_dev");
+      const double *grad = cora_point_rgrad_dev(c);
+      D.chk(cora_precondition_projected_dev(c, grad, dPg), "precon");
+      const double *A[2] = {grad, dPg};
+      const double *B[2] = {grad, dPg};
+      double o[2];
+      D.chk(cora_dots_dev(c, 2, A, B, o), "cora_dots_dev");
+      const Scalar gn = std::sqrt(std::max(o[0], 0.0)), pgn = std::sqrt(std::max(o[1], 0.0));
+      if (gn > gradient_tolerance && pgn > preconditioned_gradient_tolerance) return download(dT);
+      D.chk(cora_set_point_dev(c, dY), "cora_set_point_dev");  // back to the saddle point for the next retraction
+    }
     alpha /= 2;
   }
   const auto it = std::min_element(fvals.begin(), fvals.end());
   const size_t k = static_cast<size_t>(std::distance(fvals.begin(), it));
-  if (fvals[k] < FY) return problem.retract(Y_aug, Ydot * alphas[k]);
+  if (fvals[k] < FY) {
+    D.chk(cora_retract_dev(c, dV, alphas[k], dT), "cora_retract_dev");
+    return download(dT);
+  }
   std::cout << "WARNING! BACKTRACKING LINE SEARCH FAILED TO ESCAPE FROM SADDLE POINT! (Try decreasing the "
                "preconditioned gradient norm tolerance)"
             << std::endl;
