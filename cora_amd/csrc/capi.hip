@@ -211,6 +211,11 @@ SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
   A.Y = c->d_Y;
   A.lam_st = c->d_lam_st;
   A.lam_ob = c->d_lam_ob;
+  const Layout &L = c->F.L;
+  A.win_rot_lo = static_cast<int32_t>(L.rot_base);
+  A.win_rot_hi = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(L.nl_poses) * L.d);
+  A.win_trn_lo = static_cast<int32_t>(L.trn_base);
+  A.win_trn_hi = static_cast<int32_t>(L.trn_base + L.nl_trans);
   return A;
 }
 

@@ -35,6 +35,9 @@ struct SpmmArgs {
   const double *lam_st;  // [local pose][d*d]
   const double *lam_ob;  // [local range]
   double *kappa_partial = nullptr;  // EPI_HVP_K: [launch_spmm_blocks()] one partial sum per block
+  // internal row ranges [lo, hi) of the LOCAL rotation and translation rows of X: the pose slices clip their LDS
+  // windows of X to them (kernels.hip, pose_slice); empty ranges switch the windows off, never the result
+  int32_t win_rot_lo = 0, win_rot_hi = 0, win_trn_lo = 0, win_trn_hi = 0;
 };
 // number of blocks (= kappa partials) of a launch with these arguments
 inline int launch_spmm_blocks(const SpmmArgs &A) { return ((A.n_chunks + 7) & ~7) + 8 * ((A.n_slices + 7) / 8); }

@@ -209,19 +209,70 @@ __device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
     }
 }
 
-// Pose slice: lane = pose, d x LD accumulators, one X-row gather per d nonzeros.
+// Pose slice: lane = pose, d x LD accumulators, one X-row read per d nonzeros.
+//
+// X window (row strides up to kWinMaxLD): along the pose chain the columns of a pose slice are the rotation rows of
+// its own poses and their chain neighbours and the translation rows of the same poses -- two CONTIGUOUS pieces of X
+// ((64 + 2) d and 64 + 2 rows).  The wavefront copies them to LDS with coalesced loads (4 cache lines per instruction)
+// and the lanes read their rows from there; a per-lane gather of a 40-byte row costs one L1 tag look-up per lane and
+// instruction (3 x 64 per slot), and the L1's look-up rate -- not bytes -- was what bounded the kernel (PMC:
+// TCP_TOTAL_CACHE_ACCESSES 10.8 M per product at 10^5 poses, the L1s busy for the whole kernel).  Columns outside
+// the windows (loop closures, rows of another shard) take the global gather as before; results are bit-identical.
+#ifndef CORA_SPMM_WINDOW
+#define CORA_SPMM_WINDOW 1
+#endif
+constexpr int kWinMaxLD = CORA_SPMM_WINDOW ? 8 : 0;
+#ifndef CORA_POSE_UNROLL_WIN
+#define CORA_POSE_UNROLL_WIN 3
+#endif
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
+  constexpr bool kWin = LD <= kWinMaxLD;
+  constexpr int kRotRows = (kWave + 2) * D, kTrnRows = kWave + 2;
+  __shared__ double win[kWin ? (kRotRows + kTrnRows) * LD : 1];
+  int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
+  if (kWin) {
+    w0 = max(sd.row0 - D, A.win_rot_lo);
+    nrot = max(min(sd.row0 + (kWave + 1) * D, A.win_rot_hi) - w0, 0);
+    t0 = max(A.win_trn_lo + sd.aux0 - 1, A.win_trn_lo);
+    ntr = max(min(A.win_trn_lo + sd.aux0 + kWave + 1, A.win_trn_hi) - t0, 0);
+    const double *__restrict__ srot = X + static_cast<size_t>(w0) * LD;
+    const double *__restrict__ strn = X + static_cast<size_t>(t0) * LD;
+    constexpr int kRotIt = (kRotRows * LD + kWave - 1) / kWave, kTrnIt = (kTrnRows * LD + kWave - 1) / kWave;
+    double stage[kRotIt + kTrnIt];
+#pragma unroll
+    for (int i = 0; i < kRotIt; ++i) {
+      const int e = i * kWave + lane;
+      stage[i] = e < nrot * LD ? srot[e] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < kTrnIt; ++i) {
+      const int e = i * kWave + lane;
+      stage[kRotIt + i] = e < ntr * LD ? strn[e] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < kRotIt; ++i) {
+      const int e = i * kWave + lane;
+      if (e < kRotRows * LD) win[e] = stage[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kTrnIt; ++i) {
+      const int e = i * kWave + lane;
+      if (e < kTrnRows * LD) win[kRotRows * LD + e] = stage[kRotIt + i];
+    }
+    __syncthreads();
+  }
   double acc[D][LD];
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int j = 0; j < LD; ++j) acc[a][j] = 0.0;
   // slots in flight per lane: 3 up to a row stride of 6, 2 above (register pressure: p = 10 Hvp 40.1 -> 39.4 us)
-  constexpr int kSlotsInFlight = LD <= 6 ? CORA_POSE_UNROLL : 2;
+  // (with the X window: 3 / 6 / 12 slots per trip measured 22.1 / 22.4 / 22.4 us at 10^5 poses -- tools/spmm_window_variants.sh)
+  constexpr int kSlotsInFlight = kWin ? CORA_POSE_UNROLL_WIN : (LD <= 6 ? CORA_POSE_UNROLL : 2);
 #pragma unroll kSlotsInFlight
   for (int k = 0; k < sd.width; ++k) {
     const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
@@ -229,7 +280,16 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
     for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
     double x[LD];
-    load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+    if (kWin) {
+      const unsigned rr = static_cast<unsigned>(c - w0), rt = static_cast<unsigned>(c - t0);
+      const bool in_rot = rr < static_cast<unsigned>(nrot), in_trn = rt < static_cast<unsigned>(ntr);
+      const int l = in_rot ? static_cast<int>(rr) : (in_trn ? kRotRows + static_cast<int>(rt) : 0);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
+      if (!(in_rot || in_trn)) load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+    } else {
+      load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+    }
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -244,7 +304,13 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
     for (int b = 0; b < D; ++b) {
       double x[LD];
-      load_row<LD>(X + (prow + b) * LD, x);
+      if (kWin) {  // the pose's own rows are inside the rotation window
+        const int l = sd.row0 + lane * D + b - w0;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
+      } else {
+        load_row<LD>(X + (prow + b) * LD, x);
+      }
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double lam = Lp[a * D + b];
@@ -337,6 +403,10 @@ __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc 
   return 0.0;
 }
 
+#ifdef CORA_SPMM_TIMES
+constexpr unsigned kSpmmTimesMax = 65536;
+__device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
+#endif
 #ifndef CORA_SPMM_WAVES_PER_EU
 #define CORA_SPMM_WAVES_PER_EU 2
 #endif
@@ -352,6 +422,10 @@ void k_spmm(const SpmmArgs A) {
   constexpr bool KAPPA = EPI == EPI_HVP_K;
   const int lane = threadIdx.x;
   double kap = 0.0;
+#ifdef CORA_SPMM_TIMES
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_meta = 0xFFull << 32;
+#endif
   if (static_cast<int>(blockIdx.x) < A.n_chunks) {
     // chunk blocks, also one contiguous range of the (column-sorted) launch order per XCD
     const int tc = static_cast<int>(blockIdx.x);
@@ -366,11 +440,23 @@ void k_spmm(const SpmmArgs A) {
     const int per_xcd = (A.n_slices + 7) >> 3;
     const int s = (t & 7) * per_xcd + (t >> 3);
     if ((t >> 3) < per_xcd && s < A.n_slices) kap = slice_wave<LD, D, EPI>(A, A.slices[s], lane);
+#ifdef CORA_SPMM_TIMES
+    if ((t >> 3) < per_xcd && s < A.n_slices)
+      dbg_meta = (static_cast<unsigned long long>(A.slices[s].type) << 32) | static_cast<unsigned>(A.slices[s].width);
+#endif
   }
   if (KAPPA) {
     kap = wave_sum(kap);
     if (lane == 0) A.kappa_partial[blockIdx.x] = kap;
   }
+#ifdef CORA_SPMM_TIMES
+  // measurement build only (tools/spmm_timeline.py): start / end of every wavefront on the 100 MHz wall clock
+  if (lane == 0 && blockIdx.x < kSpmmTimesMax) {
+    g_spmm_times[3 * blockIdx.x] = dbg_t0;
+    g_spmm_times[3 * blockIdx.x + 1] = wall_clock64();
+    g_spmm_times[3 * blockIdx.x + 2] = dbg_meta;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -2254,3 +2340,11 @@ hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double 
 }
 
 }  // namespace cora
+
+#ifdef CORA_SPMM_TIMES
+// measurement build only (-DCORA_SPMM_TIMES, tools/spmm_timeline.py): the wavefront timestamps of the last k_spmm launch
+extern "C" int cora_debug_spmm_times(unsigned long long *out, int n_blocks) {
+  if (n_blocks < 0 || static_cast<unsigned>(n_blocks) > cora::kSpmmTimesMax) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cora::g_spmm_times), sizeof(unsigned long long) * 3 * n_blocks) == hipSuccess ? 0 : -2;
+}
+#endif
