@@ -221,7 +221,11 @@ __device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
 #ifndef CORA_SPMM_WINDOW
 #define CORA_SPMM_WINDOW 1
 #endif
-constexpr int kWinMaxLD = CORA_SPMM_WINDOW ? 8 : 0;
+constexpr int kWinMaxLD = CORA_SPMM_WINDOW ? 12 : 0;   // rotation window: 198 x 12 doubles = 19 KB per wavefront
+constexpr int kWinTrnMaxLD = 8;                        // + the translation window while 8 wavefronts per CU fit the LDS
+#ifndef CORA_POSE_COOP_EPI
+#define CORA_POSE_COOP_EPI 1
+#endif
 #ifndef CORA_POSE_UNROLL_WIN
 #define CORA_POSE_UNROLL_WIN 3
 #endif
@@ -231,18 +235,26 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
   constexpr bool kWin = LD <= kWinMaxLD;
-  constexpr int kRotRows = (kWave + 2) * D, kTrnRows = kWave + 2;
-  __shared__ double win[kWin ? (kRotRows + kTrnRows) * LD : 1];
+  constexpr int kRotRows = (kWave + 2) * D, kTrnRows = LD <= kWinTrnMaxLD ? kWave + 2 : 0;
+  // cooperative Hvp epilogue (CORA_POSE_COOP_EPI): the slice's rows of Y, its Lambda blocks and its rows of the result
+  // are contiguous too -- requested with coalesced loads BEFORE the slot loop, handed to the lanes through the window's
+  // LDS after it, and the result rows leave through LDS as 512-byte runs instead of 16-byte pieces of 64 lines
+  constexpr bool kCoop = kWin && CORA_POSE_COOP_EPI && EPI >= EPI_HVP;
+  constexpr int kYEl = kWave * D * LD, kLEl = kWave * D * D;
+  constexpr int kWinEl = (kRotRows + kTrnRows) * LD;
+  constexpr int kSmemEl = !kWin ? 1 : (kCoop && kYEl + kLEl > kWinEl ? kYEl + kLEl : kWinEl);
+  __shared__ double win[kSmemEl];
+  double ystage[kCoop ? D * LD : 1], lstage[kCoop ? D * D : 1];
   int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
   if (kWin) {
     w0 = max(sd.row0 - D, A.win_rot_lo);
     nrot = max(min(sd.row0 + (kWave + 1) * D, A.win_rot_hi) - w0, 0);
     t0 = max(A.win_trn_lo + sd.aux0 - 1, A.win_trn_lo);
-    ntr = max(min(A.win_trn_lo + sd.aux0 + kWave + 1, A.win_trn_hi) - t0, 0);
+    ntr = kTrnRows ? max(min(A.win_trn_lo + sd.aux0 + kWave + 1, A.win_trn_hi) - t0, 0) : 0;
     const double *__restrict__ srot = X + static_cast<size_t>(w0) * LD;
     const double *__restrict__ strn = X + static_cast<size_t>(t0) * LD;
     constexpr int kRotIt = (kRotRows * LD + kWave - 1) / kWave, kTrnIt = (kTrnRows * LD + kWave - 1) / kWave;
-    double stage[kRotIt + kTrnIt];
+    double stage[kRotIt + kTrnIt + 1];
 #pragma unroll
     for (int i = 0; i < kRotIt; ++i) {
       const int e = i * kWave + lane;
@@ -264,6 +276,20 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       if (e < kTrnRows * LD) win[kRotRows * LD + e] = stage[kRotIt + i];
     }
     __syncthreads();
+    if (kCoop) {
+      const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
+      const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
+#pragma unroll
+      for (int i = 0; i < D * LD; ++i) {
+        const int e = i * kWave + lane;
+        ystage[i] = e < sd.nrows * D * LD ? Yp[e] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < D * D; ++i) {
+        const int e = i * kWave + lane;
+        lstage[i] = e < sd.nrows * D * D ? Lq[e] : 0.0;
+      }
+    }
   }
   double acc[D][LD];
 #pragma unroll
@@ -294,6 +320,52 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+  }
+  if constexpr (kCoop) {
+    double xo[D][LD];  // the pose's own rows of X (inside the rotation window; lanes past nrows read rows they ignore)
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      const int l = sd.row0 + lane * D + b - w0;
+#pragma unroll
+      for (int j = 0; j < LD; ++j) xo[b][j] = win[l * LD + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < D * LD; ++i) win[i * kWave + lane] = ystage[i];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) win[kYEl + i * kWave + lane] = lstage[i];
+    __syncthreads();
+    double y[D][LD];
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) y[b][j] = win[(lane * D + b) * LD + j];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double lam = win[kYEl + lane * (D * D) + a * D + b];
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[a][j] = fma(-lam, xo[b][j], acc[a][j]);
+      }
+    }
+    stiefel_project_thread<LD, D>(y, acc);
+    double kap = 0.0;
+    if (EPI == EPI_HVP_K && lane < sd.nrows) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) kap += dot_row<LD>(xo[a], acc[a]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int j = 0; j < LD; ++j) win[(lane * D + a) * LD + j] = acc[a][j];
+    __syncthreads();
+    double *__restrict__ op = A.out + static_cast<size_t>(sd.row0) * LD;
+#pragma unroll
+    for (int i = 0; i < D * LD; ++i) {
+      const int e = i * kWave + lane;
+      if (e < sd.nrows * D * LD) op[e] = win[e];
+    }
+    return kap;
   }
   if (lane >= sd.nrows) return 0.0;
   const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(lane) * D;
