@@ -32,6 +32,7 @@ struct cora_ctx {
   int p = 0, ld = 0;
 
   SliceDesc *d_slices = nullptr;
+  SliceDesc *d_slices_pf = nullptr;  // HostFormat::slices_pose_first (empty: nullptr)
   double *d_sval = nullptr;
   int32_t *d_scol = nullptr;
   int32_t *d_perm = nullptr;
@@ -195,6 +196,7 @@ RowArgs row_args(const cora_ctx *c) {
 SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
   SpmmArgs A;
   A.slices = c->d_slices;
+  A.slices_pose_first = c->d_slices_pf;
   A.n_slices = static_cast<int>(c->F.slices.size());
   A.n_chunks = static_cast<int>(c->F.chunks.size());
   A.sval = c->d_sval;
@@ -380,6 +382,7 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
   c->own_stream = true;
   const HostFormat &F = c->F;
   CREATE_TRY(to_device(&c->d_slices, F.slices));
+  if (!F.slices_pose_first.empty()) CREATE_TRY(to_device(&c->d_slices_pf, F.slices_pose_first));
   CREATE_TRY(to_device(&c->d_sval, F.sval));
   CREATE_TRY(to_device(&c->d_scol, F.scol));
   CREATE_TRY(to_device(&c->d_perm, F.perm));
@@ -429,7 +432,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_rank_state(c);
-    void *ptrs[] = {c->d_slices, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
+    void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
                     c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg};
     for (void *p : ptrs)

@@ -83,6 +83,7 @@ struct HostFormat {
   std::vector<int32_t> api2int;   // N: internal row of API row
   std::vector<int32_t> int2api;   // rows: API row of internal row (-1 = padding)
   std::vector<SliceDesc> slices;
+  std::vector<SliceDesc> slices_pose_first;  // same slices, pose slices first inside each eighth (small row strides)
   std::vector<double> sval;
   std::vector<int32_t> scol;
   std::vector<int32_t> perm;      // internal rows for kSliceEuclidPerm slices

@@ -380,16 +380,20 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     sorted.reserve(F.slices.size());
     for (size_t i : order) sorted.push_back(F.slices[i]);
     F.slices.swap(sorted);
-    // Inside each XCD's contiguous eighth of the list (k_spmm: per_xcd = ceil(n_slices / 8)) the pose slices go
-    // first: their wavefronts live longest (X window + d x LD accumulators + the Hvp epilogue), and launched last
-    // they were the tail of the kernel.  The eighth still covers the same poses, so its rows of X stay in that
-    // XCD's L2.  CORA_SLICE_LJF=0 keeps the plain chain order (measurement switch).
+    // Second order of the same list for small row strides: inside each XCD's contiguous eighth (k_spmm: per_xcd =
+    // ceil(n_slices / 8)) the pose slices go first -- their wavefronts live longest (X window + d x LD accumulators
+    // + the Hvp epilogue), and launched last they were the tail of the kernel.  The eighth still covers the same
+    // poses, so its rows of X stay in that XCD's L2.  Measured at 10^5 poses (profiles/r02_rank_sweep.md): Hvp
+    // 2-4 % faster up to a row stride of 6, 3-9 % SLOWER from 10 on, hence kPoseFirstMaxLD.  CORA_SLICE_LJF=0
+    // switches it off (measurement switch).
+    F.slices_pose_first.clear();
     const char *ljf = std::getenv("CORA_SLICE_LJF");
     if (!(ljf && ljf[0] == '0')) {
+      F.slices_pose_first = F.slices;
       const size_t per = (F.slices.size() + 7) / 8;
       for (size_t x = 0; x < 8; ++x) {
         const size_t b = std::min(x * per, F.slices.size()), e = std::min(b + per, F.slices.size());
-        std::stable_partition(F.slices.begin() + b, F.slices.begin() + e,
+        std::stable_partition(F.slices_pose_first.begin() + b, F.slices_pose_first.begin() + e,
                               [](const SliceDesc &sd) { return sd.type == kSliceStiefel; });
       }
     }

@@ -38,7 +38,11 @@ struct SpmmArgs {
   // internal row ranges [lo, hi) of the LOCAL rotation and translation rows of X: the pose slices clip their LDS
   // windows of X to them (kernels.hip, pose_slice); empty ranges switch the windows off, never the result
   int32_t win_rot_lo = 0, win_rot_hi = 0, win_trn_lo = 0, win_trn_hi = 0;
+  // the same slices with the pose slices first inside each XCD's eighth of the list (HostFormat::slices_pose_first);
+  // launch_spmm takes this order up to a row stride of kPoseFirstMaxLD (measured: better below, worse above)
+  const SliceDesc *slices_pose_first = nullptr;
 };
+constexpr int kPoseFirstMaxLD = 6;
 // number of blocks (= kappa partials) of a launch with these arguments
 inline int launch_spmm_blocks(const SpmmArgs &A) { return ((A.n_chunks + 7) & ~7) + 8 * ((A.n_slices + 7) / 8); }
 

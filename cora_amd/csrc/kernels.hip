@@ -2066,6 +2066,7 @@ static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
 template <int LD, int D>
 static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) {
   SpmmArgs A = A_in;
+  if (LD <= kPoseFirstMaxLD && A.slices_pose_first) A.slices = A.slices_pose_first;
   A.n_real_chunks = A.n_chunks;
   A.n_chunks = (A.n_chunks + 7) & ~7;
   A.n_slice_blocks = A.n_slices;

@@ -33,4 +33,4 @@ def run(n, ranks):
 print("| poses | p | LD | Q·X µs | GB/s | of 8 TB/s | Hvp µs | GB/s | of 8 TB/s | (Q−Λ)X µs | GB/s | of 8 TB/s |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 run(10000, [3, 4, 5, 6, 7, 10])
-run(100000, [3, 4, 5, 6, 7, 10, 12])
+run(100000, [3, 4, 5, 6, 7, 10, 12, 14, 16])
