@@ -41,8 +41,10 @@ struct SpmmArgs {
   // the same slices with the pose slices first inside each XCD's eighth of the list (HostFormat::slices_pose_first);
   // launch_spmm takes this order up to a row stride of kPoseFirstMaxLD (measured: better below, worse above)
   const SliceDesc *slices_pose_first = nullptr;
+  int32_t win_on = 0;  // set by launch_spmm: X window + cooperative epilogue of the pose slices (n_slices >= kWinMinSlices)
 };
 constexpr int kPoseFirstMaxLD = 6;
+constexpr int kWinMinSlices = 2048;  // = the wavefronts resident at once (256 CUs x 8)
 // number of blocks (= kappa partials) of a launch with these arguments
 inline int launch_spmm_blocks(const SpmmArgs &A) { return ((A.n_chunks + 7) & ~7) + 8 * ((A.n_slices + 7) / 8); }
 

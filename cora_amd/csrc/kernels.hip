@@ -234,19 +234,24 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
-  constexpr bool kWin = LD <= kWinMaxLD;
+  constexpr bool kWinLD = LD <= kWinMaxLD;
+  // launch-time switch (SpmmArgs::win_on, launch_spmm): below kWinMinSlices wavefronts every wavefront is resident at
+  // once and its chain of dependent latencies sets the time -- the window copy and the LDS hand-overs of the
+  // cooperative epilogue are extra stages there (10^4 poses: Hvp 5.9 -> 7.1 us with them)
+  const bool kWin = kWinLD && A.win_on;
   constexpr int kRotRows = (kWave + 2) * D, kTrnRows = LD <= kWinTrnMaxLD ? kWave + 2 : 0;
   // cooperative Hvp epilogue (CORA_POSE_COOP_EPI): the slice's rows of Y, its Lambda blocks and its rows of the result
   // are contiguous too -- requested with coalesced loads BEFORE the slot loop, handed to the lanes through the window's
   // LDS after it, and the result rows leave through LDS as 512-byte runs instead of 16-byte pieces of 64 lines
-  constexpr bool kCoop = kWin && CORA_POSE_COOP_EPI && EPI >= EPI_HVP;
+  constexpr bool kCoopT = kWinLD && CORA_POSE_COOP_EPI && EPI >= EPI_HVP;
+  const bool kCoop = kCoopT && A.win_on;
   constexpr int kYEl = kWave * D * LD, kLEl = kWave * D * D;
   constexpr int kWinEl = (kRotRows + kTrnRows) * LD;
-  constexpr int kSmemEl = !kWin ? 1 : (kCoop && kYEl + kLEl > kWinEl ? kYEl + kLEl : kWinEl);
+  constexpr int kSmemEl = !kWinLD ? 1 : (kCoopT && kYEl + kLEl > kWinEl ? kYEl + kLEl : kWinEl);
   __shared__ double win[kSmemEl];
-  double ystage[kCoop ? D * LD : 1], lstage[kCoop ? D * D : 1];
+  double ystage[kCoopT ? D * LD : 1], lstage[kCoopT ? D * D : 1];
   int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
-  if (kWin) {
+  if constexpr (kWinLD) if (kWin) {
     w0 = max(sd.row0 - D, A.win_rot_lo);
     nrot = max(min(sd.row0 + (kWave + 1) * D, A.win_rot_hi) - w0, 0);
     t0 = max(A.win_trn_lo + sd.aux0 - 1, A.win_trn_lo);
@@ -276,7 +281,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       if (e < kTrnRows * LD) win[kRotRows * LD + e] = stage[kRotIt + i];
     }
     __syncthreads();
-    if (kCoop) {
+    if constexpr (kCoopT) {
       const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
       const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
 #pragma unroll
@@ -298,30 +303,44 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     for (int j = 0; j < LD; ++j) acc[a][j] = 0.0;
   // slots in flight per lane: 3 up to a row stride of 6, 2 above (register pressure: p = 10 Hvp 40.1 -> 39.4 us)
   // (with the X window: 3 / 6 / 12 slots per trip measured 22.1 / 22.4 / 22.4 us at 10^5 poses -- tools/spmm_window_variants.sh)
-  constexpr int kSlotsInFlight = kWin ? CORA_POSE_UNROLL_WIN : (LD <= 6 ? CORA_POSE_UNROLL : 2);
-#pragma unroll kSlotsInFlight
-  for (int k = 0; k < sd.width; ++k) {
-    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
-    double v[D];
+  if (kWin) {
+    if constexpr (kWinLD) {
+#pragma unroll CORA_POSE_UNROLL_WIN
+      for (int k = 0; k < sd.width; ++k) {
+        const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
+        double v[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
-    double x[LD];
-    if (kWin) {
-      const unsigned rr = static_cast<unsigned>(c - w0), rt = static_cast<unsigned>(c - t0);
-      const bool in_rot = rr < static_cast<unsigned>(nrot), in_trn = rt < static_cast<unsigned>(ntr);
-      const int l = in_rot ? static_cast<int>(rr) : (in_trn ? kRotRows + static_cast<int>(rt) : 0);
+        for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+        double x[LD];
+        const unsigned rr = static_cast<unsigned>(c - w0), rt = static_cast<unsigned>(c - t0);
+        const bool in_rot = rr < static_cast<unsigned>(nrot), in_trn = rt < static_cast<unsigned>(ntr);
+        const int l = in_rot ? static_cast<int>(rr) : (in_trn ? kRotRows + static_cast<int>(rt) : 0);
 #pragma unroll
-      for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
-      if (!(in_rot || in_trn)) load_row<LD>(X + static_cast<size_t>(c) * LD, x);
-    } else {
-      load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+        for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
+        if (!(in_rot || in_trn)) load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+      }
     }
+  } else {
+    constexpr int kSlotsInFlight = LD <= 6 ? CORA_POSE_UNROLL : 2;
+#pragma unroll kSlotsInFlight
+    for (int k = 0; k < sd.width; ++k) {
+      const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
+      double v[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a)
+      for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+      double x[LD];
+      load_row<LD>(X + static_cast<size_t>(c) * LD, x);
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+    }
   }
-  if constexpr (kCoop) {
+  if constexpr (kCoopT) if (kCoop) {
     double xo[D][LD];  // the pose's own rows of X (inside the rotation window; lanes past nrows read rows they ignore)
 #pragma unroll
     for (int b = 0; b < D; ++b) {
@@ -376,7 +395,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
     for (int b = 0; b < D; ++b) {
       double x[LD];
-      if (kWin) {  // the pose's own rows are inside the rotation window
+      if (kWinLD && kWin) {  // the pose's own rows are inside the rotation window
         const int l = sd.row0 + lane * D + b - w0;
 #pragma unroll
         for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
@@ -2067,6 +2086,8 @@ template <int LD, int D>
 static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) {
   SpmmArgs A = A_in;
   if (LD <= kPoseFirstMaxLD && A.slices_pose_first) A.slices = A.slices_pose_first;
+  static const int win_env = [] { const char *e = std::getenv("CORA_SPMM_WINDOW_MIN_SLICES"); return e ? std::atoi(e) : kWinMinSlices; }();
+  A.win_on = A.n_slices >= win_env ? 1 : 0;
   A.n_real_chunks = A.n_chunks;
   A.n_chunks = (A.n_chunks + 7) & ~7;
   A.n_slice_blocks = A.n_slices;
