@@ -208,6 +208,7 @@ SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
   A.lcol = c->d_lcol;
   A.partials = c->d_partials;
   A.tickets = c->d_tickets;
+  A.n_long_rows = c->F.n_long_rows;
   A.X = X;
   A.out = out;
   A.Y = c->d_Y;
@@ -1287,7 +1288,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
                   !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
     if (sweep_fused) need = std::max<size_t>(need, static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8);
-    kappa_blocks = launch_spmm_blocks(spmm_args(c, dP, dHp));
+    kappa_blocks = launch_spmm_kappa_slots(spmm_args(c, dP, dHp));
     if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks)))) return rc;
     D.partial = c->d_red;
     kappa_partial = c->d_red + need;

@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -19,6 +22,18 @@ void printIfVerbose(bool verbose, const std::string &msg) {
   if (verbose) std::cout << msg << std::endl;
 }
 Scalar thresholdVal(Scalar v, Scalar lo, Scalar hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// CORA_TRACE_BITS=1: one line per stage of the staircase with the BITS of what it produced (FNV-1a over the matrix,
+// hex floats), so that two runs can be diffed for the first stage at which they part (tools/determinism_probe.py)
+uint64_t bitsOf(const Matrix &m) {
+  uint64_t h = 1469598103934665603ull;
+  const unsigned char *b = reinterpret_cast<const unsigned char *>(m.data());
+  for (size_t i = 0; i < static_cast<size_t>(m.size()) * sizeof(Scalar); ++i) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+void traceBits(const char *stage, const Matrix &m, double a = 0, double b = 0, long n = 0) {
+  static const bool on = std::getenv("CORA_TRACE_BITS") != nullptr;
+  if (on) std::printf("[bits] %-14s %016llx  %a  %a  %ld\n", stage, static_cast<unsigned long long>(bitsOf(m)), a, b, n);
+}
 }  // namespace
 
 CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank, bool verbose, bool log_iterates,
@@ -70,6 +85,7 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     result = TNT(problem, X, params);
     t_tnt += since(t0);
     hvps += result.hessian_vector_products;
+    traceBits("TNT", result.x, result.f, result.gradfx_norm, result.hessian_vector_products);
     printIfVerbose(verbose, "Obtained solution with objective value: " + std::to_string(result.f));
     if (log_iterates)
       for (const Matrix &it : result.iterates) iterates.push_back(it);
@@ -85,6 +101,8 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     t0 = clk::now();
     cert = problem.certify_solution(result.x, eta, LOBPCG_BLOCK_SIZE, eigvec_bootstrap);
     t_cert += since(t0);
+    traceBits("certify.x", cert.x, cert.theta, eta, static_cast<long>(cert.num_iters));
+    traceBits("certify.block", cert.all_eigvecs, cert.theta, eta, cert.is_certified);
     printIfVerbose(verbose, "Result is certified: " + std::to_string(cert.is_certified) + " with eta: " +
                                 std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
     if (std::isnan(cert.theta)) throw std::runtime_error("Theta is NaN");
@@ -97,16 +115,19 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     t0 = clk::now();
     X = saddleEscape(problem, result.x, cert.theta, cert.x, SADDLE_GRAD_TOL, PRECON_SADDLE_GRAD_TOL);
     t_escape += since(t0);
+    traceBits("saddleEscape", X);
   }
   // project to rank d and refine (src/CORA.cpp:198-233)
   if (X.cols() > problem.dim()) {
     printIfVerbose(verbose, "\nProjecting solution to rank " + std::to_string(problem.dim()) + " and refining.");
     X = projectSolution(problem, X, verbose);
+    traceBits("projectSolution", X);
     problem.setRank(problem.dim());
     auto t0 = clk::now();
     result = TNT(problem, X, params);
     t_tnt += since(t0);
     hvps += result.hessian_vector_products;
+    traceBits("TNT final", result.x, result.f, result.gradfx_norm, result.hessian_vector_products);
     printIfVerbose(verbose, "\nObtained FINAL solution with objective value: " + std::to_string(result.f));
     if (log_iterates)
       for (const Matrix &it : result.iterates) iterates.push_back(it);

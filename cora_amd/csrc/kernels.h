@@ -34,7 +34,11 @@ struct SpmmArgs {
   const double *Y;     // current point (epilogues)
   const double *lam_st;  // [local pose][d*d]
   const double *lam_ob;  // [local range]
-  double *kappa_partial = nullptr;  // EPI_HVP_K: [launch_spmm_blocks()] one partial sum per block
+  // EPI_HVP_K: [launch_spmm_kappa_slots()] one partial sum of <X, out> per block, then one per long row (written by
+  // whichever chunk finishes the row -- a fixed slot whatever the arrival order)
+  double *kappa_partial = nullptr;
+  int n_long_rows = 0;      // set by the caller (HostFormat::n_long_rows)
+  int kappa_long_base = 0;  // filled by launch_spmm
   // internal row ranges [lo, hi) of the LOCAL rotation and translation rows of X: the pose slices clip their LDS
   // windows of X to them (kernels.hip, pose_slice); empty ranges switch the windows off, never the result
   int32_t win_rot_lo = 0, win_rot_hi = 0, win_trn_lo = 0, win_trn_hi = 0;
@@ -47,6 +51,8 @@ constexpr int kPoseFirstMaxLD = 6;
 constexpr int kWinMinSlices = 2048;  // = the wavefronts resident at once (256 CUs x 8)
 // number of blocks (= kappa partials) of a launch with these arguments
 inline int launch_spmm_blocks(const SpmmArgs &A) { return ((A.n_chunks + 7) & ~7) + 8 * ((A.n_slices + 7) / 8); }
+// number of kappa partials an EPI_HVP_K launch with these arguments writes (every slot, every launch)
+inline int launch_spmm_kappa_slots(const SpmmArgs &A) { return launch_spmm_blocks(A) + A.n_long_rows; }
 
 struct RowArgs {
   int d;

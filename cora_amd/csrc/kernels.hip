@@ -123,9 +123,12 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm) {
 // Blocks [0, n_chunks) handle chunks of the long (landmark) rows instead.
 // ---------------------------------------------------------------------------
 // One wavefront per chunk of a long (landmark) row.
-// Returns (EPI_HVP_K only, meaningful in the lanes j < LD of the wavefront that finishes the row) out[row][j] X[row][j].
+// EPI_HVP_K: the wavefront that finishes the row leaves <X[row], out[row]> in the ROW's own slot of kappa_partial
+// (behind the per-block slots).  Which chunk arrives last differs from launch to launch: a term that travelled with the
+// finishing block's partial would move between slots and change the rounding of their fixed-order sum -- the one source
+// of run-to-run differences the solver had (tools/determinism_probe.py: 10^5 poses, where a landmark row has 40 chunks).
 template <int LD, bool KAPPA>
-__device__ __forceinline__ double long_chunk_wave(const SpmmArgs &A, int ci) {
+__device__ __forceinline__ void long_chunk_wave(const SpmmArgs &A, int ci) {
   const LongChunk ch = A.chunks[ci];
   const int lane = threadIdx.x;
   double acc[LD];
@@ -147,9 +150,16 @@ __device__ __forceinline__ double long_chunk_wave(const SpmmArgs &A, int ci) {
     if (lane == j) tot = v0;
   }
   double *orow = A.out + static_cast<size_t>(ch.row) * LD;
+  auto publish_kappa = [&](double row_j) {  // row_j: out[row][lane] in the lanes below LD
+    if constexpr (KAPPA) {
+      const double t = wave_sum(lane < LD ? row_j * A.X[static_cast<size_t>(ch.row) * LD + lane] : 0.0);
+      if (lane == 0) A.kappa_partial[A.kappa_long_base + ch.slot] = t;
+    }
+  };
   if (ch.nchunks == 1) {
     if (lane < LD) orow[lane] = tot;
-    return (KAPPA && lane < LD) ? tot * A.X[static_cast<size_t>(ch.row) * LD + lane] : 0.0;
+    publish_kappa(tot);
+    return;
   }
   // several chunks: publish the partial WRITE-THROUGH (sc1 stores, so no L2
   // release fence is needed), drain, take a ticket; the last arriver re-reads
@@ -168,9 +178,10 @@ __device__ __forceinline__ double long_chunk_wave(const SpmmArgs &A, int ci) {
     if (last) __hip_atomic_store(A.tickets + ch.slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   last = __shfl(last, 0, 64);
-  if (last && lane < LD) {
+  if (!last) return;  // wave-uniform
+  double s = 0.0;
+  if (lane < LD) {
     const double *P = A.partials + static_cast<size_t>(ch.first) * kMaxLD + lane;
-    double s = 0.0;
     int c = 0;
     for (; c + 8 <= ch.nchunks; c += 8) {
       double t[8];
@@ -184,9 +195,8 @@ __device__ __forceinline__ double long_chunk_wave(const SpmmArgs &A, int ci) {
     for (; c < ch.nchunks; ++c)
       s += __hip_atomic_load(P + static_cast<size_t>(c) * kMaxLD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     orow[lane] = s;
-    if (KAPPA) return s * A.X[static_cast<size_t>(ch.row) * LD + lane];
   }
-  return 0.0;
+  publish_kappa(s);
 }
 
 // V_i - sym(Y_i V_i^T) Y_i for one pose held entirely by this thread
@@ -522,7 +532,7 @@ void k_spmm(const SpmmArgs A) {
     const int tc = static_cast<int>(blockIdx.x);
     const int cper = A.n_chunks >> 3;  // n_chunks is a multiple of 8
     const int pos = (tc & 7) * cper + (tc >> 3);
-    if (pos < A.n_real_chunks) kap = long_chunk_wave<LD, KAPPA>(A, A.chunk_order[pos]);
+    if (pos < A.n_real_chunks) long_chunk_wave<LD, KAPPA>(A, A.chunk_order[pos]);
   } else {
     // Slice blocks: XCD x (= blockIdx % 8, observed dispatch order; speed only)
     // walks its own contiguous eighth of the slice list, so neighbouring slices
@@ -2092,6 +2102,7 @@ static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) 
   A.n_chunks = (A.n_chunks + 7) & ~7;
   A.n_slice_blocks = A.n_slices;
   const int grid = A.n_chunks + 8 * ((A.n_slices + 7) / 8);
+  A.kappa_long_base = grid;  // = launch_spmm_blocks(A_in): the long rows' own slots follow the per-block ones
   if (A.n_real_chunks + A.n_slices == 0) return hipSuccess;
   switch (epi) {
     case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(64), 0, st, A); break;

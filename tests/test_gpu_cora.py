@@ -57,14 +57,12 @@ def test_solve_cora_synthetic_noisy(d, n):
 
 def test_config3_staircase_on_the_10k_pose_graph():
     """BASELINE config 3: synthetic 10^4-pose SE(3) chain + 5 000 ranges, odometry initialisation, full
-    staircase from r0 = 3.  Odometry drift over 10^4 poses puts the start at f0 ~ 1e10, and the reference's limits
-    (250 outer iterations per level, src/CORA.cpp:95-109) end the first levels unconverged, where a saddle escape moves
-    the cost by less than its rounding error and eta = 0.1 (the cap of src/CORA.cpp:111-116) accepts a certificate of
-    S + eta I at points that are far from stationary.  Which level stops the staircase therefore depends on rounding --
-    observed end values: 2 410 (five levels; the chi-square sized optimum, #ranges / 2 = 2 500), 28 959 and 39 333
-    (three / two levels) -- exactly as it would in the reference.  What does not depend on it is checked: the returned
-    point is feasible, its cost, gradient and certificate decision are the oracle's, and the cost fell by five orders of
-    magnitude."""
+    staircase from r0 = 3.  Odometry drift over 10^4 poses puts the start at f0 ~ 1e10; the staircase climbs to rank 7
+    (five levels, ~24 000 Hessian-vector products) and the refined rank-3 solution sits at the chi-square sized optimum
+    (#ranges / 2 = 2 500 for unit-variance whitened residuals; 2 410.0 on this graph).  The solver is bit-reproducible
+    (tests/test_gpu_determinism.py), so the window below is a property of the build, not of a lucky run.  (Round 2
+    accepted any f < 1e-5 f0 here because runs ended at 2 410 / 28 959 / 39 333: that spread was the moving kappa
+    slot of the landmark rows at 10^5 poses and build-to-build rounding at 10^4)"""
     n = 10_000
     P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42,
                                precond=capi.PRECOND_REGULARIZED_CHOLESKY)
@@ -79,7 +77,7 @@ def test_config3_staircase_on_the_10k_pose_graph():
     assert np.abs(X - orc.project_manifold(dims, X)).max() < 1e-9
     # f = 1/2 <X, QX> cancels many digits here (|Q| |X|^2 ~ 1e12 against f ~ 1e3..1e4)
     assert abs(orc.cost(Q, X) - res["f"]) < 1e-6 * res["f"]
-    assert f0 > 1e9 and 0.5 * (n // 2) / 2 < res["f"] < 1e-5 * f0
+    assert f0 > 1e9 and 0.8 * (n // 2) / 2 < res["f"] < 1.2 * (n // 2) / 2
     assert res["levels"] >= 1 and res["final_rank"] == 3
     g = orc.rgrad(Q, dims, X)
     assert abs(np.linalg.norm(g) - res["grad_norm"]) < 1e-6 * max(1.0, res["grad_norm"])
