@@ -151,6 +151,12 @@ def main():
                          "(Q - Lambda) X with --rank columns (BASELINE config 5, use --rank 10)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON result: whatever the libraries print on the way (the C++ host reports like the
+    # reference does, on std::cout) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from cora_amd import capi, host
 
@@ -414,7 +420,8 @@ def main():
                 "sample": "%d Hessian-vector products of the same 10^5-pose workload with oracle/cora_oracle.c "
                           "(single thread, like the reference; host has %s logical cores)" % (reps_cpu, cores),
             }
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

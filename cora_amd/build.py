@@ -17,10 +17,27 @@ FLAGS = os.environ.get("CORA_EXTRA_HIPCC_FLAGS", "").split() + ["--offload-arch=
          "-I" + os.path.join(os.path.dirname(HERE), "include"), "-I" + CSRC]
 
 
+# kernels.hip is compiled as several translation units in parallel (CORA_TU / CORA_LDG, see the head of the file)
+KERNEL_PARTS = [("spmm_g0", 1, 1), ("spmm_g1", 1, 2), ("spmm_g2", 1, 4), ("spmm_g3", 1, 8), ("rows", 2, 15),
+                ("tri_g0", 4, 1), ("tri_g1", 4, 2), ("tri_g2", 4, 4), ("tri_g3", 4, 8)]
+
+
 def sources():
     srcs = [os.path.join(CSRC, f) for f in ("format_build.cpp", "trisolve_build.cpp", "kernels.hip", "capi.hip")]
     srcs += sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
     return srcs
+
+
+def units():
+    """(source, object name, extra flags) of every translation unit."""
+    out = []
+    for s in sources():
+        if os.path.basename(s) == "kernels.hip":
+            for name, tu, ldg in KERNEL_PARTS:
+                out.append((s, "kernels_%s.o" % name, ["-DCORA_TU=%d" % tu, "-DCORA_LDG=%d" % ldg]))
+        else:
+            out.append((s, os.path.basename(s) + ".o", []))
+    return out
 
 
 def _deps():
@@ -43,23 +60,44 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    for s in sources():
-        o = os.path.join(objdir, os.path.basename(s) + ".o")
+    jobs = []
+    for s, oname, extra in units():
+        o = os.path.join(objdir, oname)
         objs.append(o)
         newest = max(os.path.getmtime(p) for p in _deps() if p.endswith(".h") or p == s)
         if not force and os.path.exists(o) and os.path.getmtime(o) > newest:
             continue
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
+        jobs.append((s, [HIPCC] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]))
+    # the kernel units are the long poles: start them first; at most MAXJOBS compilers at a time
+    jobs.sort(key=lambda j: 0 if j[0].endswith("kernels.hip") else 1)
+    maxjobs = int(os.environ.get("CORA_BUILD_JOBS", str(max(2, (os.cpu_count() or 4)))))
+    running = []
+
+    def reap(block):
+        for s, p in list(running):
+            if block or p.poll() is not None:
+                out, _ = p.communicate()
+                running.remove((s, p))
+                if p.returncode != 0:
+                    sys.stderr.write(out.decode())
+                    for _, q in running:
+                        q.kill()
+                    raise RuntimeError("hipcc failed on " + s)
+                if verbose and out:
+                    sys.stderr.write(out.decode())
+                if block:
+                    return
+    for s, cmd in jobs:
+        while len(running) >= maxjobs:
+            reap(False)
+            if len(running) >= maxjobs:
+                import time
+                time.sleep(0.2)
         if verbose:
             print(" ".join(cmd))
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            sys.stderr.write(out.decode())
-            raise RuntimeError("hipcc failed on " + s)
-        if verbose and out:
-            sys.stderr.write(out.decode())
+        running.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    while running:
+        reap(True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     return LIB

@@ -407,10 +407,10 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_lam_ob),
                        std::max<size_t>(F.L.nl_ranges, 1) * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_scalars), 8 * sizeof(double)));
-  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), sizeof(unsigned)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), 4 * sizeof(unsigned)));  // [0] inner products, [1] kappa (k_spmm)
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_stpcg), sizeof(StpcgState)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_stpcg), 2 * sizeof(StpcgState)));
-  CREATE_TRY(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
+  CREATE_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), 8 * sizeof(double)));
   std::memset(c->h_scalars, 0, 8 * sizeof(double));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_flag), sizeof(int)));
@@ -903,7 +903,10 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
 // out[rows of the factor] = (P^T L L^T P)^-1 rhs[rows of the factor]; rows outside the factor are not
 // written.  rhs and out must be different resident vectors.  A fixed sequence of 4K-2 sparse products
 // (trisolve.h): forward stages ascending, backward stages descending.
-static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, const double *rhs, double *out) {
+// project != nullptr (two-stage plans that allow it): the solution leaves the backward sweep projected to the tangent
+// space of the current point (SubFuse with p == nullptr) and *project is set; otherwise the caller projects.
+static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, const double *rhs, double *out, bool *project = nullptr) {
+  if (project) *project = false;
   if (rhs == out) return fail(c, CORA_ERR_ARG, "factor_solve: output aliases the right-hand side");
   const int K = static_cast<int>(f.stages.size());
   if (K == 0) return CORA_OK;
@@ -917,6 +920,19 @@ static int factor_solve(cora_ctx *c, cora_ctx::DevFactor &f, int ld, const doubl
     if (S1.aux_sum) HIP_TRY(c, launch_rowop(S1.fwd_a, ld, t, t, t, c->stream));  // t_1 += its aux rows (in place: a row is read and written by its own lanes only)
     HIP_TRY(c, launch_rowop(S1.fwd_b, ld, nullptr, t, t2, c->stream));       // y_1 = W_1 t_1 (with the aux sums folded in otherwise)
     HIP_TRY(c, launch_rowop(S1.bwd_b, ld, nullptr, t2, t, c->stream));       // x_1 = W_1^T y_1 -> t
+    if (project && f.fuse_ok && ld * c->F.L.d <= 24 && ld <= 12 && c->have_point) {
+      const Layout &L = c->F.L;
+      SubFuse FB;
+      FB.dot.st = c->d_stpcg;  // (coefficients unused in this mode)
+      FB.Y = c->d_Y;
+      FB.d = L.d;
+      FB.rot_base = L.rot_base;
+      FB.rng_base = L.rng_base;
+      FB.trn_base = L.trn_base;
+      HIP_TRY(c, launch_subblock_fused(S0.sub, ld, true, FB, t, out, c->stream));  // Proj_Y(x) -> out
+      *project = true;
+      return CORA_OK;
+    }
     HIP_TRY(c, launch_subblock(S0.sub, ld, true, out, t, out, c->stream));   // x_0, and x_1 -> out
     return CORA_OK;
   }
@@ -1115,12 +1131,13 @@ int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut)
                                   static_cast<size_t>(c->F.L.nl_trans) * c->ld * sizeof(double), c->stream));
       rhs = tmp;
     }
-    int rc = chol_solve(c, c->ld, rhs, dOut);
+    bool projected = false;
+    int rc = factor_solve(c, c->precond_f, c->ld, rhs, dOut, c->implicit ? nullptr : &projected);
     if (rc) return rc;
     if (c->implicit)
       HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(c->F.L.trn_base) * c->ld, 0,
                                 static_cast<size_t>(c->F.L.nl_trans) * c->ld * sizeof(double), c->stream));
-    HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dOut, nullptr, dOut, c->stream));
+    if (!projected) HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dOut, nullptr, dOut, c->stream));
     return CORA_OK;
   } else if (c->precond != CORA_PRECOND_NONE) return fail(c, CORA_ERR_NOT_READY, "preconditioner not set up");
   HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, scale, dOut, c->stream));
@@ -1280,6 +1297,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   SubFuse FF, FB;
   double *kappa_partial = nullptr;
   int kappa_blocks = 0;
+  RvTail tail{}, sq{};
   if (fused) {
     const RowArgs R = row_args(c);
     const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
@@ -1287,33 +1305,50 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     const cora_ctx::DevFactor &f = c->precond_f;
     sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
                   !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
-    if (sweep_fused) need = std::max<size_t>(need, static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8);
+    // slots of the sweep-fused reductions: <r, r> per block of the forward sweep's launch, |y|^2 per solve block,
+    // |row|^2 per row of the last stage's forward product
+    size_t rr_slots = 0, yy_slots = 0, sq_slots = 0;
+    if (sweep_fused) {
+      rr_slots = static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8;
+      yy_slots = static_cast<size_t>(f.stages[0].sub.nblocks) + 8;
+      const RowOpDev &fb = f.stages[1].fwd_b;
+      sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
+    }
     kappa_blocks = launch_spmm_kappa_slots(spmm_args(c, dP, dHp));
-    if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks)))) return rc;
+    if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks) + rr_slots + yy_slots + sq_slots))) return rc;
     D.partial = c->d_red;
     kappa_partial = c->d_red + need;
     if (sweep_fused) {
       const Layout &L = c->F.L;
+      double *rr_partial = kappa_partial + kappa_blocks, *yy_partial = rr_partial + rr_slots, *rowsq = yy_partial + yy_slots;
       FF.dot = D;
-      FF.dot.count = 1;
-      FF.dot.mode = DOTS_STPCG_RR;
-      FF.dot.seq_out = nullptr;
-      FF.dot.seq = 0;
       FF.Hp = dHp;
       FF.r = dR;
       FF.d = L.d;
       FF.rot_base = L.rot_base;
       FF.rng_base = L.rng_base;
       FF.trn_base = L.trn_base;
+      FF.rr_partial = rr_partial;
+      FF.yy_partial = yy_partial;
       FB = FF;
-      FB.dot.mode = DOTS_STPCG_RV;
-      FB.dot.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
       FB.Y = c->d_Y;
+      FB.p = dP;
+      FB.s = dS;
+      // the two reductions of the iteration are finished by an extra block of the last stage's SECOND product:
+      // <r, r> from the forward sweep's slots, <r, v> = |L^-1 r|^2 from its |y|^2 slots + the squared norms of the rows
+      // of t_1, which the last stage's FIRST product leaves (sq)
+      sq.rowsq_out = rowsq;
+      tail.rr_partial = rr_partial;
+      tail.n_rr = launch_subblock_blocks(f.stages[0].sub);
+      tail.yy_partial = yy_partial;
+      tail.n_yy = f.stages[0].sub.nblocks;
+      tail.rowsq = rowsq;
+      tail.n_rowsq = static_cast<int>(sq_slots) - 8;
+      tail.st = c->d_stpcg;
+      tail.st_host = &c->h_stpcg[0];
+      tail.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
     }
   }
-  // residual pass inside the forward sweep (144.0 us per iteration at 10^5 poses) or in one launch with the kappa step
-  // (147.5 us; what the other plans use)
-  const bool fwd_fuse_env = std::getenv("CORA_NO_FWD_FUSE") == nullptr;
   c->stpcg_path = sweep_fused ? 2 : fused ? 1 : 0;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
@@ -1326,25 +1361,26 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         A.kappa_partial = kappa_partial;
         HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP_K, c->stream));
         if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
-        const bool fwd_fuse = sweep_fused && fwd_fuse_env;
-        if (fwd_fuse) HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
-        else HIP_TRY(c, launch_kappa_residual(D, kappa_partial, kappa_blocks, n, dHp + off, dR + off, c->stream));
+        HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
         if (sweep_fused) {
+          // Hp = H p | kappa | forward sweep: r += alpha Hp, <r, r>, |y|^2 | last stage, <r, v> in its second product |
+          // backward sweep: v = Proj_Y(x), s += alpha p, p = -v + beta p   -- six launches
           cora_ctx::DevFactor &f = c->precond_f;
           double *t, *t2;
           if ((rc = get_scratch(c, 6, c->ld, &t, f.aux_rows))) return rc;
           if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
           const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
-          if (fwd_fuse) HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
-          else HIP_TRY(c, launch_subblock(S0.sub, c->ld, false, dR, t, dV, c->stream));
+          HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
           if (S1.aux_sum) HIP_TRY(c, launch_rowop(S1.fwd_a, c->ld, t, t, t, c->stream));
-          HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream));
-          HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream));
-          FB.dot.seq = seq = ++c->dot_seq;
+          HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream, &sq));
+          tail.seq = seq = ++c->dot_seq;
+          HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream, &tail));
           HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
-          HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
           continue;
         }
+        D.mode = DOTS_STPCG_RR;
+        D.count = 1;
+        HIP_TRY(c, launch_stpcg_residual(D, n, dHp + off, dR + off, c->stream));
         const double *x = dR, *scale = nullptr;
         if (chol) {
           if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;

@@ -14,6 +14,7 @@ namespace cora {
 // kappa = <p, Hp> of an STPCG iteration without a pass of its own)
 enum Epilogue : int { EPI_NONE = 0, EPI_S = 1, EPI_HVP = 2, EPI_HVP_K = 3 };
 
+struct StpcgState;
 struct SpmmArgs {
   const SliceDesc *slices;
   int n_slices;
@@ -39,6 +40,7 @@ struct SpmmArgs {
   double *kappa_partial = nullptr;
   int n_long_rows = 0;      // set by the caller (HostFormat::n_long_rows)
   int kappa_long_base = 0;  // filled by launch_spmm
+
   // internal row ranges [lo, hi) of the LOCAL rotation and translation rows of X: the pose slices clip their LDS
   // windows of X to them (kernels.hip, pose_slice); empty ranges switch the windows off, never the result
   int32_t win_rot_lo = 0, win_rot_hi = 0, win_trn_lo = 0, win_trn_hi = 0;
@@ -72,7 +74,7 @@ struct StpcgState {
   double kappa, rr, step_M_norm;
   int iters, status, max_iters, pad;
 };
-enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4, DOTS_STPCG_KAPPA_RR = 5 };
+enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4 };
 
 struct DotArgs {
   const double *a[4];
@@ -144,24 +146,43 @@ struct SubOpDev {
   int max_level_lanes, max_npl;  // widest level (rows x lanes per row) and most entries per lane of the plan
 };
 // STPCG passes fused into the two sweeps (cora_stpcg_dev; one shard, explicit formulation):
-//   forward : the right-hand side IS the residual and is updated on the way in:  r += coef_r Hp  with <r, r>
-//             (dot.mode = DOTS_STPCG_RR); every row of the vector is a block row or a row of the last stage
-//   backward: the solution is projected on the way out:  v = Proj_Y(x)  with <r, v>  (DOTS_STPCG_RV); needs the d
-//             rotation rows of a pose at consecutive tile positions (checked when the factor is installed)
-// dot.partial holds one slot per block of the launch (launch_subblock_blocks).
+//   forward : the right-hand side IS the residual and is updated on the way in:  r += coef_r Hp; every row of the vector
+//             is a block row or a row of the last stage; every block leaves <r, r> and |y|^2 over its rows in slots
+//   backward: the solution is projected on the way out, v = Proj_Y(x), and the step and the direction are updated in the
+//             same epilogue (s += coef_s p, p = coef_v v + coef_beta p); needs the d rotation rows of a pose at
+//             consecutive tile positions (checked when the factor is installed)
+// Between the sweeps, an extra block of the last stage's second product (RvTail) adds the slots and the squared norms of
+// the rows of t_1 in fixed order and runs the scalar steps that follow <r, r> and <r, v>: no ticket, no atomics.
+struct RvTail {
+  const double *rr_partial;  // [n_rr]  <r, r> slots of the forward sweep (one per block of its launch)
+  int n_rr;
+  const double *yy_partial;  // [n_yy]  |y|^2 slots of the forward sweep's solve blocks
+  int n_yy;
+  const double *rowsq;       // [n_rowsq] squared norms of the rows of t_1 (the last stage's first product leaves them)
+  int n_rowsq;
+  StpcgState *st, *st_host;  // st == nullptr: no tail block in this launch ...
+  double *rowsq_out;         // ... but, if set, the product leaves the squared norm of its k-th row in rowsq_out[k]
+  unsigned long long *seq_out;  // pinned: set to seq after the mirror is visible to the host
+  unsigned long long seq;
+};
 struct SubFuse {
-  DotArgs dot;
+  DotArgs dot;                 // only dot.st (the coefficients of the state) is used
   const double *Hp = nullptr;  // forward
-  double *r = nullptr;         // forward: the right-hand side (updated in place); backward: read for <r, v>
+  double *r = nullptr;         // forward: the right-hand side (updated in place)
+  // forward: slot b of rr_partial receives <r, r> over the rows of block b of the launch (solve blocks, then the blocks
+  // that carry the rows of the last stage); slot b of yy_partial |y|^2 over the rows of solve block b (y = L^-1 r).  With
+  // |t_1|^2 of the last stage they make <r, v> = <r, Proj_Y(L^-T L^-1 r)> = |L^-1 r|^2 (r is a tangent vector and
+  // Proj_Y is an orthogonal projector), so beta is known BEFORE the backward sweep (RvTail, k_rowop) and the direction
+  // update rides on its epilogue.
+  double *rr_partial = nullptr, *yy_partial = nullptr;
   const double *Y = nullptr;   // backward: the current point
+  double *p = nullptr, *s = nullptr;  // backward: s += coef_s p, then p = coef_v v + coef_beta p  (v = Proj_Y(x), not stored)
   int d = 0;
   int64_t rot_base = 0, rng_base = 0, trn_base = 0;  // internal rows: rotations | ranges | translations
 };
 inline int launch_subblock_blocks(const SubOpDev &S) { return S.nblocks + (S.ntop + 255) / 256; }
 hipError_t launch_subblock_fused(const SubOpDev &S, int ld, bool backward, const SubFuse &F, double *work, double *out,
                                  hipStream_t st);
-// kappa = sum of the n per-block partials of an EPI_HVP_K product (fixed order), then the scalar step that follows it
-hipError_t launch_kappa_finish(const double *partial, int n, StpcgState *state, hipStream_t st);
 
 // forward : y[block rows] = L_bb^-1 rhs[block rows] -> y;  work[aux rows] = couplings to the last stage;  work[top rows] = rhs[top rows]
 // backward: x[block rows] = L_bb^-T (y[block rows] - L[top, rows]^T work[top rows]) -> x (may be y);  x[top rows] = work[top rows]
@@ -171,8 +192,11 @@ hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const doubl
 // forward: dst[rows] = W src[rows];  backward: dst[rows] = W^T (src[rows] - L[later, rows]^T src[later])
 hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st);
 // dst[out_row] = (src0 ? src0[out_row] : 0) + sum_k val_k * src[col_k] for every row of the product
+// kappa = sum of the n partials of an EPI_HVP_K product (fixed order), then the scalar step that follows it
+hipError_t launch_kappa_finish(const double *partial, int n, StpcgState *state, hipStream_t st);
+// tail: optional RvTail (see SubFuse) -- per-row squared norms out, or one extra block that runs the reductions
 hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const double *src, double *dst,
-                        hipStream_t st);
+                        hipStream_t st, const RvTail *tail = nullptr);
 hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
                        double *partial, int nblocks, double *out, hipStream_t st);
 hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double *const *x, const int *kx,
@@ -198,9 +222,6 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 //   r += coef_r Hp with <r, r> (DOTS_STPCG_RR)  |  out = Proj_Y(V) with <r, out> (DOTS_STPCG_RV)  |
 //   s += coef_s p, then p = coef_v v + coef_beta p
 hipError_t launch_stpcg_residual(const DotArgs &D, int64_t n, const double *Hp, double *r, hipStream_t st);
-// the same after an EPI_HVP_K product: kappa from its nk per-block partials, the scalar step, then the pass above -- one launch
-hipError_t launch_kappa_residual(const DotArgs &D, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
-                                 hipStream_t st);
 hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D, int ld, const double *Y, const double *V,
                                       const double *scale, const double *r, double *out, hipStream_t st);
 // s = 0, r = g, p = -Pg (start of a solve whose preconditioned gradient is known)

@@ -16,6 +16,16 @@
 #include "cora_internal.h"
 #include "kernels.h"
 
+// The file is compiled several times in parallel (cora_amd/build.py): CORA_TU selects the kernel families of a
+// translation unit (1 SpMM, 2 row-unit / vector / block kernels, 4 staged triangular solves), CORA_LDG the row strides
+// it instantiates of the two big families (1: LD 2-5, 2: 6-9, 4: 10-12, 8: 16-24).  Default: everything.
+#ifndef CORA_TU
+#define CORA_TU 7
+#endif
+#ifndef CORA_LDG
+#define CORA_LDG 15
+#endif
+
 namespace cora {
 
 // ---------------------------------------------------------------------------
@@ -113,6 +123,53 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm) {
   __syncthreads();
   return sm[0] + sm[1] + sm[2] + sm[3];
 }
+
+// Scalar recurrences of the device-resident Steihaug-Toint PCG (StpcgState, kernels.h), run by ONE thread of the
+// kernel that finished the inner product they need.
+__device__ __forceinline__ void stpcg_after_kappa(StpcgState &S, double kappa) {  // after Hp = H p:  kappa = <p, Hp>
+  if (S.status == 0 && S.iters >= S.max_iters) S.status = 3;
+  if (S.status != 0) {
+    S.coef_s = 0.0;
+    S.coef_r = 0.0;
+    return;
+  }
+  S.iters++;
+  S.kappa = kappa;
+  const double alpha = S.r_v / kappa;
+  const double sigma_next = S.sigma_M2 + 2 * alpha * S.s_Mp + alpha * alpha * S.p_M2;
+  if (!(kappa > 0.0) || sigma_next >= S.Delta2) {  // negative curvature / leaves the trust region
+    S.coef_s = (-S.s_Mp + sqrt(S.s_Mp * S.s_Mp + S.p_M2 * (S.Delta2 - S.sigma_M2))) / S.p_M2;
+    S.coef_r = 0.0;
+    S.status = 2;
+    S.step_M_norm = sqrt(S.Delta2);
+  } else {
+    S.alpha = alpha;
+    S.coef_s = alpha;
+    S.coef_r = alpha;
+    S.sigma_M2 = sigma_next;
+    S.step_M_norm = sqrt(sigma_next);
+  }
+}
+__device__ __forceinline__ void stpcg_after_rr(StpcgState &S, double rr) {  // after r += alpha Hp:  <r, r>
+  if (S.status == 0) {
+    S.rr = rr;
+    if (sqrt(rr) <= S.target) S.status = 1;
+  }
+}
+__device__ __forceinline__ void stpcg_after_rv(StpcgState &S, double rv) {  // after v = P r:  <r, v>
+  if (S.status != 0) {
+    S.coef_v = 0.0;
+    S.coef_beta = 1.0;
+    return;
+  }
+  const double beta = rv / S.r_v;
+  S.r_v = rv;
+  S.coef_v = -1.0;
+  S.coef_beta = beta;
+  S.s_Mp = beta * (S.s_Mp + S.alpha * S.p_M2);
+  S.p_M2 = S.r_v + beta * beta * S.p_M2;
+}
+
 
 // ---------------------------------------------------------------------------
 // Sliced SpMM with fused epilogues.
@@ -504,6 +561,7 @@ __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc 
   return 0.0;
 }
 
+#if CORA_TU & 1
 #ifdef CORA_SPMM_TIMES
 constexpr unsigned kSpmmTimesMax = 65536;
 __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
@@ -519,7 +577,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM
 void k_spmm(const SpmmArgs A) {
   // one wavefront per block: the dispatcher balances the (uneven) slices.
   // EPI_HVP_K: the wavefront also leaves sum <X[row], out[row]> over the rows it finished in
-  // kappa_partial[blockIdx.x] (every block writes its slot; k_kappa_finish adds them in block order).
+  // kappa_partial[blockIdx.x] (every block writes its slot; k_kappa_finish adds them in slot order).
   constexpr bool KAPPA = EPI == EPI_HVP_K;
   const int lane = threadIdx.x;
   double kap = 0.0;
@@ -560,6 +618,9 @@ void k_spmm(const SpmmArgs A) {
 #endif
 }
 
+#endif  // CORA_TU & 1
+
+#if CORA_TU & 2
 // ---------------------------------------------------------------------------
 // Row-unit kernels: one thread per pose (d x LD block), per range row or per
 // translation row of the LOCAL shard.
@@ -862,57 +923,12 @@ __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const 
     y[i] = scale[i / ld] * x[i];
 }
 
-// Scalar recurrences of the device-resident Steihaug-Toint PCG (StpcgState, kernels.h), run by ONE thread of the
-// kernel that finished the inner product they need.
-__device__ __forceinline__ void stpcg_after_kappa(StpcgState &S, double kappa) {  // after Hp = H p:  kappa = <p, Hp>
-  if (S.status == 0 && S.iters >= S.max_iters) S.status = 3;
-  if (S.status != 0) {
-    S.coef_s = 0.0;
-    S.coef_r = 0.0;
-    return;
-  }
-  S.iters++;
-  S.kappa = kappa;
-  const double alpha = S.r_v / kappa;
-  const double sigma_next = S.sigma_M2 + 2 * alpha * S.s_Mp + alpha * alpha * S.p_M2;
-  if (!(kappa > 0.0) || sigma_next >= S.Delta2) {  // negative curvature / leaves the trust region
-    S.coef_s = (-S.s_Mp + sqrt(S.s_Mp * S.s_Mp + S.p_M2 * (S.Delta2 - S.sigma_M2))) / S.p_M2;
-    S.coef_r = 0.0;
-    S.status = 2;
-    S.step_M_norm = sqrt(S.Delta2);
-  } else {
-    S.alpha = alpha;
-    S.coef_s = alpha;
-    S.coef_r = alpha;
-    S.sigma_M2 = sigma_next;
-    S.step_M_norm = sqrt(sigma_next);
-  }
-}
-__device__ __forceinline__ void stpcg_after_rr(StpcgState &S, double rr) {  // after r += alpha Hp:  <r, r>
-  if (S.status == 0) {
-    S.rr = rr;
-    if (sqrt(rr) <= S.target) S.status = 1;
-  }
-}
-__device__ __forceinline__ void stpcg_after_rv(StpcgState &S, double rv) {  // after v = P r:  <r, v>
-  if (S.status != 0) {
-    S.coef_v = 0.0;
-    S.coef_beta = 1.0;
-    return;
-  }
-  const double beta = rv / S.r_v;
-  S.r_v = rv;
-  S.coef_v = -1.0;
-  S.coef_beta = beta;
-  S.s_Mp = beta * (S.s_Mp + S.alpha * S.p_M2);
-  S.p_M2 = S.r_v + beta * beta * S.p_M2;
-}
-
+#endif  // CORA_TU & 2
 // Tail of the inner-product kernels: every block publishes its partial sums write-through, takes a
 // ticket, and the last block to arrive adds all partials in block order (deterministic) and writes the
 // results to D.out -- pinned host memory, so the caller only has to wait for the stream.  Same
 // inter-workgroup hand-off as the long rows of k_spmm.
-__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm, double kappa = 0.0) {
+__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm) {
   __shared__ int s_last;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -941,10 +957,6 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
   }
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA) stpcg_after_kappa(*D.st, sm[4]);
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RR) stpcg_after_rr(*D.st, sm[4]);
-  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA_RR) {  // k_kappa_residual: every block used the same kappa
-    stpcg_after_kappa(*D.st, kappa);
-    stpcg_after_rr(*D.st, sm[4]);
-  }
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RV) {
     stpcg_after_rv(*D.st, sm[4]);
     *D.st_host = *D.st;  // pinned mirror for the host's (infrequent) look
@@ -960,6 +972,7 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
   }
 }
 
+#if CORA_TU & 2
 // r += coef_r Hp with <r, r> of the result in the same pass (the scalar step that follows it runs in the last block)
 __global__ __launch_bounds__(256) void k_stpcg_residual(DotArgs D, const double2 *__restrict__ Hp, double2 *__restrict__ r) {
   __shared__ double sm[8];
@@ -988,45 +1001,6 @@ __global__ __launch_bounds__(256) void k_stpcg_init(int64_t n, const double *__r
     r[i] = g[i];
     p[i] = -Pg[i];
   }
-}
-
-// kappa = <p, Hp> from the per-block partials of an EPI_HVP_K product, then r += coef_r Hp with <r, r> in the same
-// launch: EVERY block adds the partials (same order, same bits; they sit in L2) and runs the scalar step on a private
-// copy of the state to get its coefficient; the state itself is advanced once, by the last block to finish -- by then
-// every block has read it.
-__global__ __launch_bounds__(256) void k_kappa_residual(DotArgs D, const double *__restrict__ kpartial, int nk,
-                                                        const double2 *__restrict__ Hp, double2 *__restrict__ r) {
-  __shared__ double sm[8];
-  __shared__ double s_kappa;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = threadIdx.x;
-  for (; b + 768 < nk; b += 1024) {
-    s0 += kpartial[b];
-    s1 += kpartial[b + 256];
-    s2 += kpartial[b + 512];
-    s3 += kpartial[b + 768];
-  }
-  for (; b < nk; b += 256) s0 += kpartial[b];
-  const double t = block_sum_256((s0 + s1) + (s2 + s3), sm);
-  if (threadIdx.x == 0) s_kappa = t;
-  __syncthreads();
-  const double kappa = s_kappa;
-  StpcgState L = *D.st;
-  stpcg_after_kappa(L, kappa);
-  const double cr = L.coef_r;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
-       i += static_cast<int64_t>(gridDim.x) * 256) {
-    double2 rv = r[i];
-    if (cr != 0.0) {
-      const double2 h = Hp[i];
-      rv.x = fma(cr, h.x, rv.x);
-      rv.y = fma(cr, h.y, rv.y);
-      r[i] = rv;
-    }
-    acc[0] = fma(rv.x, rv.x, fma(rv.y, rv.y, acc[0]));
-  }
-  dots_finish(D, acc, sm, kappa);
 }
 
 // s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
@@ -1350,6 +1324,9 @@ __global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, Com
   }
 }
 
+#endif  // CORA_TU & 2
+
+#if CORA_TU & 4
 // ---------------------------------------------------------------------------
 // Staged sparse Cholesky solves (trisolve.h): every step is one dependency-free
 // sparse product  dst[out_row] = src0[out_row] + sum_k val_k * src[col_k]  over the
@@ -1390,11 +1367,50 @@ __device__ __forceinline__ void rowop_entries(const int32_t *__restrict__ col, c
   }
 }
 
+// The two reductions of a sweep-fused STPCG iteration (RvTail, kernels.h) in ONE block, fixed order: <r, r> from the
+// forward sweep's slots, then <r, v> = |L^-1 r|^2 from its |y|^2 slots and the squared norms of the last stage's rows.
+__device__ __forceinline__ double sum_slots_256(const double *__restrict__ x, int n, double *sm) {
+  double s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.0;
+  for (int b0 = threadIdx.x; b0 < n; b0 += 256 * 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = b0 + 256 * u;
+      t[u] = x[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += (b0 + 256 * u < n) ? t[u] : 0.0;
+  }
+  return block_sum_256(((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])), sm);
+}
+__device__ __forceinline__ void rv_tail_block(const RvTail &T) {
+  __shared__ double sm[12];
+  const double rr = sum_slots_256(T.rr_partial, T.n_rr, sm);
+  const double yy = sum_slots_256(T.yy_partial, T.n_yy, sm + 4);
+  const double tt = sum_slots_256(T.rowsq, T.n_rowsq, sm + 8);
+  if (threadIdx.x == 0) {
+    stpcg_after_rr(*T.st, rr);
+    stpcg_after_rv(*T.st, yy + tt);
+    *T.st_host = *T.st;  // pinned mirror for the host's (infrequent) look
+    if (T.seq_out) {
+      __threadfence_system();
+      __hip_atomic_store(T.seq_out, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <int LD>
 __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__restrict__ src0,
-                                               const double *__restrict__ src, double *__restrict__ dst) {
+                                               const double *__restrict__ src, double *__restrict__ dst, const RvTail tail) {
   const int nb8 = (op.n8 + 31) >> 5, nb64 = (op.n64 + 3) >> 2;
   const int b = static_cast<int>(blockIdx.x);
+  if (tail.st && b == static_cast<int>(gridDim.x) - 1) {  // the extra block of a launch with a tail
+    rv_tail_block(tail);
+    return;
+  }
+  double *__restrict__ rowsq = tail.st ? nullptr : tail.rowsq_out;  // squared norm of every row of the product (optional)
   double acc[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
@@ -1411,7 +1427,10 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
     for (int off = 4; off > 0; off >>= 1)
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
-    if (ok && g == 0) store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
+    if (ok && g == 0) {
+      store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
+      if (rowsq) rowsq[r] = dot_row<LD>(acc, acc);
+    }
   } else if (b < nb8 + nb64) {  // one wavefront per row
     const int r = op.n8 + ((b - nb8) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
     if (r >= op.n8 + op.n64) return;
@@ -1420,7 +1439,10 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
     rowop_entries<LD>(op.col, op.val, src, op.begin[r] + g, op.end[r], 64, acc);
 #pragma unroll
     for (int j = 0; j < LD; ++j) acc[j] = wave_sum(acc[j]);
-    if (g == 0) store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
+    if (g == 0) {
+      store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
+      if (rowsq) rowsq[r] = dot_row<LD>(acc, acc);
+    }
   } else {  // one wavefront per chunk of a long row
     const int ch = ((b - nb8 - nb64) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
     if (ch >= op.nchunks) return;
@@ -1467,6 +1489,7 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
           for (int j = 0; j < LD; ++j) part[j] += b0[j];
         }
         store_row<LD>(dst + orow * LD, part);
+        if (rowsq) rowsq[op.n8 + op.n64 + r] = dot_row<LD>(part, part);
       }
     }
   }
@@ -1685,13 +1708,12 @@ __device__ __forceinline__ void sub_touch(SubRegs &R) {
 }
 
 // v = Proj_Y(x) for the row unit that starts at `row` (a pose's d rotation rows: only its first row does the work;
-// a range row; a translation row), v -> dst, returns <r, v> over the rows written.  row_of_x(a) -> the a-th row of x.
+// a range row; a translation row); sink(row, v) receives every row of the result.  row_of_x(a) -> the a-th row of x.
 // (Rows of the last stage in the fused backward sweep.)
-template <int LD, int D, typename RowOfX>
-__device__ __forceinline__ double project_unit_dot(const SubFuse &F, size_t row, RowOfX row_of_x, double *dst) {
-  double acc = 0.0;
+template <int LD, int D, typename RowOfX, typename Sink>
+__device__ __forceinline__ void project_unit(const SubFuse &F, size_t row, RowOfX row_of_x, Sink sink) {
   if (row < static_cast<size_t>(F.rng_base)) {
-    if ((row - static_cast<size_t>(F.rot_base)) % D != 0) return 0.0;
+    if ((row - static_cast<size_t>(F.rot_base)) % D != 0) return;
     double y[D][LD], v[D][LD];
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -1700,12 +1722,8 @@ __device__ __forceinline__ double project_unit_dot(const SubFuse &F, size_t row,
     }
     stiefel_project_thread<LD, D>(y, v);
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      load_row<LD>(F.r + (row + a) * LD, y[a]);
-      acc += dot_row<LD>(y[a], v[a]);
-      store_row<LD>(dst + (row + a) * LD, v[a]);
-    }
-    return acc;
+    for (int a = 0; a < D; ++a) sink(row + a, v[a]);
+    return;
   }
   double y[LD], v[LD];
   row_of_x(0, v);
@@ -1715,10 +1733,7 @@ __device__ __forceinline__ double project_unit_dot(const SubFuse &F, size_t row,
 #pragma unroll
     for (int c = 0; c < LD; ++c) v[c] = fma(-ip, y[c], v[c]);
   }
-  load_row<LD>(F.r + row * LD, y);
-  acc = dot_row<LD>(y, v);
-  store_row<LD>(dst + row * LD, v);
-  return acc;
+  sink(row, v);
 }
 
 #ifndef CORA_SUB_MIN_BLOCKS
@@ -1742,6 +1757,13 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   const int b = static_cast<int>(blockIdx.x);
   double dacc[4] = {0.0, 0.0, 0.0, 0.0};
   const double cr = (FD == 1) ? F.dot.st->coef_r : 0.0;
+  // fused backward sweep: the step and the direction are updated on the way out (the scalars are final: the launch
+  // before this one finished <r, v>)
+  const double cs = (FD >= 2) ? F.dot.st->coef_s : 0.0, cv = (FD >= 2) ? F.dot.st->coef_v : 0.0,
+               cb = (FD >= 2) ? F.dot.st->coef_beta : 1.0;
+  // F.p == nullptr: the projected solution itself is the result (v -> dst: the stand-alone preconditioner apply)
+  const bool store_v = FD >= 2 && F.p == nullptr;
+  const bool upd = FD >= 2 && (store_v || !(cs == 0.0 && cv == 0.0 && cb == 1.0));  // false: solve already finished (enqueued ahead)
   if (b >= S.nblocks) {  // rows of the last stage: forward rhs -> work, backward work -> x
     const int t = (b - S.nblocks) * kSubThreads + tid;
     if (t < S.ntop) {
@@ -1762,12 +1784,31 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
         }
         dacc[0] = dot_row<LD>(x, x);
         store_row<LD>(work + row * LD, x);
-      } else {
+      } else if (upd) {
         constexpr int D = FD >= 2 ? FD : 2;
-        dacc[0] = project_unit_dot<LD, D>(F, row, [&](int a, double (&x)[LD]) { load_row<LD>(work + (row + a) * LD, x); }, dst);
+        project_unit<LD, D>(F, row, [&](int a, double (&x)[LD]) { load_row<LD>(work + (row + a) * LD, x); },
+                            [&](size_t rw, const double (&v)[LD]) {
+                              if (store_v) {
+                                store_row<LD>(dst + rw * LD, v);
+                                return;
+                              }
+                              double pv[LD], sv[LD];
+                              load_row<LD>(F.p + rw * LD, pv);
+                              load_row<LD>(F.s + rw * LD, sv);
+#pragma unroll
+                              for (int j = 0; j < LD; ++j) {
+                                sv[j] = fma(cs, pv[j], sv[j]);
+                                pv[j] = fma(cv, v[j], cb * pv[j]);
+                              }
+                              store_row<LD>(F.s + rw * LD, sv);
+                              store_row<LD>(F.p + rw * LD, pv);
+                            });
       }
     }
-    if (FD != 0) dots_finish(F.dot, dacc, dot_sm);
+    if (FD == 1) {  // <r, r> over these rows: a slot of its own (RvTail adds the slots up, no ticket)
+      const double rr = block_sum_256(dacc[0], dot_sm);
+      if (tid == 0) F.rr_partial[b] = rr;
+    }
     return;
   }
   const SubSweep &Q = BWD ? S.bwd : S.fwd;
@@ -1891,8 +1932,6 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
       }
     }
   }
-  // <r, r> is complete for this block: published now, so that the last block's scalar step overlaps the solve
-  if (FD == 1) dots_finish(F.dot, dacc, dot_sm);
   __syncthreads();
 
   // ---- the triangular solve, level by level
@@ -1997,30 +2036,62 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     }
     __syncthreads();
   }
-  // ... and the tile -> dst in memory order (fused backward: with <r, v>)
+  // ... and the tile -> dst in memory order.  Fused backward: the tile holds v; nothing is stored but the updated step
+  // and direction, s += coef_s p and p = coef_v v + coef_beta p, element by element in the same order.  Fused forward:
+  // with |y|^2 of the block's rows (SubFuse::yy_partial).
+  if (FD >= 2) {
+    if (!upd) return;
+    if (store_v) {
+      for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
+        IoAt at[kIoBatch];
+        io_index(e0, at);
+#pragma unroll
+        for (int u = 0; u < kIoBatch; ++u)
+          if (e0 + u * kSubThreads < ne) dst[at[u].g] = T[at[u].t];
+      }
+      return;
+    }
+    for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
+      IoAt at[kIoBatch];
+      io_index(e0, at);
+#pragma unroll
+      for (int half = 0; half < kIoBatch; half += kIoSub) {
+        double pv[kIoSub], sv[kIoSub];
+#pragma unroll
+        for (int u = 0; u < kIoSub; ++u)
+          if (half + u < kIoBatch) {
+            pv[u] = F.p[at[half + u].g];
+            sv[u] = F.s[at[half + u].g];
+          }
+#pragma unroll
+        for (int u = 0; u < kIoSub; ++u)
+          if (half + u < kIoBatch && e0 + (half + u) * kSubThreads < ne) {
+            const double v = T[at[half + u].t];
+            F.s[at[half + u].g] = fma(cs, pv[u], sv[u]);
+            F.p[at[half + u].g] = fma(cv, v, cb * pv[u]);
+          }
+      }
+    }
+    return;
+  }
   for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
     IoAt at[kIoBatch];
     io_index(e0, at);
 #pragma unroll
-    for (int half = 0; half < kIoBatch; half += kIoSub) {
-      double rr[FD >= 2 ? kIoSub : 1];
-      if (FD >= 2) {
-#pragma unroll
-        for (int u = 0; u < kIoSub; ++u)
-          if (half + u < kIoBatch) rr[FD >= 2 ? u : 0] = F.r[at[half + u].g];
+    for (int u = 0; u < kIoBatch; ++u)
+      if (e0 + u * kSubThreads < ne) {
+        const double v = T[at[u].t];
+        dst[at[u].g] = v;
+        if (FD == 1) dacc[1] = fma(v, v, dacc[1]);
       }
-#pragma unroll
-      for (int u = 0; u < kIoSub; ++u)
-        if (half + u < kIoBatch && e0 + (half + u) * kSubThreads < ne) {
-          const double v = T[at[half + u].t];
-          dst[at[half + u].g] = v;
-          if (FD >= 2) dacc[0] = fma(rr[FD >= 2 ? u : 0], v, dacc[0]);
-        }
-    }
   }
-  if (FD >= 2) {
-    dots_finish(F.dot, dacc, dot_sm);
-    return;
+  if (FD == 1) {  // <r, r> and |y|^2 over the block's rows (RvTail adds the slots of all blocks in fixed order)
+    const double rr = block_sum_256(dacc[0], dot_sm);
+    const double yy = block_sum_256(dacc[1], dot_sm + 4);
+    if (tid == 0) {
+      F.rr_partial[b] = rr;
+      F.yy_partial[b] = yy;
+    }
   }
   if (!BWD) {  // couplings to the last stage: aux row of target g = -sum_v L_gv y_v, 16 lanes per target
     const int ntgt = bd.ntgt;
@@ -2058,7 +2129,11 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   }
 }
 
-// kappa = <p, Hp> from the per-block partials of an EPI_HVP_K product (one block, fixed order), then the scalar step
+#if CORA_LDG & 1
+// kappa = <p, Hp> from the partials of an EPI_HVP_K product (one block, fixed order), then the scalar step.
+// (Measured and not kept, round 3: the same sum in the product's own last block behind a ticket -- one counter for the
+// 4 016 blocks serialises 4 016 returning atomics on one address, 63 us; a two-level ticket, 64 blocks per counter, costs
+// every wavefront a drain of its stores and an atomic round trip before it frees its slot: 29.8 us against 24.4 + 4.7.)
 __global__ __launch_bounds__(256) void k_kappa_finish(const double *__restrict__ partial, int n, StpcgState *st) {
   __shared__ double sm[4];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -2079,6 +2154,9 @@ __global__ __launch_bounds__(256) void k_kappa_finish(const double *__restrict__
 __global__ void k_zero_row(double *x, size_t row, int ld) {
   if (static_cast<int>(threadIdx.x) < ld) x[row * ld + threadIdx.x] = 0.0;
 }
+#endif  // CORA_LDG & 1
+
+#endif  // CORA_TU & 4
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -2092,6 +2170,12 @@ static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
   return static_cast<int>(g);
 }
 
+#define CORA_LD_CASES_G0(M) M(2) M(3) M(4) M(5)
+#define CORA_LD_CASES_G1(M) M(6) M(7) M(8) M(9)
+#define CORA_LD_CASES_G2(M) M(10) M(11) M(12)
+#define CORA_LD_CASES_G3(M) M(16) M(20) M(24)
+
+#if CORA_TU & 1
 template <int LD, int D>
 static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) {
   SpmmArgs A = A_in;
@@ -2116,14 +2200,42 @@ static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) 
   return hipGetLastError();
 }
 
-hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st) {
+// one launcher per row-stride group, each in the translation unit that instantiates the group's kernels
 #define CASE(L)                                                      \
   if (ld == L)                                                       \
     return d == 2 ? launch_spmm_ld<L, 2>(A, epi, st) : launch_spmm_ld<L, 3>(A, epi, st);
-  CORA_LD_CASES(CASE)
-#undef CASE
-  return hipErrorInvalidValue;
+#define SPMM_GROUP(G)                                                                       \
+  hipError_t launch_spmm_g##G(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st) { \
+    CORA_LD_CASES_G##G(CASE)                                                                \
+    return hipErrorInvalidValue;                                                            \
+  }
+hipError_t launch_spmm_g0(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+hipError_t launch_spmm_g1(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+hipError_t launch_spmm_g2(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+hipError_t launch_spmm_g3(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+#if CORA_LDG & 1
+SPMM_GROUP(0)
+hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st) {
+  if (ld <= 5) return launch_spmm_g0(A, ld, d, epi, st);
+  if (ld <= 9) return launch_spmm_g1(A, ld, d, epi, st);
+  if (ld <= 12) return launch_spmm_g2(A, ld, d, epi, st);
+  return launch_spmm_g3(A, ld, d, epi, st);
 }
+#endif
+#if CORA_LDG & 2
+SPMM_GROUP(1)
+#endif
+#if CORA_LDG & 4
+SPMM_GROUP(2)
+#endif
+#if CORA_LDG & 8
+SPMM_GROUP(3)
+#endif
+#undef SPMM_GROUP
+#undef CASE
+#endif  // CORA_TU & 1
+
+#if CORA_TU & 2
 
 hipError_t launch_point_finish(const RowArgs &R, int ld, const double *Y, const double *G,
                                double *rgrad, double *lam_st, double *lam_ob, double *partial,
@@ -2216,17 +2328,6 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 }
 
 // D: mode / st / st_host / partial / ticket / seq fields set by the caller; n doubles, even, 16-byte aligned
-hipError_t launch_kappa_residual(const DotArgs &D_in, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
-                                 hipStream_t st) {
-  if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
-  DotArgs D = D_in;
-  D.count = 1;
-  D.n2 = n / 2;
-  D.mode = DOTS_STPCG_KAPPA_RR;
-  hipLaunchKernelGGL(k_kappa_residual, dim3(grid_for(n / 2, 256, 256)), dim3(256), 0, st, D, kpartial, nk,
-                     reinterpret_cast<const double2 *>(Hp), reinterpret_cast<double2 *>(r));
-  return hipGetLastError();
-}
 hipError_t launch_stpcg_residual(const DotArgs &D_in, int64_t n, const double *Hp, double *r, hipStream_t st) {
   if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
   DotArgs D = D_in;
@@ -2329,14 +2430,19 @@ hipError_t launch_download(int64_t N, int k, int ld, const double *src, const in
   return hipGetLastError();
 }
 
+#endif  // CORA_TU & 2
 }  // namespace cora
 
 namespace cora {
+#if CORA_TU & 4
 
 template <int LD>
-static hipError_t rowop_ld(const RowOpDev &op, const double *src0, const double *src, double *dst, hipStream_t st) {
-  const int grid = ((op.n8 + 31) >> 5) + ((op.n64 + 3) >> 2) + ((op.nchunks + 3) >> 2);
-  if (grid > 0) hipLaunchKernelGGL((k_rowop<LD>), dim3(grid), dim3(256), 0, st, op, src0, src, dst);
+static hipError_t rowop_ld(const RowOpDev &op, const double *src0, const double *src, double *dst, hipStream_t st,
+                           const RvTail *tail) {
+  const int grid = ((op.n8 + 31) >> 5) + ((op.n64 + 3) >> 2) + ((op.nchunks + 3) >> 2) + ((tail && tail->st) ? 1 : 0);
+  RvTail T{};
+  if (tail) T = *tail;
+  if (grid > 0) hipLaunchKernelGGL((k_rowop<LD>), dim3(grid), dim3(256), 0, st, op, src0, src, dst, T);
   return hipGetLastError();
 }
 
@@ -2349,24 +2455,6 @@ static hipError_t blockop_ld(const BlockOpDev &B, bool backward, const double *s
   return hipGetLastError();
 }
 
-hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st) {
-#define CASE(L) \
-  if (ld == L) return blockop_ld<L>(B, backward, src, dst, st);
-  CORA_LD_CASES(CASE)
-#undef CASE
-  return hipErrorInvalidValue;
-}
-
-hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const double *src, double *dst,
-                        hipStream_t st) {
-#define CASE(L) \
-  if (ld == L) return rowop_ld<L>(op, src0, src, dst, st);
-  CORA_LD_CASES(CASE)
-#undef CASE
-  return hipErrorInvalidValue;
-}
-
-
 template <int LD>
 static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *src, double *work, double *dst, hipStream_t st,
                               const SubFuse *F = nullptr) {
@@ -2376,51 +2464,107 @@ static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *sr
   if (S.max_level_lanes > kSubThreads || S.max_npl > kSubNpl || S.max_lev + 1 > kSubThreads || lds > 64 * 1024) return hipErrorInvalidValue;
   const dim3 g(grid), t(kSubThreads);
   if (F) {
-    if constexpr (LD <= 12) {
-      if (!backward) hipLaunchKernelGGL((k_subblock<LD, false, 1>), g, t, lds, st, S, src, work, dst, *F);
-      else if (F->d == 2) hipLaunchKernelGGL((k_subblock<LD, true, 2>), g, t, lds, st, S, src, work, dst, *F);
-      else if (F->d == 3) hipLaunchKernelGGL((k_subblock<LD, true, 3>), g, t, lds, st, S, src, work, dst, *F);
+    // the fused sweeps exist where cora_stpcg_dev dispatches them (row stride x d <= 24: above, the fused backward sweep
+    // spills -- 172 to 380 bytes of scratch per lane at row strides 10-12 with d = 3 -- and was never launched)
+    if (!backward) {
+      if constexpr (LD <= 12) hipLaunchKernelGGL((k_subblock<LD, false, 1>), g, t, lds, st, S, src, work, dst, *F);
       else return hipErrorInvalidValue;
-      return hipGetLastError();
+    } else if (F->d == 2) {
+      if constexpr (LD <= 12) hipLaunchKernelGGL((k_subblock<LD, true, 2>), g, t, lds, st, S, src, work, dst, *F);
+      else return hipErrorInvalidValue;
+    } else if (F->d == 3) {
+      if constexpr (LD <= 8) hipLaunchKernelGGL((k_subblock<LD, true, 3>), g, t, lds, st, S, src, work, dst, *F);
+      else return hipErrorInvalidValue;
     } else {
       return hipErrorInvalidValue;
     }
+    return hipGetLastError();
   }
   const SubFuse none{};
   if (backward) hipLaunchKernelGGL((k_subblock<LD, true, 0>), g, t, lds, st, S, src, work, dst, none);
   else hipLaunchKernelGGL((k_subblock<LD, false, 0>), g, t, lds, st, S, src, work, dst, none);
   return hipGetLastError();
 }
+
+// one set of launchers per row-stride group, each in the translation unit that instantiates the group's kernels
+struct TriCall {  // what a staged-solve launch needs, whichever kernel it is
+  int kind;       // 0 blockop, 1 rowop, 2 subblock, 3 subblock fused
+  int ld;
+  bool backward;
+  const BlockOpDev *B;
+  const RowOpDev *R;
+  const SubOpDev *S;
+  const SubFuse *F;
+  const double *a, *b;  // blockop: src, -;  rowop: src0, src;  subblock: rhs_or_y, -
+  double *work, *dst;
+  const RvTail *tail = nullptr;
+};
+#define CASE(L)                                                                                       \
+  if (c.ld == L) {                                                                                    \
+    if (c.kind == 0) return blockop_ld<L>(*c.B, c.backward, c.a, c.dst, st);                          \
+    if (c.kind == 1) return rowop_ld<L>(*c.R, c.a, c.b, c.dst, st, c.tail);                           \
+    if (c.kind == 2) return subblock_ld<L>(*c.S, c.backward, c.a, c.work, c.dst, st);                 \
+    return subblock_ld<L>(*c.S, c.backward, c.a, c.work, c.dst, st, c.F);                             \
+  }
+#define TRI_GROUP(G)                                             \
+  hipError_t launch_tri_g##G(const TriCall &c, hipStream_t st) { \
+    CORA_LD_CASES_G##G(CASE)                                     \
+    return hipErrorInvalidValue;                                 \
+  }
+hipError_t launch_tri_g0(const TriCall &c, hipStream_t st);
+hipError_t launch_tri_g1(const TriCall &c, hipStream_t st);
+hipError_t launch_tri_g2(const TriCall &c, hipStream_t st);
+hipError_t launch_tri_g3(const TriCall &c, hipStream_t st);
+#if CORA_LDG & 2
+TRI_GROUP(1)
+#endif
+#if CORA_LDG & 4
+TRI_GROUP(2)
+#endif
+#if CORA_LDG & 8
+TRI_GROUP(3)
+#endif
+#if CORA_LDG & 1
+TRI_GROUP(0)
+static hipError_t launch_tri(const TriCall &c, hipStream_t st) {
+  if (c.ld <= 5) return launch_tri_g0(c, st);
+  if (c.ld <= 9) return launch_tri_g1(c, st);
+  if (c.ld <= 12) return launch_tri_g2(c, st);
+  return launch_tri_g3(c, st);
+}
+hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st) {
+  return launch_tri(TriCall{0, ld, backward, &B, nullptr, nullptr, nullptr, src, nullptr, nullptr, dst}, st);
+}
+hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const double *src, double *dst,
+                        hipStream_t st, const RvTail *tail) {
+  return launch_tri(TriCall{1, ld, false, nullptr, &op, nullptr, nullptr, src0, src, nullptr, dst, tail}, st);
+}
 hipError_t launch_subblock_fused(const SubOpDev &S, int ld, bool backward, const SubFuse &F, double *work, double *out,
                                  hipStream_t st) {
   // forward: the right-hand side is F.r, y -> out;  backward: y is read from `out`, v -> out
-#define CASE(L) \
-  if (ld == L) return subblock_ld<L>(S, backward, backward ? out : F.r, work, out, st, &F);
-  CORA_LD_CASES(CASE)
-#undef CASE
-  return hipErrorInvalidValue;
+  return launch_tri(TriCall{3, ld, backward, nullptr, nullptr, &S, &F, backward ? out : F.r, nullptr, work, out}, st);
+}
+hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const double *rhs_or_y, double *work, double *out,
+                           hipStream_t st) {
+  return launch_tri(TriCall{2, ld, backward, nullptr, nullptr, &S, nullptr, rhs_or_y, nullptr, work, out}, st);
 }
 hipError_t launch_kappa_finish(const double *partial, int n, StpcgState *state, hipStream_t st) {
   hipLaunchKernelGGL(k_kappa_finish, dim3(1), dim3(256), 0, st, partial, n, state);
   return hipGetLastError();
 }
-hipError_t launch_subblock(const SubOpDev &S, int ld, bool backward, const double *rhs_or_y, double *work, double *out,
-                           hipStream_t st) {
-#define CASE(L) \
-  if (ld == L) return subblock_ld<L>(S, backward, rhs_or_y, work, out, st);
-  CORA_LD_CASES(CASE)
-#undef CASE
-  return hipErrorInvalidValue;
-}
-
 hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st) {
   hipLaunchKernelGGL(k_zero_row, dim3(1), dim3(64), 0, st, x, row, ld);
   return hipGetLastError();
 }
+#endif  // CORA_LDG & 1
+#undef TRI_GROUP
+#undef CASE
 
+#endif  // CORA_TU & 4
 }  // namespace cora
 
 namespace cora {
+#if CORA_TU & 2
 
 hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
                        double *partial, int nblocks, double *out, hipStream_t st) {
@@ -2444,9 +2588,10 @@ hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double 
   return hipGetLastError();
 }
 
+#endif  // CORA_TU & 2
 }  // namespace cora
 
-#ifdef CORA_SPMM_TIMES
+#if defined(CORA_SPMM_TIMES) && (CORA_TU & 1) && (CORA_LDG & 1)
 // measurement build only (-DCORA_SPMM_TIMES, tools/spmm_timeline.py): the wavefront timestamps of the last k_spmm launch
 extern "C" int cora_debug_spmm_times(unsigned long long *out, int n_blocks) {
   if (n_blocks < 0 || static_cast<unsigned>(n_blocks) > cora::kSpmmTimesMax) return -1;

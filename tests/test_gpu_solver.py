@@ -221,10 +221,11 @@ def test_precondition_in_place_and_out_of_place_agree():
 @pytest.mark.parametrize("p", [5, 4])
 def test_fused_stpcg_matches_unfused(d, n, precond, p):
     """cora_stpcg_dev folds the residual update with <r, r>, the tangent projection with <r, v> and the step
-    with the new direction into three passes (six launches per iteration instead of nine), and -- with a two-stage
-    Cholesky solve plan -- the first two into the sweeps of the solve, kappa into the product's epilogue (seven
-    launches with the solve instead of ten).  Same iteration as the unfused sequence (CORA_NO_FUSE=1): iteration count,
-    M-norm of the step, step and residual agree."""
+    with the new direction into three passes, kappa into the product's last block, and -- with a two-stage
+    Cholesky solve plan -- all of them into the product and the two sweeps of the solve: <r, v> is taken as |L^-1 r|^2
+    from the forward sweep, so that beta is known before the backward sweep and the step / direction update rides on its
+    epilogue (five launches per iteration with the solve).  Same iteration as the unfused sequence (CORA_NO_FUSE=1):
+    iteration count, M-norm of the step, step, residual and direction agree."""
     P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=6, n_ranges=n // 2, seed=5, precond=precond)
     P.update()
     P.set_rank(p)
@@ -267,7 +268,9 @@ def test_fused_stpcg_matches_unfused(d, n, precond, p):
             a, b = out[(mode, delta)], out[("unfused", delta)]
             assert a[0] == b[0] and a[0] > 0
             assert abs(a[1] - b[1]) <= 1e-10 * abs(b[1])
-            for k in (2, 3, 4, 5):
+            # (the sweep-fused form never stores v = P r: the direction update rides on the backward sweep's epilogue,
+            # and dV -- a work vector of the C ABI -- is left holding L^-1 r)
+            for k in (2, 3, 5) if out[mode] == 2 else (2, 3, 4, 5):
                 assert np.abs(a[k] - b[k]).max() <= 1e-9 * np.abs(b[k]).max(), (mode, delta, k)
     for q in vecs:
         h.dev_free(q)

@@ -9,8 +9,10 @@ import csv, glob
 f = glob.glob("gpurun_out/stpcg_trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "step_direction" in r["Kernel_Name"] or "k_stpcg_direction" in r["Kernel_Name"]]
-a, b = idx[-3] + 1, idx[-2] + 1
+import re
+# an iteration starts with the product that carries kappa (k_spmm<LD, d, 3> = EPI_HVP_K)
+idx = [i for i, r in enumerate(rows) if re.search(r"k_spmm<\d+, \d, 3>", r["Kernel_Name"])]
+a, b = idx[-3], idx[-2]
 t0 = int(rows[a - 1]["End_Timestamp"])
 busy = 0
 prev_end = t0
