@@ -2,6 +2,14 @@
 // device memory and stream; every compute entry point ends in a HIP kernel of
 // kernels.hip -- there is no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enums only: the entry points are resolved with dlsym (native communication, end of file)
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <mutex>
 
 #include <cmath>
 #include <cstdlib>
@@ -23,8 +31,11 @@ thread_local std::string g_create_error;
 constexpr int kScratchSlots = 9;
 }  // namespace
 
+struct cora_native_comm;
+static void native_comm_destroy(cora_native_comm *nc);
 struct cora_ctx {
   HostFormat F;
+  cora_native_comm *native_comm = nullptr;  // owned: the library's own communication (cora_comm_create_*)
   int device = -1;
   bool has_device = false;
   hipStream_t stream = nullptr;
@@ -432,6 +443,8 @@ void cora_ctx_destroy(cora_ctx *c) {
   if (c->has_device) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    native_comm_destroy(c->native_comm);
+    c->native_comm = nullptr;
     free_rank_state(c);
     void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
@@ -1826,5 +1839,356 @@ int cora_debug_factor_solve_host(int m, const int32_t *Lp, const int32_t *Li, co
   }
   return CORA_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Native communication of a partitioned handle (the collective steps of include/cora_hip.h,
+// cora_set_comm, provided by the library itself instead of injected callbacks).  Two transports behind one plan:
+//   RCCL  -- one process per GPU: ncclAllGather / ncclAllReduce on the handle's stream (librccl.so is opened at run
+//            time, so single-GPU users carry no dependency); the id is created on rank 0 (cora_rccl_unique_id) and
+//            handed to the other ranks by whatever launched them (torch.distributed in bench.py, MPI, a file);
+//   local -- every rank a thread of ONE process with its own handle (and stream) on one or several visible devices:
+//            device-to-device copies between the ranks' buffers behind a host barrier.  This is how the sharded
+//            solver is tested on a one-GPU box, and it runs the same planning, pack and scatter code as RCCL.
+// The exchange moves only the rows somebody reads: pack (k_move_rows) -> ONE all-gather of the packed rows ->
+// scatter.  Every rank pads its export list to the longest one with its own first row.
+// ---------------------------------------------------------------------------------------------------------
+
+struct cora_local_group {
+  int world = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  uint64_t generation = 0;
+  bool broken = false;
+  std::vector<const void *> ptrs;          // what every rank published for the current step
+  std::vector<std::vector<double>> vals;   // host all-reduce operands
+  // returns false if the group was broken (a rank failed): nobody waits for ever
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
+    const uint64_t gen = generation;
+    if (++waiting == world) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    if (!cv.wait_for(lk, std::chrono::seconds(600), [&] { return generation != gen || broken; })) broken = true;
+    if (broken) cv.notify_all();
+    return !broken;
+  }
+};
+
+namespace {
+
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const RcclApi *rccl_api(std::string *err) {
+  static RcclApi api;
+  static std::once_flag once;
+  static std::string load_error;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      load_error = std::string("cannot open librccl.so: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char *n) {
+      void *q = dlsym(api.lib, n);
+      if (!q && load_error.empty()) load_error = std::string("librccl.so lacks ") + n;
+      return q;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  if (!load_error.empty()) {
+    if (err) *err = load_error;
+    return nullptr;
+  }
+  return &api;
+}
+
+}  // namespace
+
+struct cora_native_comm {
+  cora_ctx *c = nullptr;
+  int rank = 0, world = 1;
+  cora_local_group *g = nullptr;  // local transport
+  const RcclApi *api = nullptr;   // RCCL transport
+  ncclComm_t nccl = nullptr;
+  // exchange plan
+  int e_max = 0;
+  int64_t exchanged_rows = 0;       // rows received per exchange (world * e_max)
+  int32_t *d_export = nullptr;      // [e_max] rows of this rank's shard that some other rank reads (padded)
+  int32_t *d_recv_idx = nullptr;    // [world * e_max] where the gathered rows go, rank by rank
+  struct Buf { double *send = nullptr, *recv = nullptr; };
+  std::map<int, Buf> buf;           // per row stride
+  double *d_scal = nullptr, *h_scal = nullptr;  // 64 doubles each (device / pinned): all-reduce staging
+  std::string err;
+
+  int fail_(const std::string &m) {
+    err = m;
+    if (c) c->err = m;
+    if (g) {  // release the other ranks
+      std::lock_guard<std::mutex> lk(g->m);
+      g->broken = true;
+      g->cv.notify_all();
+    }
+    return 1;
+  }
+  int hip(hipError_t e, const char *what) { return e == hipSuccess ? 0 : fail_(std::string(what) + ": " + hipGetErrorString(e)); }
+  int nc(ncclResult_t r, const char *what) {
+    return r == ncclSuccess ? 0 : fail_(std::string(what) + ": " + (api && api->GetErrorString ? api->GetErrorString(r) : "RCCL error"));
+  }
+
+  // all-gather of `bytes` bytes per rank between DEVICE buffers, ordered on the handle's stream
+  int allgather_dev(const void *send, void *recv, size_t bytes) {
+    if (nccl) return nc(api->AllGather(send, recv, bytes, ncclChar, nccl, c->stream), "ncclAllGather");
+    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+    g->ptrs[rank] = send;
+    if (!g->barrier()) return fail_("local group broken");
+    for (int r = 0; r < world; ++r)
+      if (hip(hipMemcpyAsync(static_cast<char *>(recv) + static_cast<size_t>(r) * bytes, g->ptrs[r], bytes,
+                             hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync")) return 1;
+    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+    if (!g->barrier()) return fail_("local group broken");  // nobody reuses its send buffer before everyone has copied
+    return 0;
+  }
+  // sum of n device doubles over the ranks, in place, ordered on the handle's stream (the same bits on every rank)
+  int allreduce_dev(double *d, int n) {
+    if (nccl) return nc(api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce");
+    std::vector<double> h(static_cast<size_t>(n));
+    if (hip(hipMemcpyAsync(h.data(), d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync")) return 1;
+    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+    if (allreduce_host(h.data(), n)) return 1;
+    if (hip(hipMemcpyAsync(d, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync")) return 1;
+    return hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+  }
+  int allreduce_host(double *vals, int n) {
+    if (nccl) {
+      if (n > 64) return fail_("all-reduce of more than 64 doubles");
+      std::memcpy(h_scal, vals, sizeof(double) * n);
+      if (hip(hipMemcpyAsync(d_scal, h_scal, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync")) return 1;
+      if (nc(api->AllReduce(d_scal, d_scal, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce")) return 1;
+      if (hip(hipMemcpyAsync(h_scal, d_scal, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync")) return 1;
+      if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+      std::memcpy(vals, h_scal, sizeof(double) * n);
+      return 0;
+    }
+    g->vals[rank].assign(vals, vals + n);
+    if (!g->barrier()) return fail_("local group broken");
+    std::vector<double> tot(static_cast<size_t>(n), 0.0);
+    for (int r = 0; r < world; ++r)  // rank order: the same bits on every rank
+      for (int i = 0; i < n; ++i) tot[i] += g->vals[r][i];
+    if (!g->barrier()) return fail_("local group broken");
+    std::copy(tot.begin(), tot.end(), vals);
+    return 0;
+  }
+  // all-gather of host data (planning): `bytes` per rank
+  int allgather_host(const void *send, void *recv, size_t bytes) {
+    void *ds = nullptr, *dr = nullptr;
+    if (hip(hipMalloc(&ds, std::max<size_t>(bytes, 8)), "hipMalloc") || hip(hipMalloc(&dr, std::max<size_t>(bytes, 8) * world), "hipMalloc")) return 1;
+    int rc = hip(hipMemcpy(ds, send, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+    if (!rc) rc = allgather_dev(ds, dr, bytes);
+    if (!rc) rc = hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (!rc) rc = hip(hipMemcpy(recv, dr, bytes * world, hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(ds);
+    (void)hipFree(dr);
+    return rc;
+  }
+
+  int plan() {
+    const Layout &L = c->F.L;
+    int64_t n_need = 0;
+    cora_remote_rows(c, nullptr, &n_need);
+    std::vector<int32_t> need(static_cast<size_t>(std::max<int64_t>(n_need, 1)));
+    cora_remote_rows(c, need.data(), &n_need);
+    // every rank learns every need-list (padded to the longest with -1)
+    std::vector<int64_t> counts(static_cast<size_t>(world));
+    if (allgather_host(&n_need, counts.data(), sizeof(int64_t))) return 1;
+    const int64_t n_max = std::max<int64_t>(1, *std::max_element(counts.begin(), counts.end()));
+    std::vector<int32_t> padded(static_cast<size_t>(n_max), -1), lists(static_cast<size_t>(n_max) * world);
+    std::copy(need.begin(), need.begin() + n_need, padded.begin());
+    if (allgather_host(padded.data(), lists.data(), sizeof(int32_t) * n_max)) return 1;
+    // rows of rank r's shard that any OTHER rank reads, ascending
+    std::vector<std::vector<int32_t>> exports(static_cast<size_t>(world));
+    {
+      std::vector<char> wanted(static_cast<size_t>(L.rows), 0);
+      for (int r = 0; r < world; ++r)
+        for (int64_t k = 0; k < counts[r]; ++k) wanted[lists[static_cast<size_t>(r) * n_max + k]] = 1;  // a rank never lists its own rows
+      for (int r = 0; r < world; ++r)
+        for (int64_t row = L.shard_rows * r; row < L.shard_rows * (r + 1); ++row)
+          if (wanted[row]) exports[r].push_back(static_cast<int32_t>(row));
+    }
+    size_t em = 1;
+    for (const auto &e : exports) em = std::max(em, e.size());
+    e_max = static_cast<int>(em);
+    exchanged_rows = static_cast<int64_t>(world) * e_max;
+    std::vector<int32_t> recv_idx;
+    for (int r = 0; r < world; ++r) {
+      std::vector<int32_t> e = exports[r];
+      e.resize(em, static_cast<int32_t>(L.shard_rows * r));  // padding: the shard's first row, sent with its own value
+      recv_idx.insert(recv_idx.end(), e.begin(), e.end());
+      if (r == rank) {
+        if (hip(hipMalloc(reinterpret_cast<void **>(&d_export), sizeof(int32_t) * em), "hipMalloc")) return 1;
+        if (hip(hipMemcpy(d_export, e.data(), sizeof(int32_t) * em, hipMemcpyHostToDevice), "hipMemcpy")) return 1;
+      }
+    }
+    if (hip(hipMalloc(reinterpret_cast<void **>(&d_recv_idx), sizeof(int32_t) * recv_idx.size()), "hipMalloc")) return 1;
+    return hip(hipMemcpy(d_recv_idx, recv_idx.data(), sizeof(int32_t) * recv_idx.size(), hipMemcpyHostToDevice), "hipMemcpy");
+  }
+
+  int buffers(int ld, Buf **out) {
+    Buf &b = buf[ld];
+    if (!b.send) {
+      if (hip(hipMalloc(reinterpret_cast<void **>(&b.send), sizeof(double) * e_max * ld), "hipMalloc")) return 1;
+      if (hip(hipMalloc(reinterpret_cast<void **>(&b.recv), sizeof(double) * e_max * ld * world), "hipMalloc")) return 1;
+    }
+    *out = &b;
+    return 0;
+  }
+
+  int exchange(double *dX, int ld) {
+    if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
+    Buf *b;
+    if (buffers(ld, &b)) return 1;
+    if (hip(launch_move_rows(0, e_max, ld, d_export, dX, b->send, c->stream), "pack")) return 1;
+    if (allgather_dev(b->send, b->recv, sizeof(double) * e_max * ld)) return 1;
+    return hip(launch_move_rows(1, static_cast<int64_t>(world) * e_max, ld, d_recv_idx, b->recv, dX, c->stream), "scatter");
+  }
+  int allgather(double *dX, int ld) {  // whole shards, in place
+    if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
+    const Layout &L = c->F.L;
+    const size_t n = static_cast<size_t>(L.shard_rows) * ld;
+    if (nccl) return nc(api->AllGather(dX + n * rank, dX, n, ncclDouble, nccl, c->stream), "ncclAllGather");
+    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+    g->ptrs[rank] = dX;
+    if (!g->barrier()) return fail_("local group broken");
+    for (int r = 0; r < world; ++r)
+      if (r != rank && hip(hipMemcpyAsync(dX + n * r, static_cast<const double *>(g->ptrs[r]) + n * r, n * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync")) return 1;
+    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+    return g->barrier() ? 0 : fail_("local group broken");
+  }
+  ~cora_native_comm() {
+    if (c && c->has_device) (void)hipSetDevice(c->device);
+    for (auto &kv : buf) {
+      if (kv.second.send) (void)hipFree(kv.second.send);
+      if (kv.second.recv) (void)hipFree(kv.second.recv);
+    }
+    if (d_export) (void)hipFree(d_export);
+    if (d_recv_idx) (void)hipFree(d_recv_idx);
+    if (d_scal) (void)hipFree(d_scal);
+    if (h_scal) (void)hipHostFree(h_scal);
+    if (nccl && api) (void)api->CommDestroy(nccl);
+  }
+};
+
+static void native_comm_destroy(cora_native_comm *nc) { delete nc; }
+
+namespace {
+int native_exchange_cb(void *u, double *dX, int ld) { return static_cast<cora_native_comm *>(u)->exchange(dX, ld); }
+int native_allreduce_cb(void *u, double *vals, int n) { return static_cast<cora_native_comm *>(u)->allreduce_host(vals, n); }
+int native_allgather_cb(void *u, double *dX, int ld) { return static_cast<cora_native_comm *>(u)->allgather(dX, ld); }
+
+int native_finish(cora_ctx *c, cora_native_comm *nc) {
+  if (nc->hip(hipMalloc(reinterpret_cast<void **>(&nc->d_scal), 64 * sizeof(double)), "hipMalloc") ||
+      nc->hip(hipHostMalloc(reinterpret_cast<void **>(&nc->h_scal), 64 * sizeof(double)), "hipHostMalloc") || nc->plan()) {
+    const std::string m = nc->err;
+    delete nc;
+    return fail(c, CORA_ERR_HIP, "native communication: " + m);
+  }
+  delete c->native_comm;
+  c->native_comm = nc;
+  c->comm_exchange = native_exchange_cb;
+  c->comm_allreduce = native_allreduce_cb;
+  c->comm_allgather = native_allgather_cb;
+  c->comm_user = nc;
+  return CORA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cora_rccl_unique_id(void *id128) {
+  if (!id128) return CORA_ERR_ARG;
+  std::string err;
+  const RcclApi *api = rccl_api(&err);
+  if (!api) return fail(nullptr, CORA_ERR_HIP, err);
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return fail(nullptr, CORA_ERR_HIP, "ncclGetUniqueId failed");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, sizeof(id));
+  return CORA_OK;
+}
+
+int cora_comm_create_rccl(cora_ctx *c, const void *id128) {
+  NEED_DEVICE(c);
+  if (!id128) return fail(c, CORA_ERR_ARG, "bad arguments");
+  std::string err;
+  const RcclApi *api = rccl_api(&err);
+  if (!api) return fail(c, CORA_ERR_HIP, err);
+  auto *nc = new cora_native_comm;
+  nc->c = c;
+  nc->rank = c->F.L.rank;
+  nc->world = c->F.L.world;
+  nc->api = api;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  const ncclResult_t r = api->CommInitRank(&nc->nccl, nc->world, id, nc->rank);
+  if (r != ncclSuccess) {
+    const std::string m = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+    nc->nccl = nullptr;
+    delete nc;
+    return fail(c, CORA_ERR_HIP, m);
+  }
+  return native_finish(c, nc);
+}
+
+cora_local_group *cora_local_group_create(int world) {
+  if (world < 1) return nullptr;
+  auto *g = new cora_local_group;
+  g->world = world;
+  g->ptrs.assign(static_cast<size_t>(world), nullptr);
+  g->vals.resize(static_cast<size_t>(world));
+  return g;
+}
+void cora_local_group_destroy(cora_local_group *g) { delete g; }
+void cora_local_group_abort(cora_local_group *g) {  // a rank gave up: nobody keeps waiting for it
+  if (!g) return;
+  std::lock_guard<std::mutex> lk(g->m);
+  g->broken = true;
+  g->cv.notify_all();
+}
+
+int cora_comm_create_local(cora_ctx *c, cora_local_group *g) {
+  NEED_DEVICE(c);
+  if (!g || g->world != c->F.L.world) return fail(c, CORA_ERR_ARG, "the group's size is not the handle's world size");
+  auto *nc = new cora_native_comm;
+  nc->c = c;
+  nc->rank = c->F.L.rank;
+  nc->world = c->F.L.world;
+  nc->g = g;
+  return native_finish(c, nc);
+}
+
+int64_t cora_comm_exchanged_rows(const cora_ctx *c) { return (c && c->native_comm) ? c->native_comm->exchanged_rows : 0; }
 
 }  // extern "C"

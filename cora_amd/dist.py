@@ -315,3 +315,75 @@ class ThreadComm(_CommBase):
                 self.ctx.copy_shard_dev(self.g.ptrs[r], ld, r, ptr)
         self.ctx.sync()
         self._meet()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The library's own communication (include/cora_hip.h, cora_comm_create_*): planning, pack, transport and
+# scatter all run in C++ -- Python only creates the communicator.
+# ----------------------------------------------------------------------------------------------------------
+class NativeLocalGroup:
+    """cora_local_group: meeting point of `world` ranks that are threads of this process (tests on a 1-GPU box)."""
+
+    def __init__(self, world):
+        from . import capi
+        L = capi.load()
+        L.cora_local_group_create.restype = _C.c_void_p
+        L.cora_local_group_create.argtypes = [_C.c_int]
+        L.cora_local_group_destroy.restype = None
+        L.cora_local_group_destroy.argtypes = [_C.c_void_p]
+        self.L, self.world = L, world
+        self.h = L.cora_local_group_create(int(world))
+        if not self.h:
+            raise RuntimeError("cora_local_group_create failed")
+        L.cora_local_group_abort.restype = None
+        L.cora_local_group_abort.argtypes = [_C.c_void_p]
+        self.barrier = self   # the test harness calls group.barrier.abort() when a rank fails
+
+    def abort(self):
+        self.L.cora_local_group_abort(_C.c_void_p(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.cora_local_group_destroy(_C.c_void_p(self.h))
+            self.h = None
+
+
+class _NativeComm:
+    def _finish(self, ctx):
+        L = ctx.L
+        L.cora_comm_exchanged_rows.restype = _C.c_int64
+        L.cora_comm_exchanged_rows.argtypes = [_C.c_void_p]
+        self.ctx = ctx
+        self.rank, self.world = ctx.rank, ctx.world
+        self.exchanged_rows = int(L.cora_comm_exchanged_rows(ctx.h))
+
+
+class NativeLocalComm(_NativeComm):
+    """Rank `ctx.rank` of a NativeLocalGroup: cora_comm_create_local (collective over the group's threads)."""
+
+    def __init__(self, ctx, group):
+        ctx.L.cora_comm_create_local.argtypes = [_C.c_void_p, _C.c_void_p]
+        ctx._chk(ctx.L.cora_comm_create_local(ctx.h, _C.c_void_p(group.h)))
+        self.group = group
+        self._finish(ctx)
+
+
+class NativeRcclComm(_NativeComm):
+    """One rank per process and GPU: RCCL called by the library itself (cora_comm_create_rccl).  The 128-byte id is
+    made on rank 0 and broadcast with torch.distributed (any backend); after that torch is not on the data path."""
+
+    def __init__(self, ctx, group=None, device=None):
+        L = ctx.L
+        L.cora_rccl_unique_id.argtypes = [_C.c_void_p]
+        L.cora_comm_create_rccl.argtypes = [_C.c_void_p, _C.c_void_p]
+        buf = (_C.c_ubyte * 128)()
+        if ctx.rank == 0:
+            ctx._chk(L.cora_rccl_unique_id(buf))
+        if ctx.world > 1:
+            dev = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
+            t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0, group=group)
+            raw = bytes(t.cpu().tolist())
+            buf = (_C.c_ubyte * 128).from_buffer_copy(raw)
+        ctx._chk(L.cora_comm_create_rccl(ctx.h, buf))
+        self._finish(ctx)

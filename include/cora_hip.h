@@ -328,6 +328,24 @@ typedef int (*cora_allreduce_fn)(void *user, double *vals, int n);
 typedef int (*cora_allgather_fn)(void *user, double *dX, int ld);
 int cora_set_comm(cora_ctx *ctx, cora_exchange_fn exchange, cora_allreduce_fn allreduce, cora_allgather_fn allgather,
                   void *user);
+/* The library's OWN communication for a partitioned handle: the three steps above implemented natively, so that no
+ * callback (and no Python) sits on the data path.  Two transports:
+ *   RCCL : one process per GPU.  Rank 0 calls cora_rccl_unique_id (128 bytes), the launcher hands the bytes to every
+ *          rank (torch.distributed broadcast in bench.py, MPI_Bcast, a file), every rank calls cora_comm_create_rccl:
+ *          collective.  The exchange is pack kernel -> ncclAllGather -> scatter kernel, the reductions ncclAllReduce,
+ *          all on the handle's stream.  librccl.so is opened at run time: single-GPU users do not depend on it.
+ *   local: every rank a thread of one process with its own handle (tests on a one-GPU box; several GPUs of one process):
+ *          cora_local_group_create(world) once, cora_comm_create_local(handle, group) from every rank's thread.
+ * Both replace whatever cora_set_comm installed; the communicator is destroyed with the handle.
+ * cora_comm_exchanged_rows: rows a rank receives per exchange (world x the longest export list). */
+typedef struct cora_local_group cora_local_group;
+int cora_rccl_unique_id(void *id128);
+int cora_comm_create_rccl(cora_ctx *ctx, const void *id128);
+cora_local_group *cora_local_group_create(int world);
+void cora_local_group_destroy(cora_local_group *group);
+void cora_local_group_abort(cora_local_group *group); /* a rank failed outside the library: release the others */
+int cora_comm_create_local(cora_ctx *ctx, cora_local_group *group);
+int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
 /* Building blocks of an exchange, on the handle's stream: dPacked[k] = dX[rows[k]], dX[rows[k]] = dPacked[k],
  * dDst[rows[k]] = dSrc[rows[k]] (rows: device array of n internal rows; ld = row stride in doubles). */
 int cora_pack_rows_dev(cora_ctx *ctx, const double *dX, int ld, const int32_t *d_rows, int64_t n, double *dPacked);

@@ -10,14 +10,18 @@ import numpy as np
 import pytest
 
 from cora_amd import capi, host
-from cora_amd.dist import ThreadComm, ThreadGroup
+from cora_amd.dist import NativeLocalComm, NativeLocalGroup, NativeRcclComm, ThreadComm, ThreadGroup
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(world, body):
-    group = ThreadGroup(world)
+# the two in-process transports: Python callbacks (cora_set_comm) and the library's own (cora_comm_create_local)
+TRANSPORTS = {"callbacks": (ThreadGroup, ThreadComm), "native": (NativeLocalGroup, NativeLocalComm)}
+
+
+def _run_ranks(world, body, transport="callbacks"):
+    group = TRANSPORTS[transport][0](world)
     out, err = [None] * world, [None] * world
 
     def run(r):
@@ -49,9 +53,11 @@ def _problem(n, p, seed=11, loops=4):
     return P
 
 
+@pytest.mark.parametrize("transport", ["callbacks", "native"])
 @pytest.mark.parametrize("world,n", [(2, 900), (4, 3000)])
-def test_sharded_operators_and_tnt_match_single_handle(world, n):
+def test_sharded_operators_and_tnt_match_single_handle(world, n, transport):
     p = 4
+    Comm = TRANSPORTS[transport][1]
     P1 = _problem(n, p)
     dm = P1.dims()
     _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
@@ -66,14 +72,14 @@ def test_sharded_operators_and_tnt_match_single_handle(world, n):
 
     def body(r, group):
         P = _problem(n, p)
-        comm = P.set_partition(r, world, lambda ctx: ThreadComm(ctx, group))
+        comm = P.set_partition(r, world, lambda ctx: Comm(ctx, group))
         assert 0 < comm.exchanged_rows < dm["N"]
         f = P.op("evaluateObjective", Y)
         H = P.op("Riemannian_Hessian_vector_product", Y, P.op("Euclidean_gradient", Y), V)
         res = P.tnt(Y, max_iterations=6)   # partitioned handles take the host-driven STPCG (collective calls)
         return f, H, res
 
-    outs = _run_ranks(world, body)
+    outs = _run_ranks(world, body, transport)
     for f, H, res in outs:
         assert abs(f - orc.cost(Q, Y)) < 1e-11 * abs(f)
         assert np.abs(H - ref_hvp).max() < 1e-10 * np.abs(ref_hvp).max()
@@ -85,10 +91,12 @@ def test_sharded_operators_and_tnt_match_single_handle(world, n):
         assert f == outs[0][0] and np.array_equal(res["x"], outs[0][2]["x"])
 
 
-def test_eight_partitions_of_the_headline_graph():
+@pytest.mark.parametrize("transport", ["callbacks", "native"])
+def test_eight_partitions_of_the_headline_graph(transport):
     """BASELINE config 4 / 5 on one GPU: the 10^5-pose graph cut into 8 row partitions, the Hessian-vector
     product at rank 5 and the certificate operator (Q - Lambda) X with 10 columns against the CPU oracle."""
     world, n, p = 8, 100000, 5
+    Comm = TRANSPORTS[transport][1]
     P1 = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42, precond=capi.PRECOND_JACOBI)
     P1.update()
     dm = P1.dims()
@@ -109,7 +117,7 @@ def test_eight_partitions_of_the_headline_graph():
         P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42, precond=capi.PRECOND_JACOBI)
         P.update()
         P.set_rank(p)
-        comm = P.set_partition(r, world, lambda ctx: ThreadComm(ctx, group))
+        comm = P.set_partition(r, world, lambda ctx: Comm(ctx, group))
         ctx = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
         y, x, o = ctx.dev_alloc(p), ctx.dev_alloc(p), ctx.dev_alloc(p)
         x10, o10 = ctx.dev_alloc(10), ctx.dev_alloc(10)
@@ -123,8 +131,26 @@ def test_eight_partitions_of_the_headline_graph():
         S = ctx.download(o10, 10)
         return comm.exchanged_rows, ctx.rows, H, S
 
-    outs = _run_ranks(world, body)
+    outs = _run_ranks(world, body, transport)
     for exch, rows, H, S in outs:
         assert exch < rows // 3
         assert np.abs(H - ref_hvp).max() < 1e-10 * np.abs(ref_hvp).max()
         assert np.abs(S - ref_S).max() < 1e-10 * np.abs(ref_S).max()
+
+
+def test_rccl_transport_world_one():
+    """The RCCL transport on the one GPU of the test box: librccl.so is opened at run time, a communicator of one rank is
+    created by the library (cora_rccl_unique_id + cora_comm_create_rccl) and the collective entry points run through
+    it (world 1: nothing to exchange, the reductions are identities) -- the plumbing the 8-GPU bench relies on."""
+    n, p = 900, 4
+    P = _problem(n, p)
+    dm = P.dims()
+    ctx = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    comm = NativeRcclComm(ctx)
+    assert comm.world == 1 and comm.exchanged_rows >= 0
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    rng = np.random.default_rng(5)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dm["N"], p)))
+    assert abs(P.op("evaluateObjective", Y) - orc.cost(Q, Y)) < 1e-11 * abs(orc.cost(Q, Y))
