@@ -33,6 +33,9 @@ constexpr int kScratchSlots = 9;
 
 struct cora_native_comm;
 static void native_comm_destroy(cora_native_comm *nc);
+static double *native_scalars(cora_native_comm *nc);                       // 8 device doubles of the sharded STPCG
+static int native_allreduce_dev(cora_native_comm *nc, double *d, int n);   // sum over the ranks, in place, on the stream
+static const std::string &native_error(const cora_native_comm *nc);
 struct cora_ctx {
   HostFormat F;
   cora_native_comm *native_comm = nullptr;  // owned: the library's own communication (cora_comm_create_*)
@@ -104,6 +107,7 @@ struct cora_ctx {
   cora_allreduce_fn comm_allreduce = nullptr;
   cora_allgather_fn comm_allgather = nullptr;
   void *comm_user = nullptr;
+  bool comm_required = false;  // cora_require_comm: a collective step without communication is an error, not a no-op
   bool prof_stpcg = false;
   std::vector<hipEvent_t> prof_events;
   double prof_hvp_us = 0.0;
@@ -174,19 +178,28 @@ int get_scratch(cora_ctx *c, int slot, int ld, double **out, int64_t extra_rows 
 // collective steps of a partitioned handle; no-ops on a single-GPU one
 // (a partitioned handle WITHOUT communication keeps the round-1 contract: the caller keeps the rows the products
 // read current and adds up the per-rank partial results itself)
+int comm_missing(cora_ctx *c) {
+  if (!c->comm_required) return CORA_OK;
+  return fail(c, CORA_ERR_NOT_READY,
+              "partitioned handle without communication: install it with cora_set_comm or cora_comm_create_* (again after "
+              "every rebuild of the handle, e.g. Problem::updateProblemData or a second setPartition)");
+}
 int comm_exchange(cora_ctx *c, const double *dX, int ld) {
-  if (c->F.L.world == 1 || !c->comm_exchange) return CORA_OK;
-  if (c->comm_exchange(c->comm_user, const_cast<double *>(dX), ld)) return fail(c, CORA_ERR_HIP, "exchange callback failed");
+  if (c->F.L.world == 1) return CORA_OK;
+  if (!c->comm_exchange) return comm_missing(c);
+  if (c->comm_exchange(c->comm_user, const_cast<double *>(dX), ld)) return fail(c, CORA_ERR_HIP, "exchange step failed");
   return CORA_OK;
 }
 int comm_allreduce(cora_ctx *c, double *vals, int n) {
-  if (c->F.L.world == 1 || !c->comm_allreduce) return CORA_OK;
-  if (c->comm_allreduce(c->comm_user, vals, n)) return fail(c, CORA_ERR_HIP, "all-reduce callback failed");
+  if (c->F.L.world == 1) return CORA_OK;
+  if (!c->comm_allreduce) return comm_missing(c);
+  if (c->comm_allreduce(c->comm_user, vals, n)) return fail(c, CORA_ERR_HIP, "all-reduce step failed");
   return CORA_OK;
 }
 int comm_allgather(cora_ctx *c, const double *dX, int ld) {
-  if (c->F.L.world == 1 || !c->comm_allgather) return CORA_OK;
-  if (c->comm_allgather(c->comm_user, const_cast<double *>(dX), ld)) return fail(c, CORA_ERR_HIP, "all-gather callback failed");
+  if (c->F.L.world == 1) return CORA_OK;
+  if (!c->comm_allgather) return comm_missing(c);
+  if (c->comm_allgather(c->comm_user, const_cast<double *>(dX), ld)) return fail(c, CORA_ERR_HIP, "all-gather step failed");
   return CORA_OK;
 }
 
@@ -1233,6 +1246,17 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
   return comm_allreduce(c, out, count);
 }
 
+// can cora_stpcg_dev run on this handle?  One GPU: always.  Partitioned: with the library's own communication (the
+// reductions stay on the device), the explicit formulation, a row-local preconditioner and 16-byte aligned shards.
+// The answer is the same on every rank (the two loops make different collective calls): nothing in it depends on the
+// rank's own rows.  The flat vector passes of a partitioned handle run over the PADDED shard (shard_rows is a multiple
+// of 8, so the range is even and 64-byte aligned whatever the row stride); padding rows are zero in every resident
+// vector -- allocations are zeroed and no kernel writes them -- and add nothing to an update or an inner product.
+static bool stpcg_device_ok(const cora_ctx *c) {
+  if (c->F.L.world == 1) return true;
+  return c->native_comm && !c->implicit && c->ld <= 12 && (c->precond == CORA_PRECOND_JACOBI || c->precond == CORA_PRECOND_NONE);
+}
+
 // Steihaug-Toint truncated PCG for  min <g,s> + 1/2 <s,Hs>,  ||s||_M <= Delta, entirely on the device
 // (the inner solver of Optimization::Riemannian::TNT, called from src/CORA.cpp:139-140).  The scalar
 // recurrences live in a StpcgState that the inner-product kernels update themselves, so the host only
@@ -1247,7 +1271,14 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dGrad || !dS || !dR || !dV || !dP || !dHp || !iters || !step_M_norm || max_iters < 0)
     return fail(c, CORA_ERR_ARG, "bad arguments");
-  if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "the device-resident STPCG is single-GPU");
+  // Partitioned handle: the same fused iteration, every rank on its own rows, with the library's own communication
+  // (cora_comm_create_*): the operand's remote rows are exchanged before the product, and the three inner products are
+  // summed over the ranks ON THE DEVICE -- kappa after the product, <r, r> and <r, v> together after the projection --
+  // by an all-reduce on the handle's stream, followed by a one-thread launch for the scalar step.  The host enqueues
+  // and looks at the pinned mirror between batches, exactly as on one GPU.
+  const bool sharded = c->F.L.world != 1;
+  if (sharded && !stpcg_device_ok(c))
+    return fail(c, CORA_ERR_ARG, "the device-resident STPCG on a partitioned handle needs cora_comm_create_* and a Jacobi / no preconditioner");
   int rc;
   double rr_rv[2];
   if (dPg) {  // s = 0, r = g, p = -P g in one pass
@@ -1276,7 +1307,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   H.max_iters = max_iters;
   c->h_stpcg[0] = H;
   HIP_TRY(c, hipMemcpyAsync(c->d_stpcg, &H, sizeof(StpcgState), hipMemcpyHostToDevice, c->stream));
-  const int64_t n = c->F.L.local_rows * c->ld;
+  const int64_t n = (sharded ? c->F.L.shard_rows : c->F.L.local_rows) * c->ld;  // sharded: the padded shard (stpcg_device_ok)
   DotArgs D;
   for (int j = 0; j < 4; ++j) D.a[j] = D.b[j] = nullptr;
   D.n2 = n;
@@ -1301,8 +1332,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // The scalar steps run in the last block of the pass that finishes the inner product they need.
   const bool chol = c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY;
   const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
-  const bool fused = !c->implicit && c->ld <= 12 && n % 2 == 0 && (off * sizeof(double)) % 16 == 0 &&
-                     !std::getenv("CORA_NO_FUSE");
+  const bool fused = sharded || (!c->implicit && c->ld <= 12 && n % 2 == 0 && (off * sizeof(double)) % 16 == 0 &&
+                                 !std::getenv("CORA_NO_FUSE"));
   // Sweep-fused iteration (the above, with a two-stage Cholesky solve plan): five passes and a scalar step --
   //   Hp = H p with the partials of kappa | kappa | forward sweep on r += alpha Hp with <r, r> | last stage (2 products) |
   //   backward sweep with v = Proj_Y(x) and <r, v> | s += alpha p, p = -v + beta p
@@ -1316,7 +1347,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
     size_t need = std::max<size_t>(4 * 512, static_cast<size_t>((units + 255) / 256) + 8);
     const cora_ctx::DevFactor &f = c->precond_f;
-    sweep_fused = chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
+    sweep_fused = !sharded && chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
                   !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
     // slots of the sweep-fused reductions: <r, r> per block of the forward sweep's launch, |y|^2 per solve block,
     // |row|^2 per row of the last stage's forward product
@@ -1370,10 +1401,35 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
       if (fused) {
         // Hp = H p with the partials of kappa | kappa, alpha, r += alpha Hp with <r, r> | preconditioner | ...
+        if (sharded && (rc = comm_exchange(c, dP, c->ld))) return rc;
         SpmmArgs A = spmm_args(c, dP, dHp);
         A.kappa_partial = kappa_partial;
         HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP_K, c->stream));
         if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
+        if (sharded) {
+          // kappa: local partials (fixed order) -> sum over the ranks -> scalar step;  then r += alpha Hp with <r, r>
+          // and v = Proj_Y(D^-1 r) with <r, v>, both left on the device, one all-reduce for the two, scalar step
+          double *ds = native_scalars(c->native_comm);
+          HIP_TRY(c, launch_reduce_partials(kappa_partial, kappa_blocks, 1, ds, c->stream));
+          if (native_allreduce_dev(c->native_comm, ds, 1)) return fail(c, CORA_ERR_HIP, "all-reduce step failed: " + native_error(c->native_comm));
+          HIP_TRY(c, launch_stpcg_scalar_step(0, ds, c->d_stpcg, nullptr, nullptr, 0, c->stream));
+          DotArgs Ds = D;
+          Ds.mode = DOTS_PLAIN;
+          Ds.count = 1;
+          Ds.seq_out = nullptr;
+          Ds.seq = 0;
+          Ds.out = ds + 2;
+          HIP_TRY(c, launch_stpcg_residual(Ds, n, dHp + off, dR + off, c->stream));
+          Ds.out = ds + 3;
+          HIP_TRY(c, launch_tangent_project_dot(row_args(c), Ds, c->ld, c->d_Y, dR, c->precond == CORA_PRECOND_JACOBI ? c->d_diag_inv : nullptr,
+                                                dR, dV, c->stream));
+          if (native_allreduce_dev(c->native_comm, ds + 2, 2)) return fail(c, CORA_ERR_HIP, "all-reduce step failed: " + native_error(c->native_comm));
+          seq = ++c->dot_seq;
+          HIP_TRY(c, launch_stpcg_scalar_step(1, ds + 2, c->d_stpcg, &c->h_stpcg[0],
+                                              reinterpret_cast<unsigned long long *>(c->h_scalars + 7), seq, c->stream));
+          HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
+          continue;
+        }
         HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
         if (sweep_fused) {
           // Hp = H p | kappa | forward sweep: r += alpha Hp, <r, r>, |y|^2 | last stage, <r, v> in its second product |
@@ -1476,6 +1532,14 @@ int cora_set_comm(cora_ctx *c, cora_exchange_fn exchange, cora_allreduce_fn allr
   c->comm_allreduce = allreduce;
   c->comm_allgather = allgather;
   c->comm_user = user;
+  return CORA_OK;
+}
+
+int cora_stpcg_device_ok(const cora_ctx *c) { return (c && c->has_device && c->p > 0 && stpcg_device_ok(c)) ? 1 : 0; }
+
+int cora_require_comm(cora_ctx *c, int on) {
+  if (!c) return CORA_ERR_ARG;
+  c->comm_required = on != 0;
   return CORA_OK;
 }
 
@@ -1749,10 +1813,35 @@ int cora_precondition(cora_ctx *c, const double *V, int ldv, double *out, int ld
 int cora_compute_lambda_blocks(cora_ctx *c, const double *Y, int ldy, double *stiefel, double *oblique) {
   NEED_DEVICE(c);
   NEED_RANK(c);
-  if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "host Lambda blocks need a 1-GPU handle");
   int rc = cora_set_point(c, Y, ldy);
   if (rc) return rc;
   const Layout &L = c->F.L;
+  if (L.world != 1) {
+    // Partitioned handle: every rank holds the blocks of its own poses and range rows.  They travel as a resident
+    // vector with d columns -- row (pose, a) carries row a of the pose's block, a range row its multiplier in column 0
+    // -- through the collective download (one all-gather of the shards); every rank gets all of them.
+    const int k = L.d, ld = ld_for(k);
+    if (ld != L.d) return fail(c, CORA_ERR_ARG, "unexpected row stride");
+    double *vec;
+    if ((rc = get_scratch(c, 2, ld, &vec))) return rc;
+    HIP_TRY(c, hipMemsetAsync(vec, 0, vec_bytes(c, ld), c->stream));
+    if (L.nl_poses > 0)  // [pose][d * d] IS rows (pose, a) x d columns at row stride d
+      HIP_TRY(c, hipMemcpyAsync(vec + static_cast<size_t>(L.rot_base) * ld, c->d_lam_st,
+                                static_cast<size_t>(L.nl_poses) * L.d * L.d * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (L.nl_ranges > 0)
+      HIP_TRY(c, hipMemcpy2DAsync(vec + static_cast<size_t>(L.rng_base) * ld, ld * sizeof(double), c->d_lam_ob, sizeof(double),
+                                  sizeof(double), static_cast<size_t>(L.nl_ranges), hipMemcpyDeviceToDevice, c->stream));
+    std::vector<double> M(static_cast<size_t>(L.N) * k);
+    if ((rc = download_impl(c, vec, k, M.data(), static_cast<int>(L.N)))) return rc;
+    if (stiefel)
+      for (int64_t i = 0; i < L.n; ++i)
+        for (int a = 0; a < L.d; ++a)
+          for (int b = 0; b < L.d; ++b)
+            stiefel[(i * L.d + b) * L.d + a] = M[static_cast<size_t>(i * L.d + a) + static_cast<size_t>(L.N) * b];
+    if (oblique)
+      for (int64_t j = 0; j < L.r; ++j) oblique[j] = M[static_cast<size_t>(L.d) * L.n + j];
+    return CORA_OK;
+  }
   // a symmetric d x d block is the same row- or column-major, so the device
   // array [pose][d*d] already is the d x (d n) column-major matrix
   if (L.n > 0 && stiefel)
@@ -1940,7 +2029,7 @@ struct cora_native_comm {
   int32_t *d_recv_idx = nullptr;    // [world * e_max] where the gathered rows go, rank by rank
   struct Buf { double *send = nullptr, *recv = nullptr; };
   std::map<int, Buf> buf;           // per row stride
-  double *d_scal = nullptr, *h_scal = nullptr;  // 64 doubles each (device / pinned): all-reduce staging
+  double *d_scal = nullptr, *h_scal = nullptr;  // 1024 doubles each (device / pinned): all-reduce staging
   std::string err;
 
   int fail_(const std::string &m) {
@@ -1983,7 +2072,7 @@ struct cora_native_comm {
   }
   int allreduce_host(double *vals, int n) {
     if (nccl) {
-      if (n > 64) return fail_("all-reduce of more than 64 doubles");
+      if (n > 1016) return fail_("all-reduce of more than 1016 doubles");
       std::memcpy(h_scal, vals, sizeof(double) * n);
       if (hip(hipMemcpyAsync(d_scal, h_scal, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync")) return 1;
       if (nc(api->AllReduce(d_scal, d_scal, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce")) return 1;
@@ -2102,6 +2191,9 @@ struct cora_native_comm {
 };
 
 static void native_comm_destroy(cora_native_comm *nc) { delete nc; }
+static double *native_scalars(cora_native_comm *nc) { return nc->d_scal + 1016; }  // behind the host all-reduce's staging
+static int native_allreduce_dev(cora_native_comm *nc, double *d, int n) { return nc->allreduce_dev(d, n); }
+static const std::string &native_error(const cora_native_comm *nc) { return nc->err; }
 
 namespace {
 int native_exchange_cb(void *u, double *dX, int ld) { return static_cast<cora_native_comm *>(u)->exchange(dX, ld); }
@@ -2109,8 +2201,8 @@ int native_allreduce_cb(void *u, double *vals, int n) { return static_cast<cora_
 int native_allgather_cb(void *u, double *dX, int ld) { return static_cast<cora_native_comm *>(u)->allgather(dX, ld); }
 
 int native_finish(cora_ctx *c, cora_native_comm *nc) {
-  if (nc->hip(hipMalloc(reinterpret_cast<void **>(&nc->d_scal), 64 * sizeof(double)), "hipMalloc") ||
-      nc->hip(hipHostMalloc(reinterpret_cast<void **>(&nc->h_scal), 64 * sizeof(double)), "hipHostMalloc") || nc->plan()) {
+  if (nc->hip(hipMalloc(reinterpret_cast<void **>(&nc->d_scal), 1024 * sizeof(double)), "hipMalloc") ||
+      nc->hip(hipHostMalloc(reinterpret_cast<void **>(&nc->h_scal), 1024 * sizeof(double)), "hipHostMalloc") || nc->plan()) {
     const std::string m = nc->err;
     delete nc;
     return fail(c, CORA_ERR_HIP, "native communication: " + m);

@@ -298,7 +298,10 @@ void Problem::ensureContext() const {
       throw std::runtime_error(std::string("CORA::Problem: cannot create the device problem: ") +
                                cora_last_error(nullptr));
     ctx_ = std::shared_ptr<cora_ctx>(c, [](cora_ctx *p) { cora_ctx_destroy(p); });
-    if (part_world_ > 1) cora_set_comm(c, comm_exchange_, comm_allreduce_, comm_allgather_, comm_user_);
+    if (part_world_ > 1) {
+      cora_set_comm(c, comm_exchange_, comm_allreduce_, comm_allgather_, comm_user_);
+      cora_require_comm(c, 1);  // no callbacks (they are installed on the handle afterwards): fail loudly until then
+    }
     implicit_ready_ = false;
   }
   if (formulation_ == Formulation::Implicit && !implicit_ready_) fillImplicitFormulationMatrices();

@@ -114,7 +114,9 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
     }
     if (!done) {
       std::optional<DeviceOperator> T = precond;
-      if (!T && (!lab || lab->use_ildl)) {
+      // (partitioned handles: the incomplete factor is a sequential recurrence over the whole chain and does not shard --
+      // the remaining budget runs unpreconditioned, every rank in step)
+      if (!T && (!lab || lab->use_ildl) && cora_world(c) == 1) {
         const CholeskyFactor I = incompleteLDLT(S, static_cast<int>(n), eta, perm, max_fill_factor, drop_tol);
         if (cora_aux_set_cholesky(c, static_cast<int>(n), I.Lp.data(), I.Li.data(), I.Lx.data(), I.perm.data()) != CORA_OK)
           throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(c));

@@ -66,7 +66,8 @@ struct Dev {
 int STPCG(Dev &D, const double *grad, const double *Pg, double g_g, double g_Pg, double Delta, const TNTParams &prm,
           double *s, double *r, double *v, double *pk, double *Hp, double &step_M_norm) {
   cora_ctx *c = D.c;
-  if (prm.device_stpcg && cora_world(c) == 1) {  // partitioned handles: the host-driven loop below (collective calls)
+  // (partitioned handles without the library's own communication: the host-driven loop below, collective calls)
+  if (prm.device_stpcg && cora_stpcg_device_ok(c)) {
     int iters = 0;
     D.chk(cora_stpcg_warm_dev(c, grad, Pg, g_g, g_Pg, Delta, prm.kappa_fgr, prm.theta, prm.max_TPCG_iterations, s, r, v,
                               pk, Hp, &iters, &step_M_norm),

@@ -224,6 +224,9 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 hipError_t launch_stpcg_residual(const DotArgs &D, int64_t n, const double *Hp, double *r, hipStream_t st);
 hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D, int ld, const double *Y, const double *V,
                                       const double *scale, const double *r, double *out, hipStream_t st);
+// the scalar step of a partitioned handle's iteration, after the all-reduce of its inner products (k_stpcg_scalar_step)
+hipError_t launch_stpcg_scalar_step(int what, const double *vals, StpcgState *state, StpcgState *state_host,
+                                    unsigned long long *seq_out, unsigned long long seq, hipStream_t st);
 // s = 0, r = g, p = -Pg (start of a solve whose preconditioned gradient is known)
 hipError_t launch_stpcg_init(int64_t n, const double *g, const double *Pg, double *s, double *r, double *p, hipStream_t st);
 hipError_t launch_stpcg_step_direction(int64_t n, const StpcgState *S, const double *v, double *p, double *s,

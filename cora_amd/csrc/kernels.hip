@@ -1003,6 +1003,25 @@ __global__ __launch_bounds__(256) void k_stpcg_init(int64_t n, const double *__r
   }
 }
 
+// Partitioned handles: the inner products are summed over the ranks between the pass that forms them and the scalar
+// step (an all-reduce of the device values on the handle's stream), so the step is a launch of its own: one thread.
+//   what = 0: vals[0] = kappa;   what = 1: vals[0] = <r, r>, vals[1] = <r, v>, then the pinned mirror and its sequence number
+__global__ void k_stpcg_scalar_step(int what, const double *__restrict__ vals, StpcgState *st, StpcgState *st_host,
+                                    unsigned long long *seq_out, unsigned long long seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (what == 0) {
+    stpcg_after_kappa(*st, vals[0]);
+    return;
+  }
+  stpcg_after_rr(*st, vals[0]);
+  stpcg_after_rv(*st, vals[1]);
+  *st_host = *st;
+  if (seq_out) {
+    __threadfence_system();
+    __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
 __global__ __launch_bounds__(256) void k_stpcg_step_direction(int64_t n2, const StpcgState *__restrict__ S,
                                                               const double2 *__restrict__ v, double2 *__restrict__ p,
@@ -2338,6 +2357,11 @@ hipError_t launch_stpcg_residual(const DotArgs &D_in, int64_t n, const double *H
   return hipGetLastError();
 }
 
+hipError_t launch_stpcg_scalar_step(int what, const double *vals, StpcgState *state, StpcgState *state_host,
+                                    unsigned long long *seq_out, unsigned long long seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_stpcg_scalar_step, dim3(1), dim3(64), 0, st, what, vals, state, state_host, seq_out, seq);
+  return hipGetLastError();
+}
 hipError_t launch_stpcg_init(int64_t n, const double *g, const double *Pg, double *s, double *r, double *p, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_stpcg_init, dim3(grid_for(n)), dim3(256), 0, st, n, g, Pg, s, r, p);

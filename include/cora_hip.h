@@ -328,6 +328,14 @@ typedef int (*cora_allreduce_fn)(void *user, double *vals, int n);
 typedef int (*cora_allgather_fn)(void *user, double *dX, int ld);
 int cora_set_comm(cora_ctx *ctx, cora_exchange_fn exchange, cora_allreduce_fn allreduce, cora_allgather_fn allgather,
                   void *user);
+/* on != 0: a collective step on this (partitioned) handle without communication installed fails with
+ * CORA_ERR_NOT_READY instead of being left to the caller.  CORA::Problem sets it on the handles it creates for a
+ * partition, so that a rebuilt handle cannot silently compute per-rank partial results. */
+int cora_require_comm(cora_ctx *ctx, int on);
+/* 1 if cora_stpcg_dev / cora_stpcg_warm_dev can run on this handle: always on one GPU; on a partitioned handle with
+ * the library's own communication (cora_comm_create_*: the inner products are all-reduced on the device, no host
+ * round trip), the explicit formulation and a row-local preconditioner (Jacobi / none). */
+int cora_stpcg_device_ok(const cora_ctx *ctx);
 /* The library's OWN communication for a partitioned handle: the three steps above implemented natively, so that no
  * callback (and no Python) sits on the data path.  Two transports:
  *   RCCL : one process per GPU.  Rank 0 calls cora_rccl_unique_id (128 bytes), the launcher hands the bytes to every
