@@ -211,8 +211,21 @@ def main():
     # (cora_pack_rows_dev), moved by ONE RCCL all-gather and scattered (cora_scatter_rows_dev)
     comm = None
     if world > 1:
-        from cora_amd.dist import TorchComm
-        comm = TorchComm(ctx, device=dev)
+        if backend == "nccl":   # the library's own RCCL communicator: torch only broadcasts its 128-byte id
+            from cora_amd.dist import NativeRcclComm, TorchComm
+            try:
+                comm = NativeRcclComm(ctx, device=dev)
+                ok = 1.0
+            except Exception as e:  # noqa: BLE001 -- reported, and the run goes on through torch.distributed's RCCL
+                sys.stderr.write("rank %d: native RCCL communicator failed (%s)\n" % (rank, e))
+                ok = 0.0
+            flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same path
+            if float(flag.item()) == 0.0:
+                comm = TorchComm(ctx, device=dev)
+        else:                   # functional check of the N > 1 path on a 1-GPU box (gloo): callbacks
+            from cora_amd.dist import TorchComm
+            comm = TorchComm(ctx, device=dev)
     ctx.upload(Yh, y.data_ptr())
     ctx.project_to_manifold_dev(y.data_ptr(), y.data_ptr())   # row-local: every rank projects its own rows
     ctx.set_point_dev(y.data_ptr())                           # collective: exchanges Y, reduces the cost
@@ -255,8 +268,11 @@ def main():
     # remote rows are current after the timed region above)
     ex_fn = None
     if world > 1:
-        ex_fn = comm.exchange
-        comm.exchange = lambda ptr, ld_: None
+        if hasattr(comm, "enable"):
+            comm.enable(False)
+        else:
+            ex_fn = comm.exchange
+            comm.exchange = lambda ptr, ld_: None
     for _ in range(20):
         step()
     ctx.sync()
@@ -266,7 +282,10 @@ def main():
         step()
     kernel_us = ctx.timer_stop_ms() * 1e3 / reps
     if world > 1:
-        comm.exchange = ex_fn
+        if hasattr(comm, "enable"):
+            comm.enable(True)
+        else:
+            comm.exchange = ex_fn
     if args.op == "cert":
         b_spmm, _ = algorithmic_bytes(dm["d"], dm["n"], dm["r"], dm["N"], dm["nnz"], k_op)
         b_hvp = b_spmm + (dm["n"] * dm["d"] ** 2 + dm["r"]) * 8   # + the Lambda blocks
@@ -336,9 +355,9 @@ def main():
                                "Hvp = Proj_Y((Q - Lambda) Ydot)" if args.op == "hvp" else
                                "certificate operator (Q - Lambda) X, %d columns" % k_op, p, dm["N"], dm["nnz"]),
                 "parallelism": "1 GPU" if world == 1 else
-                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + one RCCL all-gather of the %d rows "
-                               "of the operand (of %d) that other ranks read, packed and scattered by the library's own "
-                               "kernels" % (world, comm.exchanged_rows, rows),
+                               "rows of Q over %d GPUs (pose-aligned, nnz-balanced) + one RCCL all-gather (issued by the library "
+                               "itself on the handle's stream) of the %d rows of the operand (of %d) that other ranks read, "
+                               "packed and scattered by the library's own kernels" % (world, comm.exchanged_rows, rows),
                 "algorithmic_bytes_per_hvp": b_hvp,
                 "algorithmic_bytes_per_spmm": b_spmm,
             },

@@ -2281,6 +2281,15 @@ int cora_comm_create_local(cora_ctx *c, cora_local_group *g) {
   return native_finish(c, nc);
 }
 
+int cora_comm_native_enable(cora_ctx *c, int on) {
+  if (!c || !c->native_comm) return fail(c, CORA_ERR_NOT_READY, "no native communication on this handle");
+  c->comm_exchange = on ? native_exchange_cb : nullptr;
+  c->comm_allreduce = on ? native_allreduce_cb : nullptr;
+  c->comm_allgather = on ? native_allgather_cb : nullptr;
+  c->comm_user = on ? c->native_comm : nullptr;
+  return CORA_OK;
+}
+
 int64_t cora_comm_exchanged_rows(const cora_ctx *c) { return (c && c->native_comm) ? c->native_comm->exchanged_rows : 0; }
 
 }  // extern "C"

@@ -358,6 +358,11 @@ class _NativeComm:
         self.exchanged_rows = int(L.cora_comm_exchanged_rows(ctx.h))
 
 
+    def enable(self, on=True):
+        self.ctx.L.cora_comm_native_enable.argtypes = [_C.c_void_p, _C.c_int]
+        self.ctx._chk(self.ctx.L.cora_comm_native_enable(self.ctx.h, int(bool(on))))
+
+
 class NativeLocalComm(_NativeComm):
     """Rank `ctx.rank` of a NativeLocalGroup: cora_comm_create_local (collective over the group's threads)."""
 

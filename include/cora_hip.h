@@ -354,6 +354,9 @@ void cora_local_group_destroy(cora_local_group *group);
 void cora_local_group_abort(cora_local_group *group); /* a rank failed outside the library: release the others */
 int cora_comm_create_local(cora_ctx *ctx, cora_local_group *group);
 int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
+/* Measurement switch: on = 0 leaves the collective steps to the caller again (a product then runs on whatever the
+ * remote rows hold: bench.py times the kernel alone this way), on = 1 re-installs the native communication. */
+int cora_comm_native_enable(cora_ctx *ctx, int on);
 /* Building blocks of an exchange, on the handle's stream: dPacked[k] = dX[rows[k]], dX[rows[k]] = dPacked[k],
  * dDst[rows[k]] = dSrc[rows[k]] (rows: device array of n internal rows; ld = row stride in doubles). */
 int cora_pack_rows_dev(cora_ctx *ctx, const double *dX, int ld, const int32_t *d_rows, int64_t n, double *dPacked);
