@@ -18,8 +18,9 @@ FLAGS = os.environ.get("CORA_EXTRA_HIPCC_FLAGS", "").split() + ["--offload-arch=
 
 
 # kernels.hip is compiled as several translation units in parallel (CORA_TU / CORA_LDG, see the head of the file)
-KERNEL_PARTS = [("spmm_g0", 1, 1), ("spmm_g1", 1, 2), ("spmm_g2", 1, 4), ("spmm_g3", 1, 8), ("rows", 2, 15),
-                ("tri_g0", 4, 1), ("tri_g1", 4, 2), ("tri_g2", 4, 4), ("tri_g3", 4, 8)]
+KERNEL_PARTS = [("spmm_g0", 1, 1), ("spmm_g1", 1, 2), ("spmm_g2", 1, 4), ("spmm_g3", 1, 8), ("spmm_g4", 1, 16),
+                ("spmm_g5", 1, 32), ("rows", 2, 63), ("tri_g0", 4, 1), ("tri_g1", 4, 2), ("tri_g2", 4, 4),
+                ("tri_g3", 4, 8), ("tri_g4", 4, 16), ("tri_g5", 4, 32)]
 
 
 def sources():

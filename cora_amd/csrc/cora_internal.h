@@ -18,13 +18,14 @@ constexpr int kSigma = 256;       // default sorting window (rows) for translati
 extern int g_sigma;               // tunable copy of kSigma (format_build.cpp)
 constexpr int kMaxLD = 24;
 
-// Row stride (doubles) used for a k-column resident vector: no padding up to 12
-// columns (odd strides cost 8-byte instead of 16-byte row accesses but save the
-// padding traffic: Hvp at p = 5 measured 24.45 -> 23.28 us), multiples of 4 above.
+// Row stride (doubles) used for a k-column resident vector: the number of columns itself, whatever k (<= kMaxLD).  Odd
+// strides cost 8-byte instead of 16-byte row accesses but save the padding traffic (Hvp at p = 5 measured 24.45 ->
+// 23.28 us against a stride of 6); rounds 1-2 padded 13..24 columns to 16 / 20 / 24 -- the certificate block of rank
+// p >= 11 has max(10, p + 2) >= 13 columns (src/CORA_problem.cpp:1062-1063) and paid up to 23 % of padding.
 extern int g_pad_even;  // lab switch: 1 = round odd k up to even (format_build.cpp)
 inline int ld_for(int k) {
-  if (k <= 12) return (g_pad_even && k > 1) ? ((k + 1) & ~1) : (k < 2 ? 2 : k);
-  return (k + 3) & ~3;
+  if (g_pad_even && k > 1) return (k + 1) & ~1;
+  return k < 2 ? 2 : k;
 }
 
 enum SliceType : int32_t {

@@ -18,12 +18,12 @@
 
 // The file is compiled several times in parallel (cora_amd/build.py): CORA_TU selects the kernel families of a
 // translation unit (1 SpMM, 2 row-unit / vector / block kernels, 4 staged triangular solves), CORA_LDG the row strides
-// it instantiates of the two big families (1: LD 2-5, 2: 6-9, 4: 10-12, 8: 16-24).  Default: everything.
+// it instantiates of the two big families (1: LD 2-5, 2: 6-9, 4: 10-12, 8: 13-16, 16: 17-20, 32: 21-24).  Default: all.
 #ifndef CORA_TU
 #define CORA_TU 7
 #endif
 #ifndef CORA_LDG
-#define CORA_LDG 15
+#define CORA_LDG 63
 #endif
 
 namespace cora {
@@ -288,14 +288,22 @@ __device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
 #ifndef CORA_SPMM_WINDOW
 #define CORA_SPMM_WINDOW 1
 #endif
-constexpr int kWinMaxLD = CORA_SPMM_WINDOW ? 12 : 0;   // rotation window: 198 x 12 doubles = 19 KB per wavefront
+#ifndef CORA_WIN_MAX_LD
+#define CORA_WIN_MAX_LD 24
+#endif
+// rotation window at every row stride: 198 x LD doubles (19 KB at 12, 25 KB at 16, 38 KB at 24: four to six wavefronts per
+// CU still keep their loads in flight).  Round 2 stopped at 12 and the strides above fell off a cliff: (Q - Lambda) X
+// with 16 columns 68.5 -> 51.6 us, 20 columns 70.5 -> 55.0 us, Hvp at p = 16 76.9 -> 60.6 us (profiles/r03_rank_sweep.md).
+// (Measured and not kept: an odd LDS row stride against bank conflicts at even strides -- the index arithmetic cost more
+// than the conflicts: Hvp at p = 10 32.8 -> 38.3 us, p = 16 unchanged.)
+constexpr int kWinMaxLD = CORA_SPMM_WINDOW ? CORA_WIN_MAX_LD : 0;
 constexpr int kWinTrnMaxLD = 8;                        // + the translation window while 8 wavefronts per CU fit the LDS
 #ifndef CORA_POSE_COOP_EPI
 #define CORA_POSE_COOP_EPI 1
 #endif
 #ifndef CORA_POSE_UNROLL_WIN
-#define CORA_POSE_UNROLL_WIN 3
-#endif
+#define CORA_POSE_UNROLL_WIN 2  // slots per trip of the window loop (round 3, with 3 waves per SIMD: 1 / 2 / 3 / 6 / 11 slots
+#endif                          // -> Hvp 21.4 / 21.5 / 21.8 / 23.0 / 30.0 us, rotated 29.2 / 29.2 / 29.3 / 32.0 / 41.0 us)
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
   const double *__restrict__ vp = A.sval + sd.off + lane;
@@ -567,11 +575,14 @@ constexpr unsigned kSpmmTimesMax = 65536;
 __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
 #endif
 #ifndef CORA_SPMM_WAVES_PER_EU
-#define CORA_SPMM_WAVES_PER_EU 2
+#define CORA_SPMM_WAVES_PER_EU 3
 #endif
 // The kernel is latency bound unless each wave keeps many loads in flight, so
-// let the register allocator spend registers (>= 2 waves / SIMD) instead of
-// squeezing for occupancy: measured 31.3 -> 20.4 us on the 10^5-pose graph.
+// let the register allocator spend registers instead of squeezing for full occupancy (round 1: 8 waves per SIMD at
+// 64 registers 31.3 us, 2 waves 20.4 us on the 10^5-pose graph).  With the X window the balance moved: what the memory
+// side sustains is requests in flight per CU, and three lighter wavefronts per SIMD (<= 168 registers, two slots per
+// trip) beat two heavier ones: Hvp 22.2 -> 21.4 us, HBM-resident 30.9 -> 29.2 us, inside the STPCG loop 27.8 -> 25.2 us;
+// four per SIMD are no better (tools/spmm_window_variants.sh, profiles/r03_kernel_evolution.md).
 template <int LD, int D, int EPI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM_WAVES_PER_EU)))
 void k_spmm(const SpmmArgs A) {
@@ -2180,7 +2191,8 @@ __global__ void k_zero_row(double *x, size_t row, int ld) {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-#define CORA_LD_CASES(M) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(16) M(20) M(24)
+#define CORA_LD_CASES(M) \
+  M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24)
 
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
   int64_t g = (n + per_block - 1) / per_block;
@@ -2192,7 +2204,9 @@ static inline int grid_for(int64_t n, int per_block = 256, int cap = 2048) {
 #define CORA_LD_CASES_G0(M) M(2) M(3) M(4) M(5)
 #define CORA_LD_CASES_G1(M) M(6) M(7) M(8) M(9)
 #define CORA_LD_CASES_G2(M) M(10) M(11) M(12)
-#define CORA_LD_CASES_G3(M) M(16) M(20) M(24)
+#define CORA_LD_CASES_G3(M) M(13) M(14) M(15) M(16)
+#define CORA_LD_CASES_G4(M) M(17) M(18) M(19) M(20)
+#define CORA_LD_CASES_G5(M) M(21) M(22) M(23) M(24)
 
 #if CORA_TU & 1
 template <int LD, int D>
@@ -2232,13 +2246,17 @@ hipError_t launch_spmm_g0(const SpmmArgs &A, int ld, int d, int epi, hipStream_t
 hipError_t launch_spmm_g1(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
 hipError_t launch_spmm_g2(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
 hipError_t launch_spmm_g3(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+hipError_t launch_spmm_g4(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
+hipError_t launch_spmm_g5(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
 #if CORA_LDG & 1
 SPMM_GROUP(0)
 hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st) {
   if (ld <= 5) return launch_spmm_g0(A, ld, d, epi, st);
   if (ld <= 9) return launch_spmm_g1(A, ld, d, epi, st);
   if (ld <= 12) return launch_spmm_g2(A, ld, d, epi, st);
-  return launch_spmm_g3(A, ld, d, epi, st);
+  if (ld <= 16) return launch_spmm_g3(A, ld, d, epi, st);
+  if (ld <= 20) return launch_spmm_g4(A, ld, d, epi, st);
+  return launch_spmm_g5(A, ld, d, epi, st);
 }
 #endif
 #if CORA_LDG & 2
@@ -2249,6 +2267,12 @@ SPMM_GROUP(2)
 #endif
 #if CORA_LDG & 8
 SPMM_GROUP(3)
+#endif
+#if CORA_LDG & 16
+SPMM_GROUP(4)
+#endif
+#if CORA_LDG & 32
+SPMM_GROUP(5)
 #endif
 #undef SPMM_GROUP
 #undef CASE
@@ -2539,6 +2563,8 @@ hipError_t launch_tri_g0(const TriCall &c, hipStream_t st);
 hipError_t launch_tri_g1(const TriCall &c, hipStream_t st);
 hipError_t launch_tri_g2(const TriCall &c, hipStream_t st);
 hipError_t launch_tri_g3(const TriCall &c, hipStream_t st);
+hipError_t launch_tri_g4(const TriCall &c, hipStream_t st);
+hipError_t launch_tri_g5(const TriCall &c, hipStream_t st);
 #if CORA_LDG & 2
 TRI_GROUP(1)
 #endif
@@ -2548,13 +2574,21 @@ TRI_GROUP(2)
 #if CORA_LDG & 8
 TRI_GROUP(3)
 #endif
+#if CORA_LDG & 16
+TRI_GROUP(4)
+#endif
+#if CORA_LDG & 32
+TRI_GROUP(5)
+#endif
 #if CORA_LDG & 1
 TRI_GROUP(0)
 static hipError_t launch_tri(const TriCall &c, hipStream_t st) {
   if (c.ld <= 5) return launch_tri_g0(c, st);
   if (c.ld <= 9) return launch_tri_g1(c, st);
   if (c.ld <= 12) return launch_tri_g2(c, st);
-  return launch_tri_g3(c, st);
+  if (c.ld <= 16) return launch_tri_g3(c, st);
+  if (c.ld <= 20) return launch_tri_g4(c, st);
+  return launch_tri_g5(c, st);
 }
 hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const double *src, double *dst, hipStream_t st) {
   return launch_tri(TriCall{0, ld, backward, &B, nullptr, nullptr, nullptr, src, nullptr, nullptr, dst}, st);

@@ -191,10 +191,11 @@ def test_partitioned_handles_match_single():
     assert abs(fsum - orc.cost(Q, Y)) < 1e-11 * orc.cost(Q, Y)
 
 
-@pytest.mark.parametrize("k", [1, 2, 9, 11, 12, 13, 17, 24])
+@pytest.mark.parametrize("k", [1, 2, 9, 11, 12, 13, 14, 15, 16, 17, 19, 20, 22, 23, 24])
 def test_wide_blocks_every_row_stride(k):
-    """Every compiled row stride (LD = k up to 12, then 16 / 20 / 24): Q*X and (Q - Lambda) X on
-    k-column blocks (the LOBPCG block sizes of certification), plus Gram / combine kernels."""
+    """Every row stride is compiled unpadded (LD = k for 2 <= k <= 24; rounds 1-2 padded 13..24 to 16 / 20 / 24): Q*X
+    and (Q - Lambda) X on k-column blocks (the LOBPCG block of certification has max(10, p + 2) columns,
+    src/CORA_problem.cpp:1062-1063), plus Gram / combine kernels."""
     A, Q, dm = make_problem(d=3, n=400, n_landmarks=3, n_ranges=250, n_loops=5, seed=12)
     p = 4
     c = ctx_for(Q, dm, p)
@@ -211,7 +212,7 @@ def test_wide_blocks_every_row_stride(k):
 def test_rank_up_to_24():
     A, Q, dm = make_problem(d=3, n=200, n_landmarks=2, n_ranges=100, seed=3)
     rng = np.random.default_rng(0)
-    for p in (9, 11, 16, 24):
+    for p in (9, 11, 13, 16, 18, 21, 24):
         c = ctx_for(Q, dm, p)
         Y = orc.project_manifold(dm, rng.uniform(-1, 1, (dm.N, p)))
         G = orc.egrad(Q, Y)

@@ -32,5 +32,8 @@ def run(n, ranks):
 
 print("| poses | p | LD | Q·X µs | GB/s | of 8 TB/s | Hvp µs | GB/s | of 8 TB/s | (Q−Λ)X µs | GB/s | of 8 TB/s |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-run(10000, [3, 4, 5, 6, 7, 10])
-run(100000, [3, 4, 5, 6, 7, 10, 12, 14, 16])
+if len(sys.argv) > 1:   # python tools/rank_sweep.py <poses> <rank> [<rank> ...]
+    run(int(float(sys.argv[1])), [int(a) for a in sys.argv[2:]])
+else:
+    run(10000, [3, 4, 5, 6, 7, 10])
+    run(100000, [3, 4, 5, 6, 7, 10, 12, 14, 16, 20])
