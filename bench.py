@@ -110,8 +110,10 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
     ex["stpcg_iteration_us"] = (time.perf_counter() - t0) / max(done, 1) * 1e6
     ex["stpcg_iterations_timed"] = done
     ex["stpcg_form"] = {0: "one pass per operation", 1: "fused vector passes (6 launches + the solve)",
-                        2: "vector passes fused into the sweeps of the Cholesky solve, kappa from the product's "
-                           "epilogue (7 launches per iteration)"}.get(h.stpcg_path(), "?")
+                        2: "6 launches per iteration: product with the kappa partials | kappa | forward sweep (r += alpha Hp, "
+                           "<r,r> and |L^-1 r|^2 slots) | last stage, two products (the second finishes <r,r> and "
+                           "<r,v> = |L^-1 r|^2) | backward sweep (v = Proj_Y(x), s += alpha p, p = -v + beta p)"}.get(
+                               h.stpcg_path(), "?")
     # the Hessian-vector product as it runs INSIDE that loop (HIP events around it in every iteration).  Two sweeps
     # over the factor (130 MB) pass between two products; their loads are non-temporal, so Q and the vectors stay in
     # the Infinity Cache and the product runs close to its back-to-back rate (round 2 before that: 32.9 us)
@@ -302,8 +304,16 @@ def main():
 
     # ---- the same kernel with its working set forced out of the 256 MiB Infinity Cache: five independent copies
     # of the problem (Q + point + operand + result, ~150 MB each) visited round-robin on one stream
-    hbm_us = None
-    if world == 1 and args.op == "hvp":
+    hbm_us, hbm_spmm_us, chunk_us = None, None, None
+    if world == 1:
+        # per-chunk statistics of the headline (median and p10 / p90): 30 chunks of 100 back-to-back products
+        chunk_us = []
+        for _ in range(30):
+            ctx.timer_start()
+            for _ in range(100):
+                step()
+            chunk_us.append(ctx.timer_stop_ms() * 1e3 / 100)
+        chunk_us.sort()
         others = []
         for _ in range(4):
             c2 = capi.Context(dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"], rowptr, colidx, vals, device=local_rank)
@@ -311,18 +321,28 @@ def main():
             c2.set_stream(stream.cuda_stream)
             y2, x2, o2 = y.clone(), x.clone(), torch.zeros_like(out)
             c2.set_point_dev(y2.data_ptr())
-            others.append((c2, y2, x2, o2))
-        ring = [(ctx, y, x, out)] + others
-        for _ in range(4):
-            for c2, _, x2, o2 in ring:
-                c2.hvp_dev(x2.data_ptr(), o2.data_ptr())
-        ctx.sync()
-        rounds = 60
-        ctx.timer_start()
-        for _ in range(rounds):
-            for c2, _, x2, o2 in ring:
-                c2.hvp_dev(x2.data_ptr(), o2.data_ptr())
-        hbm_us = ctx.timer_stop_ms() * 1e3 / (rounds * len(ring))
+            xk2 = ok2 = None
+            if args.op == "cert":
+                xk2, ok2 = xk.clone(), torch.zeros_like(ok)
+            others.append((c2, x2, o2, xk2, ok2))
+        ring = [(ctx, x, out, xk if args.op == "cert" else None, ok if args.op == "cert" else None)] + others
+
+        def rotated(fn):
+            for _ in range(4):
+                for e in ring:
+                    fn(e)
+            ctx.sync()
+            rounds = 60
+            ctx.timer_start()
+            for _ in range(rounds):
+                for e in ring:
+                    fn(e)
+            return ctx.timer_stop_ms() * 1e3 / (rounds * len(ring))
+        if args.op == "hvp":
+            hbm_us = rotated(lambda e: e[0].hvp_dev(e[1].data_ptr(), e[2].data_ptr()))
+            hbm_spmm_us = rotated(lambda e: e[0].spmm_dev(e[1].data_ptr(), p, e[2].data_ptr()))
+        else:
+            hbm_us = rotated(lambda e: e[0].certificate_product_dev(e[3].data_ptr(), k_op, e[4].data_ptr()))
         del ring, others
 
     # N > 1: one product gathered on every rank (download is collective) for the parity check on rank 0
@@ -381,11 +401,24 @@ def main():
         }
         if hbm_us is not None:
             result["roofline_hbm"] = {
-                "bound": "hbm", "kernel": "cora::k_spmm<%d, 3, 2>" % ld, "kernel_us": hbm_us,
+                "bound": "hbm", "kernel": result["roofline"]["kernel"], "kernel_us": hbm_us,
                 "achieved": b_hvp / hbm_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": b_hvp / hbm_us / 1e3 / HBM_PEAK_GBS,
                 "how": "five independent copies of the problem visited round-robin (working set ~750 MB)",
             }
+        if hbm_spmm_us is not None:   # the north star's named kernel, Q . X without an epilogue, the same way
+            result["roofline_hbm_spmm"] = {
+                "bound": "hbm", "kernel": "cora::k_spmm<%d, 3, 0> (EPI_NONE)" % ld, "kernel_us": hbm_spmm_us,
+                "achieved": b_spmm / hbm_spmm_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": b_spmm / hbm_spmm_us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": b_spmm,
+                "how": "five independent copies of the problem visited round-robin (working set ~750 MB)",
+            }
+        if chunk_us:
+            n_c = len(chunk_us)
+            result["value_stats"] = {
+                "unit": result["unit"], "p10": 1e6 / chunk_us[int(0.9 * (n_c - 1))], "p50": 1e6 / chunk_us[n_c // 2],
+                "p90": 1e6 / chunk_us[int(0.1 * (n_c - 1))],
+                "how": "30 chunks of 100 back-to-back products after the timed region, HIP events per chunk"}
         if world > 1 and args.op == "hvp":
             # parity of the sharded product against the CPU oracle on the same operands
             from oracle import oracle as orc

@@ -54,9 +54,10 @@ def stpcg(hess, precon, g, Delta, prm):
     return s, math.sqrt(sig2), it
 
 
-def tnt(Q, dm, x0, precond="jacobi", lam=None, **kw):
+def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
     """precond: "jacobi" | "none" | "chol" (RegularizedCholesky, src/CORA_problem.cpp:544-614, with
-    the regularisation `lam` and the last translation pinned)."""
+    the regularisation `lam` and the last translation pinned; `perm`: elimination order of the N - 1 rows -- the result
+    of a solve does not depend on it, the fill does: natural order is hopeless beyond a few thousand poses)."""
     prm = dict(DEFAULTS)
     prm.update(kw)
     dinv = 1.0 / orc.diag(Q)
@@ -64,7 +65,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, **kw):
     if precond == "chol":
         import scipy.sparse as sp
         M = (Q.to_scipy() + lam * sp.eye(dm.N)).tocsr()[:dm.N - 1, :dm.N - 1]
-        chol = orc.Cholesky(orc.CSR.from_scipy(M))
+        chol = orc.Cholesky(orc.CSR.from_scipy(M), perm=perm)
         assert chol.ok
 
     def precon_at(Y):

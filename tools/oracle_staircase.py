@@ -33,6 +33,28 @@ x = orc.project_manifold(dims, P.op("getOdomInitialization"))
 # RegularizedCholesky: lambda = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 (src/CORA_problem.cpp:544-614)
 lam_max = float(spla.eigsh(Qs, k=1, which="LA", tol=1e-3, return_eigenvectors=False)[0])
 lam = lam_max / (1e6 - 1)
+
+
+def pose_major_order(m):
+    """Fill-reducing elimination order for a chain graph (per pose: its rotation rows, the range rows hanging off it,
+    its translation; landmarks last), restricted to the first m rows."""
+    d, n, r, N = dims.d, dims.n, dims.r, dims.N
+    tb = d * n + r
+    C = Qs[d * n:tb][:, tb:tb + n].tocsr()
+    owner = np.full(r, -1, dtype=np.int64)
+    has = np.diff(C.indptr) > 0
+    owner[has] = C.indices[C.indptr[:-1][has]]
+    key = np.empty(N, dtype=np.float64)
+    for a in range(d):
+        key[a:d * n:d] = np.arange(n) + 0.1 * a / d
+    key[d * n:tb] = np.where(owner >= 0, owner + 0.5, n + 1.0)
+    key[tb:tb + n] = np.arange(n) + 0.9
+    key[tb + n:] = n + 2.0
+    order = np.argsort(key, kind="stable")
+    return order[order < m].astype(np.int32)
+
+
+perm_full, perm_pin = pose_major_order(dims.N), pose_major_order(dims.N - 1)
 print("N=%d nnz=%d f0=%.6e lambda_reg=%.6e" % (dims.N, dm_["nnz"], orc.cost(Q, x), lam), flush=True)
 MIN_ETA, MAX_ETA, REL_ETA = 1e-7, 1e-1, 5e-6
 t_start = time.time()
@@ -40,7 +62,7 @@ hvps = 0
 rank = x.shape[1]
 while rank <= max_rank:
     t0 = time.time()
-    res = otnt.tnt(Q, dims, x, precond="chol", lam=lam)
+    res = otnt.tnt(Q, dims, x, precond="chol", lam=lam, perm=perm_pin)
     hvps += res["hvps"]
     x = res["x"]
     eta = min(max(res["f"] * REL_ETA, MIN_ETA), MAX_ETA)
@@ -52,7 +74,7 @@ while rank <= max_rank:
     S = (Qs - Lam).tocsr()
     M = (S + eta * sp.identity(dims.N)).tocsr()
     M.sort_indices()
-    ok = orc.Cholesky(orc.CSR.from_scipy(M)).ok
+    ok = orc.Cholesky(orc.CSR.from_scipy(M), perm=perm_full).ok
     print("rank %d: TNT %s after %d outer iterations, %d Hvps, f=%.6f |g|=%.3e |Pg|=%.3e  (%.0f s) -> eta=%.3g, S + eta I PSD: %s"
           % (rank, res["status"], res["iterations"], res["hvps"], res["f"], res["grad_norm"], res["pgrad_norm"],
              time.time() - t0, eta, ok), flush=True)
@@ -82,7 +104,7 @@ while rank <= max_rank:
     Yd = np.zeros_like(Ya)
     Yd[:, -1] = v
     FY = orc.cost(Q, Ya)
-    chol = orc.Cholesky(orc.CSR.from_scipy(((Qs + lam * sp.identity(dims.N)).tocsr()[:dims.N - 1, :dims.N - 1]).tocsr()))
+    chol = orc.Cholesky(orc.CSR.from_scipy(((Qs + lam * sp.identity(dims.N)).tocsr()[:dims.N - 1, :dims.N - 1]).tocsr()), perm=perm_pin)
     alpha = max(16 * 1e-6, 100 * 1e-4 / abs(theta))
     trials, best = [], None
     escaped = False
