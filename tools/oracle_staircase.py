@@ -126,3 +126,27 @@ while rank <= max_rank:
                                                                 FY, orc.cost(Q, x)), flush=True)
 print("staircase stopped at rank %d after %d Hvps, %.0f s: f=%.6f (chi-square sized optimum %d)"
       % (x.shape[1], hvps, time.time() - t_start, orc.cost(Q, x), n // 4), flush=True)
+if x.shape[1] > dims.d:
+    # projectSolution, src/CORA.cpp:352-441: the d dominant right singular directions, determinant fix, every pose block
+    # to SO(d), range rows to the unit sphere -- then the refinement at rank d (src/CORA.cpp:198-233)
+    d, nn, r = dims.d, dims.n, dims.r
+    _, _, Vt = np.linalg.svd(x, full_matrices=False)
+    Yd = x @ Vt[:d].T
+    dets = np.array([np.linalg.det(Yd[i * d:(i + 1) * d]) for i in range(nn)])
+    if (dets > 0).sum() < nn / 2:
+        Yd[:, d - 1] = -Yd[:, d - 1]
+    for i in range(nn):
+        U, _, Wt = np.linalg.svd(Yd[i * d:(i + 1) * d])
+        R = U @ Wt
+        if np.linalg.det(R) < 0:
+            U[:, -1] = -U[:, -1]
+            R = U @ Wt
+        Yd[i * d:(i + 1) * d] = R
+    nr = np.linalg.norm(Yd[d * nn:d * nn + r], axis=1, keepdims=True)
+    Yd[d * nn:d * nn + r] /= np.where(nr > 0, nr, 1.0)
+    t0 = time.time()
+    res = otnt.tnt(Q, dims, np.asfortranarray(Yd), precond="chol", lam=lam, perm=perm_pin)
+    print("rounded to rank %d: f=%.6f; refinement: TNT %s after %d outer iterations, %d Hvps, f=%.6f |g|=%.3e (%.0f s)"
+          % (d, orc.cost(Q, Yd), res["status"], res["iterations"], res["hvps"], res["f"], res["grad_norm"], time.time() - t0),
+          flush=True)
+
