@@ -109,7 +109,8 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
     h.sync()
     ex["stpcg_iteration_us"] = (time.perf_counter() - t0) / max(done, 1) * 1e6
     ex["stpcg_iterations_timed"] = done
-    ex["stpcg_form"] = {0: "one pass per operation", 1: "fused vector passes (6 launches + the solve)",
+    ex["stpcg_form"] = {0: "one pass per operation", 1: "fused vector passes (5 launches + the solve)",
+                        3: "one explicit inverse: 5 launches per iteration, <r,v> = |W r|^2",
                         2: "6 launches per iteration: product with the kappa partials | kappa | forward sweep (r += alpha Hp, "
                            "<r,r> and |L^-1 r|^2 slots) | last stage, two products (the second finishes <r,r> and "
                            "<r,v> = |L^-1 r|^2) | backward sweep (v = Proj_Y(x), s += alpha p, p = -v + beta p)"}.get(

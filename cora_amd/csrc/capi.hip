@@ -1337,7 +1337,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // Sweep-fused iteration (the above, with a two-stage Cholesky solve plan): five passes and a scalar step --
   //   Hp = H p with the partials of kappa | kappa | forward sweep on r += alpha Hp with <r, r> | last stage (2 products) |
   //   backward sweep with v = Proj_Y(x) and <r, v> | s += alpha p, p = -v + beta p
-  bool sweep_fused = false;
+  bool sweep_fused = false, inverse_fused = false;
   SubFuse FF, FB;
   double *kappa_partial = nullptr;
   int kappa_blocks = 0;
@@ -1358,10 +1358,30 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       const RowOpDev &fb = f.stages[1].fwd_b;
       sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
     }
+    // one explicit inverse W = L^-1 and nothing else (two products per solve), no pinned-row stage in between
+    inverse_fused = !sharded && !sweep_fused && chol && f.ready && f.stages.size() == 1 && !f.stages[0].dense && !f.stages[0].is_sub &&
+                    !f.stages[0].has_fwd_a && !f.stages[0].has_bwd_a && !std::getenv("CORA_NO_INVERSE_FUSE");
+    if (inverse_fused) {
+      const RowOpDev &fb = f.stages[0].fwd_b;
+      sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
+    }
     kappa_blocks = launch_spmm_kappa_slots(spmm_args(c, dP, dHp));
     if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks) + rr_slots + yy_slots + sq_slots))) return rc;
     D.partial = c->d_red;
     kappa_partial = c->d_red + need;
+    if (inverse_fused) {
+      double *rowsq = kappa_partial + kappa_blocks;
+      sq.rowsq_out = rowsq;
+      tail.rr_partial = rowsq;  // unused (n_rr = 0)
+      tail.n_rr = 0;
+      tail.yy_partial = rowsq;
+      tail.n_yy = 0;
+      tail.rowsq = rowsq;
+      tail.n_rowsq = static_cast<int>(sq_slots) - 8;
+      tail.st = c->d_stpcg;
+      tail.st_host = &c->h_stpcg[0];
+      tail.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+    }
     if (sweep_fused) {
       const Layout &L = c->F.L;
       double *rr_partial = kappa_partial + kappa_blocks, *yy_partial = rr_partial + rr_slots, *rowsq = yy_partial + yy_slots;
@@ -1393,7 +1413,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       tail.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
     }
   }
-  c->stpcg_path = sweep_fused ? 2 : fused ? 1 : 0;
+  c->stpcg_path = sweep_fused ? 2 : inverse_fused ? 3 : fused ? 1 : 0;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
     for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
@@ -1430,8 +1450,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
           continue;
         }
-        HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
         if (sweep_fused) {
+          HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
           // Hp = H p | kappa | forward sweep: r += alpha Hp, <r, r>, |y|^2 | last stage, <r, v> in its second product |
           // backward sweep: v = Proj_Y(x), s += alpha p, p = -v + beta p   -- six launches
           cora_ctx::DevFactor &f = c->precond_f;
@@ -1447,9 +1467,23 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
           continue;
         }
-        D.mode = DOTS_STPCG_RR;
-        D.count = 1;
-        HIP_TRY(c, launch_stpcg_residual(D, n, dHp + off, dR + off, c->stream));
+        // kappa, the scalar step and r += alpha Hp with <r, r> in ONE launch (every block adds the partials: the plans
+        // that come here are small, and a launch is what costs them)
+        HIP_TRY(c, launch_kappa_residual(D, kappa_partial, kappa_blocks, n, dHp + off, dR + off, c->stream));
+        if (inverse_fused) {
+          // one explicit inverse (every data set of the reference): v = Proj_Y(W^T W r) and <r, v> = |W r|^2 -- the first
+          // product leaves the squared norms of its rows, an extra block of the second adds them and runs the scalar step,
+          // and the projection consumes v at once (s += alpha p, p = -v + beta p): five launches per iteration
+          cora_ctx::DevFactor &f = c->precond_f;
+          double *t2;
+          if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
+          const cora_ctx::DevStage &S = f.stages[0];
+          HIP_TRY(c, launch_rowop(S.fwd_b, c->ld, nullptr, dR, t2, c->stream, &sq));
+          tail.seq = seq = ++c->dot_seq;
+          HIP_TRY(c, launch_rowop(S.bwd_b, c->ld, nullptr, t2, dV, c->stream, &tail));
+          HIP_TRY(c, launch_tangent_project_update(row_args(c), c->d_stpcg, c->ld, c->d_Y, dV, dP, dS, c->stream));
+          continue;
+        }
         const double *x = dR, *scale = nullptr;
         if (chol) {
           if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;

@@ -41,8 +41,15 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   // resident device vectors carry at most 24 columns and saddleEscape lifts to rank + 1: say so before the
   // staircase starts rather than in the middle of it (the reference has no such cap; it never needs one either --
   // the staircase certifies at rank <= d + a few)
-  if (max_relaxation_rank > 23 || x0.cols() > 24)
-    throw std::invalid_argument("solveCORA: this build supports relaxation ranks up to 24 (max_relaxation_rank <= 23)");
+  // -- a cap, not a target: a generous max_relaxation_rank (the reference's default is 20, callers pass 25 or 50) is
+  // clamped with a note, and only a staircase that really has to climb past rank 24 fails, when it gets there.
+  if (x0.cols() > 24) throw std::invalid_argument("solveCORA: this build supports relaxation ranks up to 24");
+  const int requested_max_rank = max_relaxation_rank;
+  if (max_relaxation_rank > 23) {
+    max_relaxation_rank = 23;
+    printIfVerbose(verbose, "solveCORA: max_relaxation_rank " + std::to_string(requested_max_rank) +
+                                " clamped to 23 (resident vectors carry at most 24 columns)");
+  }
   if (problem.getFormulation() == Formulation::Explicit) {
     checkMatrixShape("solveCora::Explicit", problem.getDataMatrixSize(), x0.cols(), x0.rows(), x0.cols());
   } else {  // src/CORA.cpp:33-40
@@ -117,6 +124,9 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     t_escape += since(t0);
     traceBits("saddleEscape", X);
   }
+  if (!cert.is_certified && requested_max_rank > 23 && static_cast<int>(problem.getRelaxationRank()) > 23)
+    throw std::runtime_error("solveCORA: the staircase is not certified at rank 23 and max_relaxation_rank = " +
+                             std::to_string(requested_max_rank) + " asks for more; this build supports ranks up to 24");
   // project to rank d and refine (src/CORA.cpp:198-233)
   if (X.cols() > problem.dim()) {
     printIfVerbose(verbose, "\nProjecting solution to rank " + std::to_string(problem.dim()) + " and refining.");

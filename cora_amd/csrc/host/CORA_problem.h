@@ -163,10 +163,14 @@ class Problem {
   void setFormulation(Formulation f) { formulation_ = f; }
   void setDevice(int device) { device_ = device; }
   // Multi-GPU (one process per GPU): this process owns partition `rank` of `world` of the rows of Q (pose-aligned,
-  // nnz-balanced, include/cora_hip.h cora_ctx_create_part) and reaches the others through the three injected steps
-  // of cora_set_comm.  Every operator of this class, TNT, LOBPCG and solveCORA then run unchanged, all ranks calling
-  // the same sequence; the exact-Cholesky preconditioners and the host factorisation of the certificate do not
-  // shard (use Jacobi).  Call before the first operator.
+  // nnz-balanced, include/cora_hip.h cora_ctx_create_part) and reaches the others through the library's own
+  // communication (cora_comm_create_rccl / cora_comm_create_local on context(), after this call and after every
+  // rebuild of the handle -- until then a collective step fails with CORA_ERR_NOT_READY) or through three injected
+  // steps (cora_set_comm semantics; pass nullptr to install communication on the handle afterwards).  Every operator of
+  // this class, TNT, LOBPCG, certify_solution and solveCORA then run on the partition, all ranks calling the same
+  // sequence: the Lambda blocks of the certificate are gathered, every rank runs the PSD test (same decision), LOBPCG
+  // runs on the sharded operator.  Not sharded: the exact-Cholesky preconditioners and the implicit formulation (use
+  // Jacobi, explicit), the ILDL branch of fast_verification (skipped).  Call before the first operator.
   void setPartition(int rank, int world, cora_exchange_fn exchange, cora_allreduce_fn allreduce,
                     cora_allgather_fn allgather, void *user) {
     part_rank_ = rank;

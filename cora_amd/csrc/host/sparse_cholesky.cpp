@@ -73,7 +73,7 @@ namespace {
 
 // pattern-only part of a factorisation (see choleskyFactor)
 struct Symbolic {
-  uint64_t key = 0;
+  uint64_t key = 0, key2 = 0;
   int n = 0;
   size_t nnzA = 0;
   std::vector<int32_t> Cp, Ci;  // upper triangle of P A P^T by columns
@@ -111,11 +111,16 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   uint64_t key = hashWords(static_cast<uint64_t>(n) * 0x100000001B3ull + static_cast<uint64_t>(A.rows()), A.outer.data(), A.outer.size());
   key = hashWords(key, A.inner.data(), A.inner.size());
   key = hashWords(key, perm.data(), perm.size());
+  // a second, independent 64-bit hash of the same words (other seed, other order): a stale hit would write a factor
+  // through the wrong column counts, so the pair has to collide, not one word (round-2 advice)
+  uint64_t key2 = hashWords(0x243F6A8885A308D3ull ^ static_cast<uint64_t>(perm.size()), perm.data(), perm.size());
+  key2 = hashWords(key2, A.inner.data(), A.inner.size());
+  key2 = hashWords(key2 + 0x13198A2E03707344ull, A.outer.data(), A.outer.size());
   const bool use_cache = std::getenv("CORA_CHOL_NO_SYMBOLIC_CACHE") == nullptr;
   if (use_cache) {
     std::lock_guard<std::mutex> lock(g_sym_mutex);
     for (int e = 0; e < 2; ++e)
-      if (g_sym[e] && g_sym[e]->key == key && g_sym[e]->n == n && g_sym[e]->nnzA == A.inner.size()) {
+      if (g_sym[e] && g_sym[e]->key == key && g_sym[e]->key2 == key2 && g_sym[e]->n == n && g_sym[e]->nnzA == A.inner.size()) {
         if (e == 1) std::swap(g_sym[0], g_sym[1]);
         *hit = true;
         return g_sym[0];
@@ -123,6 +128,7 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   }
   auto S = std::make_shared<Symbolic>();
   S->key = key;
+  S->key2 = key2;
   S->n = n;
   S->nnzA = A.inner.size();
   // upper triangle of P A P^T by columns == rows of A restricted to iperm <= k

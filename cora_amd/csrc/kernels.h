@@ -74,7 +74,7 @@ struct StpcgState {
   double kappa, rr, step_M_norm;
   int iters, status, max_iters, pad;
 };
-enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4 };
+enum { DOTS_PLAIN = 0, DOTS_STPCG_KAPPA = 1, DOTS_STPCG_BETA = 2, DOTS_STPCG_RR = 3, DOTS_STPCG_RV = 4, DOTS_STPCG_KAPPA_RR = 5 };
 
 struct DotArgs {
   const double *a[4];
@@ -222,6 +222,13 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 //   r += coef_r Hp with <r, r> (DOTS_STPCG_RR)  |  out = Proj_Y(V) with <r, out> (DOTS_STPCG_RV)  |
 //   s += coef_s p, then p = coef_v v + coef_beta p
 hipError_t launch_stpcg_residual(const DotArgs &D, int64_t n, const double *Hp, double *r, hipStream_t st);
+// v = Proj_Y(X) consumed at once by  s += coef_s p, p = coef_v v + coef_beta p  (row strides up to 12)
+hipError_t launch_tangent_project_update(const RowArgs &R, const StpcgState *S, int ld, const double *Y, const double *X,
+                                         double *p, double *s, hipStream_t st);
+// kappa from the nk partials of an EPI_HVP_K product, the scalar step, then r += coef_r Hp with <r, r> -- ONE launch:
+// every block adds the partials itself (same order, same bits).  For the small plans, where a launch is what costs.
+hipError_t launch_kappa_residual(const DotArgs &D, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
+                                 hipStream_t st);
 hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D, int ld, const double *Y, const double *V,
                                       const double *scale, const double *r, double *out, hipStream_t st);
 // the scalar step of a partitioned handle's iteration, after the all-reduce of its inner products (k_stpcg_scalar_step)

@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const 
 // ticket, and the last block to arrive adds all partials in block order (deterministic) and writes the
 // results to D.out -- pinned host memory, so the caller only has to wait for the stream.  Same
 // inter-workgroup hand-off as the long rows of k_spmm.
-__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm) {
+__device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc)[4], double *sm, double kappa = 0.0) {
   __shared__ int s_last;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -968,6 +968,10 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
   }
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA) stpcg_after_kappa(*D.st, sm[4]);
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RR) stpcg_after_rr(*D.st, sm[4]);
+  if (threadIdx.x == 0 && D.mode == DOTS_STPCG_KAPPA_RR) {  // k_kappa_residual: every block used the same kappa
+    stpcg_after_kappa(*D.st, kappa);
+    stpcg_after_rr(*D.st, sm[4]);
+  }
   if (threadIdx.x == 0 && D.mode == DOTS_STPCG_RV) {
     stpcg_after_rv(*D.st, sm[4]);
     *D.st_host = *D.st;  // pinned mirror for the host's (infrequent) look
@@ -1031,6 +1035,45 @@ __global__ void k_stpcg_scalar_step(int what, const double *__restrict__ vals, S
     __threadfence_system();
     __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// kappa = <p, Hp> from the per-block partials of an EPI_HVP_K product, then r += coef_r Hp with <r, r> in the same
+// launch: EVERY block adds the partials (same order, same bits; they sit in L2) and runs the scalar step on a private
+// copy of the state to get its coefficient; the state itself is advanced once, by the last block to finish -- by then
+// every block has read it.
+__global__ __launch_bounds__(256) void k_kappa_residual(DotArgs D, const double *__restrict__ kpartial, int nk,
+                                                        const double2 *__restrict__ Hp, double2 *__restrict__ r) {
+  __shared__ double sm[8];
+  __shared__ double s_kappa;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < nk; b += 1024) {
+    s0 += kpartial[b];
+    s1 += kpartial[b + 256];
+    s2 += kpartial[b + 512];
+    s3 += kpartial[b + 768];
+  }
+  for (; b < nk; b += 256) s0 += kpartial[b];
+  const double t = block_sum_256((s0 + s1) + (s2 + s3), sm);
+  if (threadIdx.x == 0) s_kappa = t;
+  __syncthreads();
+  const double kappa = s_kappa;
+  StpcgState L = *D.st;
+  stpcg_after_kappa(L, kappa);
+  const double cr = L.coef_r;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < D.n2;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    double2 rv = r[i];
+    if (cr != 0.0) {
+      const double2 h = Hp[i];
+      rv.x = fma(cr, h.x, rv.x);
+      rv.y = fma(cr, h.y, rv.y);
+      r[i] = rv;
+    }
+    acc[0] = fma(rv.x, rv.x, fma(rv.y, rv.y, acc[0]));
+  }
+  dots_finish(D, acc, sm, kappa);
 }
 
 // s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
@@ -1098,6 +1141,52 @@ __global__ __launch_bounds__(256) void k_tangent_project_dot(const RowArgs R, Do
     store_row<LD>(out + un.row * LD, v);
   }
   dots_finish(Dt, acc, sm);
+}
+
+// v = Proj_Y(x) by row unit, consumed at once: s += coef_s p, p = coef_v v + coef_beta p (v is not stored).  The last
+// pass of an STPCG iteration whose <r, v> is already known (explicit-inverse plans: <r, v> = |W r|^2 from the first
+// product of the solve), so the projection needs no reduction and the step / direction pass rides on it.
+template <int LD, int D>
+__global__ __launch_bounds__(256) void k_tangent_project_update(const RowArgs R, const StpcgState *__restrict__ S,
+                                                                const double *__restrict__ Y, const double *__restrict__ X,
+                                                                double *__restrict__ p, double *__restrict__ s) {
+  const double cs = S->coef_s, cv = S->coef_v, cb = S->coef_beta;
+  if (cs == 0.0 && cv == 0.0 && cb == 1.0) return;  // solve already finished: enqueued ahead of the host's check
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const Unit un = unit_of(R, u);
+  auto update = [&](size_t row, const double (&v)[LD]) {
+    double pv[LD], sv[LD];
+    load_row<LD>(p + row * LD, pv);
+    load_row<LD>(s + row * LD, sv);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      sv[j] = fma(cs, pv[j], sv[j]);
+      pv[j] = fma(cv, v[j], cb * pv[j]);
+    }
+    store_row<LD>(s + row * LD, sv);
+    store_row<LD>(p + row * LD, pv);
+  };
+  if (un.kind == 0) {
+    double y[D][LD], v[D][LD];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      load_row<LD>(Y + (un.row + a) * LD, y[a]);
+      load_row<LD>(X + (un.row + a) * LD, v[a]);
+    }
+    stiefel_project_thread<LD, D>(y, v);
+#pragma unroll
+    for (int a = 0; a < D; ++a) update(un.row + a, v[a]);
+  } else if (un.kind == 1 || un.kind == 2) {
+    double y[LD], v[LD];
+    load_row<LD>(X + un.row * LD, v);
+    if (un.kind == 1) {
+      load_row<LD>(Y + un.row * LD, y);
+      const double ip = dot_row<LD>(y, v);
+#pragma unroll
+      for (int c = 0; c < LD; ++c) v[c] = fma(-ip, y[c], v[c]);
+    }
+    update(un.row, v);
+  }
 }
 
 // scalar variant for odd lengths / 8-byte aligned shards
@@ -1421,7 +1510,7 @@ __device__ __forceinline__ void rv_tail_block(const RvTail &T) {
   const double yy = sum_slots_256(T.yy_partial, T.n_yy, sm + 4);
   const double tt = sum_slots_256(T.rowsq, T.n_rowsq, sm + 8);
   if (threadIdx.x == 0) {
-    stpcg_after_rr(*T.st, rr);
+    if (T.n_rr > 0) stpcg_after_rr(*T.st, rr);  // (n_rr == 0: <r, r> was finished by the residual pass)
     stpcg_after_rv(*T.st, yy + tt);
     *T.st_host = *T.st;  // pinned mirror for the host's (infrequent) look
     if (T.seq_out) {
@@ -2371,6 +2460,18 @@ hipError_t launch_stpcg_direction(int64_t n, const StpcgState *S, const double *
 }
 
 // D: mode / st / st_host / partial / ticket / seq fields set by the caller; n doubles, even, 16-byte aligned
+hipError_t launch_kappa_residual(const DotArgs &D_in, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
+                                 hipStream_t st) {
+  if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
+  DotArgs D = D_in;
+  D.count = 1;
+  D.n2 = n / 2;
+  D.mode = DOTS_STPCG_KAPPA_RR;
+  hipLaunchKernelGGL(k_kappa_residual, dim3(grid_for(n / 2, 256, 256)), dim3(256), 0, st, D, kpartial, nk,
+                     reinterpret_cast<const double2 *>(Hp), reinterpret_cast<double2 *>(r));
+  return hipGetLastError();
+}
+// D: mode / st / st_host / partial / ticket / seq fields set by the caller; n doubles, even, 16-byte aligned
 hipError_t launch_stpcg_residual(const DotArgs &D_in, int64_t n, const double *Hp, double *r, hipStream_t st) {
   if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
   DotArgs D = D_in;
@@ -2399,6 +2500,24 @@ hipError_t launch_stpcg_step_direction(int64_t n, const StpcgState *S, const dou
   hipLaunchKernelGGL(k_stpcg_step_direction, dim3(grid_for(n / 2)), dim3(256), 0, st, n / 2, S,
                      reinterpret_cast<const double2 *>(v), reinterpret_cast<double2 *>(p), reinterpret_cast<double2 *>(s));
   return hipGetLastError();
+}
+
+hipError_t launch_tangent_project_update(const RowArgs &R, const StpcgState *S, int ld, const double *Y, const double *X,
+                                         double *p, double *s, hipStream_t st) {
+  const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
+  const int grid = static_cast<int>((units + 255) / 256);
+  if (grid == 0) return hipErrorInvalidValue;
+#define CASE(L)                                                                                            \
+  if (ld == L) {                                                                                           \
+    if (R.d == 2) hipLaunchKernelGGL((k_tangent_project_update<L, 2>), dim3(grid), dim3(256), 0, st, R, S, \
+                                     Y, X, p, s);                                                          \
+    else hipLaunchKernelGGL((k_tangent_project_update<L, 3>), dim3(grid), dim3(256), 0, st, R, S, Y, X,    \
+                            p, s);                                                                         \
+    return hipGetLastError();                                                                              \
+  }
+  CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
+#undef CASE
+  return hipErrorInvalidValue;
 }
 
 // out = Proj_Y(V) and <r, out>; the partial array of D needs one slot per 256 row units

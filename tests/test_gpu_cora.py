@@ -98,3 +98,18 @@ def test_staircase_from_a_good_start_reaches_the_chi_square_optimum():
     assert 0.8 * (n // 2) / 2 < res["f"] < 1.2 * (n // 2) / 2
     print("\n10^4 poses from the ground truth: f=%.4f |g|=%.2e certified=%s theta=%.3e levels=%d hvps=%d %.2fs" % (
         res["f"], res["grad_norm"], res["certified"], res["theta"], res["levels"], res["hvps"], res["seconds"]))
+
+
+def test_generous_rank_cap_is_clamped_not_refused():
+    """max_relaxation_rank is an upper bound on the staircase (the reference's default is 20, callers pass 25 or 50): a cap
+    above what resident vectors carry (24 columns) is clamped, and the solve runs as with any other cap it never reaches
+    (round-2 advice: it used to throw before any work)."""
+    P = host.Problem.from_pyfg(os.path.join(GOLDEN, "small_ra_slam_problem", "factor_graph.pyfg"))
+    P.update()
+    x0 = P.op("getRandomInitialGuess")
+    a = P.solve(x0, max_rank=10)
+    P2 = host.Problem.from_pyfg(os.path.join(GOLDEN, "small_ra_slam_problem", "factor_graph.pyfg"))
+    P2.update()
+    b = P2.solve(x0, max_rank=50)
+    assert b["certified"] and a["certified"] and b["final_rank"] == a["final_rank"]
+    assert float(a["f"]).hex() == float(b["f"]).hex()

@@ -240,9 +240,9 @@ def test_fused_stpcg_matches_unfused(d, n, precond, p):
     h.set_point_dev(y)
     grad = h.point_ptrs()[2]
     out = {}
-    env = {"sweep": None, "fused": "CORA_NO_SWEEP_FUSE", "unfused": "CORA_NO_FUSE"}
-    for mode, var in env.items():
-        if var:
+    env = {"sweep": (), "fused": ("CORA_NO_SWEEP_FUSE", "CORA_NO_INVERSE_FUSE"), "unfused": ("CORA_NO_FUSE",)}
+    for mode, names in env.items():
+        for var in names:
             os.environ[var] = "1"
         try:
             for delta, iters in ((1e30, 7), (0.5, 40)):   # runs to the limit / stops on the trust-region boundary
@@ -250,7 +250,7 @@ def test_fused_stpcg_matches_unfused(d, n, precond, p):
                 out[(mode, delta)] = (done, step, h.download(s, p), h.download(r, p), h.download(v, p), h.download(pk, p))
             out[mode] = h.stpcg_path()
         finally:
-            if var:
+            for var in names:
                 os.environ.pop(var, None)
     # the warm start (TNT hands over P g, <g, g>, <g, P g>) runs the same iteration as the cold one
     pg = h.dev_alloc(p)
@@ -262,7 +262,9 @@ def test_fused_stpcg_matches_unfused(d, n, precond, p):
     assert np.abs(h.download(s, p) - cold[2]).max() <= 1e-10 * np.abs(cold[2]).max()
     h.dev_free(pg)
     assert out["unfused"] == 0 and out["fused"] == 1
-    assert out["sweep"] == (2 if n >= 30000 else 1)  # the large plans are two-stage: the sweep-fused form really ran
+    # the large plans are two-stage: the sweep-fused form really ran; the small Cholesky plans are one explicit inverse:
+    # <r, v> = |W r|^2 and the projection consumes v (five launches); Jacobi: the fused vector passes
+    assert out["sweep"] == (2 if n >= 30000 else (3 if precond == capi.PRECOND_REGULARIZED_CHOLESKY else 1))
     for mode in ("sweep", "fused"):
         for delta in (1e30, 0.5):
             a, b = out[(mode, delta)], out[("unfused", delta)]
@@ -270,7 +272,7 @@ def test_fused_stpcg_matches_unfused(d, n, precond, p):
             assert abs(a[1] - b[1]) <= 1e-10 * abs(b[1])
             # (the sweep-fused form never stores v = P r: the direction update rides on the backward sweep's epilogue,
             # and dV -- a work vector of the C ABI -- is left holding L^-1 r)
-            for k in (2, 3, 5) if out[mode] == 2 else (2, 3, 4, 5):
+            for k in (2, 3, 5) if out[mode] in (2, 3) else (2, 3, 4, 5):
                 assert np.abs(a[k] - b[k]).max() <= 1e-9 * np.abs(b[k]).max(), (mode, delta, k)
     for q in vecs:
         h.dev_free(q)
