@@ -83,7 +83,8 @@ class Context:
     """One device-resident problem (cora_ctx).  Host arrays are column-major
     N x k float64, as in the reference (Eigen::MatrixXd)."""
 
-    def __init__(self, d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, device=0, rank=0, world=1):
+    def __init__(self, d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, device=0, rank=0, world=1,
+                 whole_long_rows=False):
         self.L = load()
         self.d, self.n, self.r, self.nt = int(d), int(n_poses), int(n_ranges), int(n_trans)
         self.N = self.d * self.n + self.r + self.nt
@@ -93,9 +94,10 @@ class Context:
         if len(rowptr) != self.N + 1:
             raise CoraError(1, "rowptr must have N+1 entries")
         h = C.c_void_p()
-        rc = self.L.cora_ctx_create_part(C.c_int(device), self.d, self.n, self.r, self.nt,
-                                         rowptr.ctypes.data_as(_ip), colidx.ctypes.data_as(_ip), _d(vals),
-                                         C.c_int(rank), C.c_int(world), C.byref(h))
+        rc = self.L.cora_ctx_create_part_opts(C.c_int(device), self.d, self.n, self.r, self.nt,
+                                              rowptr.ctypes.data_as(_ip), colidx.ctypes.data_as(_ip), _d(vals),
+                                              C.c_int(rank), C.c_int(world), C.c_uint(1 if whole_long_rows else 0),
+                                              C.byref(h))
         if rc:
             raise CoraError(rc, self.L.cora_last_error(None).decode())
         self.h = h
@@ -165,6 +167,14 @@ class Context:
         self._chk(self.L.cora_remote_rows(self.h, None, C.byref(n)))
         r = np.empty(max(n.value, 1), dtype=np.int32)
         self._chk(self.L.cora_remote_rows(self.h, r.ctypes.data_as(_ip), C.byref(n)))
+        return r[:n.value].astype(np.int64)
+
+    def long_rows(self):
+        """API rows of the distributed long rows of a partitioned handle (empty on one GPU)."""
+        n = C.c_int64(0)
+        self._chk(self.L.cora_long_rows(self.h, None, C.byref(n)))
+        r = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._chk(self.L.cora_long_rows(self.h, r.ctypes.data_as(_ip), C.byref(n)))
         return r[:n.value].astype(np.int64)
 
     def format_stats(self):

@@ -59,6 +59,9 @@ struct cora_ctx {
   int32_t *d_api2int = nullptr;
   double *d_diag_inv = nullptr;  // 1/diag(Q), local rows
   double *d_lam_st = nullptr, *d_lam_ob = nullptr;
+  // partitioned handles: distributed long rows (HostFormat::long_rows): partial-sum slots, rows, owners
+  double *d_long_out = nullptr;
+  int32_t *d_long_rows = nullptr, *d_long_owner = nullptr;
 
   // sparse Cholesky factors resident on the device (level-scheduled triangular solves):
   // the preconditioner's (Q + lambda I)[0:m] and, for the translation-implicit formulation,
@@ -119,6 +122,7 @@ struct cora_ctx {
 
 struct cora_ctx;
 static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut);  // formulation-aware
+static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi);  // one SpMM launch + the distributed long rows
 
 namespace {
 
@@ -365,6 +369,12 @@ int cora_ld_for(int k) { return ld_for(k); }
 
 int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_trans, const int32_t *rowptr,
                          const int32_t *colidx, const double *vals, int rank, int world, cora_ctx **out) {
+  return cora_ctx_create_part_opts(device, d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, rank, world, 0u, out);
+}
+
+int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int n_trans, const int32_t *rowptr,
+                              const int32_t *colidx, const double *vals, int rank, int world, unsigned flags,
+                              cora_ctx **out) {
   if (!out) return fail(nullptr, CORA_ERR_ARG, "out is null");
   *out = nullptr;
   if (!rowptr) return fail(nullptr, CORA_ERR_ARG, "null CSR pointer");
@@ -381,7 +391,8 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
   cora_ctx *c = new (std::nothrow) cora_ctx();
   if (!c) return fail(nullptr, CORA_ERR_NOMEM, "out of host memory");
   try {
-    build_format(d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, rank, world, c->F);
+    build_format(d, n_poses, n_ranges, n_trans, rowptr, colidx, vals, rank, world, c->F,
+                 (flags & CORA_PART_WHOLE_LONG_ROWS) == 0);
   } catch (const std::exception &e) {
     const std::string msg = e.what();
     delete c;
@@ -408,6 +419,11 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges, int n_tra
   const HostFormat &F = c->F;
   CREATE_TRY(to_device(&c->d_slices, F.slices));
   if (!F.slices_pose_first.empty()) CREATE_TRY(to_device(&c->d_slices_pf, F.slices_pose_first));
+  if (!F.long_rows.empty()) {
+    CREATE_TRY(to_device(&c->d_long_rows, F.long_rows));
+    CREATE_TRY(to_device(&c->d_long_owner, F.long_owner));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_long_out), F.long_rows.size() * kMaxLD * sizeof(double)));
+  }
   CREATE_TRY(to_device(&c->d_sval, F.sval));
   CREATE_TRY(to_device(&c->d_scol, F.scol));
   CREATE_TRY(to_device(&c->d_perm, F.perm));
@@ -459,7 +475,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     native_comm_destroy(c->native_comm);
     c->native_comm = nullptr;
     free_rank_state(c);
-    void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
+    void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_long_out, c->d_long_rows, c->d_long_owner, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
                     c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg};
     for (void *p : ptrs)
@@ -539,6 +555,15 @@ int cora_remote_rows(const cora_ctx *c, int32_t *rows, int64_t *count) {
       if (rows) rows[n] = static_cast<int32_t>(r);
       ++n;
     }
+  *count = n;
+  return CORA_OK;
+}
+
+int cora_long_rows(const cora_ctx *c, int32_t *api_rows, int64_t *count) {
+  if (!c || !count) return CORA_ERR_ARG;
+  const int64_t n = static_cast<int64_t>(c->F.long_rows.size());
+  if (api_rows)
+    for (int64_t j = 0; j < n; ++j) api_rows[j] = c->F.int2api[c->F.long_rows[static_cast<size_t>(j)]];
   *count = n;
   return CORA_OK;
 }
@@ -668,9 +693,7 @@ int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *d
     const int rc = comm_exchange(c, dX, ld_for(k));
     if (rc) return rc;
   }
-  const SpmmArgs A = spmm_args(c, dX, dOut);
-  HIP_TRY(c, launch_spmm(A, ld_for(k), c->F.L.d, EPI_S, c->stream));
-  return CORA_OK;
+  return launch_product(c, spmm_args(c, dX, dOut), ld_for(k), EPI_S);
 }
 
 int cora_tangent_space_projection_dev(cora_ctx *c, const double *dV, double *dOut) {
@@ -1071,8 +1094,42 @@ static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double 
     const int rc = comm_exchange(c, dX, ld);
     if (rc) return rc;
   }
-  const SpmmArgs A = spmm_args(c, dX, dOut);
+  return launch_product(c, spmm_args(c, dX, dOut), ld, epi);
+}
+
+// A product on a partitioned handle ends with its DISTRIBUTED long rows (format_build.cpp): the slots of partial sums
+// are added over the ranks -- on the device with the library's own communication, through the host with injected
+// callbacks -- and the owner copies its rows to the result; the rows' shares of kappa follow (EPI_HVP_K).
+static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi) {
+  const int nl = static_cast<int>(c->F.long_rows.size());
+  const bool dist = c->F.L.world > 1 && nl > 0;
+  if (dist) {
+    A.long_out = c->d_long_out;
+    HIP_TRY(c, hipMemsetAsync(c->d_long_out, 0, static_cast<size_t>(nl) * ld * sizeof(double), c->stream));
+  }
   HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
+  if (!dist) return CORA_OK;
+  const int n = nl * ld;
+  if (c->native_comm && c->comm_user == c->native_comm) {
+    if (native_allreduce_dev(c->native_comm, c->d_long_out, n))
+      return fail(c, CORA_ERR_HIP, "all-reduce step failed: " + native_error(c->native_comm));
+  } else if (c->comm_allreduce) {
+    std::vector<double> h(static_cast<size_t>(n));
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_long_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int at = 0; at < n; at += 512) {  // "a few doubles" per call: the callbacks' contract
+      const int rc = comm_allreduce(c, h.data() + at, std::min(512, n - at));
+      if (rc) return rc;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_long_out, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    const int rc = comm_missing(c);  // no communication: the caller adds the slots up itself (cora_long_row_slots)
+    if (rc) return rc;
+  }
+  const int kbase = launch_spmm_blocks(A);
+  HIP_TRY(c, launch_long_finish(nl, ld, c->F.L.rank, c->d_long_rows, c->d_long_owner, c->d_long_out, A.X, A.out,
+                                (epi == EPI_HVP_K && A.kappa_partial) ? A.kappa_partial + kbase : nullptr, c->stream));
   return CORA_OK;
 }
 
@@ -1424,7 +1481,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         if (sharded && (rc = comm_exchange(c, dP, c->ld))) return rc;
         SpmmArgs A = spmm_args(c, dP, dHp);
         A.kappa_partial = kappa_partial;
-        HIP_TRY(c, launch_spmm(A, c->ld, c->F.L.d, EPI_HVP_K, c->stream));
+        if ((rc = launch_product(c, A, c->ld, EPI_HVP_K))) return rc;
         if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
         if (sharded) {
           // kappa: local partials (fixed order) -> sum over the ranks -> scalar step;  then r += alpha Hp with <r, r>

@@ -94,15 +94,19 @@ struct HostFormat {
   std::vector<double> lval;
   std::vector<int32_t> lcol;
   int n_long_rows = 0;
+  // partitioned handles: the long rows are DISTRIBUTED (format_build.cpp) -- the same list on every rank: internal row
+  // and owner rank of long row j (LongChunk::slot = j); empty on one GPU
+  std::vector<int32_t> long_rows, long_owner;
   std::vector<double> diag;       // diag(Q) for LOCAL rows, indexed by (internal row - base)
   int64_t nnz_global = 0, nnz_local = 0, padded_nnz = 0, long_nnz = 0;
   int max_width = 0;
 };
 
 // Builds the partition + sliced format.  Throws std::runtime_error on invalid input.
+// distribute_long_rows (world > 1 only): see HostFormat::long_rows.
 void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
                   const int32_t *col, const double *val, int rank, int world,
-                  HostFormat &out);
+                  HostFormat &out, bool distribute_long_rows = true);
 
 // Host execution of the FORMAT (test hook, see cora_debug_format_spmm_host).
 void format_spmm_host(const HostFormat &F, const double *X_int, int ld,

@@ -75,7 +75,8 @@ void emit_slice(HostFormat &F, const std::vector<RowRef> &rows, size_t begin,
 
 void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
                   const int32_t *col, const double *val, int rank, int world,
-                  HostFormat &F) {
+                  HostFormat &F, bool distribute_long_rows) {
+  const bool dist_long = distribute_long_rows && world > 1;
   if (d != 2 && d != 3) throw std::runtime_error("cora: dimension d must be 2 or 3");
   if (n < 0 || r < 0 || nt < n) throw std::runtime_error("cora: invalid problem sizes");
   if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("cora: invalid rank/world");
@@ -124,7 +125,14 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       if (range_pose[k] >= 0) w[range_pose[k]] += rowlen(dn + k);
       else lw[range_owner[k]] += rowlen(dn + k);
     }
-    for (int j = 0; j < l; ++j) lw[lm_owner[j]] += rowlen(tb + n + j);
+    for (int j = 0; j < l; ++j) {
+      const int64_t len = rowlen(tb + n + j);
+      if (len > kLongRow && distribute_long_rows) {  // a distributed long row (below): every rank works on the columns it owns
+        for (int gg = 0; gg < world; ++gg) lw[gg] += len / world;
+      } else {
+        lw[lm_owner[j]] += len;
+      }
+    }
     const int64_t total = std::accumulate(w.begin(), w.end(), int64_t{0}) +
                           std::accumulate(lw.begin(), lw.end(), int64_t{0});
     int g = 0;
@@ -314,8 +322,55 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   {
     std::vector<RowRef> rows;
     rows.reserve(L.nl_trans);
+    // Partitioned handles: DISTRIBUTED long rows.  The columns of a landmark row span every rank (the translation
+    // and range rows of all the poses that saw the landmark), so its owner used to ask for ~10^4 remote rows of X per
+    // landmark (18 % of the vector at 8 ranks on the 10^5-pose graph).  Instead every rank multiplies the part of every
+    // long row that falls on the columns it owns -- the same list of long rows, in API order, on every rank -- into
+    // slot j of a small buffer (SpmmArgs::long_out), the buffers are summed over the ranks after the product and the
+    // owner copies its rows out (capi.hip, finish_long_rows): the exchange shrinks to the chain halo plus the
+    // landmarks' own rows of X.
+    F.long_rows.clear();
+    F.long_owner.clear();
+    if (dist_long) {
+      for (int64_t api = tb; api < N; ++api) {
+        const int len = rowlen(api);
+        if (len <= kLongRow) continue;
+        const int32_t int_row = F.api2int[api];
+        const int owner = static_cast<int>(int_row / shard);
+        const int32_t p0 = rowptr[api];
+        const int32_t k_begin = static_cast<int32_t>(F.lval.size());
+        for (int k = 0; k < len; ++k) {
+          const int32_t ic = F.api2int[col[p0 + k]];
+          if (ic / shard != rank) continue;
+          F.lval.push_back(val[p0 + k]);
+          F.lcol.push_back(ic);
+        }
+        const int mylen = static_cast<int>(F.lval.size()) - k_begin;
+        const int nch = (mylen + g_long_chunk - 1) / g_long_chunk;  // 0: nothing of this row on this rank
+        const int32_t first = static_cast<int32_t>(F.chunks.size());
+        for (int c = 0; c < nch; ++c) {
+          LongChunk ch{};
+          ch.row = int_row;
+          ch.k0 = k_begin + c * g_long_chunk;
+          ch.k1 = k_begin + std::min(mylen, (c + 1) * g_long_chunk);
+          ch.nchunks = nch;
+          ch.first = first;
+          ch.slot = F.n_long_rows;
+          F.chunks.push_back(ch);
+        }
+        F.long_rows.push_back(int_row);
+        F.long_owner.push_back(owner);
+        F.n_long_rows++;
+        F.long_nnz += mylen;
+        F.nnz_local += mylen;  // (the owner's local_row() below counts the whole row: taken back there)
+      }
+    }
     for (int64_t i = 0; i < L.nl_trans; ++i) {
       RowRef rr = local_row(L.trn_base + i);
+      if (rr.len > kLongRow && dist_long) {  // distributed above (local_row() has taken its diagonal)
+        F.nnz_local -= rr.len;
+        continue;
+      }
       if (rr.len > kLongRow) {
         const int32_t p0 = rowptr[rr.api_row];
         const int32_t k_begin = static_cast<int32_t>(F.lval.size());

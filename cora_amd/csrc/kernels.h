@@ -38,6 +38,9 @@ struct SpmmArgs {
   // EPI_HVP_K: [launch_spmm_kappa_slots()] one partial sum of <X, out> per block, then one per long row (written by
   // whichever chunk finishes the row -- a fixed slot whatever the arrival order)
   double *kappa_partial = nullptr;
+  // partitioned handles: [n_long_rows][ld] partial sums of the DISTRIBUTED long rows (zeroed before the launch, summed
+  // over the ranks after it: capi.hip, finish_long_rows); nullptr: long rows are whole and written to `out`
+  double *long_out = nullptr;
   int n_long_rows = 0;      // set by the caller (HostFormat::n_long_rows)
   int kappa_long_base = 0;  // filled by launch_spmm
 
@@ -243,6 +246,10 @@ hipError_t launch_scale_rows(int64_t rows, int ld, const double *scale, const do
 hipError_t launch_dots(const DotArgs &D, int *nblocks, hipStream_t st);
 hipError_t launch_reduce_partials(const double *partial, int nblocks, int count, double *out,
                                   hipStream_t st);
+// distributed long rows after the sum over the ranks: owner copies slot j -> out[rows[j]]; kappa != nullptr: kappa[j] = the
+// row's share of <X, out> (0 on the other ranks)
+hipError_t launch_long_finish(int n_long, int ld, int rank, const int32_t *rows, const int32_t *owner, const double *slots,
+                              const double *X, double *out, double *kappa, hipStream_t st);
 hipError_t launch_has_nan(int64_t n, const double *x, int *flag, hipStream_t st);
 // mode 0: dst[k] = src[rows[k]];  1: dst[rows[k]] = src[k];  2: dst[rows[k]] = src[rows[k]]  (rows of ld doubles)
 hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, const double *src, double *dst,

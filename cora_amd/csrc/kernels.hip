@@ -206,9 +206,12 @@ __device__ __forceinline__ void long_chunk_wave(const SpmmArgs &A, int ci) {
     const double v0 = __shfl(v, 0, 64);
     if (lane == j) tot = v0;
   }
-  double *orow = A.out + static_cast<size_t>(ch.row) * LD;
+  // partitioned handles: the row is distributed -- this rank's part of it goes to slot ch.slot of long_out, to be summed
+  // over the ranks (the row's share of kappa follows the sum: k_long_finish)
+  double *orow = A.long_out ? A.long_out + static_cast<size_t>(ch.slot) * LD : A.out + static_cast<size_t>(ch.row) * LD;
   auto publish_kappa = [&](double row_j) {  // row_j: out[row][lane] in the lanes below LD
     if constexpr (KAPPA) {
+      if (A.long_out) return;  // wave-uniform
       const double t = wave_sum(lane < LD ? row_j * A.X[static_cast<size_t>(ch.row) * LD + lane] : 0.0);
       if (lane == 0) A.kappa_partial[A.kappa_long_base + ch.slot] = t;
     }
@@ -1258,6 +1261,29 @@ __global__ __launch_bounds__(256) void k_move_rows(int mode, int64_t n, int ld, 
     if (mode == 0) dst[t] = src[at];
     else if (mode == 1) dst[at] = src[t];
     else dst[at] = src[at];
+  }
+}
+
+// Distributed long rows of a partitioned handle, after their partial sums have been added over the ranks: the owner of
+// long row j copies slot j to its row of the result; with kappa != nullptr EVERY rank writes the row's kappa slot
+// (<X[row], out[row]> on the owner, 0 elsewhere -- every slot of a launch is written).  One wavefront per row.
+__global__ __launch_bounds__(64) void k_long_finish(int n_long, int ld, int rank, const int32_t *__restrict__ rows,
+                                                    const int32_t *__restrict__ owner, const double *__restrict__ slots,
+                                                    const double *__restrict__ X, double *__restrict__ out,
+                                                    double *__restrict__ kappa) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (j >= n_long) return;
+  const bool mine = owner[j] == rank;
+  double k = 0.0;
+  if (mine && lane < ld) {
+    const size_t at = static_cast<size_t>(rows[j]) * ld + lane;
+    const double v = slots[static_cast<size_t>(j) * ld + lane];
+    out[at] = v;
+    if (kappa) k = v * X[at];
+  }
+  if (kappa) {
+    k = wave_sum(k);
+    if (lane == 0) kappa[j] = k;
   }
 }
 
@@ -2574,6 +2600,13 @@ hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, co
                             hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * ld)), dim3(256), 0, st, mode, n, ld, rows, src, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_long_finish(int n_long, int ld, int rank, const int32_t *rows, const int32_t *owner, const double *slots,
+                              const double *X, double *out, double *kappa, hipStream_t st) {
+  if (n_long <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_long_finish, dim3(n_long), dim3(64), 0, st, n_long, ld, rank, rows, owner, slots, X, out, kappa);
   return hipGetLastError();
 }
 

@@ -75,6 +75,14 @@ int cora_ctx_create_part(int device, int d, int n_poses, int n_ranges,
                          int n_trans, const int32_t *rowptr,
                          const int32_t *colidx, const double *vals, int rank,
                          int world, cora_ctx **out);
+/* The same with options.  CORA_PART_WHOLE_LONG_ROWS: keep the long (landmark) rows whole on their owner, as rounds 1-2
+ * did -- the owner then reads ~10^4 remote rows of X per landmark (cora_remote_rows), but a handle WITHOUT communication
+ * computes complete rows of its shard by itself (the caller keeps the remote rows current).  Default (flags = 0): the
+ * long rows are distributed (cora_long_rows) and need the all-reduce of cora_comm_create_* / cora_set_comm. */
+#define CORA_PART_WHOLE_LONG_ROWS 1u
+int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int n_trans, const int32_t *rowptr,
+                              const int32_t *colidx, const double *vals, int rank, int world, unsigned flags,
+                              cora_ctx **out);
 
 void cora_ctx_destroy(cora_ctx *ctx);
 
@@ -104,6 +112,12 @@ int cora_row_map(const cora_ctx *ctx, int32_t *api_to_internal);
  * have to arrive before a product, so the exchange step can all-gather them instead of whole shards
  * (cora_amd/dist.py).  rows may be NULL to query the count. */
 int cora_remote_rows(const cora_ctx *ctx, int32_t *rows, int64_t *count);
+/* Partitioned handles: the DISTRIBUTED long rows (API row indices, the same list on every rank; empty on one GPU).
+ * The columns of such a row -- a landmark's translation row -- span every rank, so every rank multiplies the part of
+ * the row on the columns it owns and the partial sums are added over the ranks after the product (by the library with
+ * cora_comm_create_* / cora_set_comm); the row's owner then holds the result.  A rank therefore asks for no remote rows
+ * of X on behalf of these rows: cora_remote_rows() is the chain halo plus the landmarks' own rows. */
+int cora_long_rows(const cora_ctx *ctx, int32_t *api_rows, int64_t *count);
 
 /* Statistics of the device format: [0] slices, [1] padded nnz stored in
  * slices, [2] nnz in long rows, [3] long rows, [4] long-row chunks,

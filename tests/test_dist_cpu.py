@@ -46,6 +46,11 @@ def _worker(rank, world, port, q, rows_mode):
             xi = full_x.numpy().reshape(rows, ld)
             X = np.asfortranarray(xi[m][:, :k])
             out = ctx.debug_format_spmm_host(X)
+            lr = ctx.long_rows()   # distributed long rows: partial sums, added over the ranks
+            if len(lr):
+                t = torch.from_numpy(np.ascontiguousarray(out[lr]))
+                dist.all_reduce(t)
+                out[lr] = t.numpy()
             oi = full_out.numpy().reshape(rows, ld)
             mine = (m >= rank * shard) & (m < (rank + 1) * shard)
             oi[m[mine], :k] = out[mine]
@@ -157,6 +162,11 @@ def _comm_worker(rank, world, port, q):
             comm.exchange(buf.ctypes.data, ld)                     # the callback the library would call
             Xfull = np.where(np.isnan(buf[m][:, :k]), 0.0, buf[m][:, :k])
             out = ctx.debug_format_spmm_host(np.asfortranarray(Xfull))
+            lr = ctx.long_rows()   # distributed long rows: partial sums, added over the ranks
+            if len(lr):
+                t = torch.from_numpy(np.ascontiguousarray(out[lr]))
+                dist.all_reduce(t)
+                out[lr] = t.numpy()
             res = np.full_like(X, np.nan)
             res[mine] = out[mine] + X[mine]
             return res

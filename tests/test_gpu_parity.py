@@ -153,8 +153,10 @@ def test_rank_change_and_errors():
 
 
 def test_partitioned_handles_match_single():
-    """Row-partitioned handles (the multi-GPU layout) on one device: each rank's
-    Hvp shard equals the single-handle result."""
+    """Row-partitioned handles (the multi-GPU layout) on one device WITHOUT communication (the caller keeps the remote
+    rows current): each rank's Hvp shard equals the single-handle result.  Such handles keep their long (landmark) rows
+    whole (CORA_PART_WHOLE_LONG_ROWS); the default distributes them and needs the all-reduce of the communication
+    (tests/test_gpu_sharded.py)."""
     A, Q, dm = make_problem(d=3, n=800, n_landmarks=4, n_ranges=500, n_loops=10, seed=6)
     p = 5
     rng = np.random.default_rng(8)
@@ -165,7 +167,7 @@ def test_partitioned_handles_match_single():
     total = np.zeros_like(ref)
     fsum = 0.0
     for rank in range(world):
-        c = ctx_for(Q, dm, p, rank=rank, world=world)
+        c = ctx_for(Q, dm, p, rank=rank, world=world, whole_long_rows=True)
         c.set_point(Y)
         fsum += c.point_cost()
         x, o = c.dev_alloc(p), c.dev_alloc(p)
