@@ -1018,22 +1018,29 @@ int cora_precond_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32
                               const int32_t *perm) {
   NEED_DEVICE(c);
   const int64_t N = c->F.L.N;
-  if (c->F.L.world != 1)
-    return fail(c, CORA_ERR_ARG, "the Cholesky preconditioner does not shard (sequential triangular solves): "
-                                 "use Jacobi on partitioned handles");
-  if (!Lp || !Li || !Lx || !perm || (m != N && m != N - 1))
-    return fail(c, CORA_ERR_ARG, "factor must have N or N-1 rows");
+  const Layout &Lo = c->F.L;
+  // Partitioned handle: the factor is the one of THIS RANK'S rows -- the diagonal block of (Q + lambda I) on the rows
+  // of its shard, all of them or all but one (the pinned variable, if it lives here): block Jacobi over the ranks.
+  const bool sharded = Lo.world != 1;
+  const int64_t owned = sharded ? Lo.local_rows : N;
+  if (!Lp || !Li || !Lx || !perm || (m != owned && m != owned - 1))
+    return fail(c, CORA_ERR_ARG, sharded ? "factor must cover the rank's own rows (all, or all but the pinned one)"
+                                         : "factor must have N or N-1 rows");
   std::vector<int32_t> row_of(static_cast<size_t>(m));
   std::vector<char> seen(static_cast<size_t>(N), 0);
   for (int i = 0; i < m; ++i) {
     if (perm[i] < 0 || perm[i] >= N || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
     seen[perm[i]] = 1;
     row_of[i] = c->F.api2int[perm[i]];
+    if (sharded && (row_of[i] < Lo.base || row_of[i] >= Lo.base + Lo.shard_rows))
+      return fail(c, CORA_ERR_ARG, "the factor of a partitioned handle may only hold rows of its own shard");
   }
   int32_t zero_row = -1;  // blockCholeskySolve: last row zeroed, src/CORA_preconditioners.cpp:78-79
-  if (m == N - 1)
-    for (int64_t i = 0; i < N; ++i)
-      if (!seen[i]) zero_row = c->F.api2int[i];
+  if (m == owned - 1)
+    for (int64_t i = 0; i < N; ++i) {
+      const int32_t ir = c->F.api2int[i];
+      if (!seen[i] && (!sharded || (ir >= Lo.base && ir < Lo.base + Lo.shard_rows))) zero_row = ir;
+    }
   // the d rotation rows of a pose stay in one block of the solve plan (row-unit work can then be fused into it)
   std::vector<int32_t> group(static_cast<size_t>(m), -1);
   const int64_t dn = static_cast<int64_t>(c->F.L.d) * c->F.L.n;
@@ -1311,7 +1318,9 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
 // vector -- allocations are zeroed and no kernel writes them -- and add nothing to an update or an inner product.
 static bool stpcg_device_ok(const cora_ctx *c) {
   if (c->F.L.world == 1) return true;
-  return c->native_comm && !c->implicit && c->ld <= 12 && (c->precond == CORA_PRECOND_JACOBI || c->precond == CORA_PRECOND_NONE);
+  const bool chol = c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY;
+  return c->native_comm && !c->implicit && c->ld <= 12 &&
+         (c->precond == CORA_PRECOND_JACOBI || c->precond == CORA_PRECOND_NONE || (chol && c->precond_f.ready));
 }
 
 // Steihaug-Toint truncated PCG for  min <g,s> + 1/2 <s,Hs>,  ||s||_M <= Delta, entirely on the device
@@ -1335,7 +1344,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // and looks at the pinned mirror between batches, exactly as on one GPU.
   const bool sharded = c->F.L.world != 1;
   if (sharded && !stpcg_device_ok(c))
-    return fail(c, CORA_ERR_ARG, "the device-resident STPCG on a partitioned handle needs cora_comm_create_* and a Jacobi / no preconditioner");
+    return fail(c, CORA_ERR_ARG, "the device-resident STPCG on a partitioned handle needs cora_comm_create_* and the explicit formulation");
   int rc;
   double rr_rv[2];
   if (dPg) {  // s = 0, r = g, p = -P g in one pass
@@ -1498,7 +1507,12 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           Ds.out = ds + 2;
           HIP_TRY(c, launch_stpcg_residual(Ds, n, dHp + off, dR + off, c->stream));
           Ds.out = ds + 3;
-          HIP_TRY(c, launch_tangent_project_dot(row_args(c), Ds, c->ld, c->d_Y, dR, c->precond == CORA_PRECOND_JACOBI ? c->d_diag_inv : nullptr,
+          const double *xs = dR;  // what is projected: r (none), D^-1 r (Jacobi, scaled in the pass), or the rank's own
+          if (chol) {             // Cholesky solve of its diagonal block (block Jacobi over the ranks)
+            if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;
+            xs = dV;
+          }
+          HIP_TRY(c, launch_tangent_project_dot(row_args(c), Ds, c->ld, c->d_Y, xs, c->precond == CORA_PRECOND_JACOBI ? c->d_diag_inv : nullptr,
                                                 dR, dV, c->stream));
           if (native_allreduce_dev(c->native_comm, ds + 2, 2)) return fail(c, CORA_ERR_HIP, "all-reduce step failed: " + native_error(c->native_comm));
           seq = ++c->dot_seq;

@@ -406,9 +406,58 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
       if (timing) std::fprintf(stderr, "  [precond] %-26s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
       t_prev = now;
     };
-    const auto perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(),
-                                   data_matrix_, m, leaf);
+    // Partitioned handle: the exact solve is a sequential recurrence over the whole chain and does not shard, so the
+    // preconditioner becomes BLOCK JACOBI OVER THE RANKS -- every rank factorises the diagonal block of its own rows of
+    // (Q + lambda I) and applies it to its own rows with the same device solve plan.  The rows a rank owns,
+    // in API order, are the rotation rows of its poses | its range rows | its translations: the block is the data
+    // matrix of a smaller problem of the same shape, so the ordering, the factorisation and the plan are the ones above.
+    const bool sharded = part_world_ > 1;
+    std::vector<int32_t> own;      // API rows of this rank, ascending (sharded)
+    std::vector<int32_t> to_local; // API row -> index in `own`, -1 elsewhere
+    int n_loc = numPoses(), r_loc = static_cast<int>(numRangeMeasurements()), nt_loc = static_cast<int>(numTranslationalStates());
+    int m_fac = m;
+    auto local_block = [&](const SparseMatrix &A) {  // A[own, own] in local numbering
+      std::vector<Triplet> t;
+      for (size_t k = 0; k < own.size(); ++k)
+        for (int32_t q = A.outer[own[k]]; q < A.outer[own[k] + 1]; ++q) {
+          const int32_t j = to_local[A.inner[q]];
+          if (j >= 0) t.push_back({static_cast<Index>(k), static_cast<Index>(j), A.values[q]});
+        }
+      SparseMatrix B(static_cast<Index>(own.size()), static_cast<Index>(own.size()));
+      B.setFromTriplets(std::move(t));
+      return B;
+    };
+    if (sharded) {
+      std::vector<int32_t> map(static_cast<size_t>(N));
+      if (cora_row_map(ctx_.get(), map.data()) != CORA_OK) throwLast(CORA_ERR_ARG, "Problem::updatePreconditioner");
+      const int64_t lo = cora_shard_begin(ctx_.get()), hi = lo + cora_shard_rows(ctx_.get());
+      to_local.assign(static_cast<size_t>(N), -1);
+      const Index b1 = numPosesDim(), b2 = rotAndRangeMatrixSize(), b3 = b2 + numPoses();
+      n_loc = r_loc = nt_loc = 0;
+      for (Index i = 0; i < N; ++i)
+        if (map[i] >= lo && map[i] < hi) {
+          to_local[i] = static_cast<int32_t>(own.size());
+          own.push_back(static_cast<int32_t>(i));
+          if (i < b1) n_loc += (i % dim_ == 0);
+          else if (i < b2) ++r_loc;
+          else ++nt_loc;
+          (void)b3;
+        }
+      const bool owns_pin = pin_last_translation_ && to_local[N - 1] >= 0;  // the pinned variable is this rank's last row
+      m_fac = static_cast<int>(own.size()) - (owns_pin ? 1 : 0);
+    }
+    std::vector<int32_t> perm;
+    if (!sharded) perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_, m, leaf);
     tick("ordering");
+    // factorisation of the whole matrix, or of this rank's diagonal block (F.perm then holds API rows again)
+    auto factorise = [&](const SparseMatrix &A, double shift) {
+      if (!sharded) return choleskyFactor(A, m, shift, perm);
+      const SparseMatrix B = local_block(A);
+      const auto lperm = coraOrdering(dim_, n_loc, r_loc, nt_loc, B, m_fac, leaf);
+      CholeskyFactor Fl = choleskyFactor(B, m_fac, shift, lperm);
+      for (int32_t &q : Fl.perm) q = own[static_cast<size_t>(q)];
+      return Fl;
+    };
     CholeskyFactor F;
     if (kind == CORA_PRECOND_REGULARIZED_CHOLESKY) {
       // lambda_reg = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 or CORA_REG_CHOLESKY_MAX_COND (:581-591)
@@ -423,7 +472,7 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
       }
       precond_lambda_ = Dnorm / (max_cond - 1);
       tick("spectral norm (device)");
-      F = choleskyFactor(data_matrix_, m, precond_lambda_, perm);
+      F = factorise(data_matrix_, precond_lambda_);
       tick("factorisation");
     } else {
       // documented semantics (include/CORA/CORA_preconditioners.h:28-44): independent factors of the
@@ -438,7 +487,7 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
       SparseMatrix D(N, N);
       D.setFromTriplets(std::move(t));
       precond_lambda_ = 1e-3;
-      F = choleskyFactor(D, m, 1e-3, perm);
+      F = factorise(D, 1e-3);
     }
     if (!F.ok) throw std::runtime_error("Problem::updatePreconditioner: regularised data matrix is not positive definite");
     precond_nnz_ = static_cast<long>(F.nnz());
@@ -452,7 +501,7 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
       precond_levels_ = h;
     }
     tick("tree height");
-    const int rc = cora_precond_set_cholesky(ctx_.get(), m, F.Lp.data(), F.Li.data(), F.Lx.data(), F.perm.data());
+    const int rc = cora_precond_set_cholesky(ctx_.get(), sharded ? m_fac : m, F.Lp.data(), F.Li.data(), F.Lx.data(), F.perm.data());
     if (rc != CORA_OK) throwLast(rc, "Problem::updatePreconditioner");
     tick("solve plan + upload");
   }

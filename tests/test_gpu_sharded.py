@@ -256,3 +256,62 @@ def test_eight_partitions_tnt_and_certification_at_full_size():
     print("\n8 partitions at 10^5 poses: f=%.6f (single %.6f), %d Hvps, certified=%s theta=%.3e (single %.3e), %d of %d rows exchanged"
           % (outs[0][0]["f"], single["f"], outs[0][0]["hvps"], outs[0][1]["is_certified"], outs[0][1]["theta"], cert1["theta"],
              outs[0][3], outs[0][4]))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_block_jacobi_cholesky_on_partitions(world):
+    """RegularizedCholesky on a partitioned Problem = block Jacobi over the ranks: every rank factorises the diagonal
+    block of ITS rows of Q + lambda I (same ordering, factorisation and device solve plan as the single-GPU
+    preconditioner, src/CORA_problem.cpp:544-614 per shard) and applies it to its own rows.  Checked against a dense
+    solve of each rank's block; TNT with it (device-resident STPCG, the
+    solve between the residual update and the projection) reaches the single handle's converged cost."""
+    n, p = 500, 4
+
+    gt_box = []
+
+    def make(precond):
+        P, gt = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=4, n_ranges=n, seed=31, precond=precond, ground_truth=True)
+        P.update()
+        P.set_rank(p)
+        gt_box.append(gt)
+        return P
+    P1 = make(capi.PRECOND_REGULARIZED_CHOLESKY)
+    dm = P1.dims()
+    _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    lam = P1.precond_info()["lam"]
+    rng = np.random.default_rng(9)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dm["N"], p)))
+    V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, (dm["N"], p)))
+    # TNT from where a front end would leave the problem (the generator's ground truth): both preconditioners converge
+    gt = gt_box[0]
+    Y0 = P1.op("projectToManifold", np.hstack([gt, np.zeros((gt.shape[0], p - gt.shape[1]))]))
+    single = P1.tnt(Y0)
+    A = Q.to_scipy().toarray() + lam * np.eye(dm["N"])
+
+    def body(r, group):
+        P = make(capi.PRECOND_REGULARIZED_CHOLESKY)
+        P.set_partition(r, world, lambda ctx: NativeLocalComm(ctx, group))
+        ctx = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+        m = ctx.row_map()
+        mine = (m >= ctx.shard_begin) & (m < ctx.shard_begin + ctx.shard_rows)
+        info = P.precond_info()
+        PV = P.op("precondition", V)     # Problem::precondition: the solve alone (src/CORA_problem.cpp:869-903)
+        res = P.tnt(Y0)
+        return mine, info["lam"], PV, res, ctx.stpcg_path()
+
+    outs = _run_ranks(world, body, "native")
+    ref = np.zeros_like(V)
+    for mine, lam_r, PV, res, path in outs:
+        assert abs(lam_r - lam) < 1e-9 * lam and path == 1
+        idx = np.flatnonzero(mine)
+        if mine[dm["N"] - 1]:
+            idx = idx[idx != dm["N"] - 1]          # the pinned variable stays zero (src/CORA_preconditioners.cpp:78-79)
+        ref[idx] = np.linalg.solve(A[np.ix_(idx, idx)], V[idx])
+    for mine, lam_r, PV, res, path in outs:
+        assert np.abs(PV - ref).max() < 1e-9 * np.abs(ref).max()   # the collective download returns every rank's rows
+        # both stop on TNT's relative-decrease test (1e-6): the converged costs agree to that
+        assert abs(res["f"] - single["f"]) < 1e-5 * abs(single["f"])
+    print("\nblock-Jacobi Cholesky, %d ranks: f=%.8f in %d products (one factor: f=%.8f in %d)"
+          % (world, outs[0][3]["f"], outs[0][3]["hvps"], single["f"], single["hvps"]))
