@@ -116,7 +116,8 @@ struct cora_ctx {
   double prof_hvp_us = 0.0;
   int prof_hvp_count = 0;
   int stpcg_path = 0;  // iteration form of the last cora_stpcg_dev: 0 unfused, 1 fused vector passes, 2 sweep-fused
-  std::vector<void *> user_allocs;
+  std::vector<std::pair<double *, size_t>> user_allocs;  // live vectors of cora_dev_alloc (pointer, bytes)
+  std::vector<std::pair<double *, size_t>> pool;         // released ones, kept for the next request of the same size
   std::string err;
 };
 
@@ -482,8 +483,10 @@ void cora_ctx_destroy(cora_ctx *c) {
       if (p) (void)hipFree(p);
     for (int i = 0; i < kScratchSlots; ++i)
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    for (void *p : c->user_allocs)
-      if (p) (void)hipFree(p);
+    for (auto &p : c->user_allocs)
+      if (p.first) (void)hipFree(p.first);
+    for (auto &p : c->pool)
+      if (p.first) (void)hipFree(p.first);
     for (auto *f : {&c->precond_f, &c->implicit_f, &c->aux_f})
       for (void *p : f->allocs)
         if (p) (void)hipFree(p);
@@ -593,23 +596,45 @@ int cora_format_stats(const cora_ctx *c, int64_t s[8]) {
 
 // ------------------------------------------------------------ resident API
 
+// Resident vectors come from a small per-handle pool: TNT, the saddle escape and LOBPCG allocate and release 4-10
+// vectors per call, three to six calls per staircase level, and every hipMalloc / hipFree is a device-wide
+// synchronisation (a failed certification at 10^5 poses spent more time in them than in its eigensolver iterations).
+// A released vector is kept (up to kPoolMax of them) and handed to the next request of the same size, zeroed on the
+// handle's stream like a fresh one; everything returns to the driver with the handle.
 int cora_dev_alloc(cora_ctx *c, int k, double **dptr) {
   NEED_DEVICE(c);
   if (!dptr || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
   const size_t bytes = vec_bytes(c, ld_for(k));
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(dptr), bytes));
+  *dptr = nullptr;
+  for (size_t i = 0; i < c->pool.size(); ++i)
+    if (c->pool[i].second == bytes) {
+      *dptr = c->pool[i].first;
+      c->pool.erase(c->pool.begin() + static_cast<std::ptrdiff_t>(i));
+      break;
+    }
+  if (!*dptr) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(dptr), bytes));
   HIP_TRY(c, hipMemsetAsync(*dptr, 0, bytes, c->stream));
-  c->user_allocs.push_back(*dptr);
+  for (auto &p : c->user_allocs)
+    if (!p.first) {
+      p = {*dptr, bytes};
+      return CORA_OK;
+    }
+  c->user_allocs.push_back({*dptr, bytes});
   return CORA_OK;
 }
 
 int cora_dev_free(cora_ctx *c, double *dptr) {
   NEED_DEVICE(c);
+  constexpr size_t kPoolMax = 16;
   for (auto &p : c->user_allocs)
-    if (p == dptr) {
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      (void)hipFree(dptr);
-      p = nullptr;
+    if (p.first == dptr && dptr) {
+      if (c->pool.size() < kPoolMax) {
+        c->pool.push_back(p);  // work already enqueued on the handle's stream is ordered before any reuse
+      } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(dptr);
+      }
+      p = {nullptr, 0};
       return CORA_OK;
     }
   return fail(c, CORA_ERR_ARG, "pointer was not allocated by cora_dev_alloc");
