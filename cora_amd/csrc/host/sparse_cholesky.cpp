@@ -45,17 +45,97 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
     for (int a = 0; a < d; ++a) perm.push_back(static_cast<int32_t>(static_cast<int64_t>(i) * d + a));
     perm.push_back(static_cast<int32_t>(tb + i));
   };
-  std::function<void(int, int)> nd = [&](int lo, int hi) {  // poses [lo, hi)
-    if (hi - lo <= leaf_poses) {
-      for (int i = lo; i < hi; ++i) emit_pose(i);
-      return;
+  // The pose graph: poses i ~ j when their translations are coupled in Q33 (an odometry edge, a loop closure, a range
+  // between two poses).  On a single chain in index order -- every synthetic graph, plaza, single_drone -- nested
+  // dissection is a bisection of the index range with one pose as separator.  Anything else (several robots whose
+  // chains follow each other in the index order and are tied together by inter-robot ranges: tiers, MR.CLAM) gets a
+  // nested dissection by BFS level sets below: bisecting THEIR index range leaves every inter-robot edge across the
+  // cut, and the fill (tiers: 22 s of factorisation, an explicit inverse of 134 s) is what the chain order avoids.
+  std::vector<std::vector<int32_t>> adj(static_cast<size_t>(n));
+  bool index_chain = true;
+  for (int i = 0; i < n; ++i)
+    for (int32_t q = Q.outer[tb + i]; q < Q.outer[tb + i + 1]; ++q) {
+      const int64_t c = Q.inner[q] - tb;
+      if (c < 0 || c >= n || c == i) continue;
+      adj[static_cast<size_t>(i)].push_back(static_cast<int32_t>(c));
+      if (c != i - 1 && c != i + 1) index_chain = false;
     }
-    const int mid = lo + (hi - lo) / 2;
-    nd(lo, mid);
-    nd(mid + 1, hi);
-    emit_pose(mid);
-  };
-  nd(0, n);
+  if (index_chain) {
+    std::function<void(int, int)> nd = [&](int lo, int hi) {  // poses [lo, hi)
+      if (hi - lo <= leaf_poses) {
+        for (int i = lo; i < hi; ++i) emit_pose(i);
+        return;
+      }
+      const int mid = lo + (hi - lo) / 2;
+      nd(lo, mid);
+      nd(mid + 1, hi);
+      emit_pose(mid);
+    };
+    nd(0, n);
+  } else {
+    // Nested dissection by level sets: BFS from a pseudo-peripheral pose of the piece, the level that splits it in
+    // half is the separator (for robots that move side by side and range each other at equal times a level is one
+    // pose per robot), both halves recurse, the separator is eliminated last.  Pieces of at most leaf_poses poses are
+    // emitted in BFS order (chain neighbours stay next to each other).  Deterministic: ties by pose index.
+    std::vector<int32_t> member(static_cast<size_t>(n), 0), level(static_cast<size_t>(n), -1);
+    int32_t stamps = 0;
+    // BFS over the vertices whose member[] is `stamp`, from `root`: sets level[], returns the order of visit
+    auto bfs = [&](int32_t root, int32_t stamp, std::vector<int32_t> &order) {
+      order.clear();
+      order.push_back(root);
+      level[static_cast<size_t>(root)] = 0;
+      for (size_t h = 0; h < order.size(); ++h) {
+        const int32_t u = order[h];
+        for (int32_t v : adj[static_cast<size_t>(u)])
+          if (member[static_cast<size_t>(v)] == stamp && level[static_cast<size_t>(v)] < 0) {
+            level[static_cast<size_t>(v)] = level[static_cast<size_t>(u)] + 1;
+            order.push_back(v);
+          }
+      }
+    };
+    std::function<void(std::vector<int32_t> &)> dissect = [&](std::vector<int32_t> &S) {
+      if (S.empty()) return;
+      std::sort(S.begin(), S.end());
+      const int32_t stamp = ++stamps;
+      for (int32_t v : S) {
+        member[static_cast<size_t>(v)] = stamp;
+        level[static_cast<size_t>(v)] = -1;
+      }
+      std::vector<int32_t> comp;
+      for (int32_t seed : S) {  // connected components, in order of their smallest pose
+        // (vertices handed to a recursive call carry a later stamp; emitted ones and separators keep level >= 0)
+        if (member[static_cast<size_t>(seed)] != stamp || level[static_cast<size_t>(seed)] >= 0) continue;
+        bfs(seed, stamp, comp);
+        for (int pass = 0; pass < 2; ++pass) {  // pseudo-peripheral root: restart from the last vertex reached
+          const int32_t far = comp.back();
+          for (int32_t v : comp) level[static_cast<size_t>(v)] = -1;
+          bfs(far, stamp, comp);
+        }
+        const int depth = level[static_cast<size_t>(comp.back())] + 1;
+        if (static_cast<int>(comp.size()) <= leaf_poses || depth < 3) {
+          for (int32_t v : comp) emit_pose(v);
+          continue;
+        }
+        // the level at which the running count passes half of the component (never the first or the last level)
+        std::vector<int64_t> count(static_cast<size_t>(depth), 0);
+        for (int32_t v : comp) count[static_cast<size_t>(level[static_cast<size_t>(v)])]++;
+        int cut = 1;
+        int64_t run = count[0];
+        while (cut < depth - 2 && 2 * (run + count[static_cast<size_t>(cut)]) < static_cast<int64_t>(comp.size())) run += count[static_cast<size_t>(cut++)];
+        std::vector<int32_t> A, B, sep;
+        for (int32_t v : comp) {
+          const int l = level[static_cast<size_t>(v)];
+          (l < cut ? A : (l > cut ? B : sep)).push_back(v);
+        }
+        dissect(A);
+        dissect(B);
+        for (int32_t v : sep) emit_pose(v);
+      }
+    };
+    std::vector<int32_t> all(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) all[static_cast<size_t>(i)] = i;
+    dissect(all);
+  }
   for (int j = n; j < nt; ++j) perm.push_back(static_cast<int32_t>(tb + j));
   if (m == N - 1) {  // drop the pinned last variable (src/CORA_problem.cpp:602-609)
     std::vector<int32_t> q;

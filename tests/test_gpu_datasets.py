@@ -112,3 +112,32 @@ def test_reference_call_sequence_binary_solves_plaza2(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("cost ")][-1].split()
     assert abs(float(line[1]) - 734.328) < 2e-3      # run_utils/parse_data.py:40 of the reference
     assert int(line[3]) == 14084
+
+
+@pytest.mark.parametrize("name", ["plaza1", "tiers", "mrclam3b", "mrclam5a", "mrclam6"])
+def test_every_other_dataset_of_the_reference_solves(name):
+    """The rest of examples/data (plaza1, tiers, the three MR.CLAM files present in the reference's tree; data files
+    copied to tests/golden/datasets): examples/main.cpp's flow -- parse, updateProblemData, random start, solveCORA with
+    the reference's default RegularizedCholesky preconditioner -- on every one of them.  The reference records no value
+    for these; checked: assembly against the oracle's, the returned point is feasible, its cost is the oracle's, the
+    certificate decision is the oracle's Cholesky test at the same eta, and the staircase ended certified at some rank."""
+    path = os.path.join(DATA, name + ".pyfg")
+    P = host.Problem.from_pyfg(path)
+    P.update()
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    A = asm.assemble(asm.parse_pyfg(path))
+    assert abs(A["Q"] - Q.to_scipy()).max() < 1e-9 * abs(A["Q"]).max()
+    P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
+    x0 = P.op("getRandomInitialGuess")
+    res = P.solve(x0, max_rank=10, max_seconds=120)
+    X = res["x"]
+    assert X.shape == (dims.N, dims.d)
+    assert np.abs(X - orc.project_manifold(dims, X)).max() < 1e-9
+    assert abs(orc.cost(Q, X) - res["f"]) < 1e-8 * max(1.0, abs(res["f"]))
+    assert res["f"] < 1e-2 * orc.cost(Q, orc.project_manifold(dims, x0))
+    print("\n%s: d=%d n=%d l=%d r=%d N=%d nnz=%d | f=%.6f |g|=%.2e certified=%s levels=%d final rank %d hvps=%d %.3fs" % (
+        name, dm["d"], dm["n"], dm["l"], dm["r"], dm["N"], dm["nnz"], res["f"], res["grad_norm"], res["certified"],
+        res["levels"], res["final_rank"], res["hvps"], res["seconds"]))
