@@ -48,6 +48,7 @@ struct cora_ctx {
   SliceDesc *d_slices = nullptr;
   SliceDesc *d_slices_pf = nullptr;  // HostFormat::slices_pose_first (empty: nullptr)
   double *d_sval = nullptr;
+  double *d_head_val = nullptr;  // HostFormat::head_val
   int32_t *d_scol = nullptr;
   int32_t *d_perm = nullptr;
   LongChunk *d_chunks = nullptr;
@@ -229,6 +230,7 @@ SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
   A.n_slices = static_cast<int>(c->F.slices.size());
   A.n_chunks = static_cast<int>(c->F.chunks.size());
   A.sval = c->d_sval;
+  A.head_val = c->d_head_val;
   A.scol = c->d_scol;
   A.perm = c->d_perm;
   A.chunks = c->d_chunks;
@@ -420,6 +422,7 @@ int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int 
   const HostFormat &F = c->F;
   CREATE_TRY(to_device(&c->d_slices, F.slices));
   if (!F.slices_pose_first.empty()) CREATE_TRY(to_device(&c->d_slices_pf, F.slices_pose_first));
+  CREATE_TRY(to_device(&c->d_head_val, F.head_val));
   if (!F.long_rows.empty()) {
     CREATE_TRY(to_device(&c->d_long_rows, F.long_rows));
     CREATE_TRY(to_device(&c->d_long_owner, F.long_owner));
@@ -476,7 +479,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     native_comm_destroy(c->native_comm);
     c->native_comm = nullptr;
     free_rank_state(c);
-    void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_long_out, c->d_long_rows, c->d_long_owner, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
+    void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_head_val, c->d_long_out, c->d_long_rows, c->d_long_owner, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
                     c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg};
     for (void *p : ptrs)

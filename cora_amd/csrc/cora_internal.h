@@ -16,6 +16,7 @@ extern int g_long_chunk;
 extern int g_interleave;            // pose-slice slot order (see format_build.cpp)
 constexpr int kSigma = 256;       // default sorting window (rows) for translation slices
 extern int g_sigma;               // tunable copy of kSigma (format_build.cpp)
+extern int g_sym_blocks;          // pose slices without their predecessor blocks (format_build.cpp)
 constexpr int kMaxLD = 24;
 
 // Row stride (doubles) used for a k-column resident vector: the number of columns itself, whatever k (<= kMaxLD).  Odd
@@ -34,6 +35,10 @@ enum SliceType : int32_t {
   kSliceEuclid = 2,    // lane = one translation row, identity row order
   kSliceEuclidPerm = 3 // lane = one translation row, rows given by perm[]
 };
+constexpr int32_t kSliceTypeMask = 0xff;
+// flag on a pose slice: the blocks that couple a pose with its index predecessor are not stored (Q is symmetric: lane
+// q - 1 holds the transposed block in its slots 0 .. d-1); lane 0's comes from HostFormat::head_val
+constexpr int32_t kSliceSymFlag = 0x100;
 
 // One wavefront's work, stored slot-major ([k][lane]) so that every load is a
 // fully coalesced 512 B (values) / 256 B (columns).
@@ -85,6 +90,7 @@ struct HostFormat {
   std::vector<int32_t> int2api;   // rows: API row of internal row (-1 = padding)
   std::vector<SliceDesc> slices;
   std::vector<SliceDesc> slices_pose_first;  // same slices, pose slices first inside each eighth (small row strides)
+  std::vector<double> head_val;   // [pose slice][d * d]: predecessor block of the slice's first pose (kSliceSymFlag)
   std::vector<double> sval;
   std::vector<int32_t> scol;
   std::vector<int32_t> perm;      // internal rows for kSliceEuclidPerm slices

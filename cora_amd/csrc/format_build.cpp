@@ -21,6 +21,8 @@ int g_sigma = kSigma;
 int g_pad_even = 0;
 int g_long_chunk = kLongChunk;
 int g_interleave = 0;  // measured: no gain on MI355X (kept for the lab)
+// pose slices without their predecessor blocks (CORA_SYM_BLOCKS=0: the plain layout, measurement switch)
+int g_sym_blocks = [] { const char *e = std::getenv("CORA_SYM_BLOCKS"); return (e && e[0] == '0') ? 0 : 1; }();
 
 namespace {
 
@@ -218,7 +220,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
 
   // ---- 3. local rows -> slices ---------------------------------------------
   std::vector<double> slice_key;  // position of each slice along the pose chain (work ordering)
-  F.slices.clear(); F.sval.clear(); F.scol.clear(); F.perm.clear();
+  F.slices.clear(); F.sval.clear(); F.scol.clear(); F.perm.clear(); F.head_val.clear();
   F.chunks.clear(); F.lval.clear(); F.lcol.clear();
   F.padded_nnz = F.long_nnz = F.nnz_local = 0; F.max_width = 0; F.n_long_rows = 0;
   F.diag.assign(static_cast<size_t>(std::max<int64_t>(L.local_rows, 1)), 0.0);
@@ -274,11 +276,58 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         }
         width = std::max(width, static_cast<int>(P.c.size()));
       }
+      // Symmetric chain blocks.  Q is symmetric, so the d x d block that couples pose q with its index predecessor is the
+      // transpose of the block lane q - 1 holds for ITS successor.  When that holds exactly for the whole slice, the
+      // predecessor block is not stored: slots 0 .. d-1 of every lane are the columns of the NEXT pose's rotation rows
+      // (zeros where there is no such coupling), the kernel hands them to lane q + 1 with a lane shift, and only lane 0's
+      // predecessor block -- it lives in the previous slice -- is kept, in F.head_val.  Three of the eleven slots of a
+      // chain pose (27 % of the pose slices' stream, 7 % of the product's traffic) are gone; loop closures and anything
+      // else stay in the stream.  (g_sym_blocks = 0: the plain layout, measurement switch.)
+      bool sym = g_sym_blocks != 0;
+      std::vector<double> nextv(static_cast<size_t>(kWave) * d * d, 0.0), prevv(static_cast<size_t>(kWave) * d * d, 0.0);
+      auto block_of = [&](const PoseCols &P, int64_t first_col, double *out) {  // out[c * d + a] = value (row a, column first_col + c)
+        for (size_t k = 0; k < P.c.size(); ++k)
+          if (P.c[k] >= first_col && P.c[k] < first_col + d)
+            for (int a = 0; a < d; ++a) out[(P.c[k] - first_col) * d + a] = P.v[k * d + a];
+      };
+      for (int q = 0; q < cnt && sym; ++q) {
+        const int64_t me = L.rot_base + static_cast<int64_t>(p0 + q) * d;
+        if (p0 + q + 1 < L.nl_poses) block_of(pc[q], me + d, &nextv[static_cast<size_t>(q) * d * d]);
+        if (p0 + q > 0) block_of(pc[q], me - d, &prevv[static_cast<size_t>(q) * d * d]);
+      }
+      for (int q = 1; q < cnt && sym; ++q)  // prev(q)[c][a] = Q(rot(q)_a, rot(q-1)_c) must equal next(q-1)[a][c] = Q(rot(q-1)_c, rot(q)_a)
+        for (int a = 0; a < d && sym; ++a)
+          for (int c = 0; c < d; ++c)
+            if (prevv[(static_cast<size_t>(q) * d + c) * d + a] != nextv[(static_cast<size_t>(q - 1) * d + a) * d + c]) sym = false;
+      if (sym) {
+        width = 0;
+        for (int q = 0; q < cnt; ++q) {  // re-lay the lane: next block first, then everything else but the predecessor block
+          PoseCols &P = pc[q], R;
+          const int64_t me = L.rot_base + static_cast<int64_t>(p0 + q) * d;
+          const bool has_next = p0 + q + 1 < L.nl_poses, has_prev = p0 + q > 0;
+          for (int c = 0; c < d; ++c) {
+            R.c.push_back(static_cast<int32_t>(has_next ? me + d + c : me + c));
+            for (int a = 0; a < d; ++a) R.v.push_back(nextv[(static_cast<size_t>(q) * d + c) * d + a]);
+          }
+          for (size_t k = 0; k < P.c.size(); ++k) {
+            if (has_next && P.c[k] >= me + d && P.c[k] < me + 2 * d) continue;
+            if (has_prev && P.c[k] >= me - d && P.c[k] < me) continue;
+            R.c.push_back(P.c[k]);
+            for (int a = 0; a < d; ++a) R.v.push_back(P.v[k * d + a]);
+          }
+          P = R;
+          width = std::max(width, static_cast<int>(P.c.size()));
+        }
+      }
+      F.head_val.resize(static_cast<size_t>(p0 / kWave + 1) * d * d, 0.0);
+      if (sym)  // lane 0's predecessor block: head[a * d + c] = Q(rot(p0)_a, rot(p0 - 1)_c)
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < d; ++c) F.head_val[static_cast<size_t>(p0 / kWave) * d * d + a * d + c] = prevv[static_cast<size_t>(c) * d + a];
       SliceDesc sd{};
       sd.row0 = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(p0) * d);
       sd.nrows = cnt;
       sd.width = width;
-      sd.type = kSliceStiefel;
+      sd.type = kSliceStiefel | (sym ? kSliceSymFlag : 0);
       sd.off = static_cast<int64_t>(F.sval.size());
       sd.coff = static_cast<int32_t>(F.scol.size());
       sd.aux0 = p0;
@@ -449,7 +498,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       for (size_t x = 0; x < 8; ++x) {
         const size_t b = std::min(x * per, F.slices.size()), e = std::min(b + per, F.slices.size());
         std::stable_partition(F.slices_pose_first.begin() + b, F.slices_pose_first.begin() + e,
-                              [](const SliceDesc &sd) { return sd.type == kSliceStiefel; });
+                              [](const SliceDesc &sd) { return (sd.type & kSliceTypeMask) == kSliceStiefel; });
       }
     }
   }
@@ -461,13 +510,24 @@ void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out)
   for (const SliceDesc &s : F.slices) {
     for (int lane = 0; lane < s.nrows; ++lane) {
       std::fill(acc.begin(), acc.end(), 0.0);
-      if (s.type == kSliceStiefel) {
+      if ((s.type & kSliceTypeMask) == kSliceStiefel) {
         for (int k = 0; k < s.width; ++k) {
           const double *xr = X + static_cast<size_t>(F.scol[s.coff + static_cast<size_t>(k) * kWave + lane]) * ld;
           for (int a = 0; a < d; ++a) {
             const double v = F.sval[s.off + (static_cast<size_t>(k) * d + a) * kWave + lane];
             for (int c = 0; c < ld; ++c) acc[a * ld + c] += v * xr[c];
           }
+        }
+        if ((s.type & kSliceSymFlag) && s.aux0 + lane > 0) {
+          // the predecessor block: slot a, row c of the lane before (lane 0: the slice's head block) times the
+          // predecessor pose's rows of X
+          const double *xp = X + (static_cast<size_t>(s.row0) + static_cast<size_t>(lane - 1) * d) * ld;
+          for (int a = 0; a < d; ++a)
+            for (int c2 = 0; c2 < d; ++c2) {
+              const double v = lane > 0 ? F.sval[s.off + (static_cast<size_t>(a) * d + c2) * kWave + (lane - 1)]
+                                        : F.head_val[static_cast<size_t>(s.aux0 / kWave) * d * d + a * d + c2];
+              for (int c = 0; c < ld; ++c) acc[a * ld + c] += v * xp[c2 * ld + c];
+            }
         }
         for (int a = 0; a < d; ++a)
           for (int c = 0; c < ld; ++c)

@@ -22,6 +22,7 @@ struct SpmmArgs {
   int n_real_chunks;   // filled by launch_spmm
   int n_slice_blocks;  // filled by launch_spmm
   const double *sval;
+  const double *head_val;  // [pose slice][d * d] predecessor block of the slice's first pose (kSliceSymFlag)
   const int32_t *scol;
   const int32_t *perm;
   const LongChunk *chunks;

@@ -379,45 +379,89 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int j = 0; j < LD; ++j) acc[a][j] = 0.0;
-  // slots in flight per lane: 3 up to a row stride of 6, 2 above (register pressure: p = 10 Hvp 40.1 -> 39.4 us)
-  // (with the X window: 3 / 6 / 12 slots per trip measured 22.1 / 22.4 / 22.4 us at 10^5 poses -- tools/spmm_window_variants.sh)
-  if (kWin) {
-    if constexpr (kWinLD) {
-#pragma unroll CORA_POSE_UNROLL_WIN
-      for (int k = 0; k < sd.width; ++k) {
-        const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
-        double v[D];
+  // one slot: column index, d values, the row of X (from the windows when they are on), d x LD products
+  auto slot = [&](int k, double (&v)[D]) {
+    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
 #pragma unroll
-        for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
-        double x[LD];
-        const unsigned rr = static_cast<unsigned>(c - w0), rt = static_cast<unsigned>(c - t0);
-        const bool in_rot = rr < static_cast<unsigned>(nrot), in_trn = rt < static_cast<unsigned>(ntr);
-        const int l = in_rot ? static_cast<int>(rr) : (in_trn ? kRotRows + static_cast<int>(rt) : 0);
+    for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+    double x[LD];
+    if (kWinLD && kWin) {
+      const unsigned rr = static_cast<unsigned>(c - w0), rt = static_cast<unsigned>(c - t0);
+      const bool in_rot = rr < static_cast<unsigned>(nrot), in_trn = rt < static_cast<unsigned>(ntr);
+      const int l = in_rot ? static_cast<int>(rr) : (in_trn ? kRotRows + static_cast<int>(rt) : 0);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
+      if (!(in_rot || in_trn)) load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+    } else {
+      load_row<LD>(X + static_cast<size_t>(c) * LD, x);
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+  };
+  // Symmetric chain blocks (kSliceSymFlag, format_build.cpp): slots 0 .. D-1 are the NEXT pose's columns; their values
+  // stay in registers and become, shifted by one lane, the predecessor block of the lane after (lane 0: the slice's
+  // head block).  The predecessor block is not in the stream: 8 slots instead of 11 for a pose of the chain.
+  const bool sym = (sd.type & kSliceSymFlag) != 0;
+  // narrow rows: the next-pose slots are peeled off the loop and their values shifted by one lane; wide rows (registers
+  // are what they are short of: at a row stride of 10 the peeled form cost a wave of occupancy) re-read the previous
+  // lane's values from the stream the wavefront has just loaded (L1 / L2 hits)
+  constexpr bool kNxtRegs = LD <= 8;
+  double nxt[kNxtRegs ? D : 1][D];
+  int k0 = 0;
+  if (kNxtRegs && sym) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) slot(k, nxt[kNxtRegs ? k : 0]);
+    k0 = D;
+  }
+  // (the predecessor block is applied right here, before the rest of the slots, so that its nine values do not stay in
+  // registers across the loop: with them the Hvp kernel needed 172 registers -- two waves per SIMD instead of three)
+  auto predecessor_block = [&] {
+    const bool has_prev = sd.aux0 + lane > 0;
+    const double *__restrict__ head = A.head_val + static_cast<size_t>(sd.aux0 / kWave) * (D * D);
+    const int prow0 = has_prev ? sd.row0 + (lane - 1) * D : sd.row0;  // first rotation row of the predecessor pose
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double x[LD];
+      if (kWinLD && kWin) {
+        const int l = has_prev ? prow0 + c - w0 : 0;
 #pragma unroll
         for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
-        if (!(in_rot || in_trn)) load_row<LD>(X + static_cast<size_t>(c) * LD, x);
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+      } else {
+        load_row<LD>(X + static_cast<size_t>(prow0 + c) * LD, x);
       }
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        // predecessor block, row a, column c: slot a, value c of the lane before
+        double pv;
+        if constexpr (kNxtRegs) pv = __shfl_up(nxt[a][c], 1, kWave);
+        else pv = lane > 0 ? stream_load(vp + (static_cast<size_t>(a) * D + c) * kWave - 1) : 0.0;
+        if (lane == 0) pv = head[a * D + c];
+        if (!has_prev) pv = 0.0;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[a][j] = fma(pv, x[j], acc[a][j]);
+      }
+    }
+  };
+  if (kNxtRegs && sym) predecessor_block();
+  // slots in flight per lane: CORA_POSE_UNROLL_WIN with the windows; without, 3 up to a row stride of 6, 2 above
+  // (register pressure: p = 10 Hvp 40.1 -> 39.4 us)
+  if (kWin) {
+#pragma unroll CORA_POSE_UNROLL_WIN
+    for (int k = k0; k < sd.width; ++k) {
+      double v[D];
+      slot(k, v);
     }
   } else {
     constexpr int kSlotsInFlight = LD <= 6 ? CORA_POSE_UNROLL : 2;
 #pragma unroll kSlotsInFlight
-    for (int k = 0; k < sd.width; ++k) {
-      const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
+    for (int k = k0; k < sd.width; ++k) {
       double v[D];
-#pragma unroll
-      for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
-      double x[LD];
-      load_row<LD>(X + static_cast<size_t>(c) * LD, x);
-#pragma unroll
-      for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+      slot(k, v);
     }
   }
+  if (!kNxtRegs && sym) predecessor_block();
   if constexpr (kCoopT) if (kCoop) {
     double xo[D][LD];  // the pose's own rows of X (inside the rotation window; lanes past nrows read rows they ignore)
 #pragma unroll
@@ -520,7 +564,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 // <X, out> over the rows it wrote (EPI_HVP_K; 0 otherwise).
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc sd, int lane) {
-  if (sd.type == kSliceStiefel) return pose_slice<LD, D, EPI>(A, sd, lane);
+  if ((sd.type & kSliceTypeMask) == kSliceStiefel) return pose_slice<LD, D, EPI>(A, sd, lane);
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
