@@ -1771,6 +1771,44 @@ int cora_gram_dev(cora_ctx *c, const double *dA, int ka, const double *dB, int k
   return comm_allreduce(c, G, nel);
 }
 
+int cora_gram_batch_dev(cora_ctx *c, int n, const double *const *dA, const int *ka, const double *const *dB,
+                        const int *kb, double *const *G) {
+  NEED_DEVICE(c);
+  if (n < 1 || n > 16 || !dA || !ka || !dB || !kb || !G) return fail(c, CORA_ERR_ARG, "bad arguments");
+  const int nblocks = 256;
+  size_t need = 0, nel_all = 0;
+  for (int e = 0; e < n; ++e) {
+    if (!dA[e] || !dB[e] || !G[e] || ka[e] <= 0 || kb[e] <= 0 || ka[e] > kMaxLD || kb[e] > kMaxLD)
+      return fail(c, CORA_ERR_ARG, "bad block");
+    const size_t nel = static_cast<size_t>(ka[e]) * kb[e];
+    need += nel * nblocks;
+    nel_all += nel;
+  }
+  // every product is the kernel of cora_gram_dev on its own piece of the reduction buffer: the numbers are those of n
+  // separate calls, the stream is synchronised once
+  int rc = ensure_red(c, need + nel_all);
+  if (rc) return rc;
+  double *partial = c->d_red, *dout = c->d_red + need;
+  for (int e = 0; e < n; ++e) {
+    const size_t nel = static_cast<size_t>(ka[e]) * kb[e];
+    HIP_TRY(c, launch_gram(c->F.L.base, c->F.L.local_rows, dA[e], ka[e], dB[e], kb[e], partial, nblocks, dout, c->stream));
+    partial += nel * nblocks;
+    dout += nel;
+  }
+  std::vector<double> tmp(nel_all);
+  HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_red + need, nel_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  size_t off = 0;
+  for (int e = 0; e < n; ++e) {
+    for (int a = 0; a < ka[e]; ++a)  // device result is row-major ka x kb
+      for (int b = 0; b < kb[e]; ++b) G[e][static_cast<size_t>(b) * ka[e] + a] = tmp[off + static_cast<size_t>(a) * kb[e] + b];
+    rc = comm_allreduce(c, G[e], ka[e] * kb[e]);
+    if (rc) return rc;
+    off += static_cast<size_t>(ka[e]) * kb[e];
+  }
+  return CORA_OK;
+}
+
 int cora_combine_dev(cora_ctx *c, int n, const double *const *dX, const int *k, const double *const *C, int kout,
                      double *dOut) {
   NEED_DEVICE(c);

@@ -77,6 +77,13 @@ class Problem {
   mutable long precond_nnz_ = 0;         // nnz(L)
   mutable int precond_levels_ = 0;       // height of the elimination tree
   mutable std::vector<int32_t> cert_perm_;  // elimination order of the full certificate matrix (pattern-only: kept per data matrix)
+  // S = Q - Lambda(Y) kept between certifications: its pattern is Q's plus the Lambda blocks, only the entries under
+  // Lambda change with Y.  cert_lambda_pos_: position in cert_S_.values of every Lambda entry (pose-block entries row
+  // by row, then the range diagonal); cert_lambda_q_: the position of the same entry in Q's values, -1 when Q has none
+  mutable SparseMatrix cert_S_;
+  mutable std::vector<int32_t> cert_lambda_pos_, cert_lambda_q_;
+  mutable Matrix cert_random_;  // the random start columns of the eigensolver (fixed seed: the same numbers every time)
+  const SparseMatrix &certificateMatrixCached(const Matrix &Y) const;
 
   void checkUpToDate() const;
   void addOriginPose();

@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <memory>
 #include <numeric>
+#include <stdexcept>
+#include <thread>
 
 #include "../../../include/cora_hip.h"
 #include "dense.h"
@@ -13,21 +15,62 @@
 
 namespace CORA {
 
+namespace {
+
+// S x for one vector, rows shared out over threads (a row's sum does not depend on who forms it)
+Vector sparseTimesVector(const SparseMatrix &S, const Vector &x) {
+  const Index n = S.rows();
+  Vector y(n, 1);
+  auto rows = [&](Index lo, Index hi) {
+    for (Index i = lo; i < hi; ++i) {
+      Scalar s = 0;
+      for (int32_t q = S.outer[static_cast<size_t>(i)]; q < S.outer[static_cast<size_t>(i) + 1]; ++q)
+        s += S.values[q] * x(S.inner[q]);
+      y(i) = s;
+    }
+  };
+  const unsigned nth = n < 50000 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (nth <= 1) {
+    rows(0, n);
+    return y;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nth; ++t)
+    pool.emplace_back(rows, n * static_cast<Index>(t) / nth, n * static_cast<Index>(t + 1) / nth);
+  for (std::thread &t : pool) t.join();
+  return y;
+}
+
+}  // namespace
+
 CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X0, size_t max_iters,
                               const std::vector<int32_t> &perm_in, cora_ctx *ctx,
                               const std::optional<DeviceOperator> &S_op,
                               const std::optional<DeviceOperator> &precond, Scalar max_fill_factor, Scalar drop_tol,
                               const FastVerificationLab *lab) {
+  if (X0.rows() != S.rows()) throw std::invalid_argument("fast_verification: the start block has the wrong number of rows");
+  return fast_verification(S, eta, std::vector<HostColumns>{HostColumns{X0.data(), static_cast<int>(X0.cols())}}, max_iters,
+                           perm_in, ctx, S_op, precond, max_fill_factor, drop_tol, lab);
+}
+
+CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vector<HostColumns> &X0, size_t max_iters,
+                              const std::vector<int32_t> &perm_in, cora_ctx *ctx,
+                              const std::optional<DeviceOperator> &S_op,
+                              const std::optional<DeviceOperator> &precond, Scalar max_fill_factor, Scalar drop_tol,
+                              const FastVerificationLab *lab) {
   const Index n = S.rows();
+  int x0_cols = 0;
+  for (const HostColumns &h : X0) x0_cols += h.cols;
   CertResults results;
   results.theta = 0;
   results.num_iters = 0;
   // STEP 1: Cholesky of M = S + eta I  (src/CORA_utils.cpp:28-51)
-  std::vector<int32_t> perm = perm_in;
-  if (perm.empty()) {
-    perm.resize(static_cast<size_t>(n));
-    std::iota(perm.begin(), perm.end(), 0);
+  std::vector<int32_t> natural;
+  if (perm_in.empty()) {
+    natural.resize(static_cast<size_t>(n));
+    std::iota(natural.begin(), natural.end(), 0);
   }
+  const std::vector<int32_t> &perm = perm_in.empty() ? natural : perm_in;
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
   auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
     const auto now = std::chrono::steady_clock::now();
@@ -80,10 +123,13 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
   LOBPCGStop stopfun = [eta](size_t, const std::vector<Scalar> &Theta, const double *, int) {
     return (Theta[0] - eta) < -eta / 2;  // X orthonormal: x' S x = theta_M - eta
   };
-  // STEP 2: unpreconditioned LOBPCG for 1 % of the iteration budget (:104-119)
+  // STEP 2: unpreconditioned LOBPCG for 1 % of the iteration budget (:104-119).  The blocks of a run stay on the device;
+  // what comes back to the host is the Ritz block of the run that ended the search, once.
   const double unprecon_iter_frac = .01;
-  LOBPCGResult r = LOBPCG(c, Mop, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0,
-                          stopfun);
+  const int N = static_cast<int>(n);
+  auto solver = std::make_unique<LOBPCGSolver>(c, N);
+  LOBPCGResult r = solver->run(Mop, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0, stopfun,
+                               false);
   size_t iters = r.num_iters;
   tick("LOBPCG, 1 % of the budget");
   if (!(r.Theta(0) - eta < -eta / 2)) {
@@ -96,18 +142,24 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
     if (lab) lab->reached_step3 = true;
     const size_t budget3 = static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters);
     const bool seeded = !F.negative_direction.empty() && (!lab || lab->seed_negative_direction);
-    Matrix X0s = X0;
+    std::vector<HostColumns> X0s = X0;
     if (seeded) {
-      const Index m0 = X0.cols() < 24 ? X0.cols() + 1 : X0.cols();
-      X0s = Matrix(n, m0);
-      X0s.setBlock(0, 0, X0.block(0, 0, n, std::min<Index>(X0.cols(), m0 - 1)));
-      for (Index i = 0; i < n; ++i) X0s(i, m0 - 1) = F.negative_direction[static_cast<size_t>(i)];
+      if (x0_cols >= 24) {  // no room for one more column: the seed takes the place of the last one
+        int drop = 1;
+        while (drop > 0 && !X0s.empty()) {
+          if (X0s.back().cols > drop) { X0s.back().cols -= drop; drop = 0; }
+          else { drop -= X0s.back().cols; X0s.pop_back(); }
+        }
+      }
+      if (X0s.size() >= 4) throw std::logic_error("fast_verification: too many pieces in the start block");
+      X0s.push_back(HostColumns{F.negative_direction.data(), 1});
     }
     bool done = false;
     if (seeded && !precond) {
       // with the seed in the block the first Rayleigh-Ritz step already meets the stopping rule: a few plain
       // iterations, and the factorisation below is only paid for when they do not
-      r = LOBPCG(c, Mop, std::nullopt, X0s, 1, std::min<size_t>(budget3, 3), 0.0, stopfun);
+      solver = std::make_unique<LOBPCGSolver>(c, N);
+      r = solver->run(Mop, std::nullopt, X0s, 1, std::min<size_t>(budget3, 3), 0.0, stopfun, false);
       iters += r.num_iters;
       tick("LOBPCG, seeded");
       done = r.Theta(0) - eta < -eta / 2;
@@ -124,17 +176,20 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
           if (cora_aux_solve_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
         };
       }
-      r = LOBPCG(c, Mop, T, X0s, 1, budget3, 0.0, stopfun);
+      solver = std::make_unique<LOBPCGSolver>(c, N);
+      r = solver->run(Mop, T, X0s, 1, budget3, 0.0, stopfun, false);
       iters += r.num_iters;
     }
   }
-  results.x = r.X.col(0);
+  results.all_eigvecs = solver->block();
+  results.x = results.all_eigvecs.col(0);
+  tick("Ritz block to the host");
   // curvature along x, recomputed from S like the reference (:124-127)
   {
-    const Matrix Sx = S * results.x;
+    const Vector Sx = sparseTimesVector(S, results.x);
     results.theta = results.x.dot(Sx);
   }
-  results.all_eigvecs = r.X;
+  tick("curvature along x");
   results.num_iters = iters;
   return results;
 }

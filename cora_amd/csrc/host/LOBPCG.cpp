@@ -1,6 +1,9 @@
 #include "LOBPCG.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -46,15 +49,95 @@ Matrix sub(const Matrix &M, Index r0, Index c0, Index nr, Index nc) { return M.b
 
 }  // namespace
 
+LOBPCGSolver::LOBPCGSolver(cora_ctx *ctx, int N) : c_(ctx), N_(N) {}
+
+LOBPCGSolver::~LOBPCGSolver() {
+  for (double *p : owned_) cora_dev_free(c_, p);
+}
+
+Matrix LOBPCGSolver::block() const {
+  if (!X_) throw std::logic_error("LOBPCGSolver::block: no run yet");
+  Matrix X(N_, m_);
+  if (cora_download(c_, X_, m_, X.data(), N_) != CORA_OK) throw std::runtime_error(std::string("LOBPCG: download: ") + cora_last_error(c_));
+  return X;
+}
+
+Vector LOBPCGSolver::column(int j) const {
+  if (!X_) throw std::logic_error("LOBPCGSolver::column: no run yet");
+  if (j < 0 || j >= m_) throw std::invalid_argument("LOBPCGSolver::column: index out of range");
+  // X e_j on the device (1.0 * x + 0.0 * the rest: exact), one column over the bus
+  double *col = nullptr;
+  if (cora_dev_alloc(c_, 1, &col) != CORA_OK) throw std::runtime_error(std::string("LOBPCG: alloc: ") + cora_last_error(c_));
+  Vector v(N_, 1);
+  Matrix e(m_, 1);
+  e(j, 0) = 1.0;
+  const double *xs[1] = {X_};
+  const int ks[1] = {m_};
+  const double *cs[1] = {e.data()};
+  int rc = cora_combine_dev(c_, 1, xs, ks, cs, 1, col);
+  if (rc == CORA_OK) rc = cora_download(c_, col, 1, v.data(), N_);
+  cora_dev_free(c_, col);
+  if (rc != CORA_OK) throw std::runtime_error(std::string("LOBPCG: column: ") + cora_last_error(c_));
+  return v;
+}
+
 LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<DeviceOperator> &T, const Matrix &X0,
                     size_t nev, size_t max_iters, Scalar tau, const std::optional<LOBPCGStop> &stop) {
-  const int N = static_cast<int>(X0.rows()), m = static_cast<int>(X0.cols());
+  LOBPCGSolver S(c, static_cast<int>(X0.rows()));
+  return S.run(A, T, {HostColumns{X0.data(), static_cast<int>(X0.cols())}}, nev, max_iters, tau, stop, true);
+}
+
+LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<DeviceOperator> &T,
+                               const std::vector<HostColumns> &start, size_t nev, size_t max_iters, Scalar tau,
+                               const std::optional<LOBPCGStop> &stop, bool download) {
+  cora_ctx *c = c_;
+  const int N = N_;
+  int m = 0;
+  for (const HostColumns &h : start) m += h.cols;
   if (m < 1 || m > 24) throw std::invalid_argument("LOBPCG: block size must be in [1, 24]");
   if (static_cast<size_t>(m) < nev) throw std::invalid_argument("LOBPCG: block smaller than nev");
+  if (start.size() > 4) throw std::invalid_argument("LOBPCG: at most four pieces in the start block");
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "      [lobpcg] %-22s %.4f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  for (double *p : owned_) cora_dev_free(c_, p);
+  owned_.clear();
+  m_ = m;
+  X_ = nullptr;
   Blocks B(c, m);
   double *X = B.alloc(), *AX = B.alloc(), *W = B.alloc(), *AW = B.alloc(), *P = B.alloc(), *AP = B.alloc(),
          *t1 = B.alloc(), *t2 = B.alloc(), *t3 = B.alloc(), *t4 = B.alloc();
-  B.chk(cora_upload(c, X0.data(), N, m, t1), "upload");
+  if (start.size() == 1) {
+    B.chk(cora_upload(c, start[0].data, N, m, t1), "upload");
+  } else {
+    // pieces side by side: Out = sum_i piece_i [0 .. I .. 0]
+    std::vector<double *> dev;
+    std::vector<const double *> xs;
+    std::vector<int> ks;
+    std::vector<Matrix> sel;
+    int at = 0;
+    for (const HostColumns &h : start) {
+      double *d = nullptr;
+      B.chk(cora_dev_alloc(c, h.cols, &d), "alloc");
+      dev.push_back(d);
+      B.chk(cora_upload(c, h.data, N, h.cols, d), "upload");
+      Matrix E(h.cols, m);
+      for (int j = 0; j < h.cols; ++j) E(j, at + j) = 1.0;
+      sel.push_back(E);
+      xs.push_back(d);
+      ks.push_back(h.cols);
+      at += h.cols;
+    }
+    std::vector<const double *> cp;
+    for (const Matrix &E : sel) cp.push_back(E.data());
+    const int rc = cora_combine_dev(c, static_cast<int>(xs.size()), xs.data(), ks.data(), cp.data(), m, t1);
+    for (double *d : dev) cora_dev_free(c, d);
+    B.chk(rc, "combine");
+  }
+  tick("upload of the block");
 
   // X <- orthonormal basis of span(X0): X0 V D^-1/2
   {
@@ -94,6 +177,7 @@ LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<De
     std::swap(AX, t2);
     for (int i = 0; i < m; ++i) theta[i] = ev(i);
   }
+  tick("start: 2 products' worth");
   bool haveP = false;
   LOBPCGResult res;
   size_t it = 0;
@@ -136,9 +220,26 @@ LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<De
     const int nb = haveP ? 3 : 2, ns = nb * m;
     const double *S[3] = {X, W, P}, *AS[3] = {AX, AW, AP};
     Matrix GA(ns, ns), GB(ns, ns);
+    std::vector<Matrix> grams;  // (S_a' A S_b, S_a' S_b) for a <= b: one trip to the device for all of them
+    {
+      std::vector<const double *> ga_, gb_;
+      for (int a = 0; a < nb; ++a)
+        for (int b = a; b < nb; ++b) {
+          ga_.push_back(S[a]); gb_.push_back(AS[b]);
+          ga_.push_back(S[a]); gb_.push_back(S[b]);
+        }
+      grams.assign(ga_.size(), Matrix(m, m));
+      std::vector<int> km(ga_.size(), m);
+      std::vector<double *> out;
+      for (Matrix &G : grams) out.push_back(G.data());
+      B.chk(cora_gram_batch_dev(c, static_cast<int>(ga_.size()), ga_.data(), km.data(), gb_.data(), km.data(), out.data()),
+            "gram batch");
+    }
+    size_t gi = 0;
     for (int a = 0; a < nb; ++a)
       for (int b = a; b < nb; ++b) {
-        const Matrix ga = B.gram(S[a], AS[b]), gb = B.gram(S[a], S[b]);
+        const Matrix &ga = grams[gi], &gb = grams[gi + 1];
+        gi += 2;
         for (int i = 0; i < m; ++i)
           for (int j = 0; j < m; ++j) {
             GA(a * m + i, b * m + j) = ga(i, j);
@@ -190,11 +291,18 @@ LOBPCGResult LOBPCG(cora_ctx *c, const DeviceOperator &A, const std::optional<De
     haveP = true;
     for (int i = 0; i < m; ++i) theta[i] = er(i);
   }
+  tick("iterations");
   res.num_iters = it;
   res.Theta = Vector(m, 1);
   for (int i = 0; i < m; ++i) res.Theta(i) = theta[i];
-  res.X = Matrix(N, m);
-  B.chk(cora_download(c, X, m, res.X.data(), N), "download");
+  // the blocks live on in this object (B gives up its ownership)
+  owned_ = std::move(B.owned);
+  B.owned.clear();
+  X_ = X;
+  if (download) {
+    res.X = block();
+    tick("download of the block");
+  }
   return res;
 }
 

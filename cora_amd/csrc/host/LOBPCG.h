@@ -28,9 +28,39 @@ using LOBPCGStop = std::function<bool(size_t i, const std::vector<Scalar> &Theta
 
 struct LOBPCGResult {
   Vector Theta;  // m Ritz values, ascending
-  Matrix X;      // N x m Ritz vectors (host, API row order)
+  Matrix X;      // N x m Ritz vectors (host, API row order); empty when the run was asked to leave them on the device
   size_t num_iters = 0;
   size_t num_converged = 0;
+};
+
+/** Columns of a start block that live in host memory: `cols` columns of N doubles, leading dimension N. */
+struct HostColumns {
+  const double *data = nullptr;
+  int cols = 0;
+};
+
+/** One LOBPCG run whose blocks stay on the device until they are asked for.  The start block is the concatenation of up
+ * to four pieces (e.g. the previous level's eigenvectors | cached random columns | one seed vector): they are uploaded
+ * as they are and put side by side on the device, nothing is assembled on the host.  `block()` / `column(j)` download
+ * the Ritz vectors of the last run. */
+class LOBPCGSolver {
+ public:
+  LOBPCGSolver(cora_ctx *ctx, int N);
+  ~LOBPCGSolver();
+  LOBPCGSolver(const LOBPCGSolver &) = delete;
+  LOBPCGSolver &operator=(const LOBPCGSolver &) = delete;
+  LOBPCGResult run(const DeviceOperator &A, const std::optional<DeviceOperator> &T, const std::vector<HostColumns> &start,
+                   size_t nev, size_t max_iters, Scalar tau, const std::optional<LOBPCGStop> &stop, bool download);
+  Matrix block() const;
+  Vector column(int j) const;
+  int width() const { return m_; }
+
+ private:
+  struct Impl;
+  cora_ctx *c_;
+  int N_, m_ = 0;
+  std::vector<double *> owned_;
+  double *X_ = nullptr;
 };
 
 /** X0: N x m (host).  nev: wanted pairs; tau: residual tolerance ||r|| <= tau |theta|. */

@@ -392,13 +392,27 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
   });
 }
 
-int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_poses, int64_t info[3], double *digest,
-                                double *negative_direction) {
+int cora_problem_cholesky_probe_bumped(cora_problem *p, int m, double shift, int leaf_poses, int nbump,
+                                       const int32_t *bump_rows, const double *bump_vals, int64_t info[3],
+                                       double *digest, double *negative_direction) {
   return guarded([&] {
     Problem &q = p->problem;
-    const SparseMatrix &Q = q.getDataMatrix();
+    const SparseMatrix &Q0 = q.getDataMatrix();
     const auto perm = coraOrdering(q.dim(), q.numPoses(), q.numRangeMeasurements(), q.numTranslationalStates(),
-                                   Q, m, leaf_poses > 0 ? leaf_poses : 16);
+                                   Q0, m, leaf_poses > 0 ? leaf_poses : 16);
+    SparseMatrix bumped;
+    if (nbump > 0) {  // a copy of Q with some diagonal entries moved (a pivot that turns negative where the test wants it)
+      bumped = Q0;
+      for (int b = 0; b < nbump; ++b) {
+        const int32_t r = bump_rows[b];
+        if (r < 0 || r >= bumped.rows()) throw std::invalid_argument("cholesky_probe: bump row out of range");
+        bool found = false;
+        for (int32_t e = bumped.outer[r]; e < bumped.outer[r + 1]; ++e)
+          if (bumped.inner[e] == r) { bumped.values[e] += bump_vals[b]; found = true; }
+        if (!found) throw std::invalid_argument("cholesky_probe: no diagonal entry in the bumped row");
+      }
+    }
+    const SparseMatrix &Q = nbump > 0 ? bumped : Q0;
     const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
     info[0] = F.ok ? 1 : 0;
     info[1] = F.nnz();
@@ -416,6 +430,11 @@ int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_p
     if (negative_direction && !F.ok)
       std::memcpy(negative_direction, F.negative_direction.data(), sizeof(double) * F.negative_direction.size());
   });
+}
+
+int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_poses, int64_t info[3], double *digest,
+                                double *negative_direction) {
+  return cora_problem_cholesky_probe_bumped(p, m, shift, leaf_poses, 0, nullptr, nullptr, info, digest, negative_direction);
 }
 
 int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int nblocks,

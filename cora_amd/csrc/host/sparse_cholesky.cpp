@@ -290,7 +290,78 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   return S;
 }
 
+// Per-thread scratch of the up-looking row solve, and the factor's storage, are kept from call to call: a fresh
+// allocation of this size costs more in page faults than the arithmetic that runs in it (10^5 poses: 7 MB per thread
+// times 16 threads, 60 MB of factor).  Invariant of a pooled Work: x is all zeros.
+struct Work {
+  std::vector<double> x;
+  std::vector<int32_t> flag, stack;
+};
+std::mutex g_pool_mutex;
+std::vector<std::unique_ptr<Work>> g_work_pool;
+std::vector<std::vector<int32_t>> g_pool_i;
+std::vector<std::vector<double>> g_pool_x;
+constexpr size_t kWorkPoolMax = 64, kStoragePoolMax = 4;
+
+std::unique_ptr<Work> acquireWork(int n) {
+  std::unique_ptr<Work> W;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (!g_work_pool.empty()) {
+      W = std::move(g_work_pool.back());
+      g_work_pool.pop_back();
+    }
+  }
+  if (!W) W = std::make_unique<Work>();
+  const size_t m = static_cast<size_t>(n);
+  if (W->x.size() < m) {
+    W->x.assign(m, 0.0);
+    W->flag.resize(m);
+    W->stack.resize(m);
+  }
+  std::fill(W->flag.begin(), W->flag.begin() + static_cast<std::ptrdiff_t>(m), -1);
+  return W;
+}
+
+void releaseWork(std::unique_ptr<Work> W) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (g_work_pool.size() < kWorkPoolMax) g_work_pool.push_back(std::move(W));
+}
+
+template <class T>
+std::vector<T> takeStorage(std::vector<std::vector<T>> &pool, size_t count) {
+  std::vector<T> v;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t e = 0; e < pool.size(); ++e)
+      if (pool[e].capacity() >= count) {
+        v = std::move(pool[e]);
+        pool.erase(pool.begin() + static_cast<std::ptrdiff_t>(e));
+        break;
+      }
+  }
+  v.resize(count);  // (entries the factorisation does not write are never read: see `next`)
+  return v;
+}
+
+// runs body(thread index) on nth threads
+template <class Body>
+void parallelRun(unsigned nth, Body body) {
+  std::vector<std::thread> pool;
+  for (unsigned th = 1; th < nth; ++th) pool.emplace_back([&body, th] { body(th); });
+  body(0u);
+  for (std::thread &t : pool) t.join();
+}
+
 }  // namespace
+
+CholeskyFactor::~CholeskyFactor() {
+  // the storage of a factor goes back to the pool (the certificate's factor lives for one PSD test)
+  if (Lx.capacity() < (1u << 20)) return;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (g_pool_x.size() < kStoragePoolMax) g_pool_x.push_back(std::move(Lx));
+  if (g_pool_i.size() < kStoragePoolMax) g_pool_i.push_back(std::move(Li));
+}
 
 CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm) {
   CholeskyFactor F;
@@ -319,22 +390,20 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
   {
     const std::vector<int32_t> &Cmap = sym->Cmap;
     const size_t nc = Cx.size();
-    for (size_t w = 0; w < nc; ++w) Cx[w] = Cmap[w] >= 0 ? A.values[Cmap[w]] : 0.0;
+    const unsigned nv = nc < (1u << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    parallelRun(nv, [&](unsigned th) {
+      for (size_t w = nc * th / nv; w < nc * (th + 1) / nv; ++w) Cx[w] = Cmap[w] >= 0 ? A.values[Cmap[w]] : 0.0;
+    });
     for (int k = 0; k < n; ++k) Cx[sym->Cdiag[k]] += shift;
   }
   tick(sym_hit ? "values into the cached pattern" : "permuted upper triangle + symbolic");
   F.parent = sym->parent;
   F.Lp = sym->Lp;
-  F.Li.assign(static_cast<size_t>(tot), 0);
-  F.Lx.assign(static_cast<size_t>(tot), 0.0);
+  F.Li = takeStorage(g_pool_i, static_cast<size_t>(tot));
+  F.Lx = takeStorage(g_pool_x, static_cast<size_t>(tot));
   tick("factor storage");
   std::vector<int32_t> next(F.Lp.begin(), F.Lp.end() - 1);
   F.ok = true;
-  struct Work {  // per-thread scratch of the up-looking row solve
-    std::vector<double> x;
-    std::vector<int32_t> flag, stack;
-    explicit Work(int n) : x(static_cast<size_t>(n), 0.0), flag(static_cast<size_t>(n), -1), stack(static_cast<size_t>(n)) {}
-  };
   // Row k of L (up-looking: a sparse triangular solve over the columns of k's elimination-tree descendants).  Touches
   // only columns of the subtree rooted at k, so disjoint subtrees can be factorised by different threads; the
   // arithmetic of a row does not depend on who runs it, so the factor is the sequential one bit for bit.
@@ -373,19 +442,23 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
     return true;
   };
   int first_failure = n;  // sequential semantics: the smallest k whose pivot is not positive
-  unsigned nth = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  unsigned nth = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char *e = std::getenv("CORA_CHOL_THREADS")) nth = static_cast<unsigned>(std::max(1, std::atoi(e)));
+  std::vector<int32_t> task;  // row -> subtree task (-1: a separator above the tasks)
+  int ntask = 0;
+  std::vector<int32_t> tptr, trows;
   if (n < 20000 || nth <= 1) {
-    Work W(n);
+    std::unique_ptr<Work> W = acquireWork(n);
     for (int k = 0; k < n; ++k)
-      if (!process_row(k, W)) { first_failure = k; break; }
+      if (!process_row(k, *W)) { first_failure = k; break; }
+    releaseWork(std::move(W));
   } else {
     // tasks: maximal elimination-tree subtrees whose share of the factor's entries is below 1 / (8 threads)
     std::vector<int64_t> weight(cnt.begin(), cnt.end());
     for (int v = 0; v < n; ++v)
       if (F.parent[v] >= 0) weight[F.parent[v]] += weight[v];  // children come before parents
     const int64_t target = std::max<int64_t>(tot / (8 * static_cast<int64_t>(nth)), 1);
-    std::vector<int32_t> task(static_cast<size_t>(n), -1);
+    task.assign(static_cast<size_t>(n), -1);
     std::vector<std::pair<int64_t, int32_t>> roots;  // (weight, root)
     for (int v = n - 1; v >= 0; --v) {
       const int p = F.parent[v];
@@ -395,8 +468,9 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
         roots.push_back({weight[v], v});
       }
     }
-    const int ntask = static_cast<int>(roots.size());
-    std::vector<int32_t> tptr(static_cast<size_t>(ntask) + 1, 0), trows(static_cast<size_t>(n));
+    ntask = static_cast<int>(roots.size());
+    tptr.assign(static_cast<size_t>(ntask) + 1, 0);
+    trows.resize(static_cast<size_t>(n));
     for (int v = 0; v < n; ++v)
       if (task[v] >= 0) tptr[task[v] + 1]++;
     for (int t = 0; t < ntask; ++t) tptr[t + 1] += tptr[t];
@@ -409,55 +483,243 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
     for (int t = 0; t < ntask; ++t) order[t] = t;
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return roots[a].first > roots[b].first; });
     std::atomic<int> next_task{0}, min_fail{n};
-    std::vector<std::thread> pool;
-    for (unsigned th = 0; th < nth; ++th)
-      pool.emplace_back([&] {
-        Work W(n);
-        for (;;) {
-          const int slot = next_task.fetch_add(1);
-          if (slot >= ntask) break;
-          const int t = order[slot];
-          for (int32_t q = tptr[t]; q < tptr[t + 1]; ++q) {
-            const int k = trows[q];
-            if (k >= min_fail.load(std::memory_order_relaxed)) break;  // rows past a failure are never looked at
-            if (!process_row(k, W)) {
-              int cur = min_fail.load();
-              while (k < cur && !min_fail.compare_exchange_weak(cur, k)) {}
-              break;
-            }
+    parallelRun(nth, [&](unsigned) {
+      std::unique_ptr<Work> W = acquireWork(n);
+      for (;;) {
+        const int slot = next_task.fetch_add(1);
+        if (slot >= ntask) break;
+        const int t = order[slot];
+        for (int32_t q = tptr[t]; q < tptr[t + 1]; ++q) {
+          const int k = trows[q];
+          if (k >= min_fail.load(std::memory_order_relaxed)) break;  // rows past a failure are never looked at
+          if (!process_row(k, *W)) {
+            int cur = min_fail.load();
+            while (k < cur && !min_fail.compare_exchange_weak(cur, k)) {}
+            break;
           }
         }
-      });
-    for (std::thread &th : pool) th.join();
+      }
+      releaseWork(std::move(W));
+    });
     tick("numeric: subtrees (threads)");
-    // what is left (separators above the tasks, landmark rows) in order; stops at the first failure, wherever it was
     first_failure = min_fail.load();
-    Work W(n);
-    for (int k = 0; k < first_failure; ++k)
-      if (task[k] < 0 && !process_row(k, W)) { first_failure = k; break; }
+    // What is left -- the separators above the tasks and, last, the rows every part of the graph reaches (the
+    // landmarks of a CORA problem: ten rows of L that are nearly dense and take nine tenths of this phase at 10^5
+    // poses when they run one after the other).  The trailing rows [k0, n) with a long row of A are taken together:
+    //   A  every row solves against the columns below k0 on its own thread.  Columns are read up to where the rows
+    //      before k0 left them and nothing is appended yet; the row's values stay in its scratch vector.
+    //   B  what the trailing rows contribute to each other through those columns -- the running value
+    //      x[k'] -= L[k', i] L[k, i] over row k's columns in their elimination order -- one pair (k, k') per work item;
+    //   C  the small trailing triangle, row after row (the pivots are tested here);
+    //   D  the rows' values go to the ends of their columns, row after row, every thread on a range of columns.
+    // Each number is produced by the operations of the sequential elimination in their sequential order, so the
+    // factor is the same bit for bit.  That relies on the row's elimination order visiting every column below k0
+    // before the first trailing one; a row for which this does not hold sends the whole group down the plain path.
+    int k0 = n;
+    if (std::getenv("CORA_CHOL_NO_TRAILING_GROUP") == nullptr)
+      while (k0 > 0 && n - k0 < 32 && task[k0 - 1] < 0 && Cp[k0] - Cp[k0 - 1] >= 64) --k0;
+    if (n - k0 < 2) k0 = n;
+    {
+      std::unique_ptr<Work> W = acquireWork(n);
+      for (int k = 0; k < std::min(first_failure, k0); ++k)
+        if (task[k] < 0 && !process_row(k, *W)) { first_failure = k; break; }
+      releaseWork(std::move(W));
+    }
+    tick("numeric: separators");
+    if (k0 < n && first_failure >= k0) {
+      const int ns = n - k0;
+      std::vector<std::unique_ptr<Work>> rows(static_cast<size_t>(ns));
+      std::vector<int32_t> top_of(static_cast<size_t>(ns), n), split_of(static_cast<size_t>(ns), n);
+      std::vector<double> dk_of(static_cast<size_t>(ns), 0.0);
+      std::vector<char> unordered(static_cast<size_t>(ns), 0);
+      for (int r = 0; r < ns; ++r) rows[r] = acquireWork(n);
+      const std::vector<int32_t> next0(next.begin(), next.begin() + k0);
+      std::atomic<int> next_row{0};
+      parallelRun(std::min<unsigned>(nth, static_cast<unsigned>(ns)), [&](unsigned) {
+        for (;;) {
+          const int r = next_row.fetch_add(1);
+          if (r >= ns) break;
+          const int k = k0 + r;
+          Work &W = *rows[r];
+          std::vector<double> &x = W.x;
+          std::vector<int32_t> &flag = W.flag, &stack = W.stack;
+          int top = n;
+          flag[k] = k;
+          double dk = 0.0;
+          for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+            int i = Ci[q];
+            if (i == k) { dk += Cx[q]; continue; }
+            x[i] += Cx[q];
+            int len = 0;
+            while (flag[i] != k) {
+              stack[len++] = i;
+              flag[i] = k;
+              i = F.parent[i];
+            }
+            while (len > 0) stack[--top] = stack[--len];
+          }
+          int split = top;
+          while (split < n && stack[split] < k0) ++split;
+          for (int t = split; t < n; ++t)
+            if (stack[t] < k0) unordered[r] = 1;
+          top_of[r] = top;
+          split_of[r] = split;
+          if (unordered[r]) continue;
+          for (int t = top; t < split; ++t) {
+            const int i = stack[t];
+            const double lki = x[i] / F.Lx[F.Lp[i]];
+            for (int32_t q = F.Lp[i] + 1; q < next0[i]; ++q) x[F.Li[q]] -= F.Lx[q] * lki;
+            x[i] = lki;  // the row's value stays here until step D
+            dk -= lki * lki;
+          }
+          dk_of[r] = dk;
+        }
+      });
+      tick("  trailing A (rows)");
+      bool plain = false;
+      for (int r = 0; r < ns; ++r) plain |= unordered[r] != 0;
+      if (plain) {
+        for (int r = 0; r < ns; ++r) {  // undo step A's bookkeeping (no row went past the scatter of A's entries)
+          Work &W = *rows[r];
+          const int k = k0 + r;
+          if (!unordered[r])
+            for (int t = top_of[r]; t < n; ++t) W.x[W.stack[t]] = 0.0;
+          for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) W.x[Ci[q]] = 0.0;
+        }
+        std::unique_ptr<Work> W = acquireWork(n);
+        for (int k = k0; k < n; ++k)
+          if (!process_row(k, *W)) { first_failure = k; break; }
+        releaseWork(std::move(W));
+      } else {
+        // B: pairs (k, k'), k' < k
+        std::vector<std::pair<int32_t, int32_t>> pairs;
+        for (int r = ns - 1; r >= 1; --r)
+          for (int r2 = 0; r2 < r; ++r2) pairs.push_back({r, r2});
+        std::atomic<int> next_pair{0};
+        parallelRun(std::min<unsigned>(nth, static_cast<unsigned>(pairs.size())), [&](unsigned) {
+          for (;;) {
+            const int e = next_pair.fetch_add(1);
+            if (e >= static_cast<int>(pairs.size())) break;
+            const int r = pairs[e].first, r2 = pairs[e].second;
+            const Work &Wk = *rows[r], &Wo = *rows[r2];
+            const int k2 = k0 + r2;
+            double v = Wk.x[k2];
+            const int32_t *st = Wk.stack.data();
+            const int32_t *fo = Wo.flag.data();
+            const double *xk = Wk.x.data(), *xo = Wo.x.data();
+            for (int t = top_of[r]; t < split_of[r]; ++t) {
+              const int i = st[t];
+              if (fo[i] == k2) v -= xo[i] * xk[i];
+            }
+            rows[r]->x[k2] = v;  // (nobody else reads or writes this element during step B)
+          }
+        });
+        tick("  trailing B (pairs)");
+        // C: the trailing triangle
+        int last_row = n - 1;
+        for (int r = 0; r < ns; ++r) {
+          const int k = k0 + r;
+          Work &W = *rows[r];
+          double dk = dk_of[r];
+          for (int t = split_of[r]; t < n; ++t) {
+            const int i = W.stack[t];
+            const double lki = W.x[i] / F.Lx[F.Lp[i]];
+            W.x[i] = 0.0;
+            for (int32_t q = F.Lp[i] + 1; q < next[i]; ++q) W.x[F.Li[q]] -= F.Lx[q] * lki;
+            dk -= lki * lki;
+            const int32_t w = next[i]++;
+            F.Li[w] = k;
+            F.Lx[w] = lki;
+          }
+          if (!(dk > 0.0)) {
+            first_failure = k;
+            last_row = k;
+            break;
+          }
+          const int32_t w = next[k]++;
+          F.Li[w] = k;
+          F.Lx[w] = std::sqrt(dk);
+        }
+        tick("  trailing C (triangle)");
+        // D: values to the ends of their columns; scratch vectors back to zero
+        const unsigned nd = nth;
+        parallelRun(nd, [&](unsigned th) {
+          const int lo = static_cast<int>(static_cast<int64_t>(k0) * th / nd), hi = static_cast<int>(static_cast<int64_t>(k0) * (th + 1) / nd);
+          for (int r = 0; r < ns; ++r) {
+            const int k = k0 + r;
+            Work &W = *rows[r];
+            const int32_t *fl = W.flag.data();
+            double *x = W.x.data();
+            const bool keep = k <= last_row;
+            for (int i = lo; i < hi; ++i)
+              if (fl[i] == k) {
+                if (keep) {
+                  const int32_t w = next[i]++;
+                  F.Li[w] = k;
+                  F.Lx[w] = x[i];
+                }
+                x[i] = 0.0;
+              }
+          }
+        });
+        for (int r = 0; r < ns; ++r)
+          for (int i = k0; i < n; ++i) rows[r]->x[i] = 0.0;
+      }
+      for (int r = 0; r < ns; ++r) releaseWork(std::move(rows[r]));
+    }
   }
-  tick("numeric: rest");
+  tick("numeric: trailing rows");
   if (first_failure < n) {
     const int k = first_failure;
     F.ok = false;
     F.failed_column = k;
-    // direction of non-positive curvature from the failing pivot: solve L11^T y = l_k
+    // The storage comes from a pool: what the stopped factorisation did not write is set to zero.  Direction of
+    // non-positive curvature from the failing pivot: solve L11^T y = l_k.  Row k is the last one that was appended to
+    // a column, so its value in column j, if it has one, is the column's last entry.  y[j] needs y of j's ancestors
+    // only: the separators first, then every subtree task on its own (same numbers, whoever computes them).
     std::vector<double> y(static_cast<size_t>(k) + 1, 0.0);
-    for (int j = 0; j < k; ++j)
-      for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
-        if (F.Li[q] == k) y[j] = F.Lx[q];  // l_k (row k of L)
-    for (int j = k - 1; j >= 0; --j) {
+    const unsigned nz = n < 20000 ? 1u : nth;
+    parallelRun(nz, [&](unsigned th) {
+      const int lo = static_cast<int>(static_cast<int64_t>(n) * th / nz), hi = static_cast<int>(static_cast<int64_t>(n) * (th + 1) / nz);
+      for (int j = lo; j < hi; ++j) {
+        for (int32_t q = next[j]; q < F.Lp[j + 1]; ++q) {
+          F.Li[q] = 0;
+          F.Lx[q] = 0.0;
+        }
+        if (j < k && next[j] > F.Lp[j] + 1 && F.Li[next[j] - 1] == k) y[j] = F.Lx[next[j] - 1];
+      }
+    });
+    auto back = [&](int j) {
       double s = y[j];
       for (int32_t q = F.Lp[j] + 1; q < next[j]; ++q)
         if (F.Li[q] < k) s -= F.Lx[q] * y[F.Li[q]];
       y[j] = s / F.Lx[F.Lp[j]];
+    };
+    tick("  unwritten entries, row k");
+    if (ntask == 0) {
+      for (int j = k - 1; j >= 0; --j) back(j);
+    } else {
+      for (int j = k - 1; j >= 0; --j)
+        if (task[j] < 0) back(j);
+      tick("  back: separators");
+      std::atomic<int> next_task{0};
+      parallelRun(nth, [&](unsigned) {
+        for (;;) {
+          const int t = next_task.fetch_add(1);
+          if (t >= ntask) break;
+          for (int32_t q = tptr[t + 1] - 1; q >= tptr[t]; --q)
+            if (trows[q] < k) back(trows[q]);
+        }
+      });
     }
+    tick("  back: tasks");
     F.negative_direction.assign(static_cast<size_t>(A.rows()), 0.0);
     double nrm = 1.0;
     for (int j = 0; j < k; ++j) nrm += y[j] * y[j];
     nrm = std::sqrt(nrm);
     for (int j = 0; j < k; ++j) F.negative_direction[perm[j]] = -y[j] / nrm;
     F.negative_direction[perm[k]] = 1.0 / nrm;
+    tick("direction of non-positive curvature");
   }
   return F;
 }

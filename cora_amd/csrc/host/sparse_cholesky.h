@@ -32,6 +32,12 @@ struct CholeskyFactor {
    * from the failing pivot: z = [-L11^-T l_k; 1; 0] has z^T M z = d_k <= 0. */
   std::vector<double> negative_direction;
   int64_t nnz() const { return static_cast<int64_t>(Li.size()); }
+  CholeskyFactor() = default;
+  CholeskyFactor(const CholeskyFactor &) = default;
+  CholeskyFactor(CholeskyFactor &&) = default;
+  CholeskyFactor &operator=(const CholeskyFactor &) = default;
+  CholeskyFactor &operator=(CholeskyFactor &&) = default;
+  ~CholeskyFactor();  // hands Li / Lx back to the storage pool of choleskyFactor
   /** Solve A X = B in place (B: n x k, column-major). */
   void solveInPlace(Matrix &B) const;
 };

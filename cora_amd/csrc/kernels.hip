@@ -407,7 +407,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   // narrow rows: the next-pose slots are peeled off the loop and their values shifted by one lane; wide rows (registers
   // are what they are short of: at a row stride of 10 the peeled form cost a wave of occupancy) re-read the previous
   // lane's values from the stream the wavefront has just loaded (L1 / L2 hits)
-  constexpr bool kNxtRegs = LD <= 8;
+  constexpr bool kNxtRegs = LD <= 5 || (LD <= 8 && EPI < 2);
   double nxt[kNxtRegs ? D : 1][D];
   int k0 = 0;
   if (kNxtRegs && sym) {

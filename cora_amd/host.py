@@ -260,15 +260,19 @@ class Problem:
                                                      B.ctypes.data_as(_dp), B.shape[1], info))
         return B, dict(ok=bool(info[0]), nnz=int(info[1]), height=int(info[2]))
 
-    def cholesky_probe(self, m=None, shift=0.0, leaf_poses=16):
-        """Host factorisation of (Q + shift I)[0:m, 0:m]: ok, nnz, first failing column, digest of L, negative direction."""
+    def cholesky_probe(self, m=None, shift=0.0, leaf_poses=16, bump=None):
+        """Host factorisation of (Q + shift I)[0:m, 0:m]: ok, nnz, first failing column, digest of L, negative direction.
+        bump = {row: value}: added to those diagonal entries of a copy of Q first."""
         dm = self.dims()
         m = dm["N"] - 1 if m is None else m
         info = (C.c_int64 * 3)()
         digest = np.zeros(2)
         neg = np.zeros(dm["N"])
-        self._chk(self.L.cora_problem_cholesky_probe(self.h, int(m), C.c_double(shift), int(leaf_poses), info,
-                                                     digest.ctypes.data_as(_dp), neg.ctypes.data_as(_dp)))
+        rows = np.array(sorted(bump or {}), dtype=np.int32)
+        vals = np.array([bump[r] for r in rows], dtype=np.float64) if len(rows) else np.zeros(0)
+        self._chk(self.L.cora_problem_cholesky_probe_bumped(
+            self.h, int(m), C.c_double(shift), int(leaf_poses), len(rows), rows.ctypes.data_as(C.POINTER(C.c_int32)),
+            vals.ctypes.data_as(_dp), info, digest.ctypes.data_as(_dp), neg.ctypes.data_as(_dp)))
         return dict(ok=bool(info[0]), nnz=int(info[1]), failed_column=int(info[2]), digest=digest, negative_direction=neg)
 
     def context_ptr(self):

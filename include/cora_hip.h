@@ -303,6 +303,10 @@ int cora_dots_dev(cora_ctx *ctx, int count, const double *const *dA,
  *   combine: Out = sum_{i<n} X_i C_i, C_i host column-major k_i x kout (ld k_i), n <= 4;
  *            Out must not alias an input. */
 int cora_gram_dev(cora_ctx *ctx, const double *dA, int ka, const double *dB, int kb, double *G);
+/* n <= 16 products G[e] = A_e^T B_e with one synchronisation: the numbers of n cora_gram_dev calls (same kernel, one
+ * piece of the reduction buffer each) -- the twelve Gram blocks of one Rayleigh-Ritz step. */
+int cora_gram_batch_dev(cora_ctx *ctx, int n, const double *const *dA, const int *ka, const double *const *dB,
+                        const int *kb, double *const *G);
 int cora_combine_dev(cora_ctx *ctx, int n, const double *const *dX, const int *k, const double *const *C,
                      int kout, double *dOut);
 

@@ -143,6 +143,11 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
  * factorisation (CORA_CHOL_THREADS) must reproduce the one-thread result exactly. */
 int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_poses, int64_t info[3], double *digest,
                                 double *negative_direction);
+/* The same on a copy of Q whose diagonal entries bump_rows[b] (original numbering) have bump_vals[b] added: puts the
+ * first non-positive pivot where a test wants it (e.g. inside the group of trailing landmark rows). */
+int cora_problem_cholesky_probe_bumped(cora_problem *p, int m, double shift, int leaf_poses, int nbump,
+                                       const int32_t *bump_rows, const double *bump_vals, int64_t info[3],
+                                       double *digest, double *negative_direction);
 
 /* getBlockCholeskyFactorization + blockCholeskySolve (include/CORA/CORA_preconditioners.h:40-44) on the host:
  * A symmetric CSR n x n, block sizes summing to n, B rhs_rows x k column-major with rhs_rows = n or n + 1

@@ -266,6 +266,39 @@ def test_parallel_cholesky_is_the_sequential_one(shift):
         assert z @ (Q @ z) + shift * (z @ z) <= 1e-9  # non-positive curvature of (Q + shift I)[0:N-1]
 
 
+@pytest.mark.parametrize("which,bump", [(0, -1e9), (2, -1e7), (4, -1e12), (5, -1e6), (5, 0.0)])
+def test_cholesky_trailing_rows_taken_together(which, bump):
+    """The landmark rows close the elimination order and are nearly dense rows of L; choleskyFactor solves them against
+    the columns before them on separate threads, forms what they contribute to each other pair by pair and finishes the
+    small trailing triangle in order (sparse_cholesky.cpp, steps A-D).  Every number is produced by the sequential
+    operations in the sequential order: factor, first failing pivot -- placed here on each of the trailing rows in turn
+    by moving one diagonal entry -- and the direction of non-positive curvature must equal the one-thread, one-row-at-a-
+    time result bit for bit (the PSD test of the reference, src/CORA_utils.cpp:36-51)."""
+    P = host.Problem.synthetic(dim=3, n_poses=6000, n_landmarks=6, n_ranges=3000, n_loops=3, seed=23)
+    P.update()
+    N = P.dims()["N"]
+    assert N > 20000
+    row = N - 6 + which
+    out = []
+    for group_off, threads in (("1", "1"), ("1", "5"), (None, "5"), (None, "16")):
+        os.environ["CORA_CHOL_THREADS"] = threads
+        if group_off:
+            os.environ["CORA_CHOL_NO_TRAILING_GROUP"] = group_off
+        try:
+            out.append(P.cholesky_probe(m=N, shift=1.0, bump={row: bump}))
+        finally:
+            os.environ.pop("CORA_CHOL_THREADS", None)
+            os.environ.pop("CORA_CHOL_NO_TRAILING_GROUP", None)
+    a = out[0]
+    assert a["ok"] == (bump == 0.0)
+    if not a["ok"]:
+        assert a["failed_column"] == N - 6 + which  # the landmarks are the last rows of the order, in index order
+    for b in out[1:]:
+        assert a["ok"] == b["ok"] and a["nnz"] == b["nnz"] and a["failed_column"] == b["failed_column"]
+        assert np.array_equal(a["digest"], b["digest"])
+        assert np.array_equal(a["negative_direction"], b["negative_direction"])
+
+
 def test_cholesky_symbolic_cache_changes_nothing():
     """choleskyFactor keeps the pattern-only part of a factorisation (permuted structure, elimination tree, column
     counts) between calls on the same pattern and order -- the certificate matrix S + eta I is factorised several times
