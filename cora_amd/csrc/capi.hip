@@ -76,7 +76,11 @@ struct cora_ctx {
   struct DevFactor {
     TriPlan plan;  // host copy is dropped after upload (only the counts are kept)
     std::vector<DevStage> stages;
+    // the plan's arrays live in a few large device chunks handed out front to back (60 arrays per factor: one hipMalloc
+    // / hipFree each cost more than the copies); a re-installed factor writes over the chunks of the one before
     std::vector<void *> allocs;
+    std::vector<size_t> chunk_bytes;
+    size_t chunk_at = 0, chunk_used = 0;
     int aux_rows = 0;  // two-stage plans: rows appended to the work vector
     bool fuse_ok = false;  // substitution blocks whose tiles hold every pose's rotation rows at consecutive positions:
                            // the STPCG passes can be fused into the sweeps (SubFuse, kernels.h)
@@ -756,9 +760,14 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
                           const double *Lx, const std::vector<int32_t> &row_of, int32_t zero_row,
                           const std::vector<int32_t> *group = nullptr) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (void *p : f.allocs)
-    if (p) (void)hipFree(p);
-  f.allocs.clear();
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "  [install] %-26s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  f.chunk_at = 0;
+  f.chunk_used = 0;
   f.stages.clear();
   f.ready = false;
   f.aux_rows = 0;
@@ -768,15 +777,28 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
   } catch (const std::exception &e) {
     return fail(c, CORA_ERR_ARG, e.what());
   }
+  tick("plan (host)");
   auto up = [&](auto **dst, const auto &vec) -> hipError_t {
     using T = typename std::remove_reference<decltype(vec)>::type::value_type;
-    T *p = nullptr;
-    hipError_t e = to_device(&p, vec);
-    if (e == hipSuccess) {
-      f.allocs.push_back(p);
-      *dst = p;
+    const size_t bytes = (std::max<size_t>(vec.size(), 1) * sizeof(T) + 255) & ~static_cast<size_t>(255);
+    while (f.chunk_at < f.allocs.size() && f.chunk_used + bytes > f.chunk_bytes[f.chunk_at]) {
+      ++f.chunk_at;
+      f.chunk_used = 0;
     }
-    return e;
+    if (f.chunk_at == f.allocs.size()) {
+      const size_t cb = std::max<size_t>(bytes, static_cast<size_t>(64) << 20);
+      void *q = nullptr;
+      const hipError_t e = hipMalloc(&q, cb);
+      if (e != hipSuccess) return e;
+      f.allocs.push_back(q);
+      f.chunk_bytes.push_back(cb);
+      f.chunk_used = 0;
+    }
+    T *p = reinterpret_cast<T *>(static_cast<char *>(f.allocs[f.chunk_at]) + f.chunk_used);
+    f.chunk_used += bytes;
+    *dst = p;
+    if (vec.empty()) return hipSuccess;
+    return hipMemcpy(p, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice);  // (vec may be a temporary)
   };
   auto up_op = [&](RowOpDev &D, RowOpHost &H) -> hipError_t {
     hipError_t e;
@@ -865,6 +887,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       HIP_TRY(c, up(&Q.c_val, H.c_val));
       HIP_TRY(c, up(&Q.top_rows, f.plan.top_rows));
       f.aux_rows = H.n_aux;
+      tick("  sub: desc + arrays");
       {
         // memory-order I/O lists of both sweeps: {internal row, tile position} of every block row, sorted by row
         auto io_of = [&](const std::vector<int32_t> &rows) {
@@ -882,6 +905,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
         };
         HIP_TRY(c, up(&Q.fwd.io, io_of(H.rows)));
         HIP_TRY(c, up(&Q.bwd.io, io_of(H.b_rows)));
+        tick("  sub: io lists");
         // fused projection in the backward sweep: the first rotation row of a pose finds the others right behind it
         // in the tile, and a pose of the last stage has all its rows there.  Row units of a block: {tile position, row}
         const Layout &L = c->F.L;
@@ -922,7 +946,9 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
         if (std::getenv("CORA_TRI_TIMING")) std::fprintf(stderr, "  [tri plan] sweep fusion possible: %d\n", int(ok));
       }
       HIP_TRY(c, up(&Q.desc, desc));
+      tick("  sub: units");
       H = SubBlockOpHost();
+      tick("  sub: host copy dropped");
       continue;
     }
     if (k == 1 && f.stages[0].is_sub) {  // the last stage of a two-stage plan: only its two explicit-inverse products
@@ -973,6 +999,8 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
     if (D.has_bwd_a) HIP_TRY(c, up_op(D.bwd_a, S.bwd_a));
     HIP_TRY(c, up_op(D.bwd_b, S.bwd_b));
   }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  tick("upload");
   f.ready = true;
   return CORA_OK;
 }

@@ -659,8 +659,9 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         n_fv += pc.S.f_val.size(), n_bv += pc.S.b_val.size(), n_cp += pc.S.c_ptr.size(), n_ci += pc.S.c_idx.size();
       }
       S0.rows.reserve(n_rows), S0.b_rows.reserve(n_brows), S0.tgt_row.reserve(n_tgt), S0.tgt_slot.reserve(n_tgt);
-      S0.f_hdr.reserve(n_fh), S0.b_hdr.reserve(n_bh), S0.f_idx.reserve(n_fi), S0.b_idx.reserve(n_bi);
-      S0.f_val.reserve(n_fv), S0.b_val.reserve(n_bv), S0.c_ptr.reserve(n_cp), S0.c_idx.reserve(n_ci), S0.c_val.reserve(n_ci);
+      // (+ 8: the upload pads these arrays for the kernel's read-ahead; without the room that is a copy of 40 MB each)
+      S0.f_hdr.reserve(n_fh + 8), S0.b_hdr.reserve(n_bh + 8), S0.f_idx.reserve(n_fi + 8), S0.b_idx.reserve(n_bi + 8);
+      S0.f_val.reserve(n_fv + 8), S0.b_val.reserve(n_bv + 8), S0.c_ptr.reserve(n_cp), S0.c_idx.reserve(n_ci), S0.c_val.reserve(n_ci);
     }
     for (size_t b = 0; b < pieces.size(); ++b) {
       SubBlockOpHost &Pc = pieces[b].S;

@@ -1,3 +1,5 @@
+#define _GNU_SOURCE
+#include <sched.h>
 /*
  * cora_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
@@ -70,6 +72,53 @@ void orc_spmm(int N, const int32_t *rowptr, const int32_t *col,
       oc[i] = s;
     }
   }
+}
+
+/* ---- NUMA placement for the all-core column of bench.py -----------------
+ * Linux places a page on the memory node of the thread that touches it first.  The threaded loops above and below
+ * share rows out with schedule(static), so copies made with the same schedule put every thread's rows of Q and of
+ * the dense operands on its own node (the destinations must be untouched memory: oracle.py maps them fresh).
+ * Without this, arrays filled by numpy sit on the master thread's node and a two-socket host runs the product out
+ * of one socket's memory. */
+/* Thread t of the OpenMP team runs on logical CPU cpus[t] (n = 0: every thread may run anywhere again, so that
+ * threads created afterwards by other code do not inherit a one-core mask from the master thread). */
+int orc_bind_threads(int n, const int *cpus) {
+  int failed = 0;
+#ifdef _OPENMP
+#pragma omp parallel reduction(+ : failed)
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const int t = omp_get_thread_num();
+    if (n > 0) {
+      CPU_SET(cpus[t % n], &set);
+    } else {
+      for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &set);
+    }
+    if (sched_setaffinity(0, sizeof(set), &set) != 0) failed += 1;
+  }
+#else
+  (void)n;
+  (void)cpus;
+#endif
+  return failed;
+}
+
+void orc_first_touch_csr(int N, const int32_t *rowptr, const int32_t *col,
+                         const double *val, int32_t *col_dst, double *val_dst) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; ++i)
+    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      col_dst[q] = col[q];
+      val_dst[q] = val[q];
+    }
+}
+void orc_first_touch_dense(int N, int k, const double *src, int lds, double *dst,
+                           int ldd) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; ++i)
+    for (int c = 0; c < k; ++c)
+      dst[(size_t)c * ldd + i] = src ? src[(size_t)c * lds + i] : 0.0;
 }
 
 /* Row-at-a-time variant of the same product (all k columns of one row per

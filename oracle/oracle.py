@@ -131,11 +131,73 @@ def rgrad(Q, dm, Y):
     return tangent_proj(dm, Y, egrad(Q, Y))
 
 
-def hvp(Q, dm, Y, G, Ydot):
+def _untouched(shape, dtype):
+    """An array on freshly mapped pages (numpy's allocator may hand back memory another thread has touched)."""
+    import mmap
+    count = int(np.prod(shape))
+    mm = mmap.mmap(-1, max(count * np.dtype(dtype).itemsize, 1))
+    return np.frombuffer(mm, dtype=dtype, count=count).reshape(shape, order="F")
+
+
+def cpu_order():
+    """Logical CPUs ordered socket by socket, core by core, SMT siblings next to each other."""
+    import glob, os
+    cpus = []
+    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*"):
+        try:
+            c = int(os.path.basename(d)[3:])
+            pk = int(open(d + "/topology/physical_package_id").read())
+            co = int(open(d + "/topology/core_id").read())
+        except (OSError, ValueError):
+            continue
+        cpus.append((pk, co, c))
+    allowed = os.sched_getaffinity(0)
+    return [c for _, _, c in sorted(cpus) if c in allowed]
+
+
+def bind_threads(threads):
+    """Spread the team over the machine: thread t on the (t * cpus / threads)-th CPU of cpu_order() -- neighbouring
+    threads (neighbouring rows) on neighbouring cores, the first half of the rows on the first socket.  threads = 0
+    lifts the binding.  Returns the CPUs used."""
+    if threads <= 0:
+        lib().orc_bind_threads(0, None)
+        return []
+    order = cpu_order()
+    if not order:
+        return []
+    pick = np.array([order[(t * len(order)) // threads] if threads <= len(order) else order[t % len(order)]
+                     for t in range(threads)], dtype=np.int32)
+    lib().orc_bind_threads(len(pick), pick.ctypes.data_as(_ip))
+    return pick.tolist()
+
+
+def numa_csr(Q):
+    """Copy of Q whose rows sit on the memory node of the thread that works on them (orc_first_touch_csr)."""
+    out = CSR.__new__(CSR)
+    out.rowptr, out.N, out.nnz = Q.rowptr, Q.N, Q.nnz
+    out.col = _untouched((Q.nnz,), np.int32)
+    out.val = _untouched((Q.nnz,), np.float64)
+    lib().orc_first_touch_csr(Q.N, _i(Q.rowptr), _i(Q.col), _d(Q.val), _i(out.col), _d(out.val))
+    return out
+
+
+def numa_dense(A=None, shape=None):
+    """Column-major copy of A (or zeros of `shape`) first touched with the threaded loops' row schedule."""
+    if A is not None:
+        A = _f(A)
+        shape = A.shape
+    out = _untouched(shape, np.float64)
+    lib().orc_first_touch_dense(shape[0], shape[1], None if A is None else _d(A), shape[0], _d(out), shape[0])
+    return out
+
+
+def hvp(Q, dm, Y, G, Ydot, out=None, work=None):
     Y, G, Ydot = _f(Y), _f(G), _f(Ydot)
     p = Y.shape[1]
-    out = np.empty((dm.N, p), order="F")
-    work = np.empty((dm.N, p), order="F")
+    if out is None:
+        out = np.empty((dm.N, p), order="F")
+    if work is None:
+        work = np.empty((dm.N, p), order="F")
     lib().orc_hvp(dm.d, dm.n, dm.r, dm.N, p, _i(Q.rowptr), _i(Q.col), _d(Q.val),
                   _d(Y), dm.N, _d(G), dm.N, _d(Ydot), dm.N, _d(out), dm.N, _d(work))
     return out
