@@ -35,6 +35,7 @@ struct cora_native_comm;
 static void native_comm_destroy(cora_native_comm *nc);
 static double *native_scalars(cora_native_comm *nc);                       // 8 device doubles of the sharded STPCG
 static int native_allreduce_dev(cora_native_comm *nc, double *d, int n);   // sum over the ranks, in place, on the stream
+static int native_exchange_on(cora_native_comm *nc, double *dX, int ld, hipStream_t st);  // the exchange, ordered on st
 static const std::string &native_error(const cora_native_comm *nc);
 struct cora_ctx {
   HostFormat F;
@@ -47,6 +48,14 @@ struct cora_ctx {
 
   SliceDesc *d_slices = nullptr;
   SliceDesc *d_slices_pf = nullptr;  // HostFormat::slices_pose_first (empty: nullptr)
+  // partitioned handles: the slices that read only rows of this rank's own shard ("interior") and the ones that read a
+  // row another rank owns ("boundary"), both in chain order.  With the library's own communication the interior slices
+  // run while the exchange of the operand is still under way on comm_stream (exchange_and_product)
+  SliceDesc *d_slices_int = nullptr, *d_slices_bnd = nullptr;
+  int n_slices_int = 0, n_slices_bnd = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_operand = nullptr, ev_exchanged = nullptr;
+  int overlap_exchange = 1;  // cora_comm_overlap_enable: 0 never, 1 when the interior part is worth a launch of its own, 2 always
   double *d_sval = nullptr;
   double *d_head_val = nullptr;  // HostFormat::head_val
   int32_t *d_scol = nullptr;
@@ -128,7 +137,10 @@ struct cora_ctx {
 
 struct cora_ctx;
 static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut);  // formulation-aware
-static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi);  // one SpMM launch + the distributed long rows
+static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi, bool finish = true);  // one SpMM launch (+ the distributed long rows)
+static int finish_long_rows(cora_ctx *c, const SpmmArgs &A, int ld, int epi);
+static int exchange_and_product(cora_ctx *c, SpmmArgs A, int ld, int epi);  // exchange of the operand's remote rows + the product
+static int product_kappa_slots(const cora_ctx *c, const SpmmArgs &A);
 
 namespace {
 
@@ -427,6 +439,32 @@ int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int 
   CREATE_TRY(to_device(&c->d_slices, F.slices));
   if (!F.slices_pose_first.empty()) CREATE_TRY(to_device(&c->d_slices_pf, F.slices_pose_first));
   CREATE_TRY(to_device(&c->d_head_val, F.head_val));
+  if (F.L.world > 1) {
+    // a slice is "boundary" when one of its stored columns is a row outside this rank's shard (padding entries carry
+    // local columns; the predecessor block a symmetric pose slice does not store belongs to a local pose by
+    // construction: format_build.cpp keeps the explicit layout at the head of a shard)
+    std::vector<SliceDesc> in, bd;
+    const int64_t lo = F.L.base, hi = F.L.base + F.L.shard_rows;
+    for (const SliceDesc &sd : F.slices) {
+      bool remote = false;
+      const size_t c0 = static_cast<size_t>(sd.coff), c1 = c0 + static_cast<size_t>(sd.width) * kWave;
+      for (size_t q = c0; q < c1 && !remote; ++q) remote = F.scol[q] < lo || F.scol[q] >= hi;
+      (remote ? bd : in).push_back(sd);
+    }
+    c->n_slices_int = static_cast<int>(in.size());
+    c->n_slices_bnd = static_cast<int>(bd.size());
+    CREATE_TRY(to_device(&c->d_slices_int, in));
+    CREATE_TRY(to_device(&c->d_slices_bnd, bd));
+    {
+      // highest priority: the exchange's small kernels take the wavefront slots the product frees first, instead of
+      // queueing behind a launch that fills the GPU
+      int least = 0, greatest = 0;
+      CREATE_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      CREATE_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, greatest));
+    }
+    CREATE_TRY(hipEventCreateWithFlags(&c->ev_operand, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&c->ev_exchanged, hipEventDisableTiming));
+  }
   if (!F.long_rows.empty()) {
     CREATE_TRY(to_device(&c->d_long_rows, F.long_rows));
     CREATE_TRY(to_device(&c->d_long_owner, F.long_owner));
@@ -483,7 +521,10 @@ void cora_ctx_destroy(cora_ctx *c) {
     native_comm_destroy(c->native_comm);
     c->native_comm = nullptr;
     free_rank_state(c);
-    void *ptrs[] = {c->d_slices, c->d_slices_pf, c->d_head_val, c->d_long_out, c->d_long_rows, c->d_long_owner, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    if (c->ev_operand) (void)hipEventDestroy(c->ev_operand);
+    if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
+    void *ptrs[] = {c->d_slices_int, c->d_slices_bnd, c->d_slices, c->d_slices_pf, c->d_head_val, c->d_long_out, c->d_long_rows, c->d_long_owner, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
                     c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg};
     for (void *p : ptrs)
@@ -721,11 +762,7 @@ int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *d
   NEED_DEVICE(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
-  {
-    const int rc = comm_exchange(c, dX, ld_for(k));
-    if (rc) return rc;
-  }
-  return launch_product(c, spmm_args(c, dX, dOut), ld_for(k), EPI_S);
+  return exchange_and_product(c, spmm_args(c, dX, dOut), ld_for(k), EPI_S);
 }
 
 int cora_tangent_space_projection_dev(cora_ctx *c, const double *dV, double *dOut) {
@@ -1153,17 +1190,71 @@ static int implicit_product(cora_ctx *c, const double *dX, int ld, int epi, doub
 // one product in the active formulation
 static int apply_product(cora_ctx *c, const double *dX, int ld, int epi, double *dOut) {
   if (c->implicit) return implicit_product(c, dX, ld, epi, dOut);
-  {
-    const int rc = comm_exchange(c, dX, ld);
+  return exchange_and_product(c, spmm_args(c, dX, dOut), ld, epi);
+}
+
+// true when products of this handle run as two launches around the exchange (exchange_and_product)
+static bool product_overlaps_exchange(const cora_ctx *c) {
+  static const bool off = std::getenv("CORA_NO_EXCHANGE_OVERLAP") != nullptr;
+  // The split costs a second launch and two cross-stream dependencies (a few microseconds); it pays when the interior
+  // slices run longer than that.  Measured with the in-process transport, 8 partitions of the 10^5-pose graph on one
+  // GPU (500 slices per rank, a 3 us product): 290-350 us per step serial, 460 us split -- so the default takes the
+  // split from kOverlapMinSlices interior slices on (about 10 us of product; 10^6 poses on 8 GPUs: 5 000 per rank).
+  static const int min_slices = [] { const char *e = std::getenv("CORA_EXCHANGE_OVERLAP_MIN_SLICES"); return e ? std::atoi(e) : 2048; }();
+  const bool wanted = c->overlap_exchange == 2 || (c->overlap_exchange == 1 && c->n_slices_int >= min_slices);
+  return c->F.L.world > 1 && wanted && !off && c->native_comm && c->comm_user == c->native_comm &&
+         c->comm_exchange != nullptr && c->n_slices_int > 0 && c->n_slices_bnd > 0 &&
+         (c->F.chunks.empty() || !c->F.long_rows.empty());  // (whole long rows read columns of every shard)
+}
+
+// number of kappa slots an EPI_HVP_K product of this handle writes (launch_product / exchange_and_product)
+static int product_kappa_slots(const cora_ctx *c, const SpmmArgs &A) {
+  if (!product_overlaps_exchange(c)) return launch_spmm_kappa_slots(A);
+  SpmmArgs A1 = A, A2 = A;
+  A1.n_slices = c->n_slices_int;
+  A2.n_slices = c->n_slices_bnd;
+  A2.n_chunks = 0;
+  return launch_spmm_blocks(A1) + A.n_long_rows + launch_spmm_blocks(A2);
+}
+
+// Exchange of the operand's remote rows + the product.  With the library's own communication the two overlap: the
+// exchange (pack -> all-gather -> scatter) runs on comm_stream, the interior slices and the long-row chunks -- which
+// read rows of this rank's shard only, while the scatter writes rows of the other shards -- run on the handle's stream
+// at the same time, and the boundary slices follow when the exchange has landed.  Injected callbacks (cora_set_comm)
+// keep the serial order.
+static int exchange_and_product(cora_ctx *c, SpmmArgs A, int ld, int epi) {
+  if (!product_overlaps_exchange(c)) {
+    const int rc = comm_exchange(c, A.X, ld);
     if (rc) return rc;
+    return launch_product(c, A, ld, epi);
   }
-  return launch_product(c, spmm_args(c, dX, dOut), ld, epi);
+  HIP_TRY(c, hipEventRecord(c->ev_operand, c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_operand, 0));
+  SpmmArgs A1 = A;
+  A1.slices = c->d_slices_int;
+  A1.slices_pose_first = nullptr;
+  A1.n_slices = c->n_slices_int;
+  int rc = launch_product(c, A1, ld, epi, /*finish_long_rows=*/false);   // interior slices + chunks, no exchange needed
+  if (rc) return rc;
+  if (native_exchange_on(c->native_comm, const_cast<double *>(A.X), ld, c->comm_stream))
+    return fail(c, CORA_ERR_HIP, "exchange step failed: " + native_error(c->native_comm));
+  HIP_TRY(c, hipEventRecord(c->ev_exchanged, c->comm_stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_exchanged, 0));
+  SpmmArgs A2 = A;
+  A2.slices = c->d_slices_bnd;
+  A2.slices_pose_first = nullptr;
+  A2.n_slices = c->n_slices_bnd;
+  A2.n_chunks = 0;
+  A2.n_long_rows = 0;
+  if (A.kappa_partial) A2.kappa_partial = A.kappa_partial + launch_spmm_blocks(A1) + A.n_long_rows;
+  HIP_TRY(c, launch_spmm(A2, ld, c->F.L.d, epi, c->stream));
+  return finish_long_rows(c, A1, ld, epi);
 }
 
 // A product on a partitioned handle ends with its DISTRIBUTED long rows (format_build.cpp): the slots of partial sums
 // are added over the ranks -- on the device with the library's own communication, through the host with injected
 // callbacks -- and the owner copies its rows to the result; the rows' shares of kappa follow (EPI_HVP_K).
-static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi) {
+static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi, bool finish) {
   const int nl = static_cast<int>(c->F.long_rows.size());
   const bool dist = c->F.L.world > 1 && nl > 0;
   if (dist) {
@@ -1171,6 +1262,13 @@ static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi) {
     HIP_TRY(c, hipMemsetAsync(c->d_long_out, 0, static_cast<size_t>(nl) * ld * sizeof(double), c->stream));
   }
   HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
+  return finish ? finish_long_rows(c, A, ld, epi) : CORA_OK;
+}
+
+// (A: the arguments of the launch that ran the long-row chunks -- its block count places the rows' kappa slots)
+static int finish_long_rows(cora_ctx *c, const SpmmArgs &A, int ld, int epi) {
+  const int nl = static_cast<int>(c->F.long_rows.size());
+  const bool dist = c->F.L.world > 1 && nl > 0;
   if (!dist) return CORA_OK;
   const int n = nl * ld;
   if (c->native_comm && c->comm_user == c->native_comm) {
@@ -1487,7 +1585,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       const RowOpDev &fb = f.stages[0].fwd_b;
       sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
     }
-    kappa_blocks = launch_spmm_kappa_slots(spmm_args(c, dP, dHp));
+    kappa_blocks = product_kappa_slots(c, spmm_args(c, dP, dHp));
     if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks) + rr_slots + yy_slots + sq_slots))) return rc;
     D.partial = c->d_red;
     kappa_partial = c->d_red + need;
@@ -1543,10 +1641,9 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
       if (fused) {
         // Hp = H p with the partials of kappa | kappa, alpha, r += alpha Hp with <r, r> | preconditioner | ...
-        if (sharded && (rc = comm_exchange(c, dP, c->ld))) return rc;
         SpmmArgs A = spmm_args(c, dP, dHp);
         A.kappa_partial = kappa_partial;
-        if ((rc = launch_product(c, A, c->ld, EPI_HVP_K))) return rc;
+        if ((rc = exchange_and_product(c, A, c->ld, EPI_HVP_K))) return rc;  // (one rank: the product alone)
         if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
         if (sharded) {
           // kappa: local partials (fixed order) -> sum over the ranks -> scalar step;  then r += alpha Hp with <r, r>
@@ -2247,15 +2344,16 @@ struct cora_native_comm {
   }
 
   // all-gather of `bytes` bytes per rank between DEVICE buffers, ordered on the handle's stream
-  int allgather_dev(const void *send, void *recv, size_t bytes) {
-    if (nccl) return nc(api->AllGather(send, recv, bytes, ncclChar, nccl, c->stream), "ncclAllGather");
-    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+  int allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
+    if (nccl) return nc(api->AllGather(send, recv, bytes, ncclChar, nccl, st), "ncclAllGather");
+    if (hip(hipStreamSynchronize(st), "hipStreamSynchronize")) return 1;
     g->ptrs[rank] = send;
     if (!g->barrier()) return fail_("local group broken");
     for (int r = 0; r < world; ++r)
       if (hip(hipMemcpyAsync(static_cast<char *>(recv) + static_cast<size_t>(r) * bytes, g->ptrs[r], bytes,
-                             hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync")) return 1;
-    if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
+                             hipMemcpyDeviceToDevice, st), "hipMemcpyAsync")) return 1;
+    if (hip(hipStreamSynchronize(st), "hipStreamSynchronize")) return 1;
     if (!g->barrier()) return fail_("local group broken");  // nobody reuses its send buffer before everyone has copied
     return 0;
   }
@@ -2353,13 +2451,15 @@ struct cora_native_comm {
     return 0;
   }
 
-  int exchange(double *dX, int ld) {
+  // pack -> all-gather -> scatter, ordered on `st` (default: the handle's stream)
+  int exchange(double *dX, int ld, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
     Buf *b;
     if (buffers(ld, &b)) return 1;
-    if (hip(launch_move_rows(0, e_max, ld, d_export, dX, b->send, c->stream), "pack")) return 1;
-    if (allgather_dev(b->send, b->recv, sizeof(double) * e_max * ld)) return 1;
-    return hip(launch_move_rows(1, static_cast<int64_t>(world) * e_max, ld, d_recv_idx, b->recv, dX, c->stream), "scatter");
+    if (hip(launch_move_rows(0, e_max, ld, d_export, dX, b->send, st), "pack")) return 1;
+    if (allgather_dev(b->send, b->recv, sizeof(double) * e_max * ld, st)) return 1;
+    return hip(launch_move_rows(1, static_cast<int64_t>(world) * e_max, ld, d_recv_idx, b->recv, dX, st), "scatter");
   }
   int allgather(double *dX, int ld) {  // whole shards, in place
     if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
@@ -2392,6 +2492,7 @@ struct cora_native_comm {
 static void native_comm_destroy(cora_native_comm *nc) { delete nc; }
 static double *native_scalars(cora_native_comm *nc) { return nc->d_scal + 1016; }  // behind the host all-reduce's staging
 static int native_allreduce_dev(cora_native_comm *nc, double *d, int n) { return nc->allreduce_dev(d, n); }
+static int native_exchange_on(cora_native_comm *nc, double *dX, int ld, hipStream_t st) { return nc->exchange(dX, ld, st); }
 static const std::string &native_error(const cora_native_comm *nc) { return nc->err; }
 
 namespace {
@@ -2488,6 +2589,15 @@ int cora_comm_native_enable(cora_ctx *c, int on) {
   c->comm_user = on ? c->native_comm : nullptr;
   return CORA_OK;
 }
+
+int cora_comm_overlap_enable(cora_ctx *c, int on) {
+  if (!c) return CORA_ERR_ARG;
+  if (on < 0 || on > 2) return fail(c, CORA_ERR_ARG, "overlap mode must be 0, 1 or 2");
+  c->overlap_exchange = on;
+  return CORA_OK;
+}
+
+int cora_comm_overlap_active(const cora_ctx *c) { return c && product_overlaps_exchange(c) ? 1 : 0; }
 
 int64_t cora_comm_exchanged_rows(const cora_ctx *c) { return (c && c->native_comm) ? c->native_comm->exchanged_rows : 0; }
 

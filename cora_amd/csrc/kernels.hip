@@ -304,6 +304,12 @@ constexpr int kWinTrnMaxLD = 8;                        // + the translation wind
 #ifndef CORA_POSE_COOP_EPI
 #define CORA_POSE_COOP_EPI 1
 #endif
+#ifndef CORA_POSE_PREFETCH
+#define CORA_POSE_PREFETCH 0
+#endif
+#ifndef CORA_POSE_PREFETCH_V
+#define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
+#endif
 #ifndef CORA_POSE_UNROLL_WIN
 #define CORA_POSE_UNROLL_WIN 2  // slots per trip of the window loop (round 3, with 3 waves per SIMD: 1 / 2 / 3 / 6 / 11 slots
 #endif                          // -> Hvp 21.4 / 21.5 / 21.8 / 23.0 / 30.0 us, rotated 29.2 / 29.2 / 29.3 / 32.0 / 41.0 us)
@@ -374,6 +380,24 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       }
     }
   }
+#if CORA_POSE_PREFETCH
+  // every cache line of the slice's value and index streams is requested here, next to the window's loads: the slot
+  // loop below waits for its loads trip after trip (registers allow two slots in flight), and with the working set in
+  // HBM each of those waits was a full memory latency; now they are L2 / Infinity Cache hits.  One dword per 64-byte
+  // line and lane, results never used.
+  int pfv[CORA_POSE_PREFETCH_V + 1];
+  if (kWin) {
+    const char *vb = reinterpret_cast<const char *>(A.sval + sd.off);
+    const int vbytes = sd.width * D * kWave * 8, cbytes = sd.width * kWave * 4;
+#pragma unroll
+    for (int i = 0; i < CORA_POSE_PREFETCH_V; ++i) {
+      const int o = (i * kWave + lane) * 64;
+      pfv[i] = *reinterpret_cast<const int *>(vb + (o < vbytes ? o : 0));
+    }
+    const int o = lane * 64;
+    pfv[CORA_POSE_PREFETCH_V] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.scol + sd.coff) + (o < cbytes ? o : 0));
+  }
+#endif
   double acc[D][LD];
 #pragma unroll
   for (int a = 0; a < D; ++a)
@@ -462,6 +486,12 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     }
   }
   if (!kNxtRegs && sym) predecessor_block();
+#if CORA_POSE_PREFETCH
+  if (kWin) {
+#pragma unroll
+    for (int i = 0; i <= CORA_POSE_PREFETCH_V; ++i) asm volatile("" ::"v"(pfv[i]));
+  }
+#endif
   if constexpr (kCoopT) if (kCoop) {
     double xo[D][LD];  // the pose's own rows of X (inside the rotation window; lanes past nrows read rows they ignore)
 #pragma unroll

@@ -362,6 +362,16 @@ class _NativeComm:
         self.ctx.L.cora_comm_native_enable.argtypes = [_C.c_void_p, _C.c_int]
         self.ctx._chk(self.ctx.L.cora_comm_native_enable(self.ctx.h, int(bool(on))))
 
+    def overlap(self, mode=1):
+        """0: products run after the exchange of their operand; 1 (default): they overlap it with their interior slices
+        when those are worth a launch of their own; 2: always."""
+        self.ctx.L.cora_comm_overlap_enable.argtypes = [_C.c_void_p, _C.c_int]
+        self.ctx._chk(self.ctx.L.cora_comm_overlap_enable(self.ctx.h, int(mode)))
+
+    def overlap_active(self):
+        self.ctx.L.cora_comm_overlap_active.argtypes = [_C.c_void_p]
+        return bool(self.ctx.L.cora_comm_overlap_active(self.ctx.h))
+
 
 class NativeLocalComm(_NativeComm):
     """Rank `ctx.rank` of a NativeLocalGroup: cora_comm_create_local (collective over the group's threads)."""

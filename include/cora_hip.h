@@ -375,6 +375,15 @@ int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
 /* Measurement switch: on = 0 leaves the collective steps to the caller again (a product then runs on whatever the
  * remote rows hold: bench.py times the kernel alone this way), on = 1 re-installs the native communication. */
 int cora_comm_native_enable(cora_ctx *ctx, int on);
+/* With the native communication a product of a partitioned handle overlaps the exchange of its operand with the
+ * slices that read this rank's own rows only: exchange (pack, all-gather, scatter) on a second stream, interior
+ * slices + long-row chunks at the same time on the handle's stream, boundary slices when the exchange has landed.
+ * on = 0: always the serial order (exchange, then one launch); on = 1 (default): the split from 2 048 interior slices
+ * per rank on (CORA_EXCHANGE_OVERLAP_MIN_SLICES) -- below, a second launch and two cross-stream dependencies cost more
+ * than the interior slices take; on = 2: always the split.  The results are the same numbers either way.
+ * cora_comm_overlap_active: 1 when products of this handle take the overlapped form. */
+int cora_comm_overlap_enable(cora_ctx *ctx, int on);
+int cora_comm_overlap_active(const cora_ctx *ctx);
 /* Building blocks of an exchange, on the handle's stream: dPacked[k] = dX[rows[k]], dX[rows[k]] = dPacked[k],
  * dDst[rows[k]] = dSrc[rows[k]] (rows: device array of n internal rows; ld = row stride in doubles). */
 int cora_pack_rows_dev(cora_ctx *ctx, const double *dX, int ld, const int32_t *d_rows, int64_t n, double *dPacked);

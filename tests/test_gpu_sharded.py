@@ -95,6 +95,44 @@ def test_sharded_operators_and_tnt_match_single_handle(world, n, transport):
         assert f == outs[0][0] and np.array_equal(res["x"], outs[0][2]["x"])
 
 
+@pytest.mark.parametrize("world,n", [(2, 900), (4, 6000)])
+def test_exchange_overlaps_the_interior_slices_with_the_same_numbers(world, n):
+    """With the library's own communication a product runs as two launches around the exchange of its operand: interior
+    slices (rows of the rank's own shard only) while pack / all-gather / scatter are under way on a second stream,
+    boundary slices when the remote rows have landed (capi.hip, exchange_and_product).  Every slice computes
+    what it computed before, so operators are the serial ones bit for bit; kappa adds its per-block partials in another
+    order, so the device-resident STPCG agrees to rounding."""
+    p = 5
+    P1 = _problem(n, p)
+    dm = P1.dims()
+    rng = np.random.default_rng(11)
+    Y = P1.op("projectToManifold", rng.uniform(-1, 1, (dm["N"], p)))
+    V = P1.op("tangent_space_projection", Y, rng.uniform(-1, 1, (dm["N"], p)))
+    X = rng.uniform(-1, 1, (dm["N"], p + 2))
+
+    def body(r, group):
+        P = _problem(n, p)
+        comm = P.set_partition(r, world, lambda ctx: NativeLocalComm(ctx, group))
+        out = {}
+        assert not comm.overlap_active()  # default: these shards are too small for a launch of their own to pay
+        for mode in (True, False):
+            comm.overlap(2 if mode else 0)
+            assert comm.overlap_active() == mode
+            H = P.op("Riemannian_Hessian_vector_product", Y, P.op("Euclidean_gradient", Y), V)
+            f = P.op("evaluateObjective", Y)
+            res = P.tnt(Y, max_iterations=5)
+            out[mode] = (f, H, res)
+        return out
+
+    outs = _run_ranks(world, body, "native")
+    for o in outs:
+        assert o[True][0] == o[False][0]
+        assert np.array_equal(o[True][1], o[False][1])
+        a, b = o[True][2], o[False][2]
+        assert a["iterations"] == b["iterations"] and a["hvps"] == b["hvps"]
+        assert abs(a["f"] - b["f"]) < 1e-12 * abs(b["f"]) and np.abs(a["x"] - b["x"]).max() < 1e-9
+
+
 @pytest.mark.parametrize("transport", ["callbacks", "native"])
 def test_eight_partitions_of_the_headline_graph(transport):
     """BASELINE config 4 / 5 on one GPU: the 10^5-pose graph cut into 8 row partitions, the Hessian-vector
