@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -928,16 +929,24 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       {
         // memory-order I/O lists of both sweeps: {internal row, tile position} of every block row, sorted by row
         auto io_of = [&](const std::vector<int32_t> &rows) {
-          std::vector<int2> io(rows.size());
-          std::vector<int32_t> ord;
-          for (size_t b = 0; b < desc.size(); ++b) {
-            const int32_t r0 = desc[b].row_begin, nb = desc[b].nrows;
-            ord.resize(static_cast<size_t>(nb));
-            for (int k = 0; k < nb; ++k) ord[k] = k;
-            std::sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return rows[r0 + x] < rows[r0 + y]; });
-            for (int k = 0; k < nb; ++k) io[static_cast<size_t>(r0) + k] = make_int2(rows[r0 + ord[k]], ord[k]);
-          }
-          io.push_back(make_int2(0, 0));  // a block without rows still forms an address
+          std::vector<int2> io(rows.size() + 1);  // (+ 1: a block without rows still forms an address)
+          const size_t nblk = desc.size();
+          const unsigned nth = nblk < 64 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+          auto part = [&](unsigned t) {  // blocks are independent: a range of them per thread
+            std::vector<int32_t> ord;
+            for (size_t b = nblk * t / nth; b < nblk * (t + 1) / nth; ++b) {
+              const int32_t r0 = desc[b].row_begin, nb = desc[b].nrows;
+              ord.resize(static_cast<size_t>(nb));
+              for (int k = 0; k < nb; ++k) ord[k] = k;
+              std::sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return rows[r0 + x] < rows[r0 + y]; });
+              for (int k = 0; k < nb; ++k) io[static_cast<size_t>(r0) + k] = make_int2(rows[r0 + ord[k]], ord[k]);
+            }
+          };
+          std::vector<std::thread> pool;
+          for (unsigned t = 1; t < nth; ++t) pool.emplace_back(part, t);
+          part(0);
+          for (std::thread &th : pool) th.join();
+          io.back() = make_int2(0, 0);
           return io;
         };
         HIP_TRY(c, up(&Q.fwd.io, io_of(H.rows)));
@@ -992,7 +1001,9 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       D.aux_sum = !S.fwd_a.empty();      // (+ the sum of the aux rows as a product of its own on large plans)
       if (D.aux_sum) HIP_TRY(c, up_op(D.fwd_a, S.fwd_a));
       HIP_TRY(c, up_op(D.fwd_b, S.fwd_b));
+      tick("  top: forward product");
       HIP_TRY(c, up_op(D.bwd_b, S.bwd_b));
+      tick("  top: backward product");
       continue;
     }
     if (D.has_fwd_a) HIP_TRY(c, up_op(D.fwd_a, S.fwd_a));

@@ -16,6 +16,7 @@
 #include "CORA.h"
 #include "TNT.h"
 #include "sparse_cholesky.h"
+#include "../trisolve.h"
 #include "synthetic.h"
 
 using namespace CORA;
@@ -435,6 +436,30 @@ int cora_problem_cholesky_probe_bumped(cora_problem *p, int m, double shift, int
 int cora_problem_cholesky_probe(cora_problem *p, int m, double shift, int leaf_poses, int64_t info[3], double *digest,
                                 double *negative_direction) {
   return cora_problem_cholesky_probe_bumped(p, m, shift, leaf_poses, 0, nullptr, nullptr, info, digest, negative_direction);
+}
+
+int cora_problem_plan_probe(cora_problem *p, double shift, int leaf_poses, int64_t info[4]) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const SparseMatrix &Q = q.getDataMatrix();
+    const int N = static_cast<int>(Q.rows()), m = N - 1;
+    const auto perm = coraOrdering(q.dim(), q.numPoses(), q.numRangeMeasurements(), q.numTranslationalStates(), Q, m,
+                                   leaf_poses > 0 ? leaf_poses : 2);
+    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
+    if (!F.ok) throw std::runtime_error("plan probe: the factorisation failed");
+    // rows in API order stand in for the handle's internal order (the probe is about the builder's time and the
+    // plan's shape, not about a particular handle); pose groups as capi.hip forms them
+    std::vector<int32_t> row_of(perm.begin(), perm.end()), group(static_cast<size_t>(m), -1);
+    const int64_t dn = static_cast<int64_t>(q.dim()) * q.numPoses();
+    for (int i = 0; i < m; ++i)
+      if (perm[i] < dn) group[i] = perm[i] / q.dim();
+    cora::TriPlan P;
+    cora::build_tri_plan(m, F.Lp.data(), F.Li.data(), F.Lx.data(), row_of, N - 1, P, &group, N);
+    info[0] = static_cast<int64_t>(P.stages.size());
+    info[1] = P.nnzL;
+    info[2] = P.stages.empty() ? 0 : (P.stages[0].sub ? static_cast<int64_t>(P.stages[0].sub_op.nrows.size()) : 0);
+    info[3] = static_cast<int64_t>(P.top_rows.size());
+  });
 }
 
 int cora_host_block_cholesky_solve(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int nblocks,

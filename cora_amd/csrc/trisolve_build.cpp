@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <exception>
 #include <stdexcept>
+#include <functional>
 #include <thread>
 #include <utility>
 
@@ -97,39 +98,107 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   P.zero_row = zero_row;
   if (m <= 0) return;
   P.nnzL = Lp[m];
-  // ---- elimination tree and row lengths
+  // ---- elimination tree and row lengths, CSR of the strictly lower part (rows of L, columns ascending).
+  // Threads take ascending ranges of columns (equal shares of the entries): they check their columns, count their
+  // entries per row, and the counts of the threads before give each its place in the row.
   std::vector<int32_t> parent(m, -1), rcount(m, 0);
   bool sorted = true;  // columns with ascending row indices: the rows of a column's own block come first
-  for (int j = 0; j < m; ++j) {
-    if (Li[Lp[j]] != j) throw std::runtime_error("cora: Cholesky factor must store the diagonal first in each column");
-    for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
-      if (Li[q] <= j || Li[q] >= m) throw std::runtime_error("cora: Cholesky factor has an entry above the diagonal");
-      if (parent[j] < 0 || Li[q] < parent[j]) parent[j] = Li[q];
-      if (q > Lp[j] + 1 && Li[q] < Li[q - 1]) sorted = false;
-      rcount[Li[q]]++;
-    }
-  }
   for (int i = 0; i < m; ++i)
     if (row_of[i] < 0) throw std::runtime_error("cora: factor row outside the handle");
-  // ---- CSR of the strictly lower part (rows of L, columns ascending)
+  const unsigned hw0 = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt0 = Lp[m] < (1 << 20) ? 1u : std::min(8u, hw0);
+  std::vector<int> cut(nt0 + 1, m);
+  cut[0] = 0;
+  for (unsigned t = 1; t < nt0; ++t) {
+    const int32_t want = static_cast<int32_t>(static_cast<int64_t>(Lp[m]) * t / nt0);
+    cut[t] = static_cast<int>(std::lower_bound(Lp, Lp + m, want) - Lp);
+  }
+  std::vector<std::vector<int32_t>> at(nt0);
+  std::vector<const char *> bad(nt0, nullptr);
+  std::vector<char> unsorted(nt0, 0);
+  auto run0 = [&](auto body) {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt0; ++t) pool.emplace_back(body, t);
+    body(0u);
+    for (std::thread &th : pool) th.join();
+  };
+  run0([&](unsigned t) {
+    std::vector<int32_t> &a = at[t];
+    a.assign(static_cast<size_t>(m), 0);
+    for (int j = cut[t]; j < cut[t + 1]; ++j) {
+      if (Li[Lp[j]] != j) { bad[t] = "cora: Cholesky factor must store the diagonal first in each column"; return; }
+      for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
+        if (Li[q] <= j || Li[q] >= m) { bad[t] = "cora: Cholesky factor has an entry above the diagonal"; return; }
+        if (parent[j] < 0 || Li[q] < parent[j]) parent[j] = Li[q];
+        if (q > Lp[j] + 1 && Li[q] < Li[q - 1]) unsorted[t] = 1;
+        a[Li[q]]++;
+      }
+    }
+  });
+  for (unsigned t = 0; t < nt0; ++t) {
+    if (bad[t]) throw std::runtime_error(bad[t]);
+    if (unsorted[t]) sorted = false;
+  }
+  run0([&](unsigned t) {
+    for (int i = static_cast<int>(static_cast<int64_t>(m) * t / nt0); i < static_cast<int>(static_cast<int64_t>(m) * (t + 1) / nt0); ++i) {
+      int32_t n = 0;
+      for (unsigned u = 0; u < nt0; ++u) n += at[u][i];
+      rcount[i] = n;
+    }
+  });
   std::vector<int32_t> rptr(static_cast<size_t>(m) + 1, 0);
   for (int i = 0; i < m; ++i) rptr[i + 1] = rptr[i] + rcount[i];
   std::vector<int32_t> rcol(static_cast<size_t>(rptr[m]));
   std::vector<double> rval(static_cast<size_t>(rptr[m]));
-  {
-    std::vector<int32_t> fill(rptr.begin(), rptr.end() - 1);
-    for (int j = 0; j < m; ++j)
-      for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
-        rcol[fill[Li[q]]] = j;
-        rval[fill[Li[q]]++] = Lx[q];
+  run0([&](unsigned t) {  // counts -> start positions
+    for (int i = static_cast<int>(static_cast<int64_t>(m) * t / nt0); i < static_cast<int>(static_cast<int64_t>(m) * (t + 1) / nt0); ++i) {
+      int32_t pos = rptr[i];
+      for (unsigned u = 0; u < nt0; ++u) {
+        const int32_t n_u = at[u][i];
+        at[u][i] = pos;
+        pos += n_u;
       }
-  }
+    }
+  });
+  run0([&](unsigned t) {
+    std::vector<int32_t> &a = at[t];
+    for (int j = cut[t]; j < cut[t + 1]; ++j)
+      for (int32_t q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
+        const int32_t w = a[Li[q]]++;
+        rcol[w] = j;
+        rval[w] = Lx[q];
+      }
+  });
+  at.clear();
   tick("rows of L");
   // ---- elimination tree of the factor's own pattern (Liu's algorithm with path compression).  For a complete
   // Cholesky factor this is "parent = first sub-diagonal row of the column"; an INCOMPLETE factor (dropped entries)
   // only keeps the property the stages below rely on -- L_ij != 0 implies that i is an ancestor of j -- with the
   // tree of its actual pattern.
-  {
+  // A complete factor is recognised by its pattern being closed under elimination -- the rows of column j below its
+  // first one are rows of that first one's column -- and then the first sub-diagonal rows found above ARE the tree
+  // (checked column by column on threads, sorted columns: one merge walk each); anything else takes Liu's algorithm.
+  bool closed = sorted;
+  if (closed) {
+    std::vector<char> open_(nt0, 0);
+    run0([&](unsigned t) {
+      for (int j = static_cast<int>(static_cast<int64_t>(m) * t / nt0); j < static_cast<int>(static_cast<int64_t>(m) * (t + 1) / nt0) && !open_[t]; ++j) {
+        const int pj = parent[j];
+        if (pj < 0) continue;
+        int32_t a = Lp[j] + 2, b = Lp[pj] + 1;  // rows of column j after its first one; rows of column pj after the diagonal
+        const int32_t ae = Lp[j + 1], be = Lp[pj + 1];
+        while (a < ae) {
+          while (b < be && Li[b] < Li[a]) ++b;
+          if (b == be || Li[b] != Li[a]) { open_[t] = 1; break; }
+          ++a;
+        }
+      }
+    });
+    for (unsigned t = 0; t < nt0; ++t) closed = closed && !open_[t];
+  }
+  const bool check_tree = closed && std::getenv("CORA_TRI_CHECK_ETREE") != nullptr;  // test hook: both ways, must agree
+  const std::vector<int32_t> parent_closed = check_tree ? parent : std::vector<int32_t>();
+  if (!closed || check_tree) {
     std::fill(parent.begin(), parent.end(), -1);
     std::vector<int32_t> anc(static_cast<size_t>(m), -1);
     for (int i = 0; i < m; ++i)
@@ -143,6 +212,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         }
       }
   }
+  if (check_tree && parent != parent_closed) throw std::logic_error("cora: the closed-pattern elimination tree differs from Liu's");
   tick("elimination tree");
   // ---- stages: repeatedly peel the maximal subtrees of the remaining forest that fit the cap
   int first_border = m;  // trailing run of long rows: forced into the last stage
@@ -631,7 +701,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     };
     {
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-      size_t nth = std::min<size_t>(std::min<size_t>(hw, 16), std::max<size_t>(members.size() / 8, 1));
+      size_t nth = std::min<size_t>(std::min<size_t>(hw, 48), std::max<size_t>(members.size() / 8, 1));
       if (const char *e = std::getenv("CORA_TRI_THREADS")) nth = std::max(1, std::atoi(e));
       std::vector<std::thread> pool;
       std::vector<std::exception_ptr> errs(nth);
@@ -649,60 +719,90 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     }
     tick("blocks (threads)");
     SubBlockOpHost &S0 = SG;
-    S0.c_ptr.push_back(0);
-    auto append = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
-    {  // one allocation per array (growing them piece by piece copied the 130 MB of a 10^5-pose plan several times)
-      size_t n_rows = 0, n_brows = 0, n_tgt = 0, n_fh = 0, n_bh = 0, n_fi = 0, n_bi = 0, n_fv = 0, n_bv = 0, n_cp = 1, n_ci = 0;
-      for (const Piece &pc : pieces) {
-        n_rows += pc.S.rows.size(), n_brows += pc.S.b_rows.size(), n_tgt += pc.S.tgt_row.size();
-        n_fh += pc.S.f_hdr.size(), n_bh += pc.S.b_hdr.size(), n_fi += pc.S.f_idx.size(), n_bi += pc.S.b_idx.size();
-        n_fv += pc.S.f_val.size(), n_bv += pc.S.b_val.size(), n_cp += pc.S.c_ptr.size(), n_ci += pc.S.c_idx.size();
-      }
-      S0.rows.reserve(n_rows), S0.b_rows.reserve(n_brows), S0.tgt_row.reserve(n_tgt), S0.tgt_slot.reserve(n_tgt);
-      // (+ 8: the upload pads these arrays for the kernel's read-ahead; without the room that is a copy of 40 MB each)
-      S0.f_hdr.reserve(n_fh + 8), S0.b_hdr.reserve(n_bh + 8), S0.f_idx.reserve(n_fi + 8), S0.b_idx.reserve(n_bi + 8);
-      S0.f_val.reserve(n_fv + 8), S0.b_val.reserve(n_bv + 8), S0.c_ptr.reserve(n_cp), S0.c_idx.reserve(n_ci), S0.c_val.reserve(n_ci);
+    // The per-block pieces go into one array each.  Where every piece lands follows from the sizes (prefix sums); the
+    // 130 MB of entries are then sized by a few threads (one array each: fresh pages) and copied by all of them (one
+    // range of pieces each) -- appended one after the other this was a third of the plan's time.
+    const size_t np = pieces.size();
+    struct Off { size_t rows, brows, tgt, fh, bh, fi, bi, fv, bv, cp, ci; };
+    std::vector<Off> off(np + 1);
+    off[0] = Off{0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};  // (c_ptr starts with its leading 0)
+    for (size_t b = 0; b < np; ++b) {
+      const SubBlockOpHost &Pc = pieces[b].S;
+      const Off &o = off[b];
+      off[b + 1] = Off{o.rows + Pc.rows.size(), o.brows + Pc.b_rows.size(), o.tgt + Pc.tgt_row.size(), o.fh + Pc.f_hdr.size(),
+                       o.bh + Pc.b_hdr.size(), o.fi + Pc.f_idx.size(), o.bi + Pc.b_idx.size(), o.fv + Pc.f_val.size(),
+                       o.bv + Pc.b_val.size(), o.cp + Pc.c_ptr.size(), o.ci + Pc.c_idx.size()};
     }
-    for (size_t b = 0; b < pieces.size(); ++b) {
-      SubBlockOpHost &Pc = pieces[b].S;
+    const Off &tot = off[np];
+    {
+      // (+ 8 of capacity: the upload pads these arrays for the kernel's read-ahead; without the room that is a copy of
+      // 40 MB each)
+      std::vector<std::function<void()>> sizing = {
+          [&] { S0.f_val.reserve(tot.fv + 8); S0.f_val.resize(tot.fv); },
+          [&] { S0.b_val.reserve(tot.bv + 8); S0.b_val.resize(tot.bv); },
+          [&] { S0.f_idx.reserve(tot.fi + 8); S0.f_idx.resize(tot.fi); },
+          [&] { S0.b_idx.reserve(tot.bi + 8); S0.b_idx.resize(tot.bi); },
+          [&] { S0.f_hdr.reserve(tot.fh + 8); S0.f_hdr.resize(tot.fh); S0.b_hdr.reserve(tot.bh + 8); S0.b_hdr.resize(tot.bh); },
+          [&] { S0.c_idx.resize(tot.ci); S0.c_val.resize(tot.ci); S0.c_ptr.resize(tot.cp); S0.c_ptr[0] = 0; },
+          [&] { S0.rows.resize(tot.rows); S0.b_rows.resize(tot.brows); S0.tgt_row.resize(tot.tgt); S0.tgt_slot.resize(tot.tgt); }};
+      std::vector<std::thread> pool;
+      for (auto &fn : sizing) pool.emplace_back(fn);
+      for (std::thread &th : pool) th.join();
+    }
+    // small per-block records and the aux slots, in block order
+    S0.row_begin.reserve(np), S0.nrows.reserve(np), S0.f_ent_begin.reserve(np), S0.b_ent_begin.reserve(np);
+    S0.f_nent.reserve(np), S0.b_nent.reserve(np), S0.f_lev_begin.reserve(np + 1), S0.b_lev_begin.reserve(np + 1), S0.tgt_begin.reserve(np + 1);
+    for (size_t b = 0; b < np; ++b) {
+      const SubBlockOpHost &Pc = pieces[b].S;
+      const Off &o = off[b];
       if (!pieces[b].groups_ok) P.groups_whole = false;
-      const int32_t row0 = static_cast<int32_t>(S0.rows.size()), fe = static_cast<int32_t>(S0.f_val.size()),
-                    be = static_cast<int32_t>(S0.b_val.size()), fl = static_cast<int32_t>(S0.f_hdr.size() / 4),
-                    bl = static_cast<int32_t>(S0.b_hdr.size() / 4), tg = static_cast<int32_t>(S0.tgt_slot.size()),
-                    c0 = static_cast<int32_t>(S0.c_idx.size());
-      S0.row_begin.push_back(row0);
+      S0.row_begin.push_back(static_cast<int32_t>(o.rows));
       S0.nrows.push_back(Pc.nrows[0]);
-      S0.f_ent_begin.push_back(fe);
-      S0.b_ent_begin.push_back(be);
+      S0.f_ent_begin.push_back(static_cast<int32_t>(o.fv));
+      S0.b_ent_begin.push_back(static_cast<int32_t>(o.bv));
       S0.f_nent.push_back(Pc.f_nent[0]);
       S0.b_nent.push_back(Pc.b_nent[0]);
-      S0.f_lev_begin.push_back(fl);
-      S0.b_lev_begin.push_back(bl);
-      S0.tgt_begin.push_back(tg);
-      append(S0.rows, Pc.rows);
-      append(S0.b_rows, Pc.b_rows);
-      append(S0.tgt_row, Pc.tgt_row);
-      for (size_t q = 3; q < Pc.f_hdr.size(); q += 4) Pc.f_hdr[q] += static_cast<int32_t>(S0.f_idx.size());  // indices: absolute
-      for (size_t q = 3; q < Pc.b_hdr.size(); q += 4) Pc.b_hdr[q] += static_cast<int32_t>(S0.b_idx.size());
-      append(S0.f_hdr, Pc.f_hdr);
-      append(S0.b_hdr, Pc.b_hdr);
-      append(S0.f_idx, Pc.f_idx);
-      append(S0.b_idx, Pc.b_idx);
-      append(S0.f_val, Pc.f_val);
-      append(S0.b_val, Pc.b_val);
+      S0.f_lev_begin.push_back(static_cast<int32_t>(o.fh / 4));
+      S0.b_lev_begin.push_back(static_cast<int32_t>(o.bh / 4));
+      S0.tgt_begin.push_back(static_cast<int32_t>(o.tgt));
       for (size_t t = 0; t < Pc.tgt_slot.size(); ++t) {
         aux_of[pieces[b].tgt_var[t]].push_back(S0.n_aux);
-        S0.tgt_slot.push_back(S0.n_aux++);
+        S0.tgt_slot[o.tgt + t] = S0.n_aux++;
       }
-      for (int32_t v : Pc.c_ptr) S0.c_ptr.push_back(c0 + v);
-      append(S0.c_idx, Pc.c_idx);
-      append(S0.c_val, Pc.c_val);
       S0.max_rows = std::max(S0.max_rows, Pc.max_rows);
       S0.max_ent = std::max(S0.max_ent, Pc.max_ent);
       S0.max_lev = std::max(S0.max_lev, Pc.max_lev);
       S0.max_level_lanes = std::max(S0.max_level_lanes, Pc.max_level_lanes);
       S0.max_npl = std::max(S0.max_npl, Pc.max_npl);
-      pieces[b] = Piece();
+    }
+    {
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      const size_t nth = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw, 32), np / 8));
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < nth; ++t)
+        pool.emplace_back([&, t] {
+          auto put = [](auto &dst, size_t at, const auto &src) { std::copy(src.begin(), src.end(), dst.begin() + static_cast<std::ptrdiff_t>(at)); };
+          for (size_t b = np * t / nth; b < np * (t + 1) / nth; ++b) {
+            SubBlockOpHost &Pc = pieces[b].S;
+            const Off &o = off[b];
+            put(S0.rows, o.rows, Pc.rows);
+            put(S0.b_rows, o.brows, Pc.b_rows);
+            put(S0.tgt_row, o.tgt, Pc.tgt_row);
+            for (size_t q = 3; q < Pc.f_hdr.size(); q += 4) Pc.f_hdr[q] += static_cast<int32_t>(o.fi);  // indices: absolute
+            for (size_t q = 3; q < Pc.b_hdr.size(); q += 4) Pc.b_hdr[q] += static_cast<int32_t>(o.bi);
+            put(S0.f_hdr, o.fh, Pc.f_hdr);
+            put(S0.b_hdr, o.bh, Pc.b_hdr);
+            put(S0.f_idx, o.fi, Pc.f_idx);
+            put(S0.b_idx, o.bi, Pc.b_idx);
+            put(S0.f_val, o.fv, Pc.f_val);
+            put(S0.b_val, o.bv, Pc.b_val);
+            for (size_t q = 0; q < Pc.c_ptr.size(); ++q) S0.c_ptr[o.cp + q] = static_cast<int32_t>(o.ci) + Pc.c_ptr[q];
+            put(S0.c_idx, o.ci, Pc.c_idx);
+            put(S0.c_val, o.ci, Pc.c_val);
+            pieces[b] = Piece();
+          }
+        });
+      for (std::thread &th : pool) th.join();
     }
     S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
     S0.f_lev_begin.push_back(static_cast<int32_t>(S0.f_hdr.size() / 4));

@@ -275,6 +275,12 @@ class Problem:
             vals.ctypes.data_as(_dp), info, digest.ctypes.data_as(_dp), neg.ctypes.data_as(_dp)))
         return dict(ok=bool(info[0]), nnz=int(info[1]), failed_column=int(info[2]), digest=digest, negative_direction=neg)
 
+    def plan_probe(self, shift, leaf_poses=2):
+        """Host factorisation of (Q + shift I)[0:N-1] + the device solve plan built from it, no GPU involved."""
+        info = (C.c_int64 * 4)()
+        self._chk(self.L.cora_problem_plan_probe(self.h, C.c_double(shift), int(leaf_poses), info))
+        return dict(stages=int(info[0]), nnzL=int(info[1]), blocks=int(info[2]), top_rows=int(info[3]))
+
     def context_ptr(self):
         c = self.L.cora_problem_context(self.h)
         if not c:

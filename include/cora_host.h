@@ -149,6 +149,11 @@ int cora_problem_cholesky_probe_bumped(cora_problem *p, int m, double shift, int
                                        const int32_t *bump_rows, const double *bump_vals, int64_t info[3],
                                        double *digest, double *negative_direction);
 
+/* Test / timing hook without a GPU: factor of (Q + shift I)[0:N-1] and the device solve plan built from it (the host part
+ * of the preconditioner's set-up; CORA_TRI_TIMING=1 prints its phases).  info = {stages, nnz(L), substitution blocks,
+ * rows of the top stage}. */
+int cora_problem_plan_probe(cora_problem *p, double shift, int leaf_poses, int64_t info[4]);
+
 /* getBlockCholeskyFactorization + blockCholeskySolve (include/CORA/CORA_preconditioners.h:40-44) on the host:
  * A symmetric CSR n x n, block sizes summing to n, B rhs_rows x k column-major with rhs_rows = n or n + 1
  * (then the last row of X is zero). */

@@ -299,6 +299,19 @@ def test_cholesky_trailing_rows_taken_together(which, bump):
         assert np.array_equal(a["negative_direction"], b["negative_direction"])
 
 
+def test_solve_plan_takes_the_tree_of_a_complete_factor_from_its_columns(monkeypatch):
+    """build_tri_plan (trisolve_build.cpp) recognises a complete Cholesky factor by its pattern being closed under
+    elimination and then reads the elimination tree off the first sub-diagonal row of every column instead of running
+    Liu's algorithm over the rows of L; CORA_TRI_CHECK_ETREE makes it do both and fail when they differ.  The
+    preconditioner's factor (src/CORA_problem.cpp:544-614) of a chain with loop closures and landmarks, above the size
+    where the builder's passes run on threads."""
+    monkeypatch.setenv("CORA_TRI_CHECK_ETREE", "1")
+    P = host.Problem.synthetic(dim=3, n_poses=30000, n_landmarks=6, n_ranges=15000, n_loops=5, seed=4)
+    P.update()
+    info = P.plan_probe(50.0)
+    assert info["stages"] >= 2 and info["nnzL"] > (1 << 20) and info["blocks"] > 16
+
+
 def test_cholesky_symbolic_cache_changes_nothing():
     """choleskyFactor keeps the pattern-only part of a factorisation (permuted structure, elimination tree, column
     counts) between calls on the same pattern and order -- the certificate matrix S + eta I is factorised several times
