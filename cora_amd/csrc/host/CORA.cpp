@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -82,7 +83,8 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   bool first_loop = true;
   int levels = 0;
   long hvps = 0;
-  double t_tnt = 0, t_cert = 0, t_escape = 0;
+  double t_tnt = 0, t_cert = 0, t_escape = 0, t_project = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
   using clk = std::chrono::steady_clock;
   auto since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
   while (static_cast<int>(problem.getRelaxationRank()) <= max_relaxation_rank) {
@@ -130,7 +132,9 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   // project to rank d and refine (src/CORA.cpp:198-233)
   if (X.cols() > problem.dim()) {
     printIfVerbose(verbose, "\nProjecting solution to rank " + std::to_string(problem.dim()) + " and refining.");
+    auto tp = clk::now();
     X = projectSolution(problem, X, verbose);
+    t_project = since(tp);
     traceBits("projectSolution", X);
     problem.setRank(problem.dim());
     auto t0 = clk::now();
@@ -150,8 +154,8 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   printIfVerbose(verbose, "Final solution is certified: " + std::to_string(cert.is_certified) + " with eta: " +
                               std::to_string(eta) + " and theta: " + std::to_string(cert.theta));
   printIfVerbose(verbose, "Time: TNT " + std::to_string(t_tnt) + " s, certification " + std::to_string(t_cert) +
-                              " s, saddle escape " + std::to_string(t_escape) + " s, Hessian-vector products " +
-                              std::to_string(hvps));
+                              " s, saddle escape " + std::to_string(t_escape) + " s, rounding " + std::to_string(t_project) +
+                              " s, all " + std::to_string(since(t_begin)) + " s, Hessian-vector products " + std::to_string(hvps));
   if (info) {
     info->certified = cert.is_certified;
     info->eta = eta;
@@ -273,15 +277,36 @@ Matrix projectSolution(const Problem &problem, const Matrix &Y, bool verbose) {
   }
   Matrix Yd = Y * Vd;
   size_t ng0 = 0;
-  for (int i = 0; i < n; ++i)
-    if (determinant(Yd.block(static_cast<Index>(i) * d, 0, d, d)) > 0) ++ng0;
+  {
+    const unsigned nth = n < 20000 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<size_t> cnt(nth, 0);
+    auto part = [&](unsigned t) {
+      for (int i = static_cast<int>(static_cast<int64_t>(n) * t / nth); i < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / nth); ++i)
+        if (determinant(Yd.block(static_cast<Index>(i) * d, 0, d, d)) > 0) ++cnt[t];
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nth; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (std::thread &th : pool) th.join();
+    for (size_t c : cnt) ng0 += c;
+  }
   printIfVerbose(verbose, "Out of " + std::to_string(n) + " blocks, " + std::to_string(ng0) +
                               " have positive determinant.");
   if (n > 0 && ng0 < static_cast<size_t>(n) / 2) {
     for (Index i = 0; i < Yd.rows(); ++i) Yd(i, d - 1) = -Yd(i, d - 1);  // Yd * diag(1,..,1,-1)
   }
-  for (int i = 0; i < n; ++i)
-    Yd.setBlock(static_cast<Index>(i) * d, 0, projectToSOd(Yd.block(static_cast<Index>(i) * d, 0, d, d)));
+  {
+    // every pose block on its own: shared out over threads (the same numbers, whoever computes them)
+    const unsigned nth = n < 20000 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    auto part = [&](unsigned t) {
+      for (int i = static_cast<int>(static_cast<int64_t>(n) * t / nth); i < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / nth); ++i)
+        Yd.setBlock(static_cast<Index>(i) * d, 0, projectToSOd(Yd.block(static_cast<Index>(i) * d, 0, d, d)));
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nth; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (std::thread &th : pool) th.join();
+  }
   const Index rot = problem.numPosesDim();
   for (Index j = 0; j < r; ++j) {
     Scalar s = 0;

@@ -206,6 +206,12 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
         return g_sym[0];
       }
   }
+  const bool timing_ = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick_ = [t_prev = std::chrono::steady_clock::now(), timing_](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing_) std::fprintf(stderr, "      [symbolic] %-20s %.4f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   auto S = std::make_shared<Symbolic>();
   S->key = key;
   S->key2 = key2;
@@ -243,6 +249,7 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
     }
     if (S->Cdiag[k] < 0) { Ci[w] = k; Cmap[w] = -1; S->Cdiag[k] = w; ++w; }
   }
+  tick_("pattern of P A P'");
   // elimination tree
   std::vector<int32_t> &parent = S->parent;
   parent.assign(static_cast<size_t>(n), -1);
@@ -257,6 +264,7 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
         i = nxt;
       }
     }
+  tick_("elimination tree");
   // column counts (symbolic up-looking pass)
   std::vector<int32_t> &cnt = S->cnt;
   cnt.assign(static_cast<size_t>(n), 0);
@@ -273,6 +281,7 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
       }
     }
   }
+  tick_("column counts");
   S->Lp.assign(static_cast<size_t>(n) + 1, 0);
   int64_t tot = 0;
   for (int k = 0; k < n; ++k) {
