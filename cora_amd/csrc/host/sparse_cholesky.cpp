@@ -182,20 +182,49 @@ uint64_t hashWords(uint64_t h, const int32_t *p, size_t count) {
   return r;
 }
 
+// runs body(thread index) on nth threads
+template <class Body>
+void parallelRun(unsigned nth, Body body) {
+  std::vector<std::thread> pool;
+  for (unsigned th = 1; th < nth; ++th) pool.emplace_back([&body, th] { body(th); });
+  body(0u);
+  for (std::thread &t : pool) t.join();
+}
+
+
 std::mutex g_sym_mutex;
 std::shared_ptr<const Symbolic> g_sym[2];  // the two most recent patterns (preconditioner block, certificate matrix)
 
 std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const std::vector<int32_t> &perm,
                                             const std::vector<int32_t> &iperm, bool *hit) {
   *hit = false;
-  uint64_t key = hashWords(static_cast<uint64_t>(n) * 0x100000001B3ull + static_cast<uint64_t>(A.rows()), A.outer.data(), A.outer.size());
-  key = hashWords(key, A.inner.data(), A.inner.size());
-  key = hashWords(key, perm.data(), perm.size());
-  // a second, independent 64-bit hash of the same words (other seed, other order): a stale hit would write a factor
-  // through the wrong column counts, so the pair has to collide, not one word (round-2 advice)
-  uint64_t key2 = hashWords(0x243F6A8885A308D3ull ^ static_cast<uint64_t>(perm.size()), perm.data(), perm.size());
-  key2 = hashWords(key2, A.inner.data(), A.inner.size());
-  key2 = hashWords(key2 + 0x13198A2E03707344ull, A.outer.data(), A.outer.size());
+  // two independent 64-bit hashes of (outer, inner, perm) -- a stale hit would write a factor through the wrong column
+  // counts, so the pair has to collide, not one word (round-2 advice).  The 17 M words are hashed in eight pieces on
+  // threads; the pieces' hashes are chained in order.
+  uint64_t key = static_cast<uint64_t>(n) * 0x100000001B3ull + static_cast<uint64_t>(A.rows());
+  uint64_t key2 = 0x243F6A8885A308D3ull ^ static_cast<uint64_t>(perm.size());
+  {
+    const int32_t *arr[3] = {A.outer.data(), A.inner.data(), perm.data()};
+    const size_t len[3] = {A.outer.size(), A.inner.size(), perm.size()};
+    constexpr unsigned kPieces = 8;
+    uint64_t h1[3][kPieces], h2[3][kPieces];
+    const unsigned nt = A.inner.size() < (1u << 20) ? 1u : std::min(kPieces, std::max(1u, std::thread::hardware_concurrency()));
+    parallelRun(nt, [&](unsigned t) {
+      for (unsigned pc = t; pc < kPieces; pc += nt)
+        for (int a = 0; a < 3; ++a) {
+          const size_t lo = len[a] * pc / kPieces, hi = len[a] * (pc + 1) / kPieces;
+          h1[a][pc] = hashWords(0x9E3779B97F4A7C15ull * (pc + 1) + a, arr[a] + lo, hi - lo);
+          h2[a][pc] = hashWords(0xC2B2AE3D27D4EB4Full * (pc + 3) + 7 * a, arr[a] + lo, hi - lo);
+        }
+    });
+    for (int a = 0; a < 3; ++a)
+      for (unsigned pc = 0; pc < kPieces; ++pc) {
+        key = (key ^ h1[a][pc]) * 0xFF51AFD7ED558CCDull;
+        key ^= key >> 29;
+        key2 = (key2 + h2[2 - a][pc]) * 0xC4CEB9FE1A85EC53ull;
+        key2 ^= key2 >> 31;
+      }
+  }
   const bool use_cache = std::getenv("CORA_CHOL_NO_SYMBOLIC_CACHE") == nullptr;
   if (use_cache) {
     std::lock_guard<std::mutex> lock(g_sym_mutex);
@@ -220,35 +249,42 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   // upper triangle of P A P^T by columns == rows of A restricted to iperm <= k
   std::vector<int32_t> &Cp = S->Cp, &Ci = S->Ci, &Cmap = S->Cmap;
   Cp.assign(static_cast<size_t>(n) + 1, 0);
-  for (int k = 0; k < n; ++k) {
-    const int old = perm[k];
-    int cnt = 0;
-    bool diag = false;
-    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
-      const int i = iperm[A.inner[q]];
-      if (i >= 0 && i <= k) { ++cnt; diag |= (i == k); }
+  unsigned np_ = n < 20000 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *e = std::getenv("CORA_SYMBOLIC_THREADS")) np_ = static_cast<unsigned>(std::max(1, std::atoi(e)));
+  parallelRun(np_, [&](unsigned t) {  // entries per column (columns are independent)
+    for (int k = static_cast<int>(static_cast<int64_t>(n) * t / np_); k < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / np_); ++k) {
+      const int old = perm[k];
+      int cnt = 0;
+      bool diag = false;
+      for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+        const int i = iperm[A.inner[q]];
+        if (i >= 0 && i <= k) { ++cnt; diag |= (i == k); }
+      }
+      if (!diag) ++cnt;  // room for the shift on a structurally missing diagonal
+      Cp[k + 1] = cnt;
     }
-    if (!diag) ++cnt;  // room for the shift on a structurally missing diagonal
-    Cp[k + 1] = Cp[k] + cnt;
-  }
+  });
+  for (int k = 0; k < n; ++k) Cp[k + 1] += Cp[k];
   Ci.resize(static_cast<size_t>(Cp[n]));
   Cmap.resize(static_cast<size_t>(Cp[n]));
   S->Cdiag.assign(static_cast<size_t>(n), -1);
-  for (int k = 0; k < n; ++k) {
-    const int old = perm[k];
-    int32_t w = Cp[k];
-    for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
-      const int i = iperm[A.inner[q]];
-      if (i >= 0 && i <= k) {
-        Ci[w] = i;
-        Cmap[w] = q;
-        // (a duplicated diagonal entry cannot occur: setFromTriplets sums duplicates)
-        if (i == k) S->Cdiag[k] = w;
-        ++w;
+  parallelRun(np_, [&](unsigned t) {
+    for (int k = static_cast<int>(static_cast<int64_t>(n) * t / np_); k < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / np_); ++k) {
+      const int old = perm[k];
+      int32_t w = Cp[k];
+      for (int32_t q = A.outer[old]; q < A.outer[old + 1]; ++q) {
+        const int i = iperm[A.inner[q]];
+        if (i >= 0 && i <= k) {
+          Ci[w] = i;
+          Cmap[w] = q;
+          // (a duplicated diagonal entry cannot occur: setFromTriplets sums duplicates)
+          if (i == k) S->Cdiag[k] = w;
+          ++w;
+        }
       }
+      if (S->Cdiag[k] < 0) { Ci[w] = k; Cmap[w] = -1; S->Cdiag[k] = w; ++w; }
     }
-    if (S->Cdiag[k] < 0) { Ci[w] = k; Cmap[w] = -1; S->Cdiag[k] = w; ++w; }
-  }
+  });
   tick_("pattern of P A P'");
   // elimination tree
   std::vector<int32_t> &parent = S->parent;
@@ -266,20 +302,35 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
     }
   tick_("elimination tree");
   // column counts (symbolic up-looking pass)
+  // (rows are independent given the tree: each thread walks its rows with marks and counters of its own; the counters
+  // are added up at the end -- integer adds, the same totals in any order)
   std::vector<int32_t> &cnt = S->cnt;
   cnt.assign(static_cast<size_t>(n), 0);
-  std::vector<int32_t> flag(static_cast<size_t>(n), -1);
-  for (int k = 0; k < n; ++k) {
-    flag[k] = k;
-    cnt[k]++;
-    for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
-      int i = Ci[q];
-      while (i != -1 && i < k && flag[i] != k) {
-        cnt[i]++;
-        flag[i] = k;
-        i = parent[i];
+  {
+    std::vector<std::vector<int32_t>> acc(np_);
+    parallelRun(np_, [&](unsigned t) {
+      std::vector<int32_t> flag(static_cast<size_t>(n), -1), &mine = acc[t];
+      mine.assign(static_cast<size_t>(n), 0);
+      for (int k = static_cast<int>(t); k < n; k += static_cast<int>(np_)) {  // interleaved: rows near the root are the long walks
+        flag[k] = k;
+        mine[k]++;
+        for (int32_t q = Cp[k]; q < Cp[k + 1]; ++q) {
+          int i = Ci[q];
+          while (i != -1 && i < k && flag[i] != k) {
+            mine[i]++;
+            flag[i] = k;
+            i = parent[i];
+          }
+        }
       }
-    }
+    });
+    parallelRun(np_, [&](unsigned t) {
+      for (int k = static_cast<int>(static_cast<int64_t>(n) * t / np_); k < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / np_); ++k) {
+        int32_t tot_k = 0;
+        for (unsigned u = 0; u < np_; ++u) tot_k += acc[u][k];
+        cnt[k] = tot_k;
+      }
+    });
   }
   tick_("column counts");
   S->Lp.assign(static_cast<size_t>(n) + 1, 0);
@@ -351,15 +402,6 @@ std::vector<T> takeStorage(std::vector<std::vector<T>> &pool, size_t count) {
   }
   v.resize(count);  // (entries the factorisation does not write are never read: see `next`)
   return v;
-}
-
-// runs body(thread index) on nth threads
-template <class Body>
-void parallelRun(unsigned nth, Body body) {
-  std::vector<std::thread> pool;
-  for (unsigned th = 1; th < nth; ++th) pool.emplace_back([&body, th] { body(th); });
-  body(0u);
-  for (std::thread &t : pool) t.join();
 }
 
 }  // namespace
