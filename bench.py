@@ -111,8 +111,11 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
         "hvp_back_to_back_us": kernel_us,
     }
     # full STPCG iteration on the C++ host's own handle with the Cholesky preconditioner installed
-    t0 = time.perf_counter()
     P.set_rank(p)
+    t0 = time.perf_counter()
+    P.context_ptr()   # the Problem's own device handle (format of Q, uploads): not part of the preconditioner's set-up
+    ex["problem_handle_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
     info = P.precond_info()
     ex["preconditioner_setup_s"] = time.perf_counter() - t0

@@ -3,6 +3,7 @@
 #include "CORA_problem.h"
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 
 #include <cmath>
@@ -449,11 +450,29 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
       const bool owns_pin = pin_last_translation_ && to_local[N - 1] >= 0;  // the pinned variable is this rank's last row
       m_fac = static_cast<int>(own.size()) - (owns_pin ? 1 : 0);
     }
+    // the elimination order (host) is worked out while the device estimates ||Q||_2 below
     std::vector<int32_t> perm;
-    if (!sharded) perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_, m, leaf);
-    tick("ordering");
+    std::thread ordering;
+    std::exception_ptr ordering_error;
+    if (!sharded)
+      ordering = std::thread([&] {
+        try {
+          perm = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_, m, leaf);
+        } catch (...) {
+          ordering_error = std::current_exception();
+        }
+      });
+    struct Joiner {  // (an exception below must not leave the thread joinable)
+      std::thread &t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{ordering};
+    auto wait_for_order = [&] {
+      if (ordering.joinable()) ordering.join();
+      if (ordering_error) std::rethrow_exception(ordering_error);
+    };
     // factorisation of the whole matrix, or of this rank's diagonal block (F.perm then holds API rows again)
     auto factorise = [&](const SparseMatrix &A, double shift) {
+      wait_for_order();
       if (!sharded) return choleskyFactor(A, m, shift, perm);
       const SparseMatrix B = local_block(A);
       const auto lperm = coraOrdering(dim_, n_loc, r_loc, nt_loc, B, m_fac, leaf);
