@@ -363,6 +363,11 @@ std::vector<std::vector<int32_t>> g_pool_i;
 std::vector<std::vector<double>> g_pool_x;
 constexpr size_t kWorkPoolMax = 64, kStoragePoolMax = 4;
 
+// (what the pools may keep alive between calls: at 10^6 poses one Work is 72 MB and a factor 570 MB -- the pools
+// serve the sizes where page faults matter and let the big ones go)
+constexpr size_t kWorkPoolBytes = size_t(512) << 20, kStoragePoolBytes = size_t(1) << 30;
+size_t g_work_pool_bytes = 0;
+
 std::unique_ptr<Work> acquireWork(int n) {
   std::unique_ptr<Work> W;
   {
@@ -370,6 +375,7 @@ std::unique_ptr<Work> acquireWork(int n) {
     if (!g_work_pool.empty()) {
       W = std::move(g_work_pool.back());
       g_work_pool.pop_back();
+      g_work_pool_bytes -= W->x.capacity() * sizeof(double) + (W->flag.capacity() + W->stack.capacity()) * sizeof(int32_t);
     }
   }
   if (!W) W = std::make_unique<Work>();
@@ -384,8 +390,12 @@ std::unique_ptr<Work> acquireWork(int n) {
 }
 
 void releaseWork(std::unique_ptr<Work> W) {
+  const size_t bytes = W->x.capacity() * sizeof(double) + (W->flag.capacity() + W->stack.capacity()) * sizeof(int32_t);
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  if (g_work_pool.size() < kWorkPoolMax) g_work_pool.push_back(std::move(W));
+  if (g_work_pool.size() < kWorkPoolMax && g_work_pool_bytes + bytes <= kWorkPoolBytes) {
+    g_work_pool_bytes += bytes;
+    g_work_pool.push_back(std::move(W));
+  }
 }
 
 template <class T>
@@ -410,6 +420,10 @@ CholeskyFactor::~CholeskyFactor() {
   // the storage of a factor goes back to the pool (the certificate's factor lives for one PSD test)
   if (Lx.capacity() < (1u << 20)) return;
   std::lock_guard<std::mutex> lock(g_pool_mutex);
+  size_t held = 0;
+  for (const auto &v : g_pool_x) held += v.capacity() * sizeof(double);
+  for (const auto &v : g_pool_i) held += v.capacity() * sizeof(int32_t);
+  if (held + Lx.capacity() * sizeof(double) + Li.capacity() * sizeof(int32_t) > kStoragePoolBytes) return;
   if (g_pool_x.size() < kStoragePoolMax) g_pool_x.push_back(std::move(Lx));
   if (g_pool_i.size() < kStoragePoolMax) g_pool_i.push_back(std::move(Li));
 }
