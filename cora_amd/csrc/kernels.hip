@@ -300,7 +300,10 @@ __device__ __forceinline__ void stiefel_project_thread(const double (&y)[D][LD],
 // (Measured and not kept: an odd LDS row stride against bank conflicts at even strides -- the index arithmetic cost more
 // than the conflicts: Hvp at p = 10 32.8 -> 38.3 us, p = 16 unchanged.)
 constexpr int kWinMaxLD = CORA_SPMM_WINDOW ? CORA_WIN_MAX_LD : 0;
-constexpr int kWinTrnMaxLD = 8;                        // + the translation window while 8 wavefronts per CU fit the LDS
+#ifndef CORA_WIN_TRN_MAX_LD
+#define CORA_WIN_TRN_MAX_LD 8
+#endif
+constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation window while 8 wavefronts per CU fit the LDS
 #ifndef CORA_POSE_COOP_EPI
 #define CORA_POSE_COOP_EPI 1
 #endif
