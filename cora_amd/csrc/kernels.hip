@@ -313,6 +313,12 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_PREFETCH_V
 #define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
 #endif
+#ifndef CORA_POSE_COOP_MAX_LD
+// cooperative Hvp epilogue up to this row stride: above it the prefetched Y rows and Lambda blocks (d LD + d d doubles per
+// lane) push the kernel into AGPR spills at one wave per SIMD -- without them p = 11 / 12 / 16 / 24: 39.6 / 40.6 / 60.1 /
+// 98.7 -> 38.7 / 38.9 / 57.0 / 89.9 us (two waves per SIMD), while p = 10 loses (32.5 -> 33.7)
+#define CORA_POSE_COOP_MAX_LD 10
+#endif
 #ifndef CORA_POSE_UNROLL_WIN
 #define CORA_POSE_UNROLL_WIN 2  // slots per trip of the window loop (round 3, with 3 waves per SIMD: 1 / 2 / 3 / 6 / 11 slots
 #endif                          // -> Hvp 21.4 / 21.5 / 21.8 / 23.0 / 30.0 us, rotated 29.2 / 29.2 / 29.3 / 32.0 / 41.0 us)
@@ -330,7 +336,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   // cooperative Hvp epilogue (CORA_POSE_COOP_EPI): the slice's rows of Y, its Lambda blocks and its rows of the result
   // are contiguous too -- requested with coalesced loads BEFORE the slot loop, handed to the lanes through the window's
   // LDS after it, and the result rows leave through LDS as 512-byte runs instead of 16-byte pieces of 64 lines
-  constexpr bool kCoopT = kWinLD && CORA_POSE_COOP_EPI && EPI >= EPI_HVP;
+  constexpr bool kCoopT = kWinLD && CORA_POSE_COOP_EPI && EPI >= EPI_HVP && LD <= CORA_POSE_COOP_MAX_LD;
   const bool kCoop = kCoopT && A.win_on;
   constexpr int kYEl = kWave * D * LD, kLEl = kWave * D * D;
   constexpr int kWinEl = (kRotRows + kTrnRows) * LD;
