@@ -179,3 +179,38 @@ def test_implicit_restatement_is_the_partial_minimum(case):
         Xp = X.copy()
         Xp[I.dm.N:-1] += 1e-2 * rng.standard_normal(Xp[I.dm.N:-1].shape)
         assert orc.cost(Q, Xp) >= f - 1e-12 * max(1.0, abs(f))
+
+
+def test_threaded_numa_placed_oracle_is_the_single_thread_oracle():
+    """The all-core column of bench.py runs the oracle's row-parallel loops on bound threads over copies of Q and of the
+    vectors that each thread has touched first (oracle.numa_csr / numa_dense / bind_threads).  Every row is computed by
+    one thread in the same order, so the Hessian-vector product must equal the single-thread one bit for bit; the
+    binding is lifted afterwards (threads other code starts must not inherit a one-core mask)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    n, d, r = 7000, 3, 3000                      # above the sizes where the loops go parallel
+    N = n * (d + 1) + r
+    nz = 4 * N
+    A = sp.coo_matrix((rng.uniform(-1, 1, nz), (rng.integers(0, N, nz), rng.integers(0, N, nz))), shape=(N, N)).tocsr()
+    Qs = (A + A.T + sp.eye(N) * 5.0).tocsr()
+    Q = orc.CSR.from_scipy(Qs)
+    dims = orc.Dims(d, n, r, N)
+    Y = orc.project_manifold(dims, rng.uniform(-1, 1, (N, 4)))
+    G = orc.egrad(Q, Y)
+    V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, (N, 4)))
+    orc.set_threads(1)
+    ref = orc.hvp(Q, dims, Y, G, V)
+    before = os.sched_getaffinity(0)
+    try:
+        orc.set_threads(2)
+        used = orc.bind_threads(2)
+        assert len(used) in (0, 2)
+        Qn = orc.numa_csr(Q)
+        Yn, Gn, Vn = orc.numa_dense(Y), orc.numa_dense(G), orc.numa_dense(V)
+        out, work = orc.numa_dense(shape=Y.shape), orc.numa_dense(shape=Y.shape)
+        got = orc.hvp(Qn, dims, Yn, Gn, Vn, out=out, work=work)
+        assert got is out and np.array_equal(got, ref)
+    finally:
+        orc.bind_threads(0)
+        orc.set_threads(1)
+    assert os.sched_getaffinity(0) == before
