@@ -28,7 +28,7 @@ constexpr int kChunk = 512;
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
 int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
-constexpr int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
+int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
 int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
 int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
@@ -85,6 +85,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
   if (const char *e = std::getenv("CORA_TRI_SUB_ROWS")) kSubRows = std::min(512, std::max(32, std::atoi(e)));
   if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::min(8, std::max(1, std::atoi(e)));
+  if (const char *e = std::getenv("CORA_TRI_SN_CAP")) kSnCap = std::min(32, std::max(1, std::atoi(e)));
   if (const char *e = std::getenv("CORA_TRI_LEVEL_LANES")) kLevelLanes = std::min(256, std::max(64, std::atoi(e)));
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
   auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
@@ -213,6 +214,20 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       }
   }
   if (check_tree && parent != parent_closed) throw std::logic_error("cora: the closed-pattern elimination tree differs from Liu's");
+  // Supernodes of the substitution blocks: 4 rows (one 3-D pose) on the shallow trees of single chains; graphs of several
+  // robots that range each other dissect into separators of one pose PER ROBOT -- chains of 10 to 15 rows in a tree
+  // ten times as high for its size (MR.CLAM 3b: 560 levels at 20 k rows, a chain of 450 k rows: 77) -- and there 8 rows
+  // per supernode take 10-15 % off an iteration (mrclam6 115 -> 103, tiers 98 -> 84 us per product end to end), while
+  // on the chains they cost 8 % (rows get longer).  16 exceeds what a level of the kernel holds.
+  if (!std::getenv("CORA_TRI_SN_CAP")) {
+    std::vector<int32_t> depth(static_cast<size_t>(m), 1);
+    int height = 0;
+    for (int i = 0; i < m; ++i) {
+      if (parent[i] >= 0) depth[parent[i]] = std::max(depth[parent[i]], depth[i] + 1);
+      height = std::max(height, depth[i]);
+    }
+    kSnCap = height > 8.0 * std::log2(static_cast<double>(std::max(m, 2))) ? 8 : 4;
+  }
   tick("elimination tree");
   // ---- stages: repeatedly peel the maximal subtrees of the remaining forest that fit the cap
   int first_border = m;  // trailing run of long rows: forced into the last stage
