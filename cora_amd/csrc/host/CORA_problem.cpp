@@ -941,7 +941,29 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   {
     Vector ev;
     Matrix V;
-    symmetricEigen(Y.transpose() * Y, ev, V);
+    // Y' Y over row ranges on threads, the partial matrices added in range order (only the ratio test below reads it)
+    Matrix G(p, p);
+    {
+      const Index Nr = Y.rows();
+      const unsigned nth = Nr < 50000 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+      std::vector<Matrix> part(nth, Matrix(p, p));
+      auto rows = [&](unsigned t) {
+        Matrix &g = part[t];
+        for (Index a = 0; a < p; ++a)
+          for (Index b = a; b < p; ++b) {
+            Scalar sum = 0;
+            for (Index i = Nr * static_cast<Index>(t) / nth; i < Nr * static_cast<Index>(t + 1) / nth; ++i) sum += Y(i, a) * Y(i, b);
+            g(a, b) = sum;
+            g(b, a) = sum;
+          }
+      };
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nth; ++t) pool.emplace_back(rows, t);
+      rows(0);
+      for (std::thread &th : pool) th.join();
+      for (unsigned t = 0; t < nth; ++t) G = G + part[t];
+    }
+    symmetricEigen(G, ev, V);
     const Scalar smax = std::sqrt(std::max(ev(p - 1), 0.0)), smin = std::sqrt(std::max(ev(0), 0.0));
     if (smax / smin > 1e6) {
       CertResults r;
