@@ -228,7 +228,8 @@ void Problem::fillDataMatrix() {
 
   const Index rot = numPosesDim(), rr = rotAndRangeMatrixSize();
   std::vector<Triplet> all;
-  auto append = [&all](std::vector<Triplet> t) { all.insert(all.end(), t.begin(), t.end()); };
+  all.reserve(static_cast<size_t>(Q11.nonZeros() + 2 * Q13.nonZeros() + Q22.nonZeros() + 2 * Q23.nonZeros() + Q33.nonZeros()));
+  auto append = [&all](const std::vector<Triplet> &t) { all.insert(all.end(), t.begin(), t.end()); };
   append(Q11.triplets(0, 0));
   append(Q13.triplets(0, rr));
   append(Q22.triplets(rot, rot));
@@ -241,9 +242,18 @@ void Problem::fillDataMatrix() {
 }
 
 void Problem::updateProblemData() {  // src/CORA_problem.cpp:500-510
+  const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "  [update] %-26s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   fillRangeSubmatrices();
+  tick("range submatrices");
   fillRelPoseSubmatrices();
+  tick("relative-pose submatrices");
   fillDataMatrix();
+  tick("data matrix");
   ctx_.reset();  // the device copy of Q is rebuilt lazily
   precond_ready_ = false;
   cert_perm_.clear();

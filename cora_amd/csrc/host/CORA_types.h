@@ -236,6 +236,12 @@ class SparseMatrix {
   SparseMatrix times(const std::vector<Scalar> *w, const SparseMatrix &o) const {
     if (cols_ != o.rows_) throw std::invalid_argument("SparseMatrix product: inner dimensions differ");
     std::vector<Triplet> t;
+    {
+      size_t count = 0;  // one pass for the size: growing a vector of 24-byte triplets copies it several times
+      for (size_t q = 0; q < inner.size(); ++q)
+        count += static_cast<size_t>(o.outer[static_cast<size_t>(inner[q]) + 1] - o.outer[static_cast<size_t>(inner[q])]);
+      t.reserve(count);
+    }
     for (Index i = 0; i < rows_; ++i)
       for (int32_t q = outer[static_cast<size_t>(i)]; q < outer[static_cast<size_t>(i) + 1]; ++q) {
         const Index k = inner[q];
