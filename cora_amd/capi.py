@@ -395,6 +395,18 @@ class Context:
                                        G.ctypes.data_as(C.POINTER(C.c_double))))
         return G
 
+    def gram_batch_dev(self, pairs):
+        """[A^T B for (a, ka, b, kb) in pairs] with one synchronisation (cora_gram_batch_dev)."""
+        n = len(pairs)
+        Gs = [np.zeros((ka, kb), order="F") for _, ka, _, kb in pairs]
+        pa = (C.c_void_p * n)(*[C.c_void_p(a) for a, _, _, _ in pairs])
+        pb = (C.c_void_p * n)(*[C.c_void_p(b) for _, _, b, _ in pairs])
+        ka = (C.c_int * n)(*[int(k) for _, k, _, _ in pairs])
+        kb = (C.c_int * n)(*[int(k) for _, _, _, k in pairs])
+        out = (C.c_void_p * n)(*[G.ctypes.data_as(C.c_void_p) for G in Gs])
+        self._chk(self.L.cora_gram_batch_dev(self.h, n, pa, ka, pb, kb, out))
+        return Gs
+
     def combine_dev(self, xs, ks, Cs, kout, out):
         """out = sum_i X_i C_i with host coefficient matrices C_i (k_i x kout)."""
         n = len(xs)

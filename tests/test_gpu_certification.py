@@ -154,6 +154,29 @@ def test_gram_and_combine_blocks(ka, kb):
         h.dev_free(q)
 
 
+def test_gram_batch_equals_single_products():
+    """One Rayleigh-Ritz step of the eigensolver asks for twelve Gram blocks (S_a' A S_b and S_a' S_b, a <= b, over
+    X | W | P); cora_gram_batch_dev runs the kernel of cora_gram_dev once per block on pieces of one reduction buffer and
+    synchronises once -- the numbers must be those of the single calls bit for bit, whatever the widths."""
+    P = host.Problem.synthetic(dim=3, n_poses=3011, n_landmarks=3, n_ranges=1500, seed=9)
+    P.update()
+    dm = P.dims()
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    rng = np.random.default_rng(12)
+    widths = [5, 5, 6, 1, 24, 13]
+    blocks = []
+    for k in widths:
+        q = h.dev_alloc(k)
+        h.upload(rng.uniform(-1, 1, (dm["N"], k)) * np.linspace(1.0, 3.0, k), q)
+        blocks.append((q, k))
+    pairs = [(blocks[i][0], blocks[i][1], blocks[j][0], blocks[j][1]) for i in range(len(blocks)) for j in (0, 2, 4, 5)][:16]
+    got = h.gram_batch_dev(pairs)
+    for (a, ka, b, kb), G in zip(pairs, got):
+        assert np.array_equal(G, h.gram_dev(a, ka, b, kb))
+    for q, _ in blocks:
+        h.dev_free(q)
+
+
 def test_start_block_with_columns_of_very_different_size():
     """The eigensolver orthonormalises its start block through the block's Gram matrix.  At 10^6 poses the block holds
     columns of the iterate (translation rows: norm 1e8) next to the unit-length seed of the failed factorisation, and
