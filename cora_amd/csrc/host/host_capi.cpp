@@ -329,6 +329,26 @@ int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *col
   });
 }
 
+int cora_host_fast_verification_pieces(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                       double eta, const double *X0, int nx, int split, int max_iters, double out[3],
+                                       double *x) {
+  return guarded([&] {
+    if (!X0 || split <= 0 || split >= nx) throw std::invalid_argument("fast_verification_pieces: 0 < split < nx and a start block");
+    SparseMatrix S(n, n);
+    S.outer.assign(rowptr, rowptr + n + 1);
+    S.inner.assign(colidx, colidx + rowptr[n]);
+    S.values.assign(vals, vals + rowptr[n]);
+    // the start block as two pieces of host memory (its first `split` columns, the rest): put side by side on the device
+    const std::vector<HostColumns> pieces = {HostColumns{X0, split},
+                                             HostColumns{X0 + static_cast<size_t>(split) * static_cast<size_t>(n), nx - split}};
+    const CertResults c = fast_verification(S, eta, pieces, static_cast<size_t>(max_iters));
+    out[0] = c.is_certified ? 1.0 : 0.0;
+    out[1] = c.theta;
+    out[2] = static_cast<double>(c.num_iters);
+    if (x) std::memcpy(x, c.x.data(), sizeof(double) * static_cast<size_t>(c.x.size()));
+  });
+}
+
 int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verbose, const double *opts,
                        double *x_out, double stats[9]) {
   return guarded([&] {

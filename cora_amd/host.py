@@ -323,7 +323,7 @@ def block_cholesky_solve(A, block_sizes, B):
     return X
 
 
-def fast_verification(S, eta, X0=None, nx=1, max_iters=1000, lab=None):
+def fast_verification(S, eta, X0=None, nx=1, max_iters=1000, lab=None, split=None):
     """CORA::fast_verification on an arbitrary symmetric scipy sparse matrix.  lab = dict(max_fill_factor, drop_tol,
     seed, ildl) exposes the knobs of step 3 (tests) and adds `step3` to the result."""
     import scipy.sparse as sp
@@ -341,7 +341,11 @@ def fast_verification(S, eta, X0=None, nx=1, max_iters=1000, lab=None):
         X0 = np.asfortranarray(np.asarray(X0, dtype=np.float64).reshape(n, -1))
         nx = X0.shape[1]
         xp = X0.ctypes.data_as(_dp)
-    if lab is not None:
+    if split is not None:
+        rc = L.cora_host_fast_verification_pieces(n, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), va.ctypes.data_as(_dp),
+                                                  C.c_double(eta), xp, int(nx), int(split), int(max_iters),
+                                                  out.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    elif lab is not None:
         out = np.zeros(4)
         opts = np.array([lab.get("max_fill_factor", 3.0), lab.get("drop_tol", 1e-3), float(lab.get("seed", True)),
                          float(lab.get("ildl", True))])

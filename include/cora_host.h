@@ -113,6 +113,11 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
  * [2] iterations; x: n. */
 int cora_host_fast_verification(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                 double eta, const double *X0, int nx, int max_iters, double out[3], double *x);
+/* The same with the start block handed over as two pieces (columns [0, split) and [split, nx)) that are put side by side
+ * on the device -- the form certify_solution uses (previous eigenvectors | cached random columns); same numbers. */
+int cora_host_fast_verification_pieces(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                       double eta, const double *X0, int nx, int split, int max_iters, double out[3],
+                                       double *x);
 
 /* The same with the knobs of step 3 (src/CORA_utils.cpp:129-167) exposed for the tests: opts = {max_fill_factor,
  * drop_tol, seed the block with the failed factorisation's direction (0/1), use the ILDL preconditioner (0/1)};

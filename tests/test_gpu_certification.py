@@ -154,6 +154,25 @@ def test_gram_and_combine_blocks(ka, kb):
         h.dev_free(q)
 
 
+@pytest.mark.parametrize("nx,split", [(5, 3), (6, 1), (12, 10)])
+def test_start_block_in_pieces_gives_the_same_numbers(nx, split):
+    """certify_solution hands the eigensolver its start block as pieces of host memory -- the previous level's
+    eigenvectors, cached random columns, the seed of the failed factorisation -- that are uploaded as they are and put side
+    by side on the device (LOBPCGSolver::run, src/CORA_problem.cpp:1062-1071 builds the block on the host).  Same block, same
+    numbers: theta, the iteration count and the direction must equal the ones of the assembled block bit for bit."""
+    n = 3000
+    rng = np.random.default_rng(nx)
+    w = rng.uniform(0.5, 2.0, n - 1)
+    Lp = sp.diags([np.r_[w, 0] + np.r_[0, w], -w, -w], [0, 1, -1]).tocsr()
+    S = (Lp + sp.diags(rng.uniform(0.0, 0.3, n)) - 0.2 * sp.eye(n)).tocsr()   # indefinite, not certified at eta = 1e-3
+    X0 = rng.uniform(-1, 1, (n, nx))
+    whole = host.fast_verification(S, 1e-3, X0=X0, max_iters=300)
+    parts = host.fast_verification(S, 1e-3, X0=X0, max_iters=300, split=split)
+    assert not whole["is_certified"] and not parts["is_certified"]
+    assert whole["theta"] == parts["theta"] and whole["iters"] == parts["iters"]
+    assert np.array_equal(whole["x"], parts["x"])
+
+
 def test_gram_batch_equals_single_products():
     """One Rayleigh-Ritz step of the eigensolver asks for twelve Gram blocks (S_a' A S_b and S_a' S_b, a <= b, over
     X | W | P); cora_gram_batch_dev runs the kernel of cora_gram_dev once per block on pieces of one reduction buffer and
