@@ -23,6 +23,7 @@ using namespace CORA;
 
 struct cora_problem {
   Problem problem;
+  SparseMatrix last_certificate;  // cora_problem_certificate_matrix keeps its result alive here
   explicit cora_problem(Problem p) : problem(std::move(p)) {}
 };
 
@@ -191,6 +192,20 @@ int cora_problem_matrix(cora_problem *p, const char *name, int64_t *rows, int64_
     *rowptr = m->outerIndexPtr();
     *colidx = m->innerIndexPtr();
     *vals = m->valuePtr();
+  });
+}
+
+int cora_problem_certificate_matrix(cora_problem *p, const double *Y, int ldy, int64_t *rows, int64_t *nnz,
+                                    const int32_t **rowptr, const int32_t **colidx, const double **vals) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Matrix Ym = wrap(Y, static_cast<Index>(ldy), static_cast<Index>(q.getRelaxationRank()));
+    p->last_certificate = q.get_certificate_matrix(Ym);  // S = Q - Lambda(Y), src/CORA_problem.cpp:1162-1166
+    *rows = p->last_certificate.rows();
+    *nnz = p->last_certificate.nonZeros();
+    *rowptr = p->last_certificate.outerIndexPtr();
+    *colidx = p->last_certificate.innerIndexPtr();
+    *vals = p->last_certificate.valuePtr();
   });
 }
 

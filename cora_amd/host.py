@@ -132,6 +132,18 @@ class Problem:
         vals = np.ctypeslib.as_array(va, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0)
         return rows.value, cols.value, rowptr, colidx, vals
 
+    def certificate_matrix(self, Y):
+        """Problem::get_certificate_matrix: S = Q - Lambda(Y) as a scipy CSR matrix."""
+        import scipy.sparse as sp
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        rows, nnz = C.c_int64(), C.c_int64()
+        rp, ci, va = _ip(), _ip(), _dp()
+        self._chk(self.L.cora_problem_certificate_matrix(self.h, Y.ctypes.data_as(_dp), Y.shape[0], C.byref(rows),
+                                                         C.byref(nnz), C.byref(rp), C.byref(ci), C.byref(va)))
+        n = nnz.value
+        return sp.csr_matrix((np.ctypeslib.as_array(va, shape=(n,)).copy(), np.ctypeslib.as_array(ci, shape=(n,)).copy(),
+                              np.ctypeslib.as_array(rp, shape=(rows.value + 1,)).copy()), shape=(rows.value, rows.value))
+
     def scipy_matrix(self, name="DataMatrix"):
         import scipy.sparse as sp
         r, c, rp, ci, va = self.matrix(name)

@@ -60,6 +60,10 @@ int cora_problem_dims(const cora_problem *p, int64_t dims[8]);
  * "RangeDistances", "Apose", "OmegaPose", "T", "RotConLaplacian". */
 int cora_problem_matrix(cora_problem *p, const char *name, int64_t *rows, int64_t *cols, int64_t *nnz,
                         const int32_t **rowptr, const int32_t **colidx, const double **vals);
+/* Problem::get_certificate_matrix(Y) (src/CORA_problem.cpp:1162-1166): S = Q - Lambda(Y) as CSR, Y column-major with the
+ * current relaxation rank's columns; the arrays stay valid until the next call on this problem. */
+int cora_problem_certificate_matrix(cora_problem *p, const double *Y, int ldy, int64_t *rows, int64_t *nnz,
+                                    const int32_t **rowptr, const int32_t **colidx, const double **vals);
 
 int cora_problem_set_rank(cora_problem *p, int rank);
 int cora_problem_set_preconditioner(cora_problem *p, int kind);

@@ -154,6 +154,29 @@ def test_gram_and_combine_blocks(ka, kb):
         h.dev_free(q)
 
 
+def test_certificate_matrix_keeps_its_pattern_between_points():
+    """Problem::get_certificate_matrix (src/CORA_problem.cpp:1162-1166): S = Q - Lambda(Y).  The host keeps S between
+    certifications and rewrites only the entries under Lambda (the d x d pose blocks and the range diagonal); a second
+    and a third point, at another rank too, must give the S a fresh merge gives -- checked against the oracle's dense S."""
+    P = host.Problem.synthetic(dim=3, n_poses=150, n_landmarks=3, n_ranges=90, n_loops=2, seed=21)
+    P.update()
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    rng = np.random.default_rng(8)
+    pattern = None
+    for p in (3, 3, 5, 4):
+        P.set_rank(p)
+        Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dims.N, p)))
+        S = P.certificate_matrix(Y)
+        ref = orc.certificate_matrix_dense(Q, dims, Y)
+        assert np.abs(S.toarray() - ref).max() <= 1e-12 * np.abs(ref).max()
+        if pattern is None:
+            pattern = (S.indptr.copy(), S.indices.copy())
+        assert np.array_equal(S.indptr, pattern[0]) and np.array_equal(S.indices, pattern[1])
+
+
 @pytest.mark.parametrize("nx,split", [(5, 3), (6, 1), (12, 10)])
 def test_start_block_in_pieces_gives_the_same_numbers(nx, split):
     """certify_solution hands the eigensolver its start block as pieces of host memory -- the previous level's
