@@ -28,7 +28,7 @@ constexpr int kChunk = 512;
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
 int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
-int kSnCap = 4;            // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
+constexpr int kSnCapChain = 4;  // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
 int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
 int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
@@ -85,6 +85,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
   if (const char *e = std::getenv("CORA_TRI_SUB_ROWS")) kSubRows = std::min(512, std::max(32, std::atoi(e)));
   if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::min(8, std::max(1, std::atoi(e)));
+  int kSnCap = kSnCapChain;  // (local: plans are built from several rank threads at once)
   if (const char *e = std::getenv("CORA_TRI_SN_CAP")) kSnCap = std::min(32, std::max(1, std::atoi(e)));
   if (const char *e = std::getenv("CORA_TRI_LEVEL_LANES")) kLevelLanes = std::min(256, std::max(64, std::atoi(e)));
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
