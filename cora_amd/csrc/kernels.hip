@@ -313,6 +313,9 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_PREFETCH_V
 #define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
 #endif
+#ifndef CORA_WIN_COPY_X2
+#define CORA_WIN_COPY_X2 1
+#endif
 #ifndef CORA_POSE_COOP_MAX_LD
 // cooperative Hvp epilogue up to this row stride: above it the prefetched Y rows and Lambda blocks (d LD + d d doubles per
 // lane) push the kernel into AGPR spills at one wave per SIMD -- without them p = 11 / 12 / 16 / 24: 39.6 / 40.6 / 60.1 /
@@ -351,6 +354,42 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     ntr = kTrnRows ? max(min(A.win_trn_lo + sd.aux0 + kWave + 1, A.win_trn_hi) - t0, 0) : 0;
     const double *__restrict__ srot = X + static_cast<size_t>(w0) * LD;
     const double *__restrict__ strn = X + static_cast<size_t>(t0) * LD;
+#if CORA_WIN_COPY_X2
+    // two doubles per lane and load (half the load and LDS-store instructions of the copy; rows are 8-byte aligned,
+    // which is all a dwordx4 access needs on this part)
+    struct __attribute__((packed, aligned(8))) D2 { double x, y; };
+    constexpr int kRotEl = kRotRows * LD, kTrnEl = kTrnRows * LD;
+    constexpr int kRotIt = (kRotEl + 2 * kWave - 1) / (2 * kWave), kTrnIt = (kTrnEl + 2 * kWave - 1) / (2 * kWave);
+    D2 stage[kRotIt + kTrnIt + 1];
+#pragma unroll
+    for (int i = 0; i < kRotIt; ++i) {
+      const int e = 2 * (i * kWave + lane);
+      D2 v{0.0, 0.0};
+      if (e + 1 < nrot * LD) v = *reinterpret_cast<const D2 *>(srot + e);
+      else if (e < nrot * LD) v.x = srot[e];
+      stage[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < kTrnIt; ++i) {
+      const int e = 2 * (i * kWave + lane);
+      D2 v{0.0, 0.0};
+      if (e + 1 < ntr * LD) v = *reinterpret_cast<const D2 *>(strn + e);
+      else if (e < ntr * LD) v.x = strn[e];
+      stage[kRotIt + i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < kRotIt; ++i) {
+      const int e = 2 * (i * kWave + lane);
+      if (e < kRotEl) win[e] = stage[i].x;
+      if (e + 1 < kRotEl) win[e + 1] = stage[i].y;
+    }
+#pragma unroll
+    for (int i = 0; i < kTrnIt; ++i) {
+      const int e = 2 * (i * kWave + lane);
+      if (e < kTrnEl) win[kRotEl + e] = stage[kRotIt + i].x;
+      if (e + 1 < kTrnEl) win[kRotEl + e + 1] = stage[kRotIt + i].y;
+    }
+#else
     constexpr int kRotIt = (kRotRows * LD + kWave - 1) / kWave, kTrnIt = (kTrnRows * LD + kWave - 1) / kWave;
     double stage[kRotIt + kTrnIt + 1];
 #pragma unroll
@@ -373,6 +412,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       const int e = i * kWave + lane;
       if (e < kTrnRows * LD) win[kRotRows * LD + e] = stage[kRotIt + i];
     }
+#endif
     __syncthreads();
     if constexpr (kCoopT) {
       const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
