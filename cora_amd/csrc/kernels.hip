@@ -313,6 +313,9 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_PREFETCH_V
 #define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
 #endif
+#ifndef CORA_EPI_X2
+#define CORA_EPI_X2 1
+#endif
 #ifndef CORA_WIN_COPY_X2
 #define CORA_WIN_COPY_X2 1
 #endif
@@ -325,6 +328,10 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_UNROLL_WIN
 #define CORA_POSE_UNROLL_WIN 2  // slots per trip of the window loop (round 3, with 3 waves per SIMD: 1 / 2 / 3 / 6 / 11 slots
 #endif                          // -> Hvp 21.4 / 21.5 / 21.8 / 23.0 / 30.0 us, rotated 29.2 / 29.2 / 29.3 / 32.0 / 41.0 us)
+// two doubles behind an 8-byte aligned address: one dwordx4 access (rows of the vectors are 8-byte aligned, which is all
+// such an access needs on this part)
+struct __attribute__((packed, aligned(8))) D2 { double x, y; };
+
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
   const double *__restrict__ vp = A.sval + sd.off + lane;
@@ -345,7 +352,8 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   constexpr int kWinEl = (kRotRows + kTrnRows) * LD;
   constexpr int kSmemEl = !kWinLD ? 1 : (kCoopT && kYEl + kLEl > kWinEl ? kYEl + kLEl : kWinEl);
   __shared__ double win[kSmemEl];
-  double ystage[kCoopT ? D * LD : 1], lstage[kCoopT ? D * D : 1];
+  constexpr int kYIt = (D * LD + 1) / 2, kLIt = (D * D + 1) / 2;  // (CORA_EPI_X2: pairs of doubles per lane and access)
+  double ystage[kCoopT ? 2 * kYIt : 1], lstage[kCoopT ? 2 * kLIt : 1];
   int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
   if constexpr (kWinLD) if (kWin) {
     w0 = max(sd.row0 - D, A.win_rot_lo);
@@ -357,7 +365,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #if CORA_WIN_COPY_X2
     // two doubles per lane and load (half the load and LDS-store instructions of the copy; rows are 8-byte aligned,
     // which is all a dwordx4 access needs on this part)
-    struct __attribute__((packed, aligned(8))) D2 { double x, y; };
     constexpr int kRotEl = kRotRows * LD, kTrnEl = kTrnRows * LD;
     constexpr int kRotIt = (kRotEl + 2 * kWave - 1) / (2 * kWave), kTrnIt = (kTrnEl + 2 * kWave - 1) / (2 * kWave);
     D2 stage[kRotIt + kTrnIt + 1];
@@ -417,6 +424,26 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     if constexpr (kCoopT) {
       const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
       const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
+#if CORA_EPI_X2
+#pragma unroll
+      for (int i = 0; i < kYIt; ++i) {
+        const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
+        D2 v{0.0, 0.0};
+        if (e + 1 < n) v = *reinterpret_cast<const D2 *>(Yp + e);
+        else if (e < n) v.x = Yp[e];
+        ystage[2 * i] = v.x;
+        ystage[2 * i + 1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < kLIt; ++i) {
+        const int e = 2 * (i * kWave + lane), n = sd.nrows * D * D;
+        D2 v{0.0, 0.0};
+        if (e + 1 < n) v = *reinterpret_cast<const D2 *>(Lq + e);
+        else if (e < n) v.x = Lq[e];
+        lstage[2 * i] = v.x;
+        lstage[2 * i + 1] = v.y;
+      }
+#else
 #pragma unroll
       for (int i = 0; i < D * LD; ++i) {
         const int e = i * kWave + lane;
@@ -427,6 +454,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
         const int e = i * kWave + lane;
         lstage[i] = e < sd.nrows * D * D ? Lq[e] : 0.0;
       }
+#endif
     }
   }
 #if CORA_POSE_PREFETCH
@@ -550,10 +578,25 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       for (int j = 0; j < LD; ++j) xo[b][j] = win[l * LD + j];
     }
     __syncthreads();
+#if CORA_EPI_X2
+#pragma unroll
+    for (int i = 0; i < kYIt; ++i) {
+      const int e = 2 * (i * kWave + lane);
+      if (e < kYEl) win[e] = ystage[2 * i];
+      if (e + 1 < kYEl) win[e + 1] = ystage[2 * i + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < kLIt; ++i) {
+      const int e = 2 * (i * kWave + lane);
+      if (e < kLEl) win[kYEl + e] = lstage[2 * i];
+      if (e + 1 < kLEl) win[kYEl + e + 1] = lstage[2 * i + 1];
+    }
+#else
 #pragma unroll
     for (int i = 0; i < D * LD; ++i) win[i * kWave + lane] = ystage[i];
 #pragma unroll
     for (int i = 0; i < D * D; ++i) win[kYEl + i * kWave + lane] = lstage[i];
+#endif
     __syncthreads();
     double y[D][LD];
 #pragma unroll
@@ -580,11 +623,24 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       for (int j = 0; j < LD; ++j) win[(lane * D + a) * LD + j] = acc[a][j];
     __syncthreads();
     double *__restrict__ op = A.out + static_cast<size_t>(sd.row0) * LD;
+#if CORA_EPI_X2
+#pragma unroll
+    for (int i = 0; i < kYIt; ++i) {
+      const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
+      if (e + 1 < n) {
+        D2 v{win[e], win[e + 1]};
+        *reinterpret_cast<D2 *>(op + e) = v;
+      } else if (e < n) {
+        op[e] = win[e];
+      }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < D * LD; ++i) {
       const int e = i * kWave + lane;
       if (e < sd.nrows * D * LD) op[e] = win[e];
     }
+#endif
     return kap;
   }
   if (lane >= sd.nrows) return 0.0;
