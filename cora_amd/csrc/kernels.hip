@@ -328,10 +328,6 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_UNROLL_WIN
 #define CORA_POSE_UNROLL_WIN 2  // slots per trip of the window loop (round 3, with 3 waves per SIMD: 1 / 2 / 3 / 6 / 11 slots
 #endif                          // -> Hvp 21.4 / 21.5 / 21.8 / 23.0 / 30.0 us, rotated 29.2 / 29.2 / 29.3 / 32.0 / 41.0 us)
-// two doubles behind an 8-byte aligned address: one dwordx4 access (rows of the vectors are 8-byte aligned, which is all
-// such an access needs on this part)
-struct __attribute__((packed, aligned(8))) D2 { double x, y; };
-
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
   const double *__restrict__ vp = A.sval + sd.off + lane;
@@ -367,20 +363,20 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     // which is all a dwordx4 access needs on this part)
     constexpr int kRotEl = kRotRows * LD, kTrnEl = kTrnRows * LD;
     constexpr int kRotIt = (kRotEl + 2 * kWave - 1) / (2 * kWave), kTrnIt = (kTrnEl + 2 * kWave - 1) / (2 * kWave);
-    D2 stage[kRotIt + kTrnIt + 1];
+    Pair8 stage[kRotIt + kTrnIt + 1];
 #pragma unroll
     for (int i = 0; i < kRotIt; ++i) {
       const int e = 2 * (i * kWave + lane);
-      D2 v{0.0, 0.0};
-      if (e + 1 < nrot * LD) v = *reinterpret_cast<const D2 *>(srot + e);
+      Pair8 v{0.0, 0.0};
+      if (e + 1 < nrot * LD) v = *reinterpret_cast<const Pair8 *>(srot + e);
       else if (e < nrot * LD) v.x = srot[e];
       stage[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < kTrnIt; ++i) {
       const int e = 2 * (i * kWave + lane);
-      D2 v{0.0, 0.0};
-      if (e + 1 < ntr * LD) v = *reinterpret_cast<const D2 *>(strn + e);
+      Pair8 v{0.0, 0.0};
+      if (e + 1 < ntr * LD) v = *reinterpret_cast<const Pair8 *>(strn + e);
       else if (e < ntr * LD) v.x = strn[e];
       stage[kRotIt + i] = v;
     }
@@ -428,8 +424,8 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
       for (int i = 0; i < kYIt; ++i) {
         const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
-        D2 v{0.0, 0.0};
-        if (e + 1 < n) v = *reinterpret_cast<const D2 *>(Yp + e);
+        Pair8 v{0.0, 0.0};
+        if (e + 1 < n) v = *reinterpret_cast<const Pair8 *>(Yp + e);
         else if (e < n) v.x = Yp[e];
         ystage[2 * i] = v.x;
         ystage[2 * i + 1] = v.y;
@@ -437,8 +433,8 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
       for (int i = 0; i < kLIt; ++i) {
         const int e = 2 * (i * kWave + lane), n = sd.nrows * D * D;
-        D2 v{0.0, 0.0};
-        if (e + 1 < n) v = *reinterpret_cast<const D2 *>(Lq + e);
+        Pair8 v{0.0, 0.0};
+        if (e + 1 < n) v = *reinterpret_cast<const Pair8 *>(Lq + e);
         else if (e < n) v.x = Lq[e];
         lstage[2 * i] = v.x;
         lstage[2 * i + 1] = v.y;
@@ -628,8 +624,8 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     for (int i = 0; i < kYIt; ++i) {
       const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
       if (e + 1 < n) {
-        D2 v{win[e], win[e + 1]};
-        *reinterpret_cast<D2 *>(op + e) = v;
+        Pair8 v{win[e], win[e + 1]};
+        *reinterpret_cast<Pair8 *>(op + e) = v;
       } else if (e < n) {
         op[e] = win[e];
       }
