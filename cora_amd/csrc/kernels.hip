@@ -313,6 +313,9 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_PREFETCH_V
 #define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
 #endif
+#ifndef CORA_POSE_EARLY_SLOTS
+#define CORA_POSE_EARLY_SLOTS 0
+#endif
 #ifndef CORA_EPI_X2
 #define CORA_EPI_X2 1
 #endif
@@ -350,6 +353,27 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   __shared__ double win[kSmemEl];
   constexpr int kYIt = (D * LD + 1) / 2, kLIt = (D * D + 1) / 2;  // (CORA_EPI_X2: pairs of doubles per lane and access)
   double ystage[kCoopT ? 2 * kYIt : 1], lstage[kCoopT ? 2 * kLIt : 1];
+  // Symmetric chain blocks (kSliceSymFlag, format_build.cpp): slots 0 .. D-1 are the NEXT pose's columns; their values
+  // stay in registers and become, shifted by one lane, the predecessor block of the lane after (lane 0: the slice's
+  // head block).  The predecessor block is not in the stream: 8 slots instead of 11 for a pose of the chain.
+  const bool sym = (sd.type & kSliceSymFlag) != 0;
+  // narrow rows: the next-pose slots are peeled off the loop and their values shifted by one lane; wide rows (registers
+  // are what they are short of: at a row stride of 10 the peeled form cost a wave of occupancy) re-read the previous
+  // lane's values from the stream the wavefront has just loaded (L1 / L2 hits)
+  constexpr bool kNxtRegs = LD <= 5 || (LD <= 8 && EPI < 2);
+  double nxt[kNxtRegs ? D : 1][D];
+  // (CORA_POSE_EARLY_SLOTS) the peeled slots' indices and values are requested together with the window's rows: they
+  // do not depend on the window, and behind its barrier they cost the wavefront one more memory latency
+  int32_t nxt_col[kNxtRegs ? D : 1];
+  const bool early = CORA_POSE_EARLY_SLOTS && kNxtRegs && sym && kWin;
+  if (early) {
+#pragma unroll
+    for (int k = 0; k < (kNxtRegs ? D : 1); ++k) {
+      nxt_col[k] = stream_load(cp + static_cast<size_t>(k) * kWave);
+#pragma unroll
+      for (int a = 0; a < D; ++a) nxt[k][a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+    }
+  }
   int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
   if constexpr (kWinLD) if (kWin) {
     w0 = max(sd.row0 - D, A.win_rot_lo);
@@ -477,10 +501,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
     for (int j = 0; j < LD; ++j) acc[a][j] = 0.0;
   // one slot: column index, d values, the row of X (from the windows when they are on), d x LD products
-  auto slot = [&](int k, double (&v)[D]) {
-    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
-#pragma unroll
-    for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+  auto slot_apply = [&](const int32_t c, const double (&v)[D]) {
     double x[LD];
     if (kWinLD && kWin) {
       const unsigned rr = static_cast<unsigned>(c - w0), rt = static_cast<unsigned>(c - t0);
@@ -497,19 +518,21 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
   };
-  // Symmetric chain blocks (kSliceSymFlag, format_build.cpp): slots 0 .. D-1 are the NEXT pose's columns; their values
-  // stay in registers and become, shifted by one lane, the predecessor block of the lane after (lane 0: the slice's
-  // head block).  The predecessor block is not in the stream: 8 slots instead of 11 for a pose of the chain.
-  const bool sym = (sd.type & kSliceSymFlag) != 0;
-  // narrow rows: the next-pose slots are peeled off the loop and their values shifted by one lane; wide rows (registers
-  // are what they are short of: at a row stride of 10 the peeled form cost a wave of occupancy) re-read the previous
-  // lane's values from the stream the wavefront has just loaded (L1 / L2 hits)
-  constexpr bool kNxtRegs = LD <= 5 || (LD <= 8 && EPI < 2);
-  double nxt[kNxtRegs ? D : 1][D];
+  auto slot = [&](int k, double (&v)[D]) {
+    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
+#pragma unroll
+    for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
+    slot_apply(c, v);
+  };
   int k0 = 0;
   if (kNxtRegs && sym) {
+    if (early) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) slot(k, nxt[kNxtRegs ? k : 0]);
+      for (int k = 0; k < (kNxtRegs ? D : 1); ++k) slot_apply(nxt_col[k], nxt[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) slot(k, nxt[kNxtRegs ? k : 0]);
+    }
     k0 = D;
   }
   // (the predecessor block is applied right here, before the rest of the slots, so that its nine values do not stay in
