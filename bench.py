@@ -34,6 +34,46 @@ def algorithmic_bytes(d, n, r, N, nnz, p):
     return b_spmm, b_hvp
 
 
+def pmc_traffic(args, ld, epi):
+    """HBM-side bytes per launch of the timed kernel, collected now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
+    separate passes, no trace domains, as MI355X_MICROARCH.md prescribes) of a short child run of this command that
+    stops after its timed region.  gfx950: FETCH_SIZE counts 128-byte fabric requests at 64 bytes, so reads = 2 x
+    FETCH_SIZE (calibrated with a streaming kernel, profiles/hvp_traffic.json); both counters are in KB.  Returns
+    (bytes, how) or (None, None) when rocprofv3 is missing, this run is itself under a profiler, or a pass fails."""
+    import csv, glob, shutil, subprocess, tempfile
+    if os.environ.get("CORA_BENCH_CHILD") or shutil.which("rocprofv3") is None:
+        return None, None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, None
+    kernel = "k_spmm<%d, 3, %d>" % (ld, epi)
+    env = dict(os.environ, CORA_BENCH_CHILD="1", TMPDIR="/tmp")
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="cora_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-include-regex", kernel, "--output-format", "csv", "-d", out,
+                   "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--kernel-only", "--steps", "60",
+                   "--warmup", "5", "--poses", str(args.poses), "--rank", str(args.rank), "--op", args.op,
+                   "--pmc-traffic", "off"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, None
+            xs = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                  if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]]
+            if len(xs) < 10:
+                return None, None
+            vals[counter] = sum(xs) / len(xs)
+    except Exception:  # noqa: BLE001 -- a failed counter pass must not fail the bench: the committed figure is reported instead
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), (
+        "collected by this run: two rocprofv3 --pmc passes (FETCH_SIZE %.0f KB x 2 on gfx950, WRITE_SIZE %.0f KB; per-launch "
+        "averages over the launches of %s in a short child run of this command)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], kernel))
+
+
 def cpu_quota():
     """CPUs the container may use: cgroup v2 cpu.max / v1 cfs quota, else the CPUs it may run on."""
     try:
@@ -186,6 +226,10 @@ def main():
     ap.add_argument("--op", choices=["hvp", "cert"], default="hvp",
                     help="hvp: Riemannian Hessian-vector product (the headline metric); cert: certificate operator "
                          "(Q - Lambda) X with --rank columns (BASELINE config 5, use --rank 10)")
+    ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
+                    help="auto: HBM-side bytes of the timed kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) "
+                         "of a short child run of this command, collected by this run (N = 1; skipped under a profiler)")
+    ap.add_argument("--kernel-only", action="store_true", help=argparse.SUPPRESS)  # the child run of --pmc-traffic
     args = ap.parse_args()
 
     # stdout carries ONE line, the JSON result: whatever the libraries print on the way (the C++ host reports like the
@@ -295,6 +339,9 @@ def main():
     torch.cuda.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    if args.kernel_only:   # child of --pmc-traffic: the launches above are all a counter pass needs
+        os.write(json_fd, b"{}\n")
+        return
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,11 +376,15 @@ def main():
     stats = ctx.format_stats()
     local_frac = stats["local_nnz"] / max(dm["nnz"], 1)
     achieved = b_hvp * local_frac / kernel_us / 1e3  # GB/s, this rank's share of the bytes
-    traffic = None
+    traffic, traffic_source = None, None
+    if world == 1 and args.pmc_traffic == "auto":
+        traffic, traffic_source = pmc_traffic(args, ld, 2 if args.op == "hvp" else 1)
     tpath = os.path.join(ROOT, "profiles", "hvp_traffic.json")
-    if world == 1 and n == 100000 and p == 5 and os.path.exists(tpath):
+    if traffic is None and world == 1 and n == 100000 and p == 5 and args.op == "hvp" and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/hvp_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
+                              "an earlier run (FETCH_SIZE x 2 on gfx950), not collected in this run")
         except Exception:
             traffic = None
 
@@ -425,9 +476,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": None if traffic is None else
-                                  "profiles/hvp_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "command on an earlier run (FETCH_SIZE x 2 on gfx950), not collected in this run",
+                "traffic_source": traffic_source,
                 "kernel_us": kernel_us,
                 "bytes_per_launch": b_hvp * local_frac,
                 "note": "back-to-back launches: Q (46 MB) and the three vectors stay in the 256 MiB Infinity Cache; "
