@@ -313,6 +313,9 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_PREFETCH_V
 #define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
 #endif
+#ifndef CORA_ROW_UNROLL
+#define CORA_ROW_UNROLL 4  // gathers in flight per lane of a row slice (translation / range rows)
+#endif
 #ifndef CORA_POSE_EARLY_SLOTS
 #define CORA_POSE_EARLY_SLOTS 0
 #endif
@@ -727,7 +730,7 @@ __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
 
-#pragma unroll 4
+#pragma unroll CORA_ROW_UNROLL
   for (int k = 0; k < sd.width; ++k) {
     const double v = stream_load(vp + static_cast<size_t>(k) * kWave);
     const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
