@@ -267,6 +267,7 @@ SpmmArgs spmm_args(const cora_ctx *c, const double *X, double *out) {
   A.win_rot_hi = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(L.nl_poses) * L.d);
   A.win_trn_lo = static_cast<int32_t>(L.trn_base);
   A.win_trn_hi = static_cast<int32_t>(L.trn_base + L.nl_trans);
+  A.n_local_poses = L.nl_poses;
   return A;
 }
 
@@ -442,14 +443,16 @@ int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int 
   CREATE_TRY(to_device(&c->d_head_val, F.head_val));
   if (F.L.world > 1) {
     // a slice is "boundary" when one of its stored columns is a row outside this rank's shard (padding entries carry
-    // local columns; the predecessor block a symmetric pose slice does not store belongs to a local pose by
-    // construction: format_build.cpp keeps the explicit layout at the head of a shard)
+    // local columns; what a chain slice does not store belongs to local poses by construction: format_build.cpp puts
+    // the couplings of a shard's first pose to the shard before into the general slots and the tail)
     std::vector<SliceDesc> in, bd;
     const int64_t lo = F.L.base, hi = F.L.base + F.L.shard_rows;
+    std::vector<int32_t> cols;
     for (const SliceDesc &sd : F.slices) {
       bool remote = false;
-      const size_t c0 = static_cast<size_t>(sd.coff), c1 = c0 + static_cast<size_t>(sd.width) * kWave;
-      for (size_t q = c0; q < c1 && !remote; ++q) remote = F.scol[q] < lo || F.scol[q] >= hi;
+      cols.clear();
+      slice_columns(F, sd, cols);  // (the implied columns of a chain slice are local rows)
+      for (size_t q = 0; q < cols.size() && !remote; ++q) remote = cols[q] < lo || cols[q] >= hi;
       (remote ? bd : in).push_back(sd);
     }
     c->n_slices_int = static_cast<int>(in.size());
@@ -599,7 +602,11 @@ int cora_remote_rows(const cora_ctx *c, int32_t *rows, int64_t *count) {
   const Layout &L = c->F.L;
   const int64_t lo = L.base, hi = L.base + L.shard_rows;
   std::vector<char> seen(static_cast<size_t>(L.rows), 0);
-  for (int32_t col : c->F.scol) seen[col] = 1;   // padded slots repeat a real column of their lane
+  {
+    std::vector<int32_t> cols;  // (scol also holds the chain slices' tail descriptors: only real columns count)
+    for (const SliceDesc &sd : c->F.slices) slice_columns(c->F, sd, cols);
+    for (int32_t col : cols) seen[col] = 1;  // padded slots repeat a real column of their lane
+  }
   for (int32_t col : c->F.lcol) seen[col] = 1;
   int64_t n = 0;
   for (int64_t r = 0; r < L.rows; ++r)

@@ -16,7 +16,7 @@ extern int g_long_chunk;
 extern int g_interleave;            // pose-slice slot order (see format_build.cpp)
 constexpr int kSigma = 256;       // default sorting window (rows) for translation slices
 extern int g_sigma;               // tunable copy of kSigma (format_build.cpp)
-extern int g_sym_blocks;          // pose slices without their predecessor blocks (format_build.cpp)
+extern int g_chain_slices;        // pose slices in the chain layout (kSliceChainFlag, format_build.cpp); 0: plain layout
 constexpr int kMaxLD = 24;
 
 // Row stride (doubles) used for a k-column resident vector: the number of columns itself, whatever k (<= kMaxLD).  Odd
@@ -36,9 +36,30 @@ enum SliceType : int32_t {
   kSliceEuclidPerm = 3 // lane = one translation row, rows given by perm[]
 };
 constexpr int32_t kSliceTypeMask = 0xff;
-// flag on a pose slice: the blocks that couple a pose with its index predecessor are not stored (Q is symmetric: lane
-// q - 1 holds the transposed block in its slots 0 .. d-1); lane 0's comes from HostFormat::head_val
-constexpr int32_t kSliceSymFlag = 0x100;
+// Flag on a pose slice: the CHAIN layout.  The lane owns its pose's d rotation rows AND the pose's translation row, the
+// columns every pose of a chain has are implied by the lane (no index stored), and everything Q's symmetry gives is
+// stored once:
+//   fixed slots (values only, [..][lane], in this order; P = the lane's local pose, t_P its translation row):
+//     s0[a], a <= d : column t_P      -- Q(rot(P)_a, t_P) for a < d,  Q(t_P, t_P) for a = d
+//     s1[a], a <= d : column t_{P+1}  -- Q(rot(P)_a, t_{P+1}),        Q(t_P, t_{P+1})       (zeros without a next local pose)
+//     nxt[c][a]     : column rot(P+1)_c, rows rot(P)_a               (zeros without a next local pose)
+//     own[c][a]     : column rot(P)_c,   rows rot(P)_a
+//   taken from elsewhere (checked bit for bit when the format is built; a slice that fails keeps the plain layout and
+//   its translation rows go to row slices):
+//     Q(t_P, rot(P)_c)      = s0[c] of the same lane
+//     Q(rot(P)_a, rot(P-1)_c) = nxt[a][c], Q(t_P, rot(P-1)_c) = s1[c], Q(t_P, t_{P-1}) = s1[d] of the lane BEFORE
+//                             (lane 0: HostFormat::head_val, kChainHead(d) doubles per pose slice)
+//   general slots (index + d values, SliceDesc::width of them): every other column of the rotation rows
+//   tail (index + one value, compact, sorted by lane; lane's range in tinfo = start | count << 16): every other column
+//     of the translation row -- its range measurements, loop closures, a predecessor on another shard
+// Value stream from SliceDesc::off: fixed (kChainFixed(d) x 64) | general (width x d x 64) | tail (T);  index stream from
+// SliceDesc::coff: tinfo (64) | general (width x 64) | tail (T);  T = SliceDesc::type >> kSliceTailShift (<= 65535).
+constexpr int32_t kSliceChainFlag = 0x100;
+constexpr int kSliceTailShift = 16;
+constexpr int kSliceTailMaxShift = 9;   // SliceDesc::type bits 9..15: the longest tail of a lane of the slice
+constexpr int32_t kSliceTailMaxMask = 0x7f;
+constexpr int kChainFixed(int d) { return 2 * (d + 1) + 2 * d * d; }   // doubles per lane in the fixed slots
+constexpr int kChainHead(int d) { return d * d + d + 1; }              // doubles per slice in head_val
 
 // One wavefront's work, stored slot-major ([k][lane]) so that every load is a
 // fully coalesced 512 B (values) / 256 B (columns).
@@ -90,7 +111,9 @@ struct HostFormat {
   std::vector<int32_t> int2api;   // rows: API row of internal row (-1 = padding)
   std::vector<SliceDesc> slices;
   std::vector<SliceDesc> slices_pose_first;  // same slices, pose slices first inside each eighth (small row strides)
-  std::vector<double> head_val;   // [pose slice][d * d]: predecessor block of the slice's first pose (kSliceSymFlag)
+  // [pose slice][kChainHead(d)]: what lane 0 of a chain slice takes from the pose before it --
+  // [a * d + c] = Q(rot(P)_a, rot(P-1)_c), [d * d + c] = Q(t_P, rot(P-1)_c), [d * d + d] = Q(t_P, t_{P-1})
+  std::vector<double> head_val;
   std::vector<double> sval;
   std::vector<int32_t> scol;
   std::vector<int32_t> perm;      // internal rows for kSliceEuclidPerm slices
@@ -113,6 +136,10 @@ struct HostFormat {
 void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
                   const int32_t *col, const double *val, int rank, int world,
                   HostFormat &out, bool distribute_long_rows = true);
+
+// Every column index a slice stores (general slots and tail of a chain slice; all slots of the others); the implied
+// columns of a chain slice are rows of the local shard.
+void slice_columns(const HostFormat &F, const SliceDesc &sd, std::vector<int32_t> &out);
 
 // Host execution of the FORMAT (test hook, see cora_debug_format_spmm_host).
 void format_spmm_host(const HostFormat &F, const double *X_int, int ld,

@@ -21,8 +21,8 @@ int g_sigma = kSigma;
 int g_pad_even = 0;
 int g_long_chunk = kLongChunk;
 int g_interleave = 0;  // measured: no gain on MI355X (kept for the lab)
-// pose slices without their predecessor blocks (CORA_SYM_BLOCKS=0: the plain layout, measurement switch)
-int g_sym_blocks = [] { const char *e = std::getenv("CORA_SYM_BLOCKS"); return (e && e[0] == '0') ? 0 : 1; }();
+// pose slices in the chain layout (CORA_CHAIN_SLICES=0: the plain layout with every column explicit, measurement switch)
+int g_chain_slices = [] { const char *e = std::getenv("CORA_CHAIN_SLICES"); return (e && e[0] == '0') ? 0 : 1; }();
 
 namespace {
 
@@ -241,9 +241,23 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   // d x 1 columns (src/CORA_problem.cpp:297-377, 639-652) -- so the union
   // pattern is stored once with d values per column: one 4-byte index and one
   // X-row gather serve d nonzeros.
+  //
+  // Chain layout (kSliceChainFlag, cora_internal.h).  Along a pose chain every pose has the same columns -- its own
+  // rotation block, the next and the previous pose's, the translations t_P and t_{P+1} -- so they carry no index; Q is
+  // symmetric, so the previous pose's block, the rotation part of the pose's translation row (Q31 = Q13^T) and the
+  // sub-diagonal of Q33 are what a neighbouring slot already holds; and the lane takes the pose's translation row with
+  // it: what is left of that row (its range measurements) is a short compact tail.  26 values + a 4-byte tail
+  // descriptor per pose at d = 3 instead of 33 values + 11 indices in the pose slice and ~11 values + 11 gathered rows
+  // of X in a translation-row slice of its own.  Every identity the layout relies on is checked bit for bit here; a
+  // slice that fails one keeps the plain layout (all columns explicit) and its translation rows go to the row slices.
+  std::vector<char> trn_owned(static_cast<size_t>(std::max(L.nl_trans, 1)), 0);
   {
     struct PoseCols { std::vector<int32_t> c; std::vector<double> v; };  // v[k*d + a]
-    std::vector<PoseCols> pc(std::min(kWave, std::max(L.nl_poses, 1)));
+    struct RowEnt { std::vector<int32_t> c; std::vector<double> v; };
+    const int lanes = std::min(kWave, std::max(L.nl_poses, 1));
+    std::vector<PoseCols> pc(lanes);
+    std::vector<RowEnt> tr(lanes);
+    const int FV = kChainFixed(d), HV = kChainHead(d);
     for (int p0 = 0; p0 < L.nl_poses; p0 += kWave) {
       const int cnt = std::min(kWave, L.nl_poses - p0);
       int width = 0;
@@ -276,79 +290,154 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         }
         width = std::max(width, static_cast<int>(P.c.size()));
       }
-      // Symmetric chain blocks.  Q is symmetric, so the d x d block that couples pose q with its index predecessor is the
-      // transpose of the block lane q - 1 holds for ITS successor.  When that holds exactly for the whole slice, the
-      // predecessor block is not stored: slots 0 .. d-1 of every lane are the columns of the NEXT pose's rotation rows
-      // (zeros where there is no such coupling), the kernel hands them to lane q + 1 with a lane shift, and only lane 0's
-      // predecessor block -- it lives in the previous slice -- is kept, in F.head_val.  Three of the eleven slots of a
-      // chain pose (27 % of the pose slices' stream, 7 % of the product's traffic) are gone; loop closures and anything
-      // else stay in the stream.  (g_sym_blocks = 0: the plain layout, measurement switch.)
-      bool sym = g_sym_blocks != 0;
-      std::vector<double> nextv(static_cast<size_t>(kWave) * d * d, 0.0), prevv(static_cast<size_t>(kWave) * d * d, 0.0);
-      auto block_of = [&](const PoseCols &P, int64_t first_col, double *out) {  // out[c * d + a] = value (row a, column first_col + c)
-        for (size_t k = 0; k < P.c.size(); ++k)
-          if (P.c[k] >= first_col && P.c[k] < first_col + d)
-            for (int a = 0; a < d; ++a) out[(P.c[k] - first_col) * d + a] = P.v[k * d + a];
+      // ---- chain layout: gather what every lane stores and check what it does not store ----
+      bool chain = g_chain_slices != 0;
+      struct ChainLane {
+        double s0[4], s1[4], nxt[9], own[9], hq[3], ht, prev[9];
+        std::vector<int32_t> gc, tc;
+        std::vector<double> gv, tv;
       };
-      for (int q = 0; q < cnt && sym; ++q) {
-        const int64_t me = L.rot_base + static_cast<int64_t>(p0 + q) * d;
-        if (p0 + q + 1 < L.nl_poses) block_of(pc[q], me + d, &nextv[static_cast<size_t>(q) * d * d]);
-        if (p0 + q > 0) block_of(pc[q], me - d, &prevv[static_cast<size_t>(q) * d * d]);
-      }
-      for (int q = 1; q < cnt && sym; ++q)  // prev(q)[c][a] = Q(rot(q)_a, rot(q-1)_c) must equal next(q-1)[a][c] = Q(rot(q-1)_c, rot(q)_a)
-        for (int a = 0; a < d && sym; ++a)
-          for (int c = 0; c < d; ++c)
-            if (prevv[(static_cast<size_t>(q) * d + c) * d + a] != nextv[(static_cast<size_t>(q - 1) * d + a) * d + c]) sym = false;
-      if (sym) {
-        width = 0;
-        for (int q = 0; q < cnt; ++q) {  // re-lay the lane: next block first, then everything else but the predecessor block
-          PoseCols &P = pc[q], R;
-          const int64_t me = L.rot_base + static_cast<int64_t>(p0 + q) * d;
-          const bool has_next = p0 + q + 1 < L.nl_poses, has_prev = p0 + q > 0;
-          for (int c = 0; c < d; ++c) {
-            R.c.push_back(static_cast<int32_t>(has_next ? me + d + c : me + c));
-            for (int a = 0; a < d; ++a) R.v.push_back(nextv[(static_cast<size_t>(q) * d + c) * d + a]);
+      std::vector<ChainLane> cl(chain ? cnt : 0);
+      if (chain) {
+        for (int q = 0; q < cnt; ++q) {  // the pose's translation row, internal columns in increasing order
+          RowEnt &T = tr[q];
+          T.c.clear(); T.v.clear();
+          const int32_t api = F.int2api[L.trn_base + p0 + q];
+          if (rowptr[api + 1] - rowptr[api] > kLongRow) chain = false;  // a long row stays on the chunked path
+          std::vector<std::pair<int32_t, double>> ent;
+          for (int32_t t = rowptr[api]; t < rowptr[api + 1]; ++t) ent.push_back({F.api2int[col[t]], val[t]});
+          std::stable_sort(ent.begin(), ent.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+          for (const auto &e : ent) {
+            if (!T.c.empty() && T.c.back() == e.first) T.v.back() += e.second;
+            else { T.c.push_back(e.first); T.v.push_back(e.second); }
           }
-          for (size_t k = 0; k < P.c.size(); ++k) {
-            if (has_next && P.c[k] >= me + d && P.c[k] < me + 2 * d) continue;
-            if (has_prev && P.c[k] >= me - d && P.c[k] < me) continue;
-            R.c.push_back(P.c[k]);
-            for (int a = 0; a < d; ++a) R.v.push_back(P.v[k * d + a]);
-          }
-          P = R;
-          width = std::max(width, static_cast<int>(P.c.size()));
         }
+        for (int q = 0; q < cnt; ++q) {
+          ChainLane &C = cl[q];
+          std::memset(C.s0, 0, sizeof C.s0); std::memset(C.s1, 0, sizeof C.s1);
+          std::memset(C.nxt, 0, sizeof C.nxt); std::memset(C.own, 0, sizeof C.own);
+          std::memset(C.hq, 0, sizeof C.hq); std::memset(C.prev, 0, sizeof C.prev);
+          C.ht = 0.0;
+          const int P = p0 + q;
+          const int64_t me = L.rot_base + static_cast<int64_t>(P) * d, tme = L.trn_base + P;
+          const bool has_next = P + 1 < L.nl_poses, has_prev = P > 0;
+          const PoseCols &R = pc[q];
+          for (size_t k = 0; k < R.c.size(); ++k) {
+            const int64_t c = R.c[k];
+            const double *v = &R.v[k * d];
+            if (c == tme) { for (int a = 0; a < d; ++a) C.s0[a] = v[a]; }
+            else if (has_next && c == tme + 1) { for (int a = 0; a < d; ++a) C.s1[a] = v[a]; }
+            else if (has_next && c >= me + d && c < me + 2 * d) { for (int a = 0; a < d; ++a) C.nxt[(c - me - d) * d + a] = v[a]; }
+            else if (c >= me && c < me + d) { for (int a = 0; a < d; ++a) C.own[(c - me) * d + a] = v[a]; }
+            else if (has_prev && c >= me - d && c < me) { for (int a = 0; a < d; ++a) C.prev[(c - me + d) * d + a] = v[a]; }
+            else { C.gc.push_back(static_cast<int32_t>(c)); for (int a = 0; a < d; ++a) C.gv.push_back(v[a]); }
+          }
+          const RowEnt &T = tr[q];
+          double trot[3] = {0.0, 0.0, 0.0};  // Q(t_P, rot(P)_c)
+          for (size_t k = 0; k < T.c.size(); ++k) {
+            const int64_t c = T.c[k];
+            const double v = T.v[k];
+            if (c == tme) C.s0[d] = v;
+            else if (has_next && c == tme + 1) C.s1[d] = v;
+            else if (c >= me && c < me + d) trot[c - me] = v;
+            else if (has_prev && c >= me - d && c < me) C.hq[c - me + d] = v;
+            else if (has_prev && c == tme - 1) C.ht = v;
+            else { C.tc.push_back(static_cast<int32_t>(c)); C.tv.push_back(v); }
+          }
+          for (int c = 0; c < d; ++c)
+            if (trot[c] != C.s0[c]) chain = false;  // Q31 = Q13^T on the pose's own block
+        }
+        for (int q = 1; q < cnt && chain; ++q) {  // what lane q takes from lane q - 1
+          const ChainLane &C = cl[q], &B = cl[q - 1];
+          for (int a = 0; a < d; ++a)
+            for (int c = 0; c < d; ++c)
+              if (C.prev[c * d + a] != B.nxt[a * d + c]) chain = false;  // Q(rot(P)_a, rot(P-1)_c) = Q(rot(P-1)_c, rot(P)_a)
+          for (int c = 0; c < d; ++c)
+            if (C.hq[c] != B.s1[c]) chain = false;                        // Q(t_P, rot(P-1)_c) = Q(rot(P-1)_c, t_P)
+          if (C.ht != B.s1[d]) chain = false;                             // Q(t_P, t_{P-1}) = Q(t_{P-1}, t_P)
+        }
+        size_t T = 0;
+        for (int q = 0; q < cnt && chain; ++q) {
+          if (cl[q].tc.size() > static_cast<size_t>(kSliceTailMaxMask)) chain = false;
+          T += cl[q].tc.size();
+        }
+        if (T > 0xffffu) chain = false;
       }
-      F.head_val.resize(static_cast<size_t>(p0 / kWave + 1) * d * d, 0.0);
-      if (sym)  // lane 0's predecessor block: head[a * d + c] = Q(rot(p0)_a, rot(p0 - 1)_c)
-        for (int a = 0; a < d; ++a)
-          for (int c = 0; c < d; ++c) F.head_val[static_cast<size_t>(p0 / kWave) * d * d + a * d + c] = prevv[static_cast<size_t>(c) * d + a];
+      F.head_val.resize(static_cast<size_t>(p0 / kWave + 1) * HV, 0.0);
       SliceDesc sd{};
       sd.row0 = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(p0) * d);
       sd.nrows = cnt;
-      sd.width = width;
-      sd.type = kSliceStiefel | (sym ? kSliceSymFlag : 0);
       sd.off = static_cast<int64_t>(F.sval.size());
       sd.coff = static_cast<int32_t>(F.scol.size());
       sd.aux0 = p0;
-      F.max_width = std::max(F.max_width, width);
-      const size_t vb = F.sval.size(), cb = F.scol.size();
-      F.sval.resize(vb + static_cast<size_t>(width) * d * kWave, 0.0);
-      F.scol.resize(cb + static_cast<size_t>(width) * kWave, 0);
-      for (int lane = 0; lane < kWave; ++lane) {
-        const PoseCols &P = pc[std::min(lane, cnt - 1)];
-        const bool active = lane < cnt;
-        int32_t fill = P.c.empty() ? sd.row0 : P.c[0];
-        for (int k = 0; k < width; ++k) {
-          const bool have = k < static_cast<int>(P.c.size());
-          if (have) fill = P.c[k];
-          F.scol[cb + static_cast<size_t>(k) * kWave + lane] = fill;
-          for (int a = 0; a < d; ++a)
-            F.sval[vb + (static_cast<size_t>(k) * d + a) * kWave + lane] =
-                (have && active) ? P.v[static_cast<size_t>(k) * d + a] : 0.0;
+      if (chain) {
+        int gw = 0;
+        size_t T = 0, mc = 0;
+        for (int q = 0; q < cnt; ++q) {
+          gw = std::max(gw, static_cast<int>(cl[q].gc.size()));
+          mc = std::max(mc, cl[q].tc.size());
+          T += cl[q].tc.size();
         }
+        double *hv = &F.head_val[static_cast<size_t>(p0 / kWave) * HV];
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < d; ++c) hv[a * d + c] = cl[0].prev[c * d + a];
+        for (int c = 0; c < d; ++c) hv[d * d + c] = cl[0].hq[c];
+        hv[d * d + d] = cl[0].ht;
+        sd.width = gw;
+        sd.type = kSliceStiefel | kSliceChainFlag | static_cast<int32_t>(mc << kSliceTailMaxShift) |
+                  static_cast<int32_t>(static_cast<uint32_t>(T) << kSliceTailShift);
+        F.max_width = std::max(F.max_width, gw + 2 + 2 * d);
+        const size_t vb = F.sval.size(), cb = F.scol.size();
+        F.sval.resize(vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave + T, 0.0);
+        F.scol.resize(cb + (1 + static_cast<size_t>(gw)) * kWave + T, 0);
+        double *tv = &F.sval[vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave];
+        int32_t *tc = &F.scol[cb + (1 + static_cast<size_t>(gw)) * kWave];
+        size_t te = 0;
+        for (int lane = 0; lane < kWave; ++lane) {
+          const bool active = lane < cnt;
+          const ChainLane &C = cl[std::min(lane, cnt - 1)];
+          auto put = [&](int slot, double v) { F.sval[vb + static_cast<size_t>(slot) * kWave + lane] = active ? v : 0.0; };
+          for (int a = 0; a <= d; ++a) { put(a, C.s0[a]); put(d + 1 + a, C.s1[a]); }
+          for (int k = 0; k < d * d; ++k) { put(2 * (d + 1) + k, C.nxt[k]); put(2 * (d + 1) + d * d + k, C.own[k]); }
+          // general slots; padded slots repeat a column of the lane (or the lane's own first row) with zero values
+          int32_t fill = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(std::min(p0 + lane, L.nl_poses - 1)) * d);
+          for (int k = 0; k < gw; ++k) {
+            const bool have = k < static_cast<int>(C.gc.size());
+            if (have) fill = C.gc[k];
+            F.scol[cb + (1 + static_cast<size_t>(k)) * kWave + lane] = fill;
+            for (int a = 0; a < d; ++a) put(FV + k * d + a, have ? C.gv[static_cast<size_t>(k) * d + a] : 0.0);
+          }
+          uint32_t info = static_cast<uint32_t>(te);
+          if (active) {
+            info |= static_cast<uint32_t>(C.tc.size()) << 16;
+            for (size_t k = 0; k < C.tc.size(); ++k) { tc[te] = C.tc[k]; tv[te] = C.tv[k]; ++te; }
+            trn_owned[static_cast<size_t>(p0 + lane)] = 1;
+          }
+          F.scol[cb + lane] = static_cast<int32_t>(info);
+        }
+        F.padded_nnz += (static_cast<int64_t>(FV) + static_cast<int64_t>(gw) * d) * kWave + static_cast<int64_t>(T);
+      } else {
+        sd.width = width;
+        sd.type = kSliceStiefel;
+        F.max_width = std::max(F.max_width, width);
+        const size_t vb = F.sval.size(), cb = F.scol.size();
+        F.sval.resize(vb + static_cast<size_t>(width) * d * kWave, 0.0);
+        F.scol.resize(cb + static_cast<size_t>(width) * kWave, 0);
+        for (int lane = 0; lane < kWave; ++lane) {
+          const PoseCols &P = pc[std::min(lane, cnt - 1)];
+          const bool active = lane < cnt;
+          int32_t fill = P.c.empty() ? sd.row0 : P.c[0];
+          for (int k = 0; k < width; ++k) {
+            const bool have = k < static_cast<int>(P.c.size());
+            if (have) fill = P.c[k];
+            F.scol[cb + static_cast<size_t>(k) * kWave + lane] = fill;
+            for (int a = 0; a < d; ++a)
+              F.sval[vb + (static_cast<size_t>(k) * d + a) * kWave + lane] =
+                  (have && active) ? P.v[static_cast<size_t>(k) * d + a] : 0.0;
+          }
+        }
+        F.padded_nnz += static_cast<int64_t>(width) * d * kWave;
       }
-      F.padded_nnz += static_cast<int64_t>(width) * d * kWave;
       F.slices.push_back(sd);
       slice_key.push_back(p0);
     }
@@ -420,6 +509,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         F.nnz_local -= rr.len;
         continue;
       }
+      if (i < L.nl_poses && trn_owned[static_cast<size_t>(i)]) continue;  // the pose's chain slice has it
       if (rr.len > kLongRow) {
         const int32_t p0 = rowptr[rr.api_row];
         const int32_t k_begin = static_cast<int32_t>(F.lval.size());
@@ -504,12 +594,71 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   }
 }
 
+void slice_columns(const HostFormat &F, const SliceDesc &sd, std::vector<int32_t> &out) {
+  const int32_t *cb = F.scol.data() + sd.coff;
+  if (sd.type & kSliceChainFlag) {
+    const size_t T = static_cast<uint32_t>(sd.type) >> kSliceTailShift;
+    out.insert(out.end(), cb + kWave, cb + (1 + static_cast<size_t>(sd.width)) * kWave + T);
+  } else {
+    out.insert(out.end(), cb, cb + static_cast<size_t>(sd.width) * kWave);
+  }
+}
+
 void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out) {
   const int d = F.L.d;
+  const Layout &L = F.L;
   std::vector<double> acc(static_cast<size_t>(ld) * 4);
+  auto axpy = [&](double *y, double v, int64_t row) {
+    const double *xr = X + static_cast<size_t>(row) * ld;
+    for (int c = 0; c < ld; ++c) y[c] += v * xr[c];
+  };
   for (const SliceDesc &s : F.slices) {
     for (int lane = 0; lane < s.nrows; ++lane) {
       std::fill(acc.begin(), acc.end(), 0.0);
+      if ((s.type & kSliceTypeMask) == kSliceStiefel && (s.type & kSliceChainFlag)) {
+        // the chain layout exactly as the kernel reads it (cora_internal.h): implied columns, the lane before, the tail
+        const int FV = kChainFixed(d), HV = kChainHead(d);
+        const double *vb = F.sval.data() + s.off;
+        const int32_t *cb = F.scol.data() + s.coff;
+        const double *tv = vb + (static_cast<size_t>(FV) + static_cast<size_t>(s.width) * d) * kWave;
+        const int32_t *tc = cb + (1 + static_cast<size_t>(s.width)) * kWave;
+        auto V = [&](int slot, int ln) { return vb[static_cast<size_t>(slot) * kWave + ln]; };
+        const int P = s.aux0 + lane, np = L.nl_poses;
+        const int64_t own_row = L.rot_base + static_cast<int64_t>(P) * d;
+        const int64_t nxt_row = L.rot_base + static_cast<int64_t>(std::min(P + 1, np - 1)) * d;
+        const int64_t prv_row = L.rot_base + static_cast<int64_t>(std::max(P - 1, 0)) * d;
+        const int64_t t_own = L.trn_base + P, t_nxt = L.trn_base + std::min(P + 1, np - 1), t_prv = L.trn_base + std::max(P - 1, 0);
+        double *acct = &acc[static_cast<size_t>(d) * ld];
+        for (int a = 0; a <= d; ++a) {
+          axpy(&acc[static_cast<size_t>(a) * ld], V(a, lane), t_own);
+          axpy(&acc[static_cast<size_t>(a) * ld], V(d + 1 + a, lane), t_nxt);
+        }
+        if (P > 0) {
+          const double *hv = &F.head_val[static_cast<size_t>(s.aux0 / kWave) * HV];
+          axpy(acct, lane > 0 ? V(d + 1 + d, lane - 1) : hv[d * d + d], t_prv);
+          for (int c = 0; c < d; ++c) {
+            for (int a = 0; a < d; ++a)
+              axpy(&acc[static_cast<size_t>(a) * ld], lane > 0 ? V(2 * (d + 1) + a * d + c, lane - 1) : hv[a * d + c], prv_row + c);
+            axpy(acct, lane > 0 ? V(d + 1 + c, lane - 1) : hv[d * d + c], prv_row + c);
+          }
+        }
+        for (int c = 0; c < d; ++c) {
+          for (int a = 0; a < d; ++a) {
+            axpy(&acc[static_cast<size_t>(a) * ld], V(2 * (d + 1) + c * d + a, lane), nxt_row + c);
+            axpy(&acc[static_cast<size_t>(a) * ld], V(2 * (d + 1) + d * d + c * d + a, lane), own_row + c);
+          }
+          axpy(acct, V(c, lane), own_row + c);
+        }
+        for (int k = 0; k < s.width; ++k)
+          for (int a = 0; a < d; ++a)
+            axpy(&acc[static_cast<size_t>(a) * ld], V(FV + k * d + a, lane), cb[(1 + static_cast<size_t>(k)) * kWave + lane]);
+        const uint32_t info = static_cast<uint32_t>(cb[lane]);
+        for (uint32_t e = info & 0xffffu; e < (info & 0xffffu) + (info >> 16); ++e) axpy(acct, tv[e], tc[e]);
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < ld; ++c) out[static_cast<size_t>(own_row + a) * ld + c] = acc[a * ld + c];
+        for (int c = 0; c < ld; ++c) out[static_cast<size_t>(t_own) * ld + c] = acct[c];
+        continue;
+      }
       if ((s.type & kSliceTypeMask) == kSliceStiefel) {
         for (int k = 0; k < s.width; ++k) {
           const double *xr = X + static_cast<size_t>(F.scol[s.coff + static_cast<size_t>(k) * kWave + lane]) * ld;
@@ -517,17 +666,6 @@ void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out)
             const double v = F.sval[s.off + (static_cast<size_t>(k) * d + a) * kWave + lane];
             for (int c = 0; c < ld; ++c) acc[a * ld + c] += v * xr[c];
           }
-        }
-        if ((s.type & kSliceSymFlag) && s.aux0 + lane > 0) {
-          // the predecessor block: slot a, row c of the lane before (lane 0: the slice's head block) times the
-          // predecessor pose's rows of X
-          const double *xp = X + (static_cast<size_t>(s.row0) + static_cast<size_t>(lane - 1) * d) * ld;
-          for (int a = 0; a < d; ++a)
-            for (int c2 = 0; c2 < d; ++c2) {
-              const double v = lane > 0 ? F.sval[s.off + (static_cast<size_t>(a) * d + c2) * kWave + (lane - 1)]
-                                        : F.head_val[static_cast<size_t>(s.aux0 / kWave) * d * d + a * d + c2];
-              for (int c = 0; c < ld; ++c) acc[a * ld + c] += v * xp[c2 * ld + c];
-            }
         }
         for (int a = 0; a < d; ++a)
           for (int c = 0; c < ld; ++c)

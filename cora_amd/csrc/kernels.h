@@ -22,7 +22,7 @@ struct SpmmArgs {
   int n_real_chunks;   // filled by launch_spmm
   int n_slice_blocks;  // filled by launch_spmm
   const double *sval;
-  const double *head_val;  // [pose slice][d * d] predecessor block of the slice's first pose (kSliceSymFlag)
+  const double *head_val;  // [pose slice][kChainHead(d)]: what lane 0 of a chain slice takes from the pose before it
   const int32_t *scol;
   const int32_t *perm;
   const LongChunk *chunks;
@@ -51,6 +51,7 @@ struct SpmmArgs {
   // the same slices with the pose slices first inside each XCD's eighth of the list (HostFormat::slices_pose_first);
   // launch_spmm takes this order up to a row stride of kPoseFirstMaxLD (measured: better below, worse above)
   const SliceDesc *slices_pose_first = nullptr;
+  int32_t n_local_poses = 0;  // poses of the shard (chain slices clamp their implied columns to them)
   int32_t win_on = 0;  // set by launch_spmm: X window + cooperative epilogue of the pose slices (n_slices >= kWinMinSlices)
 };
 constexpr int kPoseFirstMaxLD = 6;

@@ -352,31 +352,22 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   const bool kCoop = kCoopT && A.win_on;
   constexpr int kYEl = kWave * D * LD, kLEl = kWave * D * D;
   constexpr int kWinEl = (kRotRows + kTrnRows) * LD;
-  constexpr int kSmemEl = !kWinLD ? 1 : (kCoopT && kYEl + kLEl > kWinEl ? kYEl + kLEl : kWinEl);
+  // (the cooperative epilogue hands Y rows + Lambda blocks in, result rows + the slice's translation rows out)
+  constexpr int kCoopEl = kYEl + (kLEl > kWave * LD ? kLEl : kWave * LD);
+  constexpr int kSmemEl = !kWinLD ? 1 : (kCoopT && kCoopEl > kWinEl ? kCoopEl : kWinEl);
   __shared__ double win[kSmemEl];
   constexpr int kYIt = (D * LD + 1) / 2, kLIt = (D * D + 1) / 2;  // (CORA_EPI_X2: pairs of doubles per lane and access)
   double ystage[kCoopT ? 2 * kYIt : 1], lstage[kCoopT ? 2 * kLIt : 1];
-  // Symmetric chain blocks (kSliceSymFlag, format_build.cpp): slots 0 .. D-1 are the NEXT pose's columns; their values
-  // stay in registers and become, shifted by one lane, the predecessor block of the lane after (lane 0: the slice's
-  // head block).  The predecessor block is not in the stream: 8 slots instead of 11 for a pose of the chain.
-  const bool sym = (sd.type & kSliceSymFlag) != 0;
-  // narrow rows: the next-pose slots are peeled off the loop and their values shifted by one lane; wide rows (registers
-  // are what they are short of: at a row stride of 10 the peeled form cost a wave of occupancy) re-read the previous
-  // lane's values from the stream the wavefront has just loaded (L1 / L2 hits)
+  // Chain layout (kSliceChainFlag, cora_internal.h): the lane owns the pose's translation row as well, the chain's columns
+  // are implied, and what Q's symmetry gives comes from the lane before (lane 0: the slice's head block).
+  const bool chain = (sd.type & kSliceChainFlag) != 0;  // wave-uniform
+  // narrow rows: the values a lane hands to the lane after it stay in registers and move with a lane shift; wide rows
+  // (registers are what they are short of) re-read the previous lane's values from the stream the wavefront has just
+  // loaded (L1 / L2 hits)
   constexpr bool kNxtRegs = LD <= 5 || (LD <= 8 && EPI < 2);
-  double nxt[kNxtRegs ? D : 1][D];
-  // (CORA_POSE_EARLY_SLOTS) the peeled slots' indices and values are requested together with the window's rows: they
-  // do not depend on the window, and behind its barrier they cost the wavefront one more memory latency
-  int32_t nxt_col[kNxtRegs ? D : 1];
-  const bool early = CORA_POSE_EARLY_SLOTS && kNxtRegs && sym && kWin;
-  if (early) {
-#pragma unroll
-    for (int k = 0; k < (kNxtRegs ? D : 1); ++k) {
-      nxt_col[k] = stream_load(cp + static_cast<size_t>(k) * kWave);
-#pragma unroll
-      for (int a = 0; a < D; ++a) nxt[k][a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
-    }
-  }
+  constexpr int kFV = kChainFixed(D);
+  int32_t tinfo = 0;
+  if (chain) tinfo = stream_load(cp);  // the lane's range of the tail: start | count << 16
   int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
   if constexpr (kWinLD) if (kWin) {
     w0 = max(sd.row0 - D, A.win_rot_lo);
@@ -444,6 +435,11 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     }
 #endif
     __syncthreads();
+  }
+  // the cooperative epilogue's operands: the slice's rows of Y and its Lambda blocks, requested with coalesced loads
+  // well before they are needed -- plain slices before their slot loop, chain slices after their fixed slots (the
+  // registers they wait in are the ones those slots' values have just left) and before the tail
+  auto coop_prefetch = [&] {
     if constexpr (kCoopT) {
       const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
       const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
@@ -479,7 +475,8 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       }
 #endif
     }
-  }
+  };
+  if (kCoop && !chain) coop_prefetch();
 #if CORA_POSE_PREFETCH
   // every cache line of the slice's value and index streams is requested here, next to the window's loads: the slot
   // loop below waits for its loads trip after trip (registers allow two slots in flight), and with the working set in
@@ -498,11 +495,30 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     pfv[CORA_POSE_PREFETCH_V] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.scol + sd.coff) + (o < cbytes ? o : 0));
   }
 #endif
-  double acc[D][LD];
+  double acc[D][LD], acct[LD];  // the pose's d rotation rows; its translation row (chain slices)
 #pragma unroll
-  for (int a = 0; a < D; ++a)
+  for (int j = 0; j < LD; ++j) {
+    acct[j] = 0.0;
 #pragma unroll
-    for (int j = 0; j < LD; ++j) acc[a][j] = 0.0;
+    for (int a = 0; a < D; ++a) acc[a][j] = 0.0;
+  }
+  // rows of X: a local rotation / translation row from the windows when they are on, from memory otherwise
+  auto x_rot = [&](int row, double (&x)[LD]) {
+    if (kWinLD && kWin) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) x[j] = win[(row - w0) * LD + j];
+    } else {
+      load_row<LD>(X + static_cast<size_t>(row) * LD, x);
+    }
+  };
+  auto x_trn = [&](int row, double (&x)[LD]) {
+    if (kWinLD && kTrnRows > 0 && kWin) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) x[j] = win[(kRotRows + row - t0) * LD + j];
+    } else {
+      load_row<LD>(X + static_cast<size_t>(row) * LD, x);
+    }
+  };
   // one slot: column index, d values, the row of X (from the windows when they are on), d x LD products
   auto slot_apply = [&](const int32_t c, const double (&v)[D]) {
     double x[LD];
@@ -521,70 +537,164 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
   };
-  auto slot = [&](int k, double (&v)[D]) {
-    const int32_t c = stream_load(cp + static_cast<size_t>(k) * kWave);
+  const double *__restrict__ vpg = vp;    // the general slots: index + d values
+  const int32_t *__restrict__ cpg = cp;
+  int t_own = 0;
+  if (chain) {
+    vpg = vp + static_cast<size_t>(kFV) * kWave;
+    cpg = cp + kWave;
+    // implied columns: rows of the lane's pose, the pose after and the pose before (clamped to the local poses where
+    // there is none: the values there are zeros)
+    const int np = A.n_local_poses, P = sd.aux0 + lane, Pc = min(P, np - 1);
+    const int own_row = A.win_rot_lo + Pc * D, nxt_row = A.win_rot_lo + min(Pc + 1, np - 1) * D,
+              prv_row = A.win_rot_lo + max(Pc - 1, 0) * D;
+    const int t_nxt = A.win_trn_lo + min(Pc + 1, np - 1), t_prv = A.win_trn_lo + max(Pc - 1, 0);
+    t_own = A.win_trn_lo + Pc;
+    const bool has_prev = P > 0;
+    const double *__restrict__ head = A.head_val + static_cast<size_t>(sd.aux0 / kWave) * kChainHead(D);
+    // value `slot` of the lane before (lane 0: entry h of the head block; no pose before: 0)
+    auto before = [&](double mine, int slot, int h) {
+      double t;
+      if constexpr (kNxtRegs) t = __shfl_up(mine, 1, kWave);
+      else t = lane > 0 ? stream_load(vp + static_cast<size_t>(slot) * kWave - 1) : 0.0;
+      if (lane == 0) t = head[h];
+      return has_prev ? t : 0.0;
+    };
+    // (a) columns t_P and t_{P+1}: d + 1 values each (the rotation rows and the translation row)
+    double s0[D + 1], s1[D + 1];
 #pragma unroll
-    for (int a = 0; a < D; ++a) v[a] = stream_load(vp + (static_cast<size_t>(k) * D + a) * kWave);
-    slot_apply(c, v);
-  };
-  int k0 = 0;
-  if (kNxtRegs && sym) {
-    if (early) {
-#pragma unroll
-      for (int k = 0; k < (kNxtRegs ? D : 1); ++k) slot_apply(nxt_col[k], nxt[k]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < D; ++k) slot(k, nxt[kNxtRegs ? k : 0]);
+    for (int a = 0; a <= D; ++a) {
+      s0[a] = stream_load(vp + static_cast<size_t>(a) * kWave);
+      s1[a] = stream_load(vp + static_cast<size_t>(D + 1 + a) * kWave);
     }
-    k0 = D;
-  }
-  // (the predecessor block is applied right here, before the rest of the slots, so that its nine values do not stay in
-  // registers across the loop: with them the Hvp kernel needed 172 registers -- two waves per SIMD instead of three)
-  auto predecessor_block = [&] {
-    const bool has_prev = sd.aux0 + lane > 0;
-    const double *__restrict__ head = A.head_val + static_cast<size_t>(sd.aux0 / kWave) * (D * D);
-    const int prow0 = has_prev ? sd.row0 + (lane - 1) * D : sd.row0;  // first rotation row of the predecessor pose
+    {
+      double x[LD];
+      x_trn(t_own, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) acc[a][j] = fma(s0[a], x[j], acc[a][j]);
+        acct[j] = fma(s0[D], x[j], acct[j]);
+      }
+      x_trn(t_nxt, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) acc[a][j] = fma(s1[a], x[j], acc[a][j]);
+        acct[j] = fma(s1[D], x[j], acct[j]);
+      }
+    }
+    // (b) what the translation row takes from the lane before: Q(t_P, rot(P-1)_c) = its s1[c], Q(t_P, t_{P-1}) = its s1[d]
+    double ps1[D + 1];
+#pragma unroll
+    for (int c = 0; c <= D; ++c) ps1[c] = before(s1[c], D + 1 + c, D * D + c);
+    {
+      double x[LD];
+      x_trn(t_prv, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[D], x[j], acct[j]);
+    }
+    // (c) the next pose's block, (d) the previous pose's block = the transposed next block of the lane before
+    double nxt[D][D];  // [c][a] = Q(rot(P)_a, rot(P+1)_c)
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int a = 0; a < D; ++a) nxt[c][a] = stream_load(vp + static_cast<size_t>(2 * (D + 1) + c * D + a) * kWave);
 #pragma unroll
     for (int c = 0; c < D; ++c) {
       double x[LD];
-      if (kWinLD && kWin) {
-        const int l = has_prev ? prow0 + c - w0 : 0;
+      x_rot(nxt_row + c, x);
 #pragma unroll
-        for (int j = 0; j < LD; ++j) x[j] = win[l * LD + j];
-      } else {
-        load_row<LD>(X + static_cast<size_t>(prow0 + c) * LD, x);
-      }
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acc[a][j] = fma(nxt[c][a], x[j], acc[a][j]);
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double x[LD];
+      x_rot(prv_row + c, x);
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        // predecessor block, row a, column c: slot a, value c of the lane before
-        double pv;
-        if constexpr (kNxtRegs) pv = __shfl_up(nxt[a][c], 1, kWave);
-        else pv = lane > 0 ? stream_load(vp + (static_cast<size_t>(a) * D + c) * kWave - 1) : 0.0;
-        if (lane == 0) pv = head[a * D + c];
-        if (!has_prev) pv = 0.0;
+        const double pv = before(nxt[a][c], 2 * (D + 1) + a * D + c, a * D + c);  // Q(rot(P)_a, rot(P-1)_c)
 #pragma unroll
         for (int j = 0; j < LD; ++j) acc[a][j] = fma(pv, x[j], acc[a][j]);
       }
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[c], x[j], acct[j]);
     }
+    // (e) the pose's own block; the translation row's share of these columns is Q(t_P, rot(P)_c) = s0[c]
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double v[D], x[LD];
+#pragma unroll
+      for (int a = 0; a < D; ++a) v[a] = stream_load(vp + static_cast<size_t>(2 * (D + 1) + D * D + c * D + a) * kWave);
+      x_rot(own_row + c, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) acc[a][j] = fma(v[a], x[j], acc[a][j]);
+        acct[j] = fma(s0[c], x[j], acct[j]);
+      }
+    }
+  }
+  auto slot = [&](int k) {
+    double v[D];
+    const int32_t c = stream_load(cpg + static_cast<size_t>(k) * kWave);
+#pragma unroll
+    for (int a = 0; a < D; ++a) v[a] = stream_load(vpg + (static_cast<size_t>(k) * D + a) * kWave);
+    slot_apply(c, v);
   };
-  if (kNxtRegs && sym) predecessor_block();
   // slots in flight per lane: CORA_POSE_UNROLL_WIN with the windows; without, 3 up to a row stride of 6, 2 above
   // (register pressure: p = 10 Hvp 40.1 -> 39.4 us)
   if (kWin) {
 #pragma unroll CORA_POSE_UNROLL_WIN
-    for (int k = k0; k < sd.width; ++k) {
-      double v[D];
-      slot(k, v);
-    }
+    for (int k = 0; k < sd.width; ++k) slot(k);
   } else {
     constexpr int kSlotsInFlight = LD <= 6 ? CORA_POSE_UNROLL : 2;
 #pragma unroll kSlotsInFlight
-    for (int k = k0; k < sd.width; ++k) {
-      double v[D];
-      slot(k, v);
+    for (int k = 0; k < sd.width; ++k) slot(k);
+  }
+  // The tail of the translation row (range measurements, loop closures): T entries of the slice, sorted by lane, gathered
+  // by the whole wavefront -- lane e takes entry e -- and handed to their owners with lane permutes in entry order (a
+  // fixed order of summation); the owner's loop runs to the longest tail of the slice (kSliceTailMaxShift).
+  double kap_t = 0.0;
+  if (kCoop && chain) coop_prefetch();
+  if (chain) {
+    const int T = static_cast<int>(static_cast<unsigned>(sd.type) >> kSliceTailShift);
+    const int mc = (sd.type >> kSliceTailMaxShift) & kSliceTailMaxMask;
+    if (T > 0) {
+      const double *__restrict__ tv = A.sval + sd.off + (static_cast<size_t>(kFV) + static_cast<size_t>(sd.width) * D) * kWave;
+      const int32_t *__restrict__ tc = A.scol + sd.coff + (1 + static_cast<size_t>(sd.width)) * kWave;
+      const int tstart = tinfo & 0xffff, tcnt = static_cast<int>(static_cast<unsigned>(tinfo) >> 16);
+      for (int r0 = 0; r0 < T; r0 += kWave) {
+        const int e = r0 + lane;
+        double pr[LD];
+#pragma unroll
+        for (int j = 0; j < LD; ++j) pr[j] = 0.0;
+        if (e < T) {
+          const double v = stream_load(tv + e);
+          double x[LD];
+          load_row<LD>(X + static_cast<size_t>(stream_load(tc + e)) * LD, x);
+#pragma unroll
+          for (int j = 0; j < LD; ++j) pr[j] = v * x[j];
+        }
+        for (int i = 0; i < mc; ++i) {  // wave-uniform
+          const int e2 = tstart + i - r0;
+          const bool mine = i < tcnt && e2 >= 0 && e2 < kWave;
+#pragma unroll
+          for (int j = 0; j < LD; ++j) {
+            const double t = __shfl(pr[j], e2 & (kWave - 1), kWave);
+            acct[j] += mine ? t : 0.0;
+          }
+        }
+      }
+    }
+    if (EPI == EPI_HVP_K && lane < sd.nrows) {  // the translation row is final (no epilogue touches it): its share of <X, out>
+      double x[LD];
+      x_trn(t_own, x);
+      kap_t = dot_row<LD>(x, acct);
     }
   }
-  if (!kNxtRegs && sym) predecessor_block();
 #if CORA_POSE_PREFETCH
   if (kWin) {
 #pragma unroll
@@ -643,6 +753,10 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int j = 0; j < LD; ++j) win[(lane * D + a) * LD + j] = acc[a][j];
+    if (chain) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) win[kYEl + lane * LD + j] = acct[j];
+    }
     __syncthreads();
     double *__restrict__ op = A.out + static_cast<size_t>(sd.row0) * LD;
 #if CORA_EPI_X2
@@ -663,9 +777,24 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       if (e < sd.nrows * D * LD) op[e] = win[e];
     }
 #endif
-    return kap;
+    if (chain) {  // the slice's translation rows: consecutive rows as well
+      double *__restrict__ ot = A.out + static_cast<size_t>(A.win_trn_lo + sd.aux0) * LD;
+      constexpr int kTIt = (LD + 1) / 2;
+#pragma unroll
+      for (int i = 0; i < kTIt; ++i) {
+        const int e = 2 * (i * kWave + lane), n = sd.nrows * LD;
+        if (e + 1 < n) {
+          Pair8 v{win[kYEl + e], win[kYEl + e + 1]};
+          *reinterpret_cast<Pair8 *>(ot + e) = v;
+        } else if (e < n) {
+          ot[e] = win[kYEl + e];
+        }
+      }
+    }
+    return kap + kap_t;
   }
   if (lane >= sd.nrows) return 0.0;
+  if (chain) store_row<LD>(A.out + static_cast<size_t>(t_own) * LD, acct);
   const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(lane) * D;
   constexpr bool kKeepX = EPI == EPI_HVP_K && D * LD <= 18;  // the pose's own rows of X stay in registers for <X, out>
   double xs[kKeepX ? D : 1][LD];
@@ -714,7 +843,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       }
     }
   }
-  return kap;
+  return kap + kap_t;
 }
 
 // One wavefront, one slice (lane = row, or lane = pose for the rotation rows).  Returns the lane's share of
@@ -781,6 +910,9 @@ __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
 #ifndef CORA_SPMM_WAVES_PER_EU
 #define CORA_SPMM_WAVES_PER_EU 3
 #endif
+#ifndef CORA_SPMM_MIN_WAVES_PER_EU
+#define CORA_SPMM_MIN_WAVES_PER_EU 2
+#endif
 // The kernel is latency bound unless each wave keeps many loads in flight, so
 // let the register allocator spend registers instead of squeezing for full occupancy (round 1: 8 waves per SIMD at
 // 64 registers 31.3 us, 2 waves 20.4 us on the 10^5-pose graph).  With the X window the balance moved: what the memory
@@ -788,7 +920,7 @@ __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
 // trip) beat two heavier ones: Hvp 22.2 -> 21.4 us, HBM-resident 30.9 -> 29.2 us, inside the STPCG loop 27.8 -> 25.2 us;
 // four per SIMD are no better (tools/spmm_window_variants.sh, profiles/r03_kernel_evolution.md).
 template <int LD, int D, int EPI>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, CORA_SPMM_WAVES_PER_EU)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORA_SPMM_MIN_WAVES_PER_EU, CORA_SPMM_WAVES_PER_EU)))
 void k_spmm(const SpmmArgs A) {
   // one wavefront per block: the dispatcher balances the (uneven) slices.
   // EPI_HVP_K: the wavefront also leaves sum <X[row], out[row]> over the rows it finished in

@@ -46,9 +46,9 @@ def test_format_synthetic(d, loops):
     ctx = _ctx(Q, dm)
     st = ctx.format_stats()
     assert st["long_rows"] == 3  # the landmark rows
-    # (pose slices do not store the block that couples a pose with its index predecessor: Q is symmetric and the
-    # lane before holds its transpose -- up to d x d entries per pose less than Q has)
-    assert st["padded_nnz"] + st["long_nnz"] >= Q.nnz - dm.d * dm.d * dm.n
+    # (chain slices do not store what Q's symmetry gives: per pose the d x d block that couples it with its index
+    # predecessor, the rotation part of its translation row -- own pose and predecessor -- and the sub-diagonal of Q33)
+    assert st["padded_nnz"] + st["long_nnz"] >= Q.nnz - (dm.d * dm.d + 2 * dm.d + 1) * dm.n
     for k in (1, 5, 10):
         X = np.random.default_rng(k).standard_normal((dm.N, k))
         got = ctx.debug_format_spmm_host(X)
