@@ -54,51 +54,46 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
+    """Compiles what is stale and links.  CORA_REBUILD_UNITS=<prefix,prefix> forces the objects whose names start
+    with one of the prefixes (variant builds of one kernel group: tools/variant.sh)."""
+    if not force and not needs_build() and not os.environ.get("CORA_REBUILD_UNITS"):
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
+    only = [u for u in os.environ.get("CORA_REBUILD_UNITS", "").split(",") if u]
     objs = []
-    procs = []
     jobs = []
     for s, oname, extra in units():
         o = os.path.join(objdir, oname)
         objs.append(o)
         newest = max(os.path.getmtime(p) for p in _deps() if p.endswith(".h") or p == s)
-        if not force and os.path.exists(o) and os.path.getmtime(o) > newest:
+        forced = force or any(oname.startswith(u) for u in only)
+        if not forced and os.path.exists(o) and os.path.getmtime(o) > newest:
             continue
         jobs.append((s, [HIPCC] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]))
-    # the kernel units are the long poles: start them first; at most MAXJOBS compilers at a time
+    # the kernel units are the long poles: start them first; at most MAXJOBS compilers at a time.  Every compiler's
+    # output is drained by subprocess.run (a child blocked on a full pipe would never exit).
     jobs.sort(key=lambda j: 0 if j[0].endswith("kernels.hip") else 1)
     maxjobs = int(os.environ.get("CORA_BUILD_JOBS", str(max(2, (os.cpu_count() or 4)))))
-    running = []
 
-    def reap(block):
-        for s, p in list(running):
-            if block or p.poll() is not None:
-                out, _ = p.communicate()
-                running.remove((s, p))
-                if p.returncode != 0:
-                    sys.stderr.write(out.decode())
-                    for _, q in running:
-                        q.kill()
-                    raise RuntimeError("hipcc failed on " + s)
-                if verbose and out:
-                    sys.stderr.write(out.decode())
-                if block:
-                    return
-    for s, cmd in jobs:
-        while len(running) >= maxjobs:
-            reap(False)
-            if len(running) >= maxjobs:
-                import time
-                time.sleep(0.2)
+    def run(job):
+        s, cmd = job
         if verbose:
             print(" ".join(cmd))
-        running.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    while running:
-        reap(True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        return s, r.returncode, r.stdout.decode(errors="replace")
+    failed = None
+    with ThreadPoolExecutor(max_workers=maxjobs) as pool:
+        for s, rc, out in pool.map(run, jobs):
+            if rc != 0 and failed is None:
+                failed = s
+                sys.stderr.write(out)
+            elif verbose and out:
+                sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("hipcc failed on " + failed)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     return LIB

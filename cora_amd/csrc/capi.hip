@@ -492,8 +492,10 @@ int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int 
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tickets),
                        std::max<size_t>(F.n_long_rows, 1) * sizeof(unsigned)));
   CREATE_TRY(hipMemset(c->d_tickets, 0, std::max<size_t>(F.n_long_rows, 1) * sizeof(unsigned)));
+  // (+ 2 doubles: the pose slices' cooperative epilogue reads the blocks in pairs of doubles, kernels.hip)
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_lam_st),
-                       std::max<size_t>(static_cast<size_t>(F.L.nl_poses) * d * d, 1) * sizeof(double)));
+                       (static_cast<size_t>(F.L.nl_poses) * d * d + 2) * sizeof(double)));
+  CREATE_TRY(hipMemset(c->d_lam_st, 0, (static_cast<size_t>(F.L.nl_poses) * d * d + 2) * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_lam_ob),
                        std::max<size_t>(F.L.nl_ranges, 1) * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_scalars), 8 * sizeof(double)));

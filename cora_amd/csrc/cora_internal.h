@@ -50,13 +50,14 @@ constexpr int32_t kSliceTypeMask = 0xff;
 //     Q(rot(P)_a, rot(P-1)_c) = nxt[a][c], Q(t_P, rot(P-1)_c) = s1[c], Q(t_P, t_{P-1}) = s1[d] of the lane BEFORE
 //                             (lane 0: HostFormat::head_val, kChainHead(d) doubles per pose slice)
 //   general slots (index + d values, SliceDesc::width of them): every other column of the rotation rows
-//   tail (index + one value, compact, sorted by lane; lane's range in tinfo = start | count << 16): every other column
-//     of the translation row -- its range measurements, loop closures, a predecessor on another shard
-// Value stream from SliceDesc::off: fixed (kChainFixed(d) x 64) | general (width x d x 64) | tail (T);  index stream from
-// SliceDesc::coff: tinfo (64) | general (width x 64) | tail (T);  T = SliceDesc::type >> kSliceTailShift (<= 65535).
+//   tail (PAIRS of {index, value}, compact, sorted by lane; lane's range of pairs in tinfo = start | count << 16):
+//     every other column of the translation row -- its range measurements (two entries each: the range row and the
+//     landmark's translation), loop closures, a predecessor on another shard; an odd count is padded with a zero
+// Value stream from SliceDesc::off: fixed (kChainFixed(d) x 64) | general (width x d x 64) | tail (T x 2);  index stream
+// from SliceDesc::coff: tinfo (64) | general (width x 64) | tail (T x 2);  T = SliceDesc::type >> kSliceTailShift pairs.
 constexpr int32_t kSliceChainFlag = 0x100;
 constexpr int kSliceTailShift = 16;
-constexpr int kSliceTailMaxShift = 9;   // SliceDesc::type bits 9..15: the longest tail of a lane of the slice
+constexpr int kSliceTailMaxShift = 9;   // SliceDesc::type bits 9..15: the longest tail (in pairs) of a lane of the slice
 constexpr int32_t kSliceTailMaxMask = 0x7f;
 constexpr int kChainFixed(int d) { return 2 * (d + 1) + 2 * d * d; }   // doubles per lane in the fixed slots
 constexpr int kChainHead(int d) { return d * d + d + 1; }              // doubles per slice in head_val

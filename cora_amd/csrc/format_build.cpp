@@ -356,10 +356,12 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
             if (C.hq[c] != B.s1[c]) chain = false;                        // Q(t_P, rot(P-1)_c) = Q(rot(P-1)_c, t_P)
           if (C.ht != B.s1[d]) chain = false;                             // Q(t_P, t_{P-1}) = Q(t_{P-1}, t_P)
         }
-        size_t T = 0;
+        size_t T = 0;  // the tail is stored as PAIRS of entries (cora_internal.h): an odd count is padded with a zero
         for (int q = 0; q < cnt && chain; ++q) {
-          if (cl[q].tc.size() > static_cast<size_t>(kSliceTailMaxMask)) chain = false;
-          T += cl[q].tc.size();
+          ChainLane &C = cl[q];
+          if (C.tc.size() & 1) { C.tc.push_back(C.tc.back()); C.tv.push_back(0.0); }
+          if (C.tc.size() / 2 > static_cast<size_t>(kSliceTailMaxMask)) chain = false;
+          T += C.tc.size() / 2;
         }
         if (T > 0xffffu) chain = false;
       }
@@ -375,8 +377,8 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         size_t T = 0, mc = 0;
         for (int q = 0; q < cnt; ++q) {
           gw = std::max(gw, static_cast<int>(cl[q].gc.size()));
-          mc = std::max(mc, cl[q].tc.size());
-          T += cl[q].tc.size();
+          mc = std::max(mc, cl[q].tc.size() / 2);
+          T += cl[q].tc.size() / 2;
         }
         double *hv = &F.head_val[static_cast<size_t>(p0 / kWave) * HV];
         for (int a = 0; a < d; ++a)
@@ -388,8 +390,8 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
                   static_cast<int32_t>(static_cast<uint32_t>(T) << kSliceTailShift);
         F.max_width = std::max(F.max_width, gw + 2 + 2 * d);
         const size_t vb = F.sval.size(), cb = F.scol.size();
-        F.sval.resize(vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave + T, 0.0);
-        F.scol.resize(cb + (1 + static_cast<size_t>(gw)) * kWave + T, 0);
+        F.sval.resize(vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave + 2 * T, 0.0);
+        F.scol.resize(cb + (1 + static_cast<size_t>(gw)) * kWave + 2 * T, 0);
         double *tv = &F.sval[vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave];
         int32_t *tc = &F.scol[cb + (1 + static_cast<size_t>(gw)) * kWave];
         size_t te = 0;
@@ -409,13 +411,17 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           }
           uint32_t info = static_cast<uint32_t>(te);
           if (active) {
-            info |= static_cast<uint32_t>(C.tc.size()) << 16;
-            for (size_t k = 0; k < C.tc.size(); ++k) { tc[te] = C.tc[k]; tv[te] = C.tv[k]; ++te; }
+            info |= static_cast<uint32_t>(C.tc.size() / 2) << 16;
+            for (size_t k = 0; k + 1 < C.tc.size(); k += 2) {
+              tc[2 * te] = C.tc[k]; tv[2 * te] = C.tv[k];
+              tc[2 * te + 1] = C.tc[k + 1]; tv[2 * te + 1] = C.tv[k + 1];
+              ++te;
+            }
             trn_owned[static_cast<size_t>(p0 + lane)] = 1;
           }
           F.scol[cb + lane] = static_cast<int32_t>(info);
         }
-        F.padded_nnz += (static_cast<int64_t>(FV) + static_cast<int64_t>(gw) * d) * kWave + static_cast<int64_t>(T);
+        F.padded_nnz += (static_cast<int64_t>(FV) + static_cast<int64_t>(gw) * d) * kWave + 2 * static_cast<int64_t>(T);
       } else {
         sd.width = width;
         sd.type = kSliceStiefel;
@@ -598,7 +604,7 @@ void slice_columns(const HostFormat &F, const SliceDesc &sd, std::vector<int32_t
   const int32_t *cb = F.scol.data() + sd.coff;
   if (sd.type & kSliceChainFlag) {
     const size_t T = static_cast<uint32_t>(sd.type) >> kSliceTailShift;
-    out.insert(out.end(), cb + kWave, cb + (1 + static_cast<size_t>(sd.width)) * kWave + T);
+    out.insert(out.end(), cb + kWave, cb + (1 + static_cast<size_t>(sd.width)) * kWave + 2 * T);
   } else {
     out.insert(out.end(), cb, cb + static_cast<size_t>(sd.width) * kWave);
   }
@@ -653,7 +659,10 @@ void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out)
           for (int a = 0; a < d; ++a)
             axpy(&acc[static_cast<size_t>(a) * ld], V(FV + k * d + a, lane), cb[(1 + static_cast<size_t>(k)) * kWave + lane]);
         const uint32_t info = static_cast<uint32_t>(cb[lane]);
-        for (uint32_t e = info & 0xffffu; e < (info & 0xffffu) + (info >> 16); ++e) axpy(acct, tv[e], tc[e]);
+        for (uint32_t e = info & 0xffffu; e < (info & 0xffffu) + (info >> 16); ++e) {  // pairs of entries
+          axpy(acct, tv[2 * e], tc[2 * e]);
+          axpy(acct, tv[2 * e + 1], tc[2 * e + 1]);
+        }
         for (int a = 0; a < d; ++a)
           for (int c = 0; c < ld; ++c) out[static_cast<size_t>(own_row + a) * ld + c] = acc[a * ld + c];
         for (int c = 0; c < ld; ++c) out[static_cast<size_t>(t_own) * ld + c] = acct[c];

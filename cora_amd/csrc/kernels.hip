@@ -325,16 +325,40 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_WIN_COPY_X2
 #define CORA_WIN_COPY_X2 1
 #endif
+#ifndef CORA_WIN_DMA
+#define CORA_WIN_DMA 1
+#endif
+#ifndef CORA_COOP_PREFETCH_LATE
+#define CORA_COOP_PREFETCH_LATE 1
+#endif
+#ifndef CORA_POSE_FUSE_T_MAX
+#define CORA_POSE_FUSE_T_MAX 20  // (d + 1) x row stride up to which the translation row is accumulated with the rotation rows
+#endif
+#ifndef CORA_POSE_EARLY_MAX
+#define CORA_POSE_EARLY_MAX 20  // (d + 1) x row stride up to which a chain slice requests all its fixed slots up front
+#endif
 #ifndef CORA_POSE_COOP_MAX_LD
 // cooperative Hvp epilogue up to this row stride: above it the prefetched Y rows and Lambda blocks (d LD + d d doubles per
 // lane) push the kernel into AGPR spills at one wave per SIMD -- without them p = 11 / 12 / 16 / 24: 39.6 / 40.6 / 60.1 /
 // 98.7 -> 38.7 / 38.9 / 57.0 / 89.9 us (two waves per SIMD), while p = 10 loses (32.5 -> 33.7)
 #define CORA_POSE_COOP_MAX_LD 10
 #endif
+#ifndef CORA_POSE_COOP_MAX_DLD
+#define CORA_POSE_COOP_MAX_DLD 18  // d x row stride up to which the Hvp epilogue's operands travel through LDS (above: per lane)
+#endif
 #ifndef CORA_POSE_UNROLL_WIN
 #define CORA_POSE_UNROLL_WIN 2  // slots per trip of the window loop (round 3, with 3 waves per SIMD: 1 / 2 / 3 / 6 / 11 slots
 #endif                          // -> Hvp 21.4 / 21.5 / 21.8 / 23.0 / 30.0 us, rotated 29.2 / 29.2 / 29.3 / 32.0 / 41.0 us)
-template <int LD, int D, int EPI>
+#ifdef CORA_SPMM_TIMES
+// measurement build: wall-clock stamps of a pose slice's phases (tools/spmm_timeline.py)
+constexpr unsigned kSpmmTimesMax = 65536;
+constexpr int kSpmmPhases = 6;
+__device__ unsigned long long g_spmm_phase[kSpmmPhases * kSpmmTimesMax];
+#define CORA_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < kSpmmTimesMax) g_spmm_phase[kSpmmPhases * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define CORA_PHASE(i) do { } while (0)
+#endif
+template <int LD, int D, int EPI, bool WIN>
 __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
@@ -343,19 +367,25 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   // launch-time switch (SpmmArgs::win_on, launch_spmm): below kWinMinSlices wavefronts every wavefront is resident at
   // once and its chain of dependent latencies sets the time -- the window copy and the LDS hand-overs of the
   // cooperative epilogue are extra stages there (10^4 poses: Hvp 5.9 -> 7.1 us with them)
-  const bool kWin = kWinLD && A.win_on;
+  // (WIN is a template parameter, the two forms are separate code: behind a run-time test every row of X was "LDS read
+  // or gather", the consumers sank below the last of them and twelve rows stayed live at once)
+  constexpr bool kWin = kWinLD && WIN;
   constexpr int kRotRows = (kWave + 2) * D, kTrnRows = LD <= kWinTrnMaxLD ? kWave + 2 : 0;
   // cooperative Hvp epilogue (CORA_POSE_COOP_EPI): the slice's rows of Y, its Lambda blocks and its rows of the result
   // are contiguous too -- requested with coalesced loads BEFORE the slot loop, handed to the lanes through the window's
   // LDS after it, and the result rows leave through LDS as 512-byte runs instead of 16-byte pieces of 64 lines
-  constexpr bool kCoopT = kWinLD && CORA_POSE_COOP_EPI && EPI >= EPI_HVP && LD <= CORA_POSE_COOP_MAX_LD;
-  const bool kCoop = kCoopT && A.win_on;
+  constexpr bool kCoopT = kWinLD && CORA_POSE_COOP_EPI && EPI >= EPI_HVP && D * LD <= CORA_POSE_COOP_MAX_DLD;
+  constexpr bool kCoop = kCoopT && WIN;
   constexpr int kYEl = kWave * D * LD, kLEl = kWave * D * D;
   constexpr int kWinEl = (kRotRows + kTrnRows) * LD;
   // (the cooperative epilogue hands Y rows + Lambda blocks in, result rows + the slice's translation rows out)
   constexpr int kCoopEl = kYEl + (kLEl > kWave * LD ? kLEl : kWave * LD);
-  constexpr int kSmemEl = !kWinLD ? 1 : (kCoopT && kCoopEl > kWinEl ? kCoopEl : kWinEl);
-  __shared__ double win[kSmemEl];
+  // staged stores (window form, row strides up to CORA_POSE_COOP_MAX_LD, every epilogue): result rows + translation rows
+  constexpr bool kStaged = kWin && LD <= CORA_POSE_COOP_MAX_LD;
+  constexpr int kStagedEl = kStaged ? kYEl + kWave * LD : 0;
+  constexpr int kNeedEl = (kCoopT && kCoopEl > kStagedEl) ? kCoopEl : kStagedEl;
+  constexpr int kSmemEl = !kWinLD ? 1 : (kNeedEl > kWinEl ? kNeedEl : kWinEl);
+  __shared__ __attribute__((aligned(16))) double win[kSmemEl];
   constexpr int kYIt = (D * LD + 1) / 2, kLIt = (D * D + 1) / 2;  // (CORA_EPI_X2: pairs of doubles per lane and access)
   double ystage[kCoopT ? 2 * kYIt : 1], lstage[kCoopT ? 2 * kLIt : 1];
   // Chain layout (kSliceChainFlag, cora_internal.h): the lane owns the pose's translation row as well, the chain's columns
@@ -366,8 +396,84 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   // loaded (L1 / L2 hits)
   constexpr bool kNxtRegs = LD <= 5 || (LD <= 8 && EPI < 2);
   constexpr int kFV = kChainFixed(D);
-  int32_t tinfo = 0;
-  if (chain) tinfo = stream_load(cp);  // the lane's range of the tail: start | count << 16
+  // Everything that does not depend on the windows is requested HERE, ahead of the windows' own loads: all wavefronts of
+  // a launch are resident at once, so a launch lasts as long as a wavefront's chain of dependent memory latencies -- the
+  // fixed slots' values, the tail's first 64 entries and (below) the epilogue's operands arrive with the window rows.
+  const int tailT = chain ? static_cast<int>(static_cast<unsigned>(sd.type) >> kSliceTailShift) : 0;  // wave-uniform
+  const double *__restrict__ tail_v = A.sval + sd.off + (static_cast<size_t>(kFV) + static_cast<size_t>(sd.width) * D) * kWave;  // [pair][2]
+  const int32_t *__restrict__ tail_c = A.scol + sd.coff + (1 + static_cast<size_t>(sd.width)) * kWave;
+  // the lane's range of the tail (pairs): start | count << 16; pair `lane` of the tail: two columns, two values
+  int32_t tinfo = 0, tc0 = sd.row0, tc1 = sd.row0;
+  double tv0 = 0.0, tv1 = 0.0;
+  // (kEarly: narrow rows only -- from d + 1 accumulator rows of 7 doubles on the values and the tail's rows would not
+  // fit the 256 registers of two wavefronts per SIMD beside the accumulators; wide rows load every group of fixed
+  // slots where it is used and gather the tail's rows in the tail)
+  constexpr bool kEarly = (D + 1) * LD <= CORA_POSE_EARLY_MAX;
+  // kFuseT: the translation row accumulates beside the rotation rows (one read of every row of X for d + 1 rows of Q).
+  // Wide rows cannot hold d + 1 accumulator rows: there the translation row goes first, on its own -- its slots' values,
+  // nine rows of X from the windows, the tail -- and is stored before the rotation rows start.
+  constexpr bool kFuseT = (D + 1) * LD <= CORA_POSE_FUSE_T_MAX;
+  double fx[kEarly ? kFV : 1];
+  auto fixed = [&](int i) { if constexpr (kEarly) return fx[i]; else return stream_load(vp + static_cast<size_t>(i) * kWave); };
+  double headv = 0.0;  // lane h < kChainHead(D): entry h of the slice's head block
+  if (chain) {
+    if (lane < kChainHead(D)) headv = A.head_val[static_cast<size_t>(sd.aux0 / kWave) * kChainHead(D) + lane];
+    tinfo = stream_load(cp);
+    if (lane < tailT) {
+      const int2 c2 = *reinterpret_cast<const int2 *>(tail_c + 2 * lane);
+      const double2 v2 = *reinterpret_cast<const double2 *>(tail_v + 2 * lane);
+      tc0 = c2.x; tc1 = c2.y;
+      tv0 = v2.x; tv1 = v2.y;
+    }
+    if constexpr (kEarly) {
+#pragma unroll
+      for (int i = 0; i < kFV; ++i) fx[i] = stream_load(vp + static_cast<size_t>(i) * kWave);
+    }
+  }
+  // the cooperative epilogue's operands: the slice's rows of Y and its Lambda blocks, requested with coalesced loads --
+  // plain slices with the window's rows; chain slices right AFTER the windows have landed: a third of the wavefront's
+  // bytes, needed last, travels while the fixed slots and the tail are computed instead of holding up their operands
+  // (all wavefronts of a launch start together and share the memory system: what is requested first lands first)
+  auto coop_prefetch = [&] {
+    if constexpr (kCoopT) {
+      const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
+      const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
+#if CORA_EPI_X2
+#pragma unroll
+      // ONE predicate per access (an odd count reads one double past the slice's rows: Y has the range rows behind
+      // its rotation rows, the Lambda array is allocated with the slack).  The two-way form -- a pair, else a single
+      // double into the same registers -- made the compiler wait for EVERY outstanding load before each pair (a
+      // write-after-write hazard on the staging registers): thirteen loads, one after the other.
+      for (int i = 0; i < kYIt; ++i) {
+        const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
+        Pair8 v{0.0, 0.0};
+        if (e < n) v = *reinterpret_cast<const Pair8 *>(Yp + e);
+        ystage[2 * i] = v.x;
+        ystage[2 * i + 1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < kLIt; ++i) {
+        const int e = 2 * (i * kWave + lane), n = sd.nrows * D * D;
+        Pair8 v{0.0, 0.0};
+        if (e < n) v = *reinterpret_cast<const Pair8 *>(Lq + e);
+        lstage[2 * i] = v.x;
+        lstage[2 * i + 1] = v.y;
+      }
+#else
+#pragma unroll
+      for (int i = 0; i < D * LD; ++i) {
+        const int e = i * kWave + lane;
+        ystage[i] = e < sd.nrows * D * LD ? Yp[e] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < D * D; ++i) {
+        const int e = i * kWave + lane;
+        lstage[i] = e < sd.nrows * D * D ? Lq[e] : 0.0;
+      }
+#endif
+    }
+  };
+  if (kCoop && !(chain && CORA_COOP_PREFETCH_LATE)) coop_prefetch();
   int w0 = 0, nrot = 0, t0 = 0, ntr = 0;
   if constexpr (kWinLD) if (kWin) {
     w0 = max(sd.row0 - D, A.win_rot_lo);
@@ -376,7 +482,35 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     ntr = kTrnRows ? max(min(A.win_trn_lo + sd.aux0 + kWave + 1, A.win_trn_hi) - t0, 0) : 0;
     const double *__restrict__ srot = X + static_cast<size_t>(w0) * LD;
     const double *__restrict__ strn = X + static_cast<size_t>(t0) * LD;
-#if CORA_WIN_COPY_X2
+#if CORA_WIN_DMA
+    // LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight into the window -- wave-uniform LDS base + lane x 16,
+    // per-lane source address --, no staging registers (44 at a row stride of 5: what kept the Hvp from holding its
+    // other operands in flight) and no LDS-store pass.  Lanes past the end of the window's rows are masked off: LDS
+    // there keeps whatever it held, and nothing reads it (chain columns are clamped to local rows, the general slots
+    // test the window's range, lanes past the slice's poses are never stored).  An odd element count leaves one double
+    // to an ordinary load.  __syncthreads() below carries the vmcnt(0).
+    {
+      typedef __attribute__((address_space(1))) const void *gptr_t;
+      typedef __attribute__((address_space(3))) void *lptr_t;
+      constexpr int kRotEl = kRotRows * LD, kTrnEl = kTrnRows * LD;
+      constexpr int kRotIt = (kRotEl + 2 * kWave - 1) / (2 * kWave), kTrnIt = (kTrnEl + 2 * kWave - 1) / (2 * kWave);
+      const int nre = nrot * LD, nte = ntr * LD;
+#pragma unroll
+      for (int i = 0; i < kRotIt; ++i) {
+        const int e = 2 * (i * kWave + lane);
+        if (e + 1 < nre)
+          __builtin_amdgcn_global_load_lds((gptr_t)(srot + e), (lptr_t)(win + 2 * i * kWave), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < kTrnIt; ++i) {
+        const int e = 2 * (i * kWave + lane);
+        if (e + 1 < nte)
+          __builtin_amdgcn_global_load_lds((gptr_t)(strn + e), (lptr_t)(win + kRotEl + 2 * i * kWave), 16, 0, 0);
+      }
+      if ((nre & 1) && lane == 0) win[nre - 1] = srot[nre - 1];
+      if ((nte & 1) && lane == 1) win[kRotEl + nte - 1] = strn[nte - 1];
+    }
+#elif CORA_WIN_COPY_X2
     // two doubles per lane and load (half the load and LDS-store instructions of the copy; rows are 8-byte aligned,
     // which is all a dwordx4 access needs on this part)
     constexpr int kRotEl = kRotRows * LD, kTrnEl = kTrnRows * LD;
@@ -436,47 +570,12 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #endif
     __syncthreads();
   }
-  // the cooperative epilogue's operands: the slice's rows of Y and its Lambda blocks, requested with coalesced loads
-  // well before they are needed -- plain slices before their slot loop, chain slices after their fixed slots (the
-  // registers they wait in are the ones those slots' values have just left) and before the tail
-  auto coop_prefetch = [&] {
-    if constexpr (kCoopT) {
-      const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
-      const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
-#if CORA_EPI_X2
-#pragma unroll
-      for (int i = 0; i < kYIt; ++i) {
-        const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
-        Pair8 v{0.0, 0.0};
-        if (e + 1 < n) v = *reinterpret_cast<const Pair8 *>(Yp + e);
-        else if (e < n) v.x = Yp[e];
-        ystage[2 * i] = v.x;
-        ystage[2 * i + 1] = v.y;
-      }
-#pragma unroll
-      for (int i = 0; i < kLIt; ++i) {
-        const int e = 2 * (i * kWave + lane), n = sd.nrows * D * D;
-        Pair8 v{0.0, 0.0};
-        if (e + 1 < n) v = *reinterpret_cast<const Pair8 *>(Lq + e);
-        else if (e < n) v.x = Lq[e];
-        lstage[2 * i] = v.x;
-        lstage[2 * i + 1] = v.y;
-      }
-#else
-#pragma unroll
-      for (int i = 0; i < D * LD; ++i) {
-        const int e = i * kWave + lane;
-        ystage[i] = e < sd.nrows * D * LD ? Yp[e] : 0.0;
-      }
-#pragma unroll
-      for (int i = 0; i < D * D; ++i) {
-        const int e = i * kWave + lane;
-        lstage[i] = e < sd.nrows * D * D ? Lq[e] : 0.0;
-      }
+  CORA_PHASE(0);  // the windows (and everything requested with them) have landed
+#ifdef CORA_SPMM_TIMES
+  if (threadIdx.x == 0 && blockIdx.x < kSpmmTimesMax)  // where the wavefront runs: HW_ID (reg 4) | XCC_ID (reg 20) << 32
+    g_spmm_phase[kSpmmPhases * blockIdx.x + 5] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+                                                 (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
 #endif
-    }
-  };
-  if (kCoop && !chain) coop_prefetch();
 #if CORA_POSE_PREFETCH
   // every cache line of the slice's value and index streams is requested here, next to the window's loads: the slot
   // loop below waits for its loads trip after trip (registers allow two slots in flight), and with the working set in
@@ -495,6 +594,14 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     pfv[CORA_POSE_PREFETCH_V] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.scol + sd.coff) + (o < cbytes ? o : 0));
   }
 #endif
+  // the tail's first round: pair `lane` gathers its two rows of X now (the indices have arrived with the window's rows;
+  // lanes past the tail read a valid row and multiply it by zero)
+  double tg[kEarly ? LD : 1], tg1[kEarly ? LD : 1];
+  if constexpr (kEarly) if (chain && tailT > 0) {
+    load_row<LD>(X + static_cast<size_t>(tc0) * LD, tg);
+    load_row<LD>(X + static_cast<size_t>(tc1) * LD, tg1);
+  }
+  if (kCoop && chain && CORA_COOP_PREFETCH_LATE) coop_prefetch();
   double acc[D][LD], acct[LD];  // the pose's d rotation rows; its translation row (chain slices)
 #pragma unroll
   for (int j = 0; j < LD; ++j) {
@@ -537,9 +644,60 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
       for (int j = 0; j < LD; ++j) acc[a][j] = fma(v[a], x[j], acc[a][j]);
   };
+  // The tail of the translation row (range measurements, loop closures): T entries of the slice, sorted by lane, gathered
+  // by the whole wavefront -- lane e takes entry e -- and handed to their owners with lane permutes in entry order (a
+  // fixed order of summation); the owner's loop runs to the longest tail of the slice (kSliceTailMaxShift).
+  double kap_t = 0.0;
+  int t_own = 0;
+  auto translation_tail = [&] {
+    const int T = tailT;
+    const int mc = (sd.type >> kSliceTailMaxShift) & kSliceTailMaxMask;
+    if (T > 0) {
+      const int tstart = tinfo & 0xffff, tcnt = static_cast<int>(static_cast<unsigned>(tinfo) >> 16);
+      for (int r0 = 0; r0 < T; r0 += kWave) {
+        double pr[LD];
+        if (kEarly && r0 == 0) {
+#pragma unroll
+          for (int j = 0; j < LD; ++j) pr[j] = fma(tv0, tg[kEarly ? j : 0], tv1 * tg1[kEarly ? j : 0]);
+        } else if (r0 == 0) {
+          double x[LD], x1[LD];
+          load_row<LD>(X + static_cast<size_t>(tc0) * LD, x);
+          load_row<LD>(X + static_cast<size_t>(tc1) * LD, x1);
+#pragma unroll
+          for (int j = 0; j < LD; ++j) pr[j] = fma(tv0, x[j], tv1 * x1[j]);
+        } else {  // more than 64 pairs (128 entries) in one slice: rare
+          const int e = r0 + lane;
+          int2 c2 = make_int2(sd.row0, sd.row0);
+          double2 v2 = make_double2(0.0, 0.0);
+          if (e < T) {
+            c2 = *reinterpret_cast<const int2 *>(tail_c + 2 * e);
+            v2 = *reinterpret_cast<const double2 *>(tail_v + 2 * e);
+          }
+          double x[LD], x1[LD];
+          load_row<LD>(X + static_cast<size_t>(c2.x) * LD, x);
+          load_row<LD>(X + static_cast<size_t>(c2.y) * LD, x1);
+#pragma unroll
+          for (int j = 0; j < LD; ++j) pr[j] = fma(v2.x, x[j], v2.y * x1[j]);
+        }
+        for (int i = 0; i < mc; ++i) {  // wave-uniform
+          const int e2 = tstart + i - r0;
+          const bool mine = i < tcnt && e2 >= 0 && e2 < kWave;
+#pragma unroll
+          for (int j = 0; j < LD; ++j) {
+            const double t = __shfl(pr[j], e2 & (kWave - 1), kWave);
+            acct[j] += mine ? t : 0.0;
+          }
+        }
+      }
+    }
+    if (EPI == EPI_HVP_K && lane < sd.nrows) {  // the translation row is final (no epilogue touches it): its share of <X, out>
+      double x[LD];
+      x_trn(t_own, x);
+      kap_t = dot_row<LD>(x, acct);
+    }
+  };
   const double *__restrict__ vpg = vp;    // the general slots: index + d values
   const int32_t *__restrict__ cpg = cp;
-  int t_own = 0;
   if (chain) {
     vpg = vp + static_cast<size_t>(kFV) * kWave;
     cpg = cp + kWave;
@@ -550,22 +708,59 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
               prv_row = A.win_rot_lo + max(Pc - 1, 0) * D;
     const int t_nxt = A.win_trn_lo + min(Pc + 1, np - 1), t_prv = A.win_trn_lo + max(Pc - 1, 0);
     t_own = A.win_trn_lo + Pc;
-    const bool has_prev = P > 0;
-    const double *__restrict__ head = A.head_val + static_cast<size_t>(sd.aux0 / kWave) * kChainHead(D);
-    // value `slot` of the lane before (lane 0: entry h of the head block; no pose before: 0)
+    // value `slot` of the lane before (lane 0: entry h of the head block, which lane h loaded with the fixed slots and
+    // hands over through a scalar register; no pose before: 0)
+    // (a DPP wave shift: lane 0 keeps the "old" operand, which is the head entry.  The head block of a shard's first
+    // pose is zeros -- format_build.cpp -- and every other lane has a pose before it, so there is nothing to mask.)
     auto before = [&](double mine, int slot, int h) {
-      double t;
-      if constexpr (kNxtRegs) t = __shfl_up(mine, 1, kWave);
-      else t = lane > 0 ? stream_load(vp + static_cast<size_t>(slot) * kWave - 1) : 0.0;
-      if (lane == 0) t = head[h];
-      return has_prev ? t : 0.0;
+      const int hlo = __builtin_amdgcn_readlane(__double2loint(headv), h), hhi = __builtin_amdgcn_readlane(__double2hiint(headv), h);
+      if constexpr (kNxtRegs) {
+        return __hiloint2double(__builtin_amdgcn_update_dpp(hhi, __double2hiint(mine), 0x138, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(hlo, __double2loint(mine), 0x138, 0xf, 0xf, false));
+      } else {
+        const double t = lane > 0 ? stream_load(vp + static_cast<size_t>(slot) * kWave - 1) : 0.0;
+        return lane == 0 ? __hiloint2double(hhi, hlo) : t;
+      }
     };
+    // (wide rows: the groups of fixed slots are kept apart -- the scheduler otherwise hoists every group's loads to the top
+    // of the block and the register file cannot hold them beside the accumulators)
+    auto phase_fence = [] { if constexpr (!kEarly) __builtin_amdgcn_sched_barrier(0); };
     // (a) columns t_P and t_{P+1}: d + 1 values each (the rotation rows and the translation row)
     double s0[D + 1], s1[D + 1];
 #pragma unroll
     for (int a = 0; a <= D; ++a) {
-      s0[a] = stream_load(vp + static_cast<size_t>(a) * kWave);
-      s1[a] = stream_load(vp + static_cast<size_t>(D + 1 + a) * kWave);
+      s0[a] = fixed(a);
+      s1[a] = fixed(D + 1 + a);
+    }
+    // (b) what the translation row takes from the lane before: Q(t_P, rot(P-1)_c) = its s1[c], Q(t_P, t_{P-1}) = its s1[d]
+    double ps1[D + 1];
+#pragma unroll
+    for (int c = 0; c <= D; ++c) ps1[c] = before(s1[c], D + 1 + c, D * D + c);
+    if constexpr (!kFuseT) {
+      // wide rows: the whole translation row now -- Q33's three entries, the rotation columns of the pose and of the pose
+      // before (Q31 = Q13^T), the tail -- stored at once; its accumulator row is free again for the rotation rows
+      double x[LD];
+      x_trn(t_own, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acct[j] = s0[D] * x[j];
+      x_trn(t_nxt, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acct[j] = fma(s1[D], x[j], acct[j]);
+      x_trn(t_prv, x);
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[D], x[j], acct[j]);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        x_rot(prv_row + c, x);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[c], x[j], acct[j]);
+        x_rot(own_row + c, x);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) acct[j] = fma(s0[c], x[j], acct[j]);
+      }
+      translation_tail();
+      if (lane < sd.nrows) store_row<LD>(A.out + static_cast<size_t>(t_own) * LD, acct);
+      phase_fence();
     }
     {
       double x[LD];
@@ -574,32 +769,29 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       for (int j = 0; j < LD; ++j) {
 #pragma unroll
         for (int a = 0; a < D; ++a) acc[a][j] = fma(s0[a], x[j], acc[a][j]);
-        acct[j] = fma(s0[D], x[j], acct[j]);
+        if constexpr (kFuseT) acct[j] = fma(s0[D], x[j], acct[j]);
       }
       x_trn(t_nxt, x);
 #pragma unroll
       for (int j = 0; j < LD; ++j) {
 #pragma unroll
         for (int a = 0; a < D; ++a) acc[a][j] = fma(s1[a], x[j], acc[a][j]);
-        acct[j] = fma(s1[D], x[j], acct[j]);
+        if constexpr (kFuseT) acct[j] = fma(s1[D], x[j], acct[j]);
       }
     }
-    // (b) what the translation row takes from the lane before: Q(t_P, rot(P-1)_c) = its s1[c], Q(t_P, t_{P-1}) = its s1[d]
-    double ps1[D + 1];
-#pragma unroll
-    for (int c = 0; c <= D; ++c) ps1[c] = before(s1[c], D + 1 + c, D * D + c);
-    {
+    if constexpr (kFuseT) {
       double x[LD];
       x_trn(t_prv, x);
 #pragma unroll
       for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[D], x[j], acct[j]);
     }
     // (c) the next pose's block, (d) the previous pose's block = the transposed next block of the lane before
+    phase_fence();
     double nxt[D][D];  // [c][a] = Q(rot(P)_a, rot(P+1)_c)
 #pragma unroll
     for (int c = 0; c < D; ++c)
 #pragma unroll
-      for (int a = 0; a < D; ++a) nxt[c][a] = stream_load(vp + static_cast<size_t>(2 * (D + 1) + c * D + a) * kWave);
+      for (int a = 0; a < D; ++a) nxt[c][a] = fixed(2 * (D + 1) + c * D + a);
 #pragma unroll
     for (int c = 0; c < D; ++c) {
       double x[LD];
@@ -619,24 +811,28 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
         for (int j = 0; j < LD; ++j) acc[a][j] = fma(pv, x[j], acc[a][j]);
       }
+      if constexpr (kFuseT) {
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[c], x[j], acct[j]);
+        for (int j = 0; j < LD; ++j) acct[j] = fma(ps1[c], x[j], acct[j]);
+      }
     }
     // (e) the pose's own block; the translation row's share of these columns is Q(t_P, rot(P)_c) = s0[c]
+    phase_fence();
 #pragma unroll
     for (int c = 0; c < D; ++c) {
       double v[D], x[LD];
 #pragma unroll
-      for (int a = 0; a < D; ++a) v[a] = stream_load(vp + static_cast<size_t>(2 * (D + 1) + D * D + c * D + a) * kWave);
+      for (int a = 0; a < D; ++a) v[a] = fixed(2 * (D + 1) + D * D + c * D + a);
       x_rot(own_row + c, x);
 #pragma unroll
       for (int j = 0; j < LD; ++j) {
 #pragma unroll
         for (int a = 0; a < D; ++a) acc[a][j] = fma(v[a], x[j], acc[a][j]);
-        acct[j] = fma(s0[c], x[j], acct[j]);
+        if constexpr (kFuseT) acct[j] = fma(s0[c], x[j], acct[j]);
       }
     }
   }
+  CORA_PHASE(1);  // fixed slots done
   auto slot = [&](int k) {
     double v[D];
     const int32_t c = stream_load(cpg + static_cast<size_t>(k) * kWave);
@@ -654,53 +850,63 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll kSlotsInFlight
     for (int k = 0; k < sd.width; ++k) slot(k);
   }
-  // The tail of the translation row (range measurements, loop closures): T entries of the slice, sorted by lane, gathered
-  // by the whole wavefront -- lane e takes entry e -- and handed to their owners with lane permutes in entry order (a
-  // fixed order of summation); the owner's loop runs to the longest tail of the slice (kSliceTailMaxShift).
-  double kap_t = 0.0;
-  if (kCoop && chain) coop_prefetch();
-  if (chain) {
-    const int T = static_cast<int>(static_cast<unsigned>(sd.type) >> kSliceTailShift);
-    const int mc = (sd.type >> kSliceTailMaxShift) & kSliceTailMaxMask;
-    if (T > 0) {
-      const double *__restrict__ tv = A.sval + sd.off + (static_cast<size_t>(kFV) + static_cast<size_t>(sd.width) * D) * kWave;
-      const int32_t *__restrict__ tc = A.scol + sd.coff + (1 + static_cast<size_t>(sd.width)) * kWave;
-      const int tstart = tinfo & 0xffff, tcnt = static_cast<int>(static_cast<unsigned>(tinfo) >> 16);
-      for (int r0 = 0; r0 < T; r0 += kWave) {
-        const int e = r0 + lane;
-        double pr[LD];
-#pragma unroll
-        for (int j = 0; j < LD; ++j) pr[j] = 0.0;
-        if (e < T) {
-          const double v = stream_load(tv + e);
-          double x[LD];
-          load_row<LD>(X + static_cast<size_t>(stream_load(tc + e)) * LD, x);
-#pragma unroll
-          for (int j = 0; j < LD; ++j) pr[j] = v * x[j];
-        }
-        for (int i = 0; i < mc; ++i) {  // wave-uniform
-          const int e2 = tstart + i - r0;
-          const bool mine = i < tcnt && e2 >= 0 && e2 < kWave;
-#pragma unroll
-          for (int j = 0; j < LD; ++j) {
-            const double t = __shfl(pr[j], e2 & (kWave - 1), kWave);
-            acct[j] += mine ? t : 0.0;
-          }
-        }
-      }
-    }
-    if (EPI == EPI_HVP_K && lane < sd.nrows) {  // the translation row is final (no epilogue touches it): its share of <X, out>
-      double x[LD];
-      x_trn(t_own, x);
-      kap_t = dot_row<LD>(x, acct);
-    }
-  }
+  CORA_PHASE(2);  // general slots done
+  if (kFuseT && chain) translation_tail();
+  CORA_PHASE(3);  // tail done
 #if CORA_POSE_PREFETCH
   if (kWin) {
 #pragma unroll
     for (int i = 0; i <= CORA_POSE_PREFETCH_V; ++i) asm volatile("" ::"v"(pfv[i]));
   }
 #endif
+  // the slice's result rows leave through LDS: rotation rows and translation rows are runs of consecutive rows, stored as
+  // full 512-byte pieces instead of 16-byte pieces of 64 different lines
+  auto staged_store = [&] {
+    __syncthreads();
+    CORA_PHASE(4);  // projected
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int j = 0; j < LD; ++j) win[(lane * D + a) * LD + j] = acc[a][j];
+    if (kFuseT && chain) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) win[kYEl + lane * LD + j] = acct[j];
+    }
+    __syncthreads();
+    double *__restrict__ op = A.out + static_cast<size_t>(sd.row0) * LD;
+#if CORA_EPI_X2
+#pragma unroll
+    for (int i = 0; i < kYIt; ++i) {
+      const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
+      if (e + 1 < n) {
+        Pair8 v{win[e], win[e + 1]};
+        *reinterpret_cast<Pair8 *>(op + e) = v;
+      } else if (e < n) {
+        op[e] = win[e];
+      }
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < D * LD; ++i) {
+      const int e = i * kWave + lane;
+      if (e < sd.nrows * D * LD) op[e] = win[e];
+    }
+#endif
+    if (kFuseT && chain) {  // the slice's translation rows: consecutive rows as well
+      double *__restrict__ ot = A.out + static_cast<size_t>(A.win_trn_lo + sd.aux0) * LD;
+      constexpr int kTIt = (LD + 1) / 2;
+#pragma unroll
+      for (int i = 0; i < kTIt; ++i) {
+        const int e = 2 * (i * kWave + lane), n = sd.nrows * LD;
+        if (e + 1 < n) {
+          Pair8 v{win[kYEl + e], win[kYEl + e + 1]};
+          *reinterpret_cast<Pair8 *>(ot + e) = v;
+        } else if (e < n) {
+          ot[e] = win[kYEl + e];
+        }
+      }
+    }
+  };
   if constexpr (kCoopT) if (kCoop) {
     double xo[D][LD];  // the pose's own rows of X (inside the rotation window; lanes past nrows read rows they ignore)
 #pragma unroll
@@ -748,57 +954,16 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 #pragma unroll
       for (int a = 0; a < D; ++a) kap += dot_row<LD>(xo[a], acc[a]);
     }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-      for (int j = 0; j < LD; ++j) win[(lane * D + a) * LD + j] = acc[a][j];
-    if (chain) {
-#pragma unroll
-      for (int j = 0; j < LD; ++j) win[kYEl + lane * LD + j] = acct[j];
-    }
-    __syncthreads();
-    double *__restrict__ op = A.out + static_cast<size_t>(sd.row0) * LD;
-#if CORA_EPI_X2
-#pragma unroll
-    for (int i = 0; i < kYIt; ++i) {
-      const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
-      if (e + 1 < n) {
-        Pair8 v{win[e], win[e + 1]};
-        *reinterpret_cast<Pair8 *>(op + e) = v;
-      } else if (e < n) {
-        op[e] = win[e];
-      }
-    }
-#else
-#pragma unroll
-    for (int i = 0; i < D * LD; ++i) {
-      const int e = i * kWave + lane;
-      if (e < sd.nrows * D * LD) op[e] = win[e];
-    }
-#endif
-    if (chain) {  // the slice's translation rows: consecutive rows as well
-      double *__restrict__ ot = A.out + static_cast<size_t>(A.win_trn_lo + sd.aux0) * LD;
-      constexpr int kTIt = (LD + 1) / 2;
-#pragma unroll
-      for (int i = 0; i < kTIt; ++i) {
-        const int e = 2 * (i * kWave + lane), n = sd.nrows * LD;
-        if (e + 1 < n) {
-          Pair8 v{win[kYEl + e], win[kYEl + e + 1]};
-          *reinterpret_cast<Pair8 *>(ot + e) = v;
-        } else if (e < n) {
-          ot[e] = win[kYEl + e];
-        }
-      }
-    }
+    staged_store();
     return kap + kap_t;
   }
-  if (lane >= sd.nrows) return 0.0;
-  if (chain) store_row<LD>(A.out + static_cast<size_t>(t_own) * LD, acct);
+  const bool active = lane < sd.nrows;
+  if (!kStaged && !active) return 0.0;
+  if (!kStaged && kFuseT && chain) store_row<LD>(A.out + static_cast<size_t>(t_own) * LD, acct);
   const size_t prow = static_cast<size_t>(sd.row0) + static_cast<size_t>(lane) * D;
   constexpr bool kKeepX = EPI == EPI_HVP_K && D * LD <= 18;  // the pose's own rows of X stay in registers for <X, out>
   double xs[kKeepX ? D : 1][LD];
-  if (EPI != EPI_NONE) {
+  if (EPI != EPI_NONE && active) {
     const double *Lp = A.lam_st + static_cast<size_t>(sd.aux0 + lane) * (D * D);
 #pragma unroll
     for (int b = 0; b < D; ++b) {
@@ -828,9 +993,14 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       stiefel_project_thread<LD, D>(y, acc);
     }
   }
-#pragma unroll
-  for (int a = 0; a < D; ++a) store_row<LD>(A.out + (prow + a) * LD, acc[a]);
   double kap = 0.0;
+  if constexpr (kStaged) {
+    staged_store();
+    if (!active) return 0.0;
+  } else {
+#pragma unroll
+    for (int a = 0; a < D; ++a) store_row<LD>(A.out + (prow + a) * LD, acc[a]);
+  }
   if (EPI == EPI_HVP_K) {
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -850,10 +1020,24 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 // <X, out> over the rows it wrote (EPI_HVP_K; 0 otherwise).
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc sd, int lane) {
-  if ((sd.type & kSliceTypeMask) == kSliceStiefel) return pose_slice<LD, D, EPI>(A, sd, lane);
+  if ((sd.type & kSliceTypeMask) == kSliceStiefel)
+    return A.win_on ? pose_slice<LD, D, EPI, true>(A, sd, lane) : pose_slice<LD, D, EPI, false>(A, sd, lane);
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
+
+  // the epilogue's operands do not depend on the slots: requested first, so that they travel with the slots' own loads
+  // (a wavefront of a row slice is a chain of dependent latencies: index -> row of X -> epilogue operands was one more)
+  const bool active = lane < sd.nrows;
+  const bool oblique = sd.type == kSliceOblique;
+  const size_t row = !active ? static_cast<size_t>(A.win_rot_lo)
+                             : (sd.type == kSliceEuclidPerm ? static_cast<size_t>(A.perm[sd.row0 + lane]) : static_cast<size_t>(sd.row0) + lane);
+  double lam = 0.0, xo[LD], yo[LD];
+  if (EPI != EPI_NONE && (oblique || EPI == EPI_HVP_K)) load_row<LD>(X + row * LD, xo);
+  if (EPI != EPI_NONE && oblique) {
+    if (active) lam = A.lam_ob[sd.aux0 + lane];
+    if (EPI >= EPI_HVP) load_row<LD>(A.Y + row * LD, yo);
+  }
 
   double acc[LD];
 #pragma unroll
@@ -869,49 +1053,34 @@ __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc 
     for (int j = 0; j < LD; ++j) acc[j] = fma(v, x[j], acc[j]);
   }
 
-  if (lane >= sd.nrows) return 0.0;
-  if (sd.type == kSliceOblique) {
-    const size_t row = static_cast<size_t>(sd.row0) + lane;
-    double kap = 0.0;
-    if (EPI != EPI_NONE) {
-      const double lam = A.lam_ob[sd.aux0 + lane];
-      double x[LD];
-      load_row<LD>(X + row * LD, x);
+  if (!active) return 0.0;
+  double kap = 0.0;
+  if (oblique && EPI != EPI_NONE) {
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, x[j], acc[j]);
-      if (EPI >= EPI_HVP) {
-        double y[LD];
-        load_row<LD>(A.Y + row * LD, y);
-        const double ip = dot_row<LD>(y, acc);
+    for (int j = 0; j < LD; ++j) acc[j] = fma(-lam, xo[j], acc[j]);
+    if (EPI >= EPI_HVP) {
+      const double ip = dot_row<LD>(yo, acc);
 #pragma unroll
-        for (int j = 0; j < LD; ++j) acc[j] = fma(-ip, y[j], acc[j]);
-      }
-      if (EPI == EPI_HVP_K) kap = dot_row<LD>(x, acc);
+      for (int j = 0; j < LD; ++j) acc[j] = fma(-ip, yo[j], acc[j]);
     }
-    store_row<LD>(A.out + row * LD, acc);
-    return kap;
   }
-  const size_t row = (sd.type == kSliceEuclidPerm) ? static_cast<size_t>(A.perm[sd.row0 + lane])
-                                                   : static_cast<size_t>(sd.row0) + lane;
   store_row<LD>(A.out + row * LD, acc);
-  if (EPI == EPI_HVP_K) {
-    double x[LD];
-    load_row<LD>(X + row * LD, x);
-    return dot_row<LD>(x, acc);
-  }
-  return 0.0;
+  if (EPI == EPI_HVP_K) kap = dot_row<LD>(xo, acc);
+  return kap;
 }
 
 #if CORA_TU & 1
 #ifdef CORA_SPMM_TIMES
-constexpr unsigned kSpmmTimesMax = 65536;
 __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
 #endif
 #ifndef CORA_SPMM_WAVES_PER_EU
 #define CORA_SPMM_WAVES_PER_EU 3
 #endif
 #ifndef CORA_SPMM_MIN_WAVES_PER_EU
-#define CORA_SPMM_MIN_WAVES_PER_EU 2
+#define CORA_SPMM_MIN_WAVES_PER_EU 2  // (up to a row stride of CORA_SPMM_MIN2_MAX_LD; above, the accumulators alone need more)
+#endif
+#ifndef CORA_SPMM_MIN2_MAX_LD
+#define CORA_SPMM_MIN2_MAX_LD 10
 #endif
 // The kernel is latency bound unless each wave keeps many loads in flight, so
 // let the register allocator spend registers instead of squeezing for full occupancy (round 1: 8 waves per SIMD at
@@ -920,7 +1089,7 @@ __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
 // trip) beat two heavier ones: Hvp 22.2 -> 21.4 us, HBM-resident 30.9 -> 29.2 us, inside the STPCG loop 27.8 -> 25.2 us;
 // four per SIMD are no better (tools/spmm_window_variants.sh, profiles/r03_kernel_evolution.md).
 template <int LD, int D, int EPI>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORA_SPMM_MIN_WAVES_PER_EU, CORA_SPMM_WAVES_PER_EU)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LD <= CORA_SPMM_MIN2_MAX_LD ? CORA_SPMM_MIN_WAVES_PER_EU : 1, CORA_SPMM_WAVES_PER_EU)))
 void k_spmm(const SpmmArgs A) {
   // one wavefront per block: the dispatcher balances the (uneven) slices.
   // EPI_HVP_K: the wavefront also leaves sum <X[row], out[row]> over the rows it finished in
@@ -2669,14 +2838,16 @@ static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) 
   const int grid = A.n_chunks + 8 * ((A.n_slices + 7) / 8);
   A.kappa_long_base = grid;  // = launch_spmm_blocks(A_in): the long rows' own slots follow the per-block ones
   if (A.n_real_chunks + A.n_slices == 0) return hipSuccess;
+  // lab switch: extra (unused) LDS per block limits the wavefronts resident per CU
+  static const unsigned xlds = [] { const char *e = std::getenv("CORA_SPMM_EXTRA_LDS"); return e ? static_cast<unsigned>(std::atoi(e)) : 0u; }();
   switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(64), 0, st, A); break;
-    case EPI_S: hipLaunchKernelGGL((k_spmm<LD, D, EPI_S>), dim3(grid), dim3(64), 0, st, A); break;
+    case EPI_NONE: hipLaunchKernelGGL((k_spmm<LD, D, EPI_NONE>), dim3(grid), dim3(64), xlds, st, A); break;
+    case EPI_S: hipLaunchKernelGGL((k_spmm<LD, D, EPI_S>), dim3(grid), dim3(64), xlds, st, A); break;
     case EPI_HVP_K:
       if (!A.kappa_partial) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP_K>), dim3(grid), dim3(64), 0, st, A);
+      hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP_K>), dim3(grid), dim3(64), xlds, st, A);
       break;
-    default: hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP>), dim3(grid), dim3(64), 0, st, A); break;
+    default: hipLaunchKernelGGL((k_spmm<LD, D, EPI_HVP>), dim3(grid), dim3(64), xlds, st, A); break;
   }
   return hipGetLastError();
 }
@@ -3139,5 +3310,9 @@ hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double 
 extern "C" int cora_debug_spmm_times(unsigned long long *out, int n_blocks) {
   if (n_blocks < 0 || static_cast<unsigned>(n_blocks) > cora::kSpmmTimesMax) return -1;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(cora::g_spmm_times), sizeof(unsigned long long) * 3 * n_blocks) == hipSuccess ? 0 : -2;
+}
+extern "C" int cora_debug_spmm_phases(unsigned long long *out, int n_blocks) {
+  if (n_blocks < 0 || static_cast<unsigned>(n_blocks) > cora::kSpmmTimesMax) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cora::g_spmm_phase), sizeof(unsigned long long) * cora::kSpmmPhases * n_blocks) == hipSuccess ? 0 : -2;
 }
 #endif

@@ -44,7 +44,7 @@ ok = t[:, 1] > 0
 t0 = t[ok, 0].astype(np.int64)
 t1 = t[ok, 1].astype(np.int64)
 meta = t[ok, 2]
-typ = (meta >> np.uint64(32)).astype(np.int64)
+typ = ((meta >> np.uint64(32)) & np.uint64(0xFF)).astype(np.int64)  # (a chain slice carries its tail sizes above)
 wid = (meta & np.uint64(0xFFFFFFFF)).astype(np.int64)
 base = t0.min()
 start = (t0 - base) / 100.0   # us (100 MHz clock)
@@ -65,3 +65,35 @@ print("resident waves at each us:", res)
 # by block index: start time of every 256th block
 idx = np.nonzero(ok)[0]
 print("start by block index (every 256th):", [(int(i), round(float(s), 2)) for i, s in zip(idx[::256], start[::256])])
+
+# phases of the pose slices (stamps inside pose_slice): offsets from the wavefront's start
+try:
+    fp = ctx.L.cora_debug_spmm_phases
+    fp.argtypes = [C.c_void_p, C.c_int]
+    ph = np.zeros(6 * nb, dtype=np.uint64)
+    assert fp(ph.ctypes.data, nb) == 0
+    ph = ph.reshape(nb, 6)[ok].astype(np.int64)
+    m = typ == 0
+    names = ["windows landed", "fixed slots", "general slots", "tail", "projected"]
+    for i, nm in enumerate(names):
+        v = (ph[m, i] - t0[m]) / 100.0
+        v = v[ph[m, i] > 0]
+        if len(v):
+            print("pose slices, %-16s after start: mean %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (nm, v.mean(), *np.percentile(v, [10, 50, 90, 100])))
+    print("pose slices, end              after start: mean %.2f" % dur[m].mean())
+    # where the pose wavefronts ran: HW_ID (wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) | XCC_ID << 32
+    hw = ph[m, 5]
+    cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (((hw >> 32) & 0xF) << 8)
+    simd = (cu << 2) | ((hw >> 4) & 3)
+    per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
+    per_simd = np.bincount(np.unique(simd, return_inverse=True)[1])
+    print("pose wavefronts per CU: %d CUs used, histogram %s; per SIMD: %d SIMDs, histogram %s" % (
+        len(per_cu), np.bincount(per_cu).tolist(), len(per_simd), np.bincount(per_simd).tolist()))
+    endp = end[m]
+    key = np.unique(cu, return_inverse=True)[1]
+    by = [endp[key == k].max() for k in range(len(per_cu))]
+    for cnt in sorted(set(per_cu.tolist())):
+        sel = [b for b, c in zip(by, per_cu) if c == cnt]
+        print("  CUs with %d pose wavefronts: %d, their last end mean %.2f max %.2f us" % (cnt, len(sel), np.mean(sel), np.max(sel)))
+except AttributeError:
+    pass
