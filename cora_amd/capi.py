@@ -184,6 +184,11 @@ class Context:
                 "max_width"]
         return dict(zip(keys, [int(x) for x in s]))
 
+    def format_bytes(self):
+        b = (C.c_int64 * 4)()
+        self._chk(self.L.cora_format_bytes(self.h, b))
+        return dict(zip(["values", "indices", "descriptors", "total"], [int(x) for x in b]))
+
     def set_stream(self, stream_ptr):
         self._chk(self.L.cora_set_stream(self.h, C.c_void_p(stream_ptr)))
 

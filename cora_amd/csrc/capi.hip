@@ -652,6 +652,17 @@ int cora_format_stats(const cora_ctx *c, int64_t s[8]) {
   return CORA_OK;
 }
 
+int cora_format_bytes(const cora_ctx *c, int64_t b[4]) {
+  if (!c || !b) return CORA_ERR_ARG;
+  const HostFormat &F = c->F;
+  b[0] = static_cast<int64_t>((F.sval.size() + F.lval.size()) * sizeof(double));
+  b[1] = static_cast<int64_t>((F.scol.size() + F.lcol.size()) * sizeof(int32_t));
+  b[2] = static_cast<int64_t>(F.slices.size() * sizeof(SliceDesc) + F.chunks.size() * sizeof(LongChunk) +
+                              (F.perm.size() + F.chunk_order.size()) * sizeof(int32_t) + F.head_val.size() * sizeof(double));
+  b[3] = b[0] + b[1] + b[2];
+  return CORA_OK;
+}
+
 // ------------------------------------------------------------ resident API
 
 // Resident vectors come from a small per-handle pool: TNT, the saddle escape and LOBPCG allocate and release 4-10

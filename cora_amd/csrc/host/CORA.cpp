@@ -117,6 +117,10 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
     if (std::isnan(cert.theta)) throw std::runtime_error("Theta is NaN");
     if (cert.is_certified) {
       X = result.x;
+      if (info) {
+        info->relaxation_certified = true;
+        info->relaxation_rank = static_cast<int>(problem.getRelaxationRank());
+      }
       break;
     }
     const Scalar SADDLE_GRAD_TOL = 1e-4, PRECON_SADDLE_GRAD_TOL = 1e-4;

@@ -19,7 +19,9 @@ using CoraTntResult = TNTResult;
 using CoraResult = std::pair<CoraTntResult, std::vector<Matrix>>;
 
 struct CoraSolveInfo {  // extra observability (the reference only prints these)
-  bool certified = false;
+  bool certified = false;            // the returned (rounded and refined) solution's certificate
+  bool relaxation_certified = false; // the staircase stopped because its last level was certified (not at the rank cap)
+  int relaxation_rank = 0;           // the rank of that level
   Scalar eta = 0, theta = 0;
   int final_rank = 0;
   int staircase_levels = 0;

@@ -200,6 +200,7 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
     res.gain_ratios.push_back(rho);
     res.trust_region_radius.push_back(Delta);
     if (accepted) {
+      ++res.accepted_steps;
       std::swap(x, xprop);
       D.chk(cora_set_point_dev(c, x), "cora_set_point_dev");
       D.chk(cora_point_cost(c, &f), "cora_point_cost");
@@ -225,6 +226,7 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
   res.gradfx_norm = grad_norm;
   res.preconditioned_gradfx_norm = pgrad_norm;
   res.elapsed_time = elapsed();
+  res.final_trust_region_radius = Delta;
   return res;
 }
 

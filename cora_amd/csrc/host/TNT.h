@@ -73,6 +73,8 @@ struct TNTResult {  // fields the reference reads: src/CORA.cpp:141-186, tests/t
   std::vector<int> inner_iterations;
   std::vector<Matrix> iterates;
   long hessian_vector_products = 0;
+  Scalar final_trust_region_radius = 0;  // Delta after the last update (a restart from res.x continues with it)
+  int accepted_steps = 0;
 };
 
 /** Minimise f(Y) = 1/2 tr(Y^T Q Y) over the problem's manifold from x0 (N x p). */

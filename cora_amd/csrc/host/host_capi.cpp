@@ -292,6 +292,28 @@ int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, doub
   });
 }
 
+int cora_problem_tnt_step(cora_problem *p, const double *x, double Delta, int host_stpcg, double *x_out, double out[8]) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    TNTParams prm;
+    prm.max_iterations = 1;
+    prm.Delta0 = Delta;
+    prm.device_stpcg = host_stpcg == 0;
+    const TNTResult res = TNT(q, wrap(x, N, r), prm);
+    std::memcpy(x_out, res.x.data(), sizeof(double) * static_cast<size_t>(res.x.size()));
+    const bool ran = !res.inner_iterations.empty();
+    out[0] = res.f;
+    out[1] = res.final_trust_region_radius;
+    out[2] = ran ? static_cast<double>(res.inner_iterations.back()) : 0.0;
+    out[3] = ran ? res.gain_ratios.back() : 0.0;
+    out[4] = static_cast<double>(res.accepted_steps);
+    out[5] = ran ? res.update_step_norms.back() : 0.0;
+    out[6] = ran ? res.update_step_M_norms.back() : 0.0;
+    out[7] = static_cast<double>(static_cast<int>(res.status));
+  });
+}
+
 int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, double out[3], double *x) {
   return guarded([&] {
     Problem &q = p->problem;
@@ -365,7 +387,7 @@ int cora_host_fast_verification_pieces(int n, const int32_t *rowptr, const int32
 }
 
 int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verbose, const double *opts,
-                       double *x_out, double stats[9]) {
+                       double *x_out, double stats[11]) {
   return guarded([&] {
     Problem &q = p->problem;
     const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
@@ -391,6 +413,8 @@ int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verb
     stats[6] = info.staircase_levels;
     stats[7] = static_cast<double>(info.hessian_vector_products);
     stats[8] = secs;
+    stats[9] = info.relaxation_certified ? 1.0 : 0.0;
+    stats[10] = info.relaxation_rank;
   });
 }
 

@@ -230,6 +230,18 @@ class Problem:
         return dict(x=out, f=st[0], grad_norm=st[1], pgrad_norm=st[2], iterations=int(st[3]), hvps=int(st[4]),
                     status=int(st[5]), seconds=st[6])
 
+    def tnt_step(self, x, Delta, host_stpcg=False):
+        """One outer TNT iteration from (x, Delta): cora_problem_tnt_step."""
+        dm = self.dims()
+        x = np.asfortranarray(np.asarray(x, dtype=np.float64))
+        assert x.shape == (self.variable_size(), dm["rank"])
+        out = np.zeros_like(x, order="F")
+        st = np.zeros(8)
+        self._chk(self.L.cora_problem_tnt_step(self.h, x.ctypes.data_as(_dp), C.c_double(Delta), int(host_stpcg),
+                                               out.ctypes.data_as(_dp), st.ctypes.data_as(_dp)))
+        return dict(x=out, f=st[0], Delta=st[1], inner=int(st[2]), rho=st[3], accepted=bool(st[4]), h_norm=st[5],
+                    h_M_norm=st[6], status=int(st[7]))
+
     def certify(self, Y, eta, nx=10):
         dm = self.dims()
         Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
@@ -244,12 +256,13 @@ class Problem:
         x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))
         opts = np.array([max_iterations, 0, 0, 0, max_seconds, 0.0])
         out = np.zeros((self.variable_size(), dm["d"]), order="F")
-        st = np.zeros(9)
+        st = np.zeros(11)
         self._chk(self.L.cora_problem_solve(self.h, x0.ctypes.data_as(_dp), int(max_rank), int(verbose),
                                             opts.ctypes.data_as(_dp), out.ctypes.data_as(_dp),
                                             st.ctypes.data_as(_dp)))
         return dict(x=out, f=st[0], grad_norm=st[1], certified=bool(st[2]), eta=st[3], theta=st[4],
-                    final_rank=int(st[5]), levels=int(st[6]), hvps=int(st[7]), seconds=st[8])
+                    final_rank=int(st[5]), levels=int(st[6]), hvps=int(st[7]), seconds=st[8],
+                    relaxation_certified=bool(st[9]), relaxation_rank=int(st[10]))
 
     def save_trajectory(self, X, path, g2o=False, robot=None):
         """saveSolnToTum / saveSolnToG20 for an N x d solution; robot = symbol character or None for all poses."""

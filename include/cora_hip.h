@@ -124,6 +124,11 @@ int cora_long_rows(const cora_ctx *ctx, int32_t *api_rows, int64_t *count);
  * [5] local rows, [6] local nnz, [7] max slice width. */
 int cora_format_stats(const cora_ctx *ctx, int64_t stats[8]);
 
+/* Bytes of the device format of this handle's share of Q -- what ONE product reads of the matrix whatever the operand:
+ * [0] values, [1] column indices and per-lane descriptors, [2] slice / chunk descriptors, row lists and head blocks,
+ * [3] their sum.  (The reference's CSR, src/CORA_problem.cpp:742-746, is 12 nnz + 4 (N + 1) bytes.) */
+int cora_format_bytes(const cora_ctx *ctx, int64_t bytes[4]);
+
 /* ------------------------------------------- host-pointer operator API */
 
 /* Problem::dataMatrixProduct (Explicit), src/CORA_problem.cpp:742-746.

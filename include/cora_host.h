@@ -107,6 +107,11 @@ int cora_problem_lambda_blocks(cora_problem *p, const double *Y, double *stiefel
  * stats out: [0] f, [1] |grad|, [2] |P grad|, [3] outer iterations, [4] Hessian-vector products,
  * [5] status (TNTStatus), [6] seconds. */
 int cora_problem_tnt(cora_problem *p, const double *x0, const double *opts, double *x_out, double stats[7]);
+/* ONE outer iteration of the same solver from x with trust-region radius Delta (test hook: the iteration is compared
+ * with the CPU restatement step by step, so that rounding differences cannot accumulate over a chaotic trajectory).
+ * out: [0] f at x_out, [1] the radius after the update, [2] inner (STPCG) iterations, [3] gain ratio rho,
+ * [4] 1 if the step was accepted (x_out = the new point, else x), [5] |h|, [6] |h|_M, [7] status as in cora_problem_tnt. */
+int cora_problem_tnt_step(cora_problem *p, const double *x, double Delta, int host_stpcg, double *x_out, double out[8]);
 
 /* Problem::certify_solution(Y, eta, nx, bootstrap = Y) (src/CORA_problem.cpp:1030-1103).
  * out: [0] is_certified, [1] theta, [2] LOBPCG iterations; x: N (direction of negative curvature or 0). */
@@ -132,10 +137,11 @@ int cora_host_fast_verification_lab(int n, const int32_t *rowptr, const int32_t 
 
 /* solveCORA (src/CORA.cpp:26-243) from x0 (N x rank): Riemannian staircase up to max_rank, final
  * projection to rank d and refinement.  x_out: N x d.  opts[0..4] as in cora_problem_tnt (may be NULL).
- * stats: [0] f, [1] |grad|, [2] certified, [3] eta, [4] theta, [5] final rank, [6] staircase levels,
- * [7] Hessian-vector products, [8] seconds. */
+ * stats: [0] f, [1] |grad|, [2] certified (the returned, rounded and refined solution), [3] eta, [4] theta, [5] final rank,
+ * [6] staircase levels, [7] Hessian-vector products, [8] seconds, [9] 1 when the staircase stopped because its last level
+ * was certified (0: it reached max_rank), [10] the rank of that level. */
 int cora_problem_solve(cora_problem *p, const double *x0, int max_rank, int verbose, const double *opts,
-                       double *x_out, double stats[9]);
+                       double *x_out, double stats[11]);
 
 /* After a preconditioned call: [0] regularisation lambda used, [1] nnz(L), [2] elimination-tree height. */
 int cora_problem_precond_info(cora_problem *p, double info[3]);

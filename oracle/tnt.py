@@ -86,6 +86,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
     hist = []
     status = "iteration_limit"
     hvps = 0
+    last = dict(inner=0, rho=0.0, accepted=False, h_norm=0.0, h_M_norm=0.0)
     for it in range(prm["max_iterations"] + 1):
         hist.append((f, gn, pgn))
         if gn < prm["gradient_tolerance"]:
@@ -108,6 +109,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
         rho = df / dmod if dmod != 0 else float("nan")
         rel = df / (math.sqrt(np.finfo(float).eps) + abs(f))
         accepted = (not math.isnan(rho)) and rho > prm["eta1"] and df > 0
+        last = dict(inner=inner, rho=rho, accepted=accepted, h_norm=hn, h_M_norm=hM)
         if accepted:
             x = xp
             G = orc.egrad(Q, x)
@@ -130,4 +132,4 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
             status = "trust_region"
             break
     return dict(x=x, f=f, grad_norm=gn, pgrad_norm=pgn, status=status, iterations=len(hist), hvps=hvps,
-                history=hist)
+                history=hist, Delta=Delta, last=last)

@@ -120,7 +120,9 @@ def test_every_other_dataset_of_the_reference_solves(name):
     copied to tests/golden/datasets): examples/main.cpp's flow -- parse, updateProblemData, random start, solveCORA with
     the reference's default RegularizedCholesky preconditioner -- on every one of them.  The reference records no value
     for these; checked: assembly against the oracle's, the returned point is feasible, its cost is the oracle's, the
-    certificate decision is the oracle's Cholesky test at the same eta, and the staircase ended certified at some rank."""
+    certificate decision on the returned (rounded, refined) point is the oracle's Cholesky test at the same eta, and
+    the staircase ended on a certified level (the rounded solution itself need not pass the test: rounding a rank-r
+    optimum to rank d leaves a local optimum of the rank-d problem, src/CORA.cpp:198-243)."""
     path = os.path.join(DATA, name + ".pyfg")
     P = host.Problem.from_pyfg(path)
     P.update()
@@ -138,6 +140,12 @@ def test_every_other_dataset_of_the_reference_solves(name):
     assert np.abs(X - orc.project_manifold(dims, X)).max() < 1e-9
     assert abs(orc.cost(Q, X) - res["f"]) < 1e-8 * max(1.0, abs(res["f"]))
     assert res["f"] < 1e-2 * orc.cost(Q, orc.project_manifold(dims, x0))
+    # the certificate decision at the returned point is the oracle's: S(X) + eta I has a Cholesky factor or not
+    # (src/CORA_utils.cpp:36-51), at the eta the solver used
+    from certhelp import oracle_is_certified
+    assert oracle_is_certified(Q, dims, X, res["eta"]) == res["certified"]
+    # and the staircase stopped because a level was certified (PSD test of S + eta I passed), not at the rank cap
+    assert res["relaxation_certified"] and res["relaxation_rank"] <= 10
     print("\n%s: d=%d n=%d l=%d r=%d N=%d nnz=%d | f=%.6f |g|=%.2e certified=%s levels=%d final rank %d hvps=%d %.3fs" % (
         name, dm["d"], dm["n"], dm["l"], dm["r"], dm["N"], dm["nnz"], res["f"], res["grad_norm"], res["certified"],
         res["levels"], res["final_rank"], res["hvps"], res["seconds"]))

@@ -65,35 +65,99 @@ def test_tnt_synthetic_noisy(d, n, p, loops, fused):
     tol = 1e-8 if got["status"] in (0, 1) else 1e-4
     assert abs(got["f"] - ref["f"]) <= tol * abs(ref["f"])
     expected_iters = ref["iterations"] - (ref["status"] in ("gradient", "preconditioned_gradient", "iteration_limit"))
-    if not fused:
-        # the unfused device iteration performs the oracle's operations one for one: over the first 40 outer iterations
-        # the two runs stay together -- product counts within 2 %, costs to 1e-4 (the Jacobi preconditioner is weak on a
-        # chain: the inner solves are long and sensitive to the rounding of every product).  Over the whole 250-iteration run the rounding of the product's sums (slices, windows, the
-        # predecessor blocks taken from the neighbouring lane since round 3) moves the point where the relative-decrease
-        # rule fires, exactly as for the fused passes below (observed: 238 iterations against the oracle's 250).
-        os.environ["CORA_NO_FUSE"] = "1"
-        try:
-            got40 = P.tnt(x0, max_iterations=40)
-        finally:
-            os.environ.pop("CORA_NO_FUSE", None)
-        ref40 = otnt.tnt(Q, dims, x0, max_iterations=40)
-        print("\n40 outer iterations: device %d products f=%.10e | oracle %d products f=%.10e" % (
-            got40["hvps"], got40["f"], ref40["hvps"], ref40["f"]))
-        assert abs(got40["hvps"] - ref40["hvps"]) <= 0.02 * ref40["hvps"] + 2
-        assert abs(got40["iterations"] - (ref40["iterations"] - 1 + (ref40["status"] != "iteration_limit"))) <= 1
-        assert abs(got40["f"] - ref40["f"]) <= 1e-4 * abs(ref40["f"])   # (observed 4e-5: f is still falling at iteration 40)
-        assert abs(got["iterations"] - expected_iters) <= max(2, 0.2 * expected_iters)
-        assert abs(got["hvps"] - ref["hvps"]) <= 0.2 * ref["hvps"] + 2
-    else:
-        # the fused passes (default) add up <r, r> and <r, v> in another order; over a 250-iteration, 17 000-product
-        # run on a weakly preconditioned chain that is enough to trip the relative-decrease rule a few iterations
-        # apart.  Direct comparison of the two device iterations: test_fused_stpcg_matches_unfused.
-        # (kappa summed per slice in the product's epilogue: relative decrease fires after 217 of the oracle's 250)
-        assert abs(got["iterations"] - expected_iters) <= max(2, 0.2 * expected_iters)
-        assert abs(got["hvps"] - ref["hvps"]) <= 0.2 * ref["hvps"] + 2
+    # Whole runs: same algorithm, same landscape, but 250 outer iterations and ~17 000 products on a weakly
+    # preconditioned chain are a chaotic trajectory -- the rounding of the product's sums moves the point where the
+    # relative-decrease rule fires (observed 191 .. 251 iterations over the builds of rounds 2-4), so the whole run is held
+    # to the same order of work.  What pins the iteration itself is the step-by-step comparison below.
+    assert abs(got["iterations"] - expected_iters) <= max(2, 0.3 * expected_iters)
+    assert abs(got["hvps"] - ref["hvps"]) <= 0.3 * ref["hvps"] + 2
     rg = orc.rgrad(Q, dims, got["x"])
     assert abs(np.linalg.norm(rg) - got["grad_norm"]) < 1e-6 * max(1.0, got["grad_norm"])
     assert abs(orc.cost(Q, got["x"]) - got["f"]) < 1e-10 * abs(got["f"])
+
+
+SHORT_SOLVE = 12  # inner iterations up to which an STPCG solve is numerically stable: two correct runs agree to 1e-8
+
+
+def _lockstep(P, Q, dims, x0, steps, oracle_kw, host_stpcg=False):
+    """Every outer iteration of the device solver against ONE iteration of the oracle from the SAME point and radius (the
+    device's), so that rounding differences cannot accumulate over the trajectory: the inner solve's length, the
+    acceptance decision, the radius update and the new cost of every iteration are pinned on their own.
+    Tolerances follow what truncated CG does to rounding: a SHORT inner solve (<= 12 iterations) is stable and the new
+    cost agrees to 1e-8; a long one on this indefinite, ill-conditioned Hessian loses orthogonality and amplifies the
+    rounding of its products (observed: 1e-12 .. 1e-7 typically, up to 2e-2 once in forty 15 .. 80-iteration solves) --
+    still the same number of inner iterations, the same decision and the same radius."""
+    x, Delta = np.asfortranarray(x0), 5.0
+    worst = dict(f_short=0.0, f_long=0.0, Delta=0.0, loose=0, long=0)
+    k = 0
+    for k in range(steps):
+        dev = P.tnt_step(x, Delta, host_stpcg=host_stpcg)
+        ref = otnt.tnt(Q, dims, x, max_iterations=1, Delta0=Delta, **oracle_kw)
+        if ref["status"] in ("gradient", "preconditioned_gradient"):
+            assert dev["status"] in (0, 1)
+            break
+        last = ref["last"]
+        if os.environ.get("CORA_LOCKSTEP_TRACE"):
+            print("  %2d inner %2d/%2d rho %.6f/%.6f f %.10e/%.10e Delta %.4e/%.4e acc %d" % (
+                k, dev["inner"], last["inner"], dev["rho"], last["rho"], dev["f"], ref["f"], dev["Delta"], ref["Delta"], dev["accepted"]))
+        assert abs(dev["inner"] - last["inner"]) <= 1, (k, dev["inner"], last["inner"])
+        assert dev["accepted"] == last["accepted"], (k, dev["rho"], last["rho"])
+        rel = abs(dev["f"] - ref["f"]) / abs(ref["f"])
+        d_rel = abs(dev["Delta"] - ref["Delta"]) / ref["Delta"]
+        if dev["inner"] == last["inner"] and dev["inner"] <= SHORT_SOLVE:
+            assert rel <= 1e-8, (k, dev["inner"], dev["f"], ref["f"])
+            assert d_rel <= 1e-9, (k, dev["Delta"], ref["Delta"])
+            worst["f_short"] = max(worst["f_short"], rel)
+            worst["Delta"] = max(worst["Delta"], d_rel)
+        else:
+            # (the radius after a long solve: equal, unless the gain ratio or the step length sits on the threshold of
+            # the update rule -- rho against eta2 = 0.9, |h|_M against 0.99 Delta -- within the solve's own error)
+            assert rel <= 5e-2, (k, dev["inner"], dev["f"], ref["f"])
+            on_threshold = abs(last["rho"] - 0.9) < 0.05 or abs(last["h_M_norm"] / Delta - 0.99) < 0.02
+            assert d_rel <= 1e-4 or on_threshold, (k, dev["Delta"], ref["Delta"], last["rho"], last["h_M_norm"] / Delta)
+            worst["f_long"] = max(worst["f_long"], rel)
+            worst["long"] += 1
+            worst["loose"] += int(rel > 1e-6)
+        x, Delta = dev["x"], dev["Delta"]
+    return worst, k + 1
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("d,n,p,loops", [(3, 150, 5, 6), (2, 200, 3, 5)])
+def test_tnt_iterations_in_lockstep_with_the_oracle_jacobi(d, n, p, loops, fused):
+    """a-T, Jacobi preconditioner (long inner solves): 40 outer iterations, each compared with the oracle's iteration
+    from the same point -- device-resident STPCG in both its forms (fused passes / one operation per launch)."""
+    P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=3, n_ranges=n // 2, n_loops=loops, seed=21)
+    P.update()
+    P.set_rank(p)
+    Q, dims = _oracle_problem(P)
+    x0 = orc.project_manifold(dims, np.random.default_rng(2).uniform(-1, 1, (dims.N, p)))
+    if not fused:
+        os.environ["CORA_NO_FUSE"] = "1"
+    try:
+        worst, steps = _lockstep(P, Q, dims, x0, 40, {})
+    finally:
+        os.environ.pop("CORA_NO_FUSE", None)
+    print("\nlockstep (jacobi, fused=%s): %d iterations, worst deviations %s" % (fused, steps, worst))
+    assert steps == 40
+
+
+@pytest.mark.parametrize("d,n,p,loops", [(3, 400, 4, 0), (2, 600, 3, 10)])
+def test_tnt_iterations_in_lockstep_with_the_oracle_cholesky(d, n, p, loops):
+    """a-T with the reference's default preconditioner (RegularizedCholesky): 25 outer iterations from a random point in
+    lockstep with the oracle.  (Whole runs under this preconditioner: test_tnt_regularized_cholesky -- the converged
+    cost agrees, the iteration at which the relative-decrease rule fires does not have to: observed 7 iterations / 129
+    products against the oracle's 19 / 1073 from the same start near the minimiser, both ending at the same cost.)"""
+    P = host.Problem.synthetic(dim=d, n_poses=n, n_landmarks=4, n_ranges=n // 2, n_loops=loops, seed=31,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    P.set_rank(p)
+    Q, dims = _oracle_problem(P)
+    lam = P.precond_info()["lam"]
+    x0 = orc.project_manifold(dims, np.random.default_rng(5).uniform(-1, 1, (dims.N, p)))
+    worst, steps = _lockstep(P, Q, dims, x0, 25, dict(precond="chol", lam=lam))
+    print("\nlockstep (cholesky): %d iterations, worst deviations %s" % (steps, worst))
+    assert steps == 25
 
 
 def test_cholesky_preconditioner_apply():
