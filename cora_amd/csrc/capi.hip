@@ -452,6 +452,26 @@ int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int 
       bool remote = false;
       cols.clear();
       slice_columns(F, sd, cols);  // (the implied columns of a chain slice are local rows)
+      if (sd.type & kSliceChainFlag) {
+        // a chain slice's tail holds its poses' range measurements -- landmark rows, mostly another rank's.  Only the
+        // general slots decide where the slice runs; a slice that could run ahead of the exchange but for its tail is
+        // split: everything except the remote pairs of the tails with the interior slices, the remote pairs (added to
+        // the translation rows) with the boundary slices.
+        const size_t ngen = static_cast<size_t>(sd.width) * kWave;
+        for (size_t q = 0; q < ngen && !remote; ++q) remote = cols[q] < lo || cols[q] >= hi;
+        bool remote_tail = false;
+        for (size_t q = ngen; q < cols.size() && !remote_tail; ++q) remote_tail = cols[q] < lo || cols[q] >= hi;
+        if (!remote && remote_tail) {
+          SliceDesc a = sd, b = sd;
+          a.nrows |= kSliceSkipRemoteTail;
+          b.nrows |= kSliceRemoteTailOnly;
+          in.push_back(a);
+          bd.push_back(b);
+          continue;
+        }
+        (remote ? bd : in).push_back(sd);
+        continue;
+      }
       for (size_t q = 0; q < cols.size() && !remote; ++q) remote = cols[q] < lo || cols[q] >= hi;
       (remote ? bd : in).push_back(sd);
     }

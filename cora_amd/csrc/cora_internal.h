@@ -56,6 +56,14 @@ constexpr int32_t kSliceTypeMask = 0xff;
 // Value stream from SliceDesc::off: fixed (kChainFixed(d) x 64) | general (width x d x 64) | tail (T x 2);  index stream
 // from SliceDesc::coff: tinfo (64) | general (width x 64) | tail (T x 2);  T = SliceDesc::type >> kSliceTailShift pairs.
 constexpr int32_t kSliceChainFlag = 0x100;
+// tinfo = start | count << 16 | nlocal << 24 (pairs; count, nlocal <= 127): the first nlocal pairs of a lane's tail have
+// columns of the handle's own shard, the rest are rows another rank owns (partitioned handles sort them so).
+// SliceDesc::nrows carries two launch-time flags above the lane count (capi.hip builds the lists of a partitioned
+// handle's overlapped product with them): kSliceSkipRemoteTail -- the slice runs before the exchange has landed and
+// leaves out the remote pairs of its tails; kSliceRemoteTailOnly -- the rest: out[t] += the remote pairs, nothing else.
+constexpr int32_t kSliceRowsMask = 0x7f;
+constexpr int32_t kSliceSkipRemoteTail = 0x100;
+constexpr int32_t kSliceRemoteTailOnly = 0x200;
 constexpr int kSliceTailShift = 16;
 constexpr int kSliceTailMaxShift = 9;   // SliceDesc::type bits 9..15: the longest tail (in pairs) of a lane of the slice
 constexpr int32_t kSliceTailMaxMask = 0x7f;

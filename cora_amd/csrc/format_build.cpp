@@ -294,6 +294,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       bool chain = g_chain_slices != 0;
       struct ChainLane {
         double s0[4], s1[4], nxt[9], own[9], hq[3], ht, prev[9];
+        int nlocal = 0;  // pairs of the tail whose columns are rows of this shard (they come first)
         std::vector<int32_t> gc, tc;
         std::vector<double> gv, tv;
       };
@@ -359,7 +360,20 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         size_t T = 0;  // the tail is stored as PAIRS of entries (cora_internal.h): an odd count is padded with a zero
         for (int q = 0; q < cnt && chain; ++q) {
           ChainLane &C = cl[q];
-          if (C.tc.size() & 1) { C.tc.push_back(C.tc.back()); C.tv.push_back(0.0); }
+          // columns of this shard first, rows of other ranks after them (each group padded to whole pairs): a
+          // partitioned handle can run the local part before the exchange of the operand has landed
+          std::vector<int32_t> lc, rc;
+          std::vector<double> lv, rv;
+          for (size_t k = 0; k < C.tc.size(); ++k) {
+            const bool local = C.tc[k] >= L.base && C.tc[k] < L.base + L.shard_rows;
+            (local ? lc : rc).push_back(C.tc[k]);
+            (local ? lv : rv).push_back(C.tv[k]);
+          }
+          if (lc.size() & 1) { lc.push_back(lc.back()); lv.push_back(0.0); }
+          if (rc.size() & 1) { rc.push_back(rc.back()); rv.push_back(0.0); }
+          C.nlocal = static_cast<int>(lc.size() / 2);
+          C.tc = lc; C.tc.insert(C.tc.end(), rc.begin(), rc.end());
+          C.tv = lv; C.tv.insert(C.tv.end(), rv.begin(), rv.end());
           if (C.tc.size() / 2 > static_cast<size_t>(kSliceTailMaxMask)) chain = false;
           T += C.tc.size() / 2;
         }
@@ -411,7 +425,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           }
           uint32_t info = static_cast<uint32_t>(te);
           if (active) {
-            info |= static_cast<uint32_t>(C.tc.size() / 2) << 16;
+            info |= static_cast<uint32_t>(C.tc.size() / 2) << 16 | static_cast<uint32_t>(C.nlocal) << 24;
             for (size_t k = 0; k + 1 < C.tc.size(); k += 2) {
               tc[2 * te] = C.tc[k]; tv[2 * te] = C.tv[k];
               tc[2 * te + 1] = C.tc[k + 1]; tv[2 * te + 1] = C.tv[k + 1];
@@ -659,7 +673,7 @@ void format_spmm_host(const HostFormat &F, const double *X, int ld, double *out)
           for (int a = 0; a < d; ++a)
             axpy(&acc[static_cast<size_t>(a) * ld], V(FV + k * d + a, lane), cb[(1 + static_cast<size_t>(k)) * kWave + lane]);
         const uint32_t info = static_cast<uint32_t>(cb[lane]);
-        for (uint32_t e = info & 0xffffu; e < (info & 0xffffu) + (info >> 16); ++e) {  // pairs of entries
+        for (uint32_t e = info & 0xffffu; e < (info & 0xffffu) + ((info >> 16) & 0x7fu); ++e) {  // pairs of entries
           axpy(acct, tv[2 * e], tc[2 * e]);
           axpy(acct, tv[2 * e + 1], tc[2 * e + 1]);
         }

@@ -358,8 +358,63 @@ __device__ unsigned long long g_spmm_phase[kSpmmPhases * kSpmmTimesMax];
 #else
 #define CORA_PHASE(i) do { } while (0)
 #endif
+// A chain slice's second launch on a partitioned handle (kSliceRemoteTailOnly): the pairs of its tails that read rows of
+// other ranks, added to the translation rows the first launch -- ahead of the exchange -- has written.
+template <int LD, int D, int EPI>
+__device__ __forceinline__ double remote_tail_only(const SpmmArgs &A, const SliceDesc &sd, int lane) {
+  const int T = static_cast<int>(static_cast<unsigned>(sd.type) >> kSliceTailShift);
+  const int mc = (sd.type >> kSliceTailMaxShift) & kSliceTailMaxMask;
+  const double *__restrict__ tail_v = A.sval + sd.off + (static_cast<size_t>(kChainFixed(D)) + static_cast<size_t>(sd.width) * D) * kWave;
+  const int32_t *__restrict__ tail_c = A.scol + sd.coff + (1 + static_cast<size_t>(sd.width)) * kWave;
+  const int32_t tinfo = A.scol[sd.coff + lane];
+  const int tstart = tinfo & 0xffff, tnloc = (tinfo >> 24) & 0x7f, tcnt = (tinfo >> 16) & 0x7f;
+  double acct[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) acct[j] = 0.0;
+  for (int r0 = 0; r0 < T; r0 += kWave) {
+    const int e = r0 + lane;
+    int2 c2 = make_int2(sd.row0, sd.row0);
+    double2 v2 = make_double2(0.0, 0.0);
+    if (e < T) {
+      c2 = *reinterpret_cast<const int2 *>(tail_c + 2 * e);
+      v2 = *reinterpret_cast<const double2 *>(tail_v + 2 * e);
+    }
+    double x[LD], x1[LD], pr[LD];
+    load_row<LD>(A.X + static_cast<size_t>(c2.x) * LD, x);
+    load_row<LD>(A.X + static_cast<size_t>(c2.y) * LD, x1);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) pr[j] = fma(v2.x, x[j], v2.y * x1[j]);
+    for (int i = 0; i < mc; ++i) {  // wave-uniform
+      const int e2 = tstart + i - r0;
+      const bool mine = i >= tnloc && i < tcnt && e2 >= 0 && e2 < kWave;
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        const double t = __shfl(pr[j], e2 & (kWave - 1), kWave);
+        acct[j] += mine ? t : 0.0;
+      }
+    }
+  }
+  const int nrows = sd.nrows & kSliceRowsMask;
+  if (lane >= nrows || tcnt == tnloc) return 0.0;
+  double *o = A.out + static_cast<size_t>(A.win_trn_lo + sd.aux0 + lane) * LD;
+  double cur[LD];
+  load_row<LD>(o, cur);
+#pragma unroll
+  for (int j = 0; j < LD; ++j) cur[j] += acct[j];
+  store_row<LD>(o, cur);
+  if (EPI == EPI_HVP_K) {  // <X, out> is linear in out: this launch's share is <X[t], what it added>
+    double x[LD];
+    load_row<LD>(A.X + static_cast<size_t>(A.win_trn_lo + sd.aux0 + lane) * LD, x);
+    return dot_row<LD>(x, acct);
+  }
+  return 0.0;
+}
+
 template <int LD, int D, int EPI, bool WIN>
-__device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd, int lane) {
+__device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc &sd_in, int lane) {
+  const int sflags = sd_in.nrows & ~kSliceRowsMask;  // launch-time flags of a partitioned handle's overlapped product
+  SliceDesc sd = sd_in;
+  sd.nrows &= kSliceRowsMask;
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
@@ -653,7 +708,15 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     const int T = tailT;
     const int mc = (sd.type >> kSliceTailMaxShift) & kSliceTailMaxMask;
     if (T > 0) {
-      const int tstart = tinfo & 0xffff, tcnt = static_cast<int>(static_cast<unsigned>(tinfo) >> 16);
+      const int tstart = tinfo & 0xffff, tnloc = (tinfo >> 24) & 0x7f;
+      // (pairs [0, nlocal) read rows of this shard, the rest rows of other ranks: a launch ahead of the exchange leaves
+      // the rest to a later launch of the same slice that adds only them)
+      const int tcnt = (sflags & kSliceSkipRemoteTail) ? tnloc : ((tinfo >> 16) & 0x7f);
+      // (the remote pairs are summed on their own and added last: the same operations in the same order as the two
+      // launches of a split slice, so the overlapped product of a partitioned handle has the serial one's bits)
+      double accr[LD];
+#pragma unroll
+      for (int j = 0; j < LD; ++j) accr[j] = 0.0;
       for (int r0 = 0; r0 < T; r0 += kWave) {
         double pr[LD];
         if (kEarly && r0 == 0) {
@@ -681,14 +744,17 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
         }
         for (int i = 0; i < mc; ++i) {  // wave-uniform
           const int e2 = tstart + i - r0;
-          const bool mine = i < tcnt && e2 >= 0 && e2 < kWave;
+          const bool mine = i < tcnt && e2 >= 0 && e2 < kWave, rem = i >= tnloc;
 #pragma unroll
           for (int j = 0; j < LD; ++j) {
             const double t = __shfl(pr[j], e2 & (kWave - 1), kWave);
-            acct[j] += mine ? t : 0.0;
+            acct[j] += (mine && !rem) ? t : 0.0;
+            accr[j] += (mine && rem) ? t : 0.0;
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < LD; ++j) acct[j] += accr[j];
     }
     if (EPI == EPI_HVP_K && lane < sd.nrows) {  // the translation row is final (no epilogue touches it): its share of <X, out>
       double x[LD];
@@ -1020,8 +1086,10 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
 // <X, out> over the rows it wrote (EPI_HVP_K; 0 otherwise).
 template <int LD, int D, int EPI>
 __device__ __forceinline__ double slice_wave(const SpmmArgs &A, const SliceDesc sd, int lane) {
-  if ((sd.type & kSliceTypeMask) == kSliceStiefel)
+  if ((sd.type & kSliceTypeMask) == kSliceStiefel) {
+    if (sd.nrows & kSliceRemoteTailOnly) return remote_tail_only<LD, D, EPI>(A, sd, lane);
     return A.win_on ? pose_slice<LD, D, EPI, true>(A, sd, lane) : pose_slice<LD, D, EPI, false>(A, sd, lane);
+  }
   const double *__restrict__ vp = A.sval + sd.off + lane;
   const int32_t *__restrict__ cp = A.scol + sd.coff + lane;
   const double *__restrict__ X = A.X;
