@@ -387,6 +387,12 @@ class Context:
         """Iteration form of the last stpcg_dev call: 0 unfused, 1 fused vector passes, 2 sweep-fused."""
         return int(self.L.cora_debug_stpcg_path(self.h))
 
+    def stpcg_graph_stats(self):
+        """(graphs captured, batches replayed) of the device-resident STPCG (cora_debug_stpcg_graph)."""
+        out = (C.c_long * 2)()
+        self._chk(self.L.cora_debug_stpcg_graph(self.h, out))
+        return int(out[0]), int(out[1])
+
     def stpcg_hvp_us(self):
         """(mean microseconds, count) of the Hessian-vector products of the last stpcg_dev call (profile_stpcg on)."""
         us, cnt = C.c_double(), C.c_int()

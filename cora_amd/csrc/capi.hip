@@ -95,6 +95,7 @@ struct cora_ctx {
     bool fuse_ok = false;  // substitution blocks whose tiles hold every pose's rotation rows at consecutive positions:
                            // the STPCG passes can be fused into the sweeps (SubFuse, kernels.h)
     bool ready = false;
+    unsigned long long generation = 0;  // counts installs: a captured STPCG graph carries the plan's arrays and sizes
   };
   DevFactor precond_f, implicit_f, aux_f;  // aux_f: the caller's own factor (cora_aux_set_cholesky)
   bool implicit = false;  // Formulation::Implicit active
@@ -131,6 +132,15 @@ struct cora_ctx {
   double prof_hvp_us = 0.0;
   int prof_hvp_count = 0;
   int stpcg_path = 0;  // iteration form of the last cora_stpcg_dev: 0 unfused, 1 fused vector passes, 2 sweep-fused
+  // A batch of device-resident STPCG iterations as a hipGraph: the launches of an iteration have the same arguments
+  // every time (the scalars live in device memory, the sequence number the host waits for is a device counter), so a
+  // batch is captured once and replayed -- replayed launches follow each other 1.3 us closer than launches enqueued
+  // one by one (tools/launch_lab.hip) and cost the host one call instead of twenty.  Kept while its key -- every
+  // pointer and size the captured launches carry -- stays the same, i.e. normally for a whole TNT call and beyond.
+  hipGraphExec_t stpcg_graph = nullptr;
+  std::vector<uintptr_t> stpcg_graph_key;
+  unsigned long long *d_seq_counter = nullptr;  // the device's copy of dot_seq (kernels.h, DotArgs::seq_counter)
+  long stpcg_graph_replays = 0, stpcg_graph_captures = 0;
   std::vector<std::pair<double *, size_t>> user_allocs;  // live vectors of cora_dev_alloc (pointer, bytes)
   std::vector<std::pair<double *, size_t>> pool;         // released ones, kept for the next request of the same size
   std::string err;
@@ -521,6 +531,8 @@ int cora_ctx_create_part_opts(int device, int d, int n_poses, int n_ranges, int 
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_scalars), 8 * sizeof(double)));
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), 4 * sizeof(unsigned)));  // [0] inner products, [1] kappa (k_spmm)
   CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_stpcg), sizeof(StpcgState)));
+  CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_seq_counter), sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(c->d_seq_counter, 0, sizeof(unsigned long long)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_stpcg), 2 * sizeof(StpcgState)));
   CREATE_TRY(hipMemset(c->d_ticket, 0, 4 * sizeof(unsigned)));
   CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), 8 * sizeof(double)));
@@ -552,7 +564,8 @@ void cora_ctx_destroy(cora_ctx *c) {
     if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     void *ptrs[] = {c->d_slices_int, c->d_slices_bnd, c->d_slices, c->d_slices_pf, c->d_head_val, c->d_long_out, c->d_long_rows, c->d_long_owner, c->d_sval, c->d_scol, c->d_perm, c->d_chunks, c->d_chunk_order, c->d_lval, c->d_lcol,
                     c->d_partials, c->d_tickets, c->d_api2int, c->d_diag_inv, c->d_lam_st, c->d_lam_ob,
-                    c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg};
+                    c->d_stage, c->d_red, c->d_scalars, c->d_flag, c->d_ticket, c->d_stpcg, c->d_seq_counter};
+    if (c->stpcg_graph) (void)hipGraphExecDestroy(c->stpcg_graph);
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     for (int i = 0; i < kScratchSlots; ++i)
@@ -1090,6 +1103,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   tick("upload");
   f.ready = true;
+  ++f.generation;
   return CORA_OK;
 }
 
@@ -1595,7 +1609,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // Iterations enqueued between two looks at the state: on small problems an iteration is a dozen launch
   // floors and the host's wait is what costs, so it runs ahead by four (work enqueued past the stopping point is
   // neutralised by the state); on large ones an iteration is worth 20 waits and running ahead would waste it.
-  const int batch = n > 1000000 ? 1 : 4;
+  static const int batch_env = [] { const char *e = std::getenv("CORA_STPCG_BATCH"); return e ? std::atoi(e) : 0; }();
+  const int batch = batch_env > 0 ? batch_env : (n > 1000000 ? 1 : 4);
   int enqueued = 0;
   // Fused iteration (explicit formulation, one shard, row strides up to 12): six passes instead of nine --
   //   Hp = H p | kappa = <p, Hp> | r += alpha Hp with <r, r> | Cholesky solve | v = Proj_Y(x) with <r, v> |
@@ -1685,9 +1700,70 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     }
   }
   c->stpcg_path = sweep_fused ? 2 : inverse_fused ? 3 : fused ? 1 : 0;
+  // hipGraph replay of whole batches (one GPU, the fused forms; CORA_STPCG_GRAPH=0 switches it off)
+  // (opt-in, CORA_STPCG_GRAPH=1: measured on this part, replaying the batches does not bring the launches of an iteration
+  // closer together -- a dependent kernel of 5 us and more already has its successor's packet waiting, what is left
+  // between them is the dependency itself -- and a six-launch graph per iteration costs the host more than six launches:
+  // iteration at 10^5 poses 116 -> 122 us, the reference's data sets unchanged.  tools/launch_lab.hip shows the gain only
+  // for kernels shorter than the launch rate, 3.5 -> 2.1 us each.  Kept: same bits, tested, one switch.)
+  const bool graphs_on = [] { const char *e = std::getenv("CORA_STPCG_GRAPH"); return e && e[0] == '1'; }();  // (read per solve: tests flip it)
+  const bool use_graph = graphs_on && fused && !sharded && !c->prof_stpcg && max_iters >= batch;
+  std::vector<uintptr_t> key;
+  if (use_graph) {
+    double *t = nullptr, *t2 = nullptr;
+    if (sweep_fused && (rc = get_scratch(c, 6, c->ld, &t, c->precond_f.aux_rows))) return rc;  // (allocations happen here,
+    if ((sweep_fused || inverse_fused) && (rc = get_scratch(c, 7, c->ld, &t2))) return rc;      // not under capture)
+    if (chol && !sweep_fused && !inverse_fused) {  // the general solve allocates its own scratch on first use: one warm call
+      if ((rc = chol_solve(c, c->ld, dR, dV))) return rc;
+    }
+    auto U = [](const void *q) { return reinterpret_cast<uintptr_t>(q); };
+    key = {static_cast<uintptr_t>(c->stpcg_path), static_cast<uintptr_t>(c->ld), static_cast<uintptr_t>(batch), static_cast<uintptr_t>(n),
+           U(dS), U(dR), U(dV), U(dP), U(dHp), U(c->d_red), static_cast<uintptr_t>(kappa_blocks), U(c->d_Y), U(c->d_lam_st), U(t), U(t2),
+           static_cast<uintptr_t>(c->precond), static_cast<uintptr_t>(c->precond_f.generation), U(c->stream),
+           static_cast<uintptr_t>(c->F.slices.size())};
+    for (int i = 0; i < kScratchSlots; ++i) key.push_back(U(c->scratch[i]));  // (whatever a solve in the batch borrows)
+    // the device's sequence counter = the host's count (launches of this solve take their numbers from it)
+    unsigned long long *stage = reinterpret_cast<unsigned long long *>(c->h_scalars + 6);
+    *stage = c->dot_seq;
+    HIP_TRY(c, hipMemcpyAsync(c->d_seq_counter, stage, sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    D.seq_counter = c->d_seq_counter;
+    tail.seq_counter = c->d_seq_counter;
+    FF.dot.seq_counter = FB.dot.seq_counter = c->d_seq_counter;
+  }
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
-    for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
+    const bool whole = use_graph && max_iters - enqueued >= batch;
+    if (whole && c->stpcg_graph && key == c->stpcg_graph_key) {  // replay: `batch` iterations in one call
+      HIP_TRY(c, hipGraphLaunch(c->stpcg_graph, c->stream));
+      enqueued += batch;
+      seq = (c->dot_seq += static_cast<unsigned long long>(batch));
+      ++c->stpcg_graph_replays;
+      if ((rc = wait_dots(c, seq))) return rc;
+      continue;
+    }
+    const bool capture = whole;
+    if (capture) {
+      if (c->stpcg_graph) (void)hipGraphExecDestroy(c->stpcg_graph);
+      c->stpcg_graph = nullptr;
+      c->stpcg_graph_key.clear();
+      HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    }
+    auto end_capture = [&](bool ok) -> int {  // closes the capture (always) and, when the batch was recorded whole, runs it
+      if (!capture) return CORA_OK;
+      hipGraph_t g = nullptr;
+      const hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (e != hipSuccess || !g) return fail(c, CORA_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      if (!ok) { (void)hipGraphDestroy(g); return CORA_OK; }
+      const hipError_t ei = hipGraphInstantiate(&c->stpcg_graph, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ei != hipSuccess) { c->stpcg_graph = nullptr; return fail(c, CORA_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+      c->stpcg_graph_key = key;
+      ++c->stpcg_graph_captures;
+      HIP_TRY(c, hipGraphLaunch(c->stpcg_graph, c->stream));
+      return CORA_OK;
+    };
+    // (the launches of one iteration; under capture an error must still close the capture: the caller does)
+    auto one_iteration = [&]() -> int {
       const bool prof = c->prof_stpcg && 2 * static_cast<size_t>(enqueued) + 1 < c->prof_events.size();
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
       if (fused) {
@@ -1723,7 +1799,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           HIP_TRY(c, launch_stpcg_scalar_step(1, ds + 2, c->d_stpcg, &c->h_stpcg[0],
                                               reinterpret_cast<unsigned long long *>(c->h_scalars + 7), seq, c->stream));
           HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
-          continue;
+          return CORA_OK;
         }
         if (sweep_fused) {
           HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
@@ -1740,7 +1816,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           tail.seq = seq = ++c->dot_seq;
           HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream, &tail));
           HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
-          continue;
+          return CORA_OK;
         }
         // kappa, the scalar step and r += alpha Hp with <r, r> in ONE launch (every block adds the partials: the plans
         // that come here are small, and a launch is what costs them)
@@ -1757,7 +1833,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           tail.seq = seq = ++c->dot_seq;
           HIP_TRY(c, launch_rowop(S.bwd_b, c->ld, nullptr, t2, dV, c->stream, &tail));
           HIP_TRY(c, launch_tangent_project_update(row_args(c), c->d_stpcg, c->ld, c->d_Y, dV, dP, dS, c->stream));
-          continue;
+          return CORA_OK;
         }
         const double *x = dR, *scale = nullptr;
         if (chol) {
@@ -1774,7 +1850,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         HIP_TRY(c, launch_stpcg_step_direction(n, c->d_stpcg, dV + off, dP + off, dS + off, c->stream));
         D.seq_out = nullptr;
         D.seq = 0;
-        continue;
+        return CORA_OK;
       }
       if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
       if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
@@ -1798,7 +1874,15 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       D.seq = seq = ++c->dot_seq;
       HIP_TRY(c, launch_dots(D, &nblocks, c->stream));
       HIP_TRY(c, launch_stpcg_direction(n, c->d_stpcg, dV, dP, c->stream));
+      return CORA_OK;
+    };
+    for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
+      if ((rc = one_iteration())) {
+        (void)end_capture(false);
+        return rc;
+      }
     }
+    if ((rc = end_capture(true))) return rc;
     if ((rc = wait_dots(c, seq))) return rc;
   }
   // an iteration that starts at the limit only records the status: flush it so that the mirror is final
@@ -1896,6 +1980,13 @@ int cora_debug_profile_stpcg(cora_ctx *c, int on) {
 }
 
 int cora_debug_stpcg_path(const cora_ctx *c) { return c ? c->stpcg_path : -1; }
+
+int cora_debug_stpcg_graph(const cora_ctx *c, long out[2]) {
+  if (!c || !out) return CORA_ERR_ARG;
+  out[0] = c->stpcg_graph_captures;
+  out[1] = c->stpcg_graph_replays;
+  return CORA_OK;
+}
 
 int cora_debug_stpcg_hvp_us(cora_ctx *c, double *mean_us, int *count) {
   if (!c || !mean_us || !count) return CORA_ERR_ARG;

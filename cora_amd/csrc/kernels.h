@@ -93,6 +93,9 @@ struct DotArgs {
   unsigned long long seq;
   int mode;                     // DOTS_*: what the last block does with the results
   StpcgState *st, *st_host;     // device state and its pinned mirror (DOTS_STPCG_*)
+  // non-null: the sequence number is ++(*seq_counter) (device memory) instead of `seq` -- launches replayed from a
+  // hipGraph carry no per-launch argument; the host keeps the counter equal to its own count (capi.hip, stpcg_run)
+  unsigned long long *seq_counter = nullptr;
 };
 
 struct RowOpDev {  // device copy of a RowOpHost (trisolve.h)
@@ -169,6 +172,7 @@ struct RvTail {
   double *rowsq_out;         // ... but, if set, the product leaves the squared norm of its k-th row in rowsq_out[k]
   unsigned long long *seq_out;  // pinned: set to seq after the mirror is visible to the host
   unsigned long long seq;
+  unsigned long long *seq_counter;  // non-null: seq = ++(*seq_counter), see DotArgs
 };
 struct SubFuse {
   DotArgs dot;                 // only dot.st (the coefficients of the state) is used

@@ -1555,8 +1555,10 @@ __device__ __forceinline__ void dots_finish(const DotArgs &D, const double (&acc
     *D.st_host = *D.st;
   }
   if (threadIdx.x == 0 && D.seq_out) {  // results first, then the sequence number the host spins on
+    unsigned long long seq = D.seq;
+    if (D.seq_counter) *D.seq_counter = seq = *D.seq_counter + 1;
     __threadfence_system();
-    __hip_atomic_store(D.seq_out, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(D.seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -2110,8 +2112,10 @@ __device__ __forceinline__ void rv_tail_block(const RvTail &T) {
     stpcg_after_rv(*T.st, yy + tt);
     *T.st_host = *T.st;  // pinned mirror for the host's (infrequent) look
     if (T.seq_out) {
+      unsigned long long seq = T.seq;
+      if (T.seq_counter) *T.seq_counter = seq = *T.seq_counter + 1;
       __threadfence_system();
-      __hip_atomic_store(T.seq_out, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(T.seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -407,6 +407,9 @@ int cora_debug_stpcg_hvp_us(cora_ctx *ctx, double *mean_us, int *count);
 /* Form of the iteration the last cora_stpcg_dev ran: 0 one pass per operation, 1 fused vector passes, 2 vector passes
  * fused into the sweeps of the Cholesky solve (tests pin which form they compare). */
 int cora_debug_stpcg_path(const cora_ctx *ctx);
+/* Batches of device-resident STPCG iterations are captured once as a hipGraph and replayed (one GPU, fused forms;
+ * CORA_STPCG_GRAPH=0 switches it off): out[0] = graphs captured so far, out[1] = batches replayed. */
+int cora_debug_stpcg_graph(const cora_ctx *ctx, long out[2]);
 
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
                                 int k, double *out, int ldo);

@@ -61,3 +61,26 @@ def test_every_stpcg_form_is_bit_reproducible_at_full_size(env, monkeypatch):
     runs = [P.tnt(Y, max_iterations=80) for P in (P1, P2, P1)]
     assert len({(float(r["f"]).hex(), r["hvps"], _bits(r["x"])) for r in runs}) == 1
     assert runs[0]["hvps"] > 500
+
+
+@pytest.mark.parametrize("n,precond", [(100_000, capi.PRECOND_REGULARIZED_CHOLESKY), (3_000, capi.PRECOND_REGULARIZED_CHOLESKY),
+                                       (3_000, capi.PRECOND_JACOBI)])
+def test_graph_replay_of_the_stpcg_batches_changes_nothing(n, precond, monkeypatch):
+    """Batches of device-resident STPCG iterations are captured once as a hipGraph and replayed (capi.hip, stpcg_run): the
+    same launches with the same arguments, so TNT takes the same path bit for bit as with the launches enqueued one by one
+    (CORA_STPCG_GRAPH=0), whichever form the iteration has -- sweep-fused (10^5 poses), one explicit inverse (3 000 poses:
+    the form of every data set of the reference), Jacobi."""
+    def run(graph):
+        monkeypatch.setenv("CORA_STPCG_GRAPH", "1" if graph else "0")  # (opt-in: see stpcg_run)
+        P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42, precond=precond)
+        P.update()
+        P.set_rank(4)
+        Y = P.op("projectToManifold", P.op("getOdomInitialization"))
+        r = P.tnt(Y, max_iterations=30)
+        h = capi.Context.from_handle(P.context_ptr(), 3, n, n // 2, n + 10)
+        return r, h.stpcg_graph_stats()
+    (a, ga), (b, gb) = run(True), run(False)
+    print("\n%d poses: %d products; graphs captured %d, batches replayed %d" % (n, a["hvps"], ga[0], ga[1]))
+    assert ga[1] > 0 and 1 <= ga[0] <= 4 and gb == (0, 0)
+    assert (float(a["f"]).hex(), a["hvps"], a["iterations"]) == (float(b["f"]).hex(), b["hvps"], b["iterations"])
+    assert _bits(a["x"]) == _bits(b["x"])
