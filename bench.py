@@ -353,8 +353,8 @@ def main():
     # remote rows are current after the timed region above)
     ex_fn = None
     if world > 1:
-        if hasattr(comm, "enable"):
-            comm.enable(False)
+        if hasattr(comm, "local_products"):
+            comm.local_products(True)
         else:
             ex_fn = comm.exchange
             comm.exchange = lambda ptr, ld_: None
@@ -367,8 +367,8 @@ def main():
         step()
     kernel_us = ctx.timer_stop_ms() * 1e3 / reps
     if world > 1:
-        if hasattr(comm, "enable"):
-            comm.enable(True)
+        if hasattr(comm, "local_products"):
+            comm.local_products(False)
         else:
             comm.exchange = ex_fn
     if args.op == "cert":
@@ -440,6 +440,24 @@ def main():
             hbm_us = rotated(lambda e: e[0].certificate_product_dev(e[3].data_ptr(), k_op, e[4].data_ptr()))
         del ring, others
 
+    # N > 1: what a product costs where, and what crosses the ranks (every rank calls; rank 0 prints)
+    phases, comm_counts = None, None
+    if dist is not None and args.op == "hvp":
+        if hasattr(comm, "product_phases"):
+            try:
+                phases = comm.product_phases(x.data_ptr(), out.data_ptr(), epi=2, reps=50)
+            except Exception as e:  # noqa: BLE001 -- a diagnostic, not the measurement
+                phases = {"error": str(e)}
+        if hasattr(comm, "counters"):
+            c0 = comm.counters()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            c1 = comm.counters()
+            comm_counts = {"allgathers_per_product": (c1[0] - c0[0]) / 10.0, "allreduces_per_product": (c1[1] - c0[1]) / 10.0,
+                           "launches_per_product": 4,
+                           "launches": "pack (+ zeroed slots) | long-row chunks | unpack (+ long rows summed in rank order) | slices",
+                           "per_stpcg_iteration": "1 all-gather (the product's) + 2 all-reduces (kappa | <r,r> and <r,v>)"}
     # N > 1: one product gathered on every rank (download is collective) for the parity check on rank 0
     gathered = None
     if dist is not None:
@@ -502,6 +520,14 @@ def main():
         if rl["traffic_read"]:
             rl["read_over_compulsory"] = rl["traffic_read"] / comp_read
             rl["write_over_compulsory"] = rl["traffic_write"] / comp_write
+        if world > 1:
+            result["multi_gpu"] = {
+                "transport": type(comm).__name__, "exchanged_rows_per_product": getattr(comm, "exchanged_rows", None),
+                "kernel_only_us": kernel_us, "step_us": elapsed / args.steps * 1e6,
+                "phases_us": phases, "collectives": comm_counts,
+                "note": "phases: HIP events on the handle's stream of rank 0, serial order (the interior / boundary overlap "
+                        "is off below 2 048 interior slices per rank); kernel_only_us: the same product with every "
+                        "collective step skipped (cora_debug_local_products)"}
         if hbm_us is not None:
             result["roofline_hbm"] = {
                 "bound": "hbm", "kernel": result["roofline"]["kernel"], "kernel_us": hbm_us,

@@ -37,6 +37,12 @@ static void native_comm_destroy(cora_native_comm *nc);
 static double *native_scalars(cora_native_comm *nc);                       // 8 device doubles of the sharded STPCG
 static int native_allreduce_dev(cora_native_comm *nc, double *d, int n);   // sum over the ranks, in place, on the stream
 static int native_exchange_on(cora_native_comm *nc, double *dX, int ld, hipStream_t st);  // the exchange, ordered on st
+// the exchange of a PRODUCT, in two halves around the launch of the distributed long rows' chunks: pack the exported rows
+// (+ zeroed slots for the long rows' partial sums, returned in *slots) | all-gather of rows and slots in ONE collective,
+// rows scattered into dX, slots summed in rank order into the owners' rows of `out` (+ their kappa slots)
+static int native_product_pack(cora_native_comm *nc, const double *dX, int ld, hipStream_t st, double **slots);
+static int native_product_gather(cora_native_comm *nc, double *dX, int ld, hipStream_t st, double *out, double *kappa,
+                                 hipEvent_t after_collective = nullptr);
 static const std::string &native_error(const cora_native_comm *nc);
 struct cora_ctx {
   HostFormat F;
@@ -127,6 +133,10 @@ struct cora_ctx {
   cora_allgather_fn comm_allgather = nullptr;
   void *comm_user = nullptr;
   bool comm_required = false;  // cora_require_comm: a collective step without communication is an error, not a no-op
+  bool local_products = false;  // cora_debug_local_products: products skip every collective step (kernel timing only)
+  // cora_debug_product_phases: events at the phase boundaries of the one-collective product (serial order)
+  std::vector<hipEvent_t> phase_events;
+  bool phase_timing = false;
   bool prof_stpcg = false;
   std::vector<hipEvent_t> prof_events;
   double prof_hvp_us = 0.0;
@@ -583,6 +593,7 @@ void cora_ctx_destroy(cora_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->phase_events) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -1272,8 +1283,26 @@ static bool product_overlaps_exchange(const cora_ctx *c) {
          (c->F.chunks.empty() || !c->F.long_rows.empty());  // (whole long rows read columns of every shard)
 }
 
+// true when a product of this handle is ONE collective: the library's own communication and distributed long rows -- the
+// chunks of the long rows run first (they read columns of this shard only), their partial sums travel with the exported
+// rows of the operand, and every owner adds them up in rank order.  (Injected callbacks: exchange, product, all-reduce
+// of the slots, as before.)
+static bool product_one_collective(const cora_ctx *c) {
+  return c->F.L.world > 1 && !c->local_products && c->native_comm && c->comm_user == c->native_comm && c->comm_exchange != nullptr &&
+         !c->F.long_rows.empty();
+}
+
 // number of kappa slots an EPI_HVP_K product of this handle writes (launch_product / exchange_and_product)
 static int product_kappa_slots(const cora_ctx *c, const SpmmArgs &A) {
+  if (product_one_collective(c)) {  // chunk launch | one slot per long row | slice launch (or interior | boundary)
+    SpmmArgs Ac = A, A1 = A, A2 = A;
+    Ac.n_slices = 0;
+    A1.n_chunks = A2.n_chunks = 0;
+    if (!product_overlaps_exchange(c)) return launch_spmm_blocks(Ac) + A.n_long_rows + launch_spmm_blocks(A1);
+    A1.n_slices = c->n_slices_int;
+    A2.n_slices = c->n_slices_bnd;
+    return launch_spmm_blocks(Ac) + A.n_long_rows + launch_spmm_blocks(A1) + launch_spmm_blocks(A2);
+  }
   if (!product_overlaps_exchange(c)) return launch_spmm_kappa_slots(A);
   SpmmArgs A1 = A, A2 = A;
   A1.n_slices = c->n_slices_int;
@@ -1282,43 +1311,95 @@ static int product_kappa_slots(const cora_ctx *c, const SpmmArgs &A) {
   return launch_spmm_blocks(A1) + A.n_long_rows + launch_spmm_blocks(A2);
 }
 
-// Exchange of the operand's remote rows + the product.  With the library's own communication the two overlap: the
-// exchange (pack -> all-gather -> scatter) runs on comm_stream, the interior slices and the long-row chunks -- which
-// read rows of this rank's shard only, while the scatter writes rows of the other shards -- run on the handle's stream
-// at the same time, and the boundary slices follow when the exchange has landed.  Injected callbacks (cora_set_comm)
-// keep the serial order.
+// Exchange of the operand's remote rows + the product.
+//   * the library's own communication: pack (+ zeroed slots) -> the long rows' chunks -> ONE all-gather of rows and slots
+//     -> unpack (rows into X, slots summed into the owners' rows) -> the slices.  With the overlap on, gather and unpack
+//     run on comm_stream while the interior slices -- which read rows of this rank's shard only -- run on the handle's
+//     stream, and the boundary slices follow when the exchange has landed.
+//   * injected callbacks (cora_set_comm): exchange, product, all-reduce of the long rows' slots, in that order.
 static int exchange_and_product(cora_ctx *c, SpmmArgs A, int ld, int epi) {
-  if (!product_overlaps_exchange(c)) {
-    const int rc = comm_exchange(c, A.X, ld);
+  if (c->local_products) return launch_product(c, A, ld, epi, /*finish=*/false);  // timing hook: no collective step at all
+  if (!product_one_collective(c)) {
+    if (!product_overlaps_exchange(c)) {
+      const int rc = comm_exchange(c, A.X, ld);
+      if (rc) return rc;
+      return launch_product(c, A, ld, epi);
+    }
+    // (overlap without distributed long rows: whole long rows are excluded by product_overlaps_exchange, so this is a
+    // handle with no long rows at all)
+    HIP_TRY(c, hipEventRecord(c->ev_operand, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_operand, 0));
+    SpmmArgs A1 = A;
+    A1.slices = c->d_slices_int;
+    A1.slices_pose_first = nullptr;
+    A1.n_slices = c->n_slices_int;
+    int rc = launch_product(c, A1, ld, epi, /*finish=*/false);
     if (rc) return rc;
-    return launch_product(c, A, ld, epi);
+    if (native_exchange_on(c->native_comm, const_cast<double *>(A.X), ld, c->comm_stream))
+      return fail(c, CORA_ERR_HIP, "exchange step failed: " + native_error(c->native_comm));
+    HIP_TRY(c, hipEventRecord(c->ev_exchanged, c->comm_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_exchanged, 0));
+    SpmmArgs A2 = A;
+    A2.slices = c->d_slices_bnd;
+    A2.slices_pose_first = nullptr;
+    A2.n_slices = c->n_slices_bnd;
+    A2.n_chunks = 0;
+    A2.n_long_rows = 0;
+    if (A.kappa_partial) A2.kappa_partial = A.kappa_partial + launch_spmm_blocks(A1) + A.n_long_rows;
+    HIP_TRY(c, launch_spmm(A2, ld, c->F.L.d, epi, c->stream));
+    return CORA_OK;
+  }
+  cora_native_comm *nc = c->native_comm;
+  const bool kap = epi == EPI_HVP_K && A.kappa_partial;
+  double *slots = nullptr;
+  auto mark = [&](int i) {  // (measurement hook: five phases, six events)
+    if (c->phase_timing && static_cast<size_t>(i) < c->phase_events.size()) (void)hipEventRecord(c->phase_events[i], c->stream);
+  };
+  mark(0);
+  if (native_product_pack(nc, A.X, ld, c->stream, &slots)) return fail(c, CORA_ERR_HIP, "exchange step failed: " + native_error(nc));
+  mark(1);
+  SpmmArgs Ac = A;  // the long rows' chunks: partial sums over this rank's columns -> the slots that travel
+  Ac.n_slices = 0;
+  Ac.slices_pose_first = nullptr;
+  Ac.long_out = slots;
+  HIP_TRY(c, launch_spmm(Ac, ld, c->F.L.d, epi, c->stream));
+  mark(2);
+  const int kc = launch_spmm_blocks(Ac);
+  double *klong = kap ? A.kappa_partial + kc : nullptr;
+  SpmmArgs A1 = A;
+  A1.n_chunks = 0;
+  A1.n_long_rows = 0;
+  if (kap) A1.kappa_partial = A.kappa_partial + kc + A.n_long_rows;
+  if (!product_overlaps_exchange(c)) {
+    if (native_product_gather(nc, const_cast<double *>(A.X), ld, c->stream, A.out, klong, c->phase_timing ? c->phase_events[3] : nullptr))
+      return fail(c, CORA_ERR_HIP, "exchange step failed: " + native_error(nc));
+    mark(4);
+    HIP_TRY(c, launch_spmm(A1, ld, c->F.L.d, epi, c->stream));
+    mark(5);
+    return CORA_OK;
   }
   HIP_TRY(c, hipEventRecord(c->ev_operand, c->stream));
   HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_operand, 0));
-  SpmmArgs A1 = A;
+  if (native_product_gather(nc, const_cast<double *>(A.X), ld, c->comm_stream, A.out, klong))
+    return fail(c, CORA_ERR_HIP, "exchange step failed: " + native_error(nc));
+  HIP_TRY(c, hipEventRecord(c->ev_exchanged, c->comm_stream));
+  SpmmArgs A2 = A1;
   A1.slices = c->d_slices_int;
   A1.slices_pose_first = nullptr;
   A1.n_slices = c->n_slices_int;
-  int rc = launch_product(c, A1, ld, epi, /*finish_long_rows=*/false);   // interior slices + chunks, no exchange needed
-  if (rc) return rc;
-  if (native_exchange_on(c->native_comm, const_cast<double *>(A.X), ld, c->comm_stream))
-    return fail(c, CORA_ERR_HIP, "exchange step failed: " + native_error(c->native_comm));
-  HIP_TRY(c, hipEventRecord(c->ev_exchanged, c->comm_stream));
+  HIP_TRY(c, launch_spmm(A1, ld, c->F.L.d, epi, c->stream));   // interior slices: no row of another rank is read
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_exchanged, 0));
-  SpmmArgs A2 = A;
   A2.slices = c->d_slices_bnd;
   A2.slices_pose_first = nullptr;
   A2.n_slices = c->n_slices_bnd;
-  A2.n_chunks = 0;
-  A2.n_long_rows = 0;
-  if (A.kappa_partial) A2.kappa_partial = A.kappa_partial + launch_spmm_blocks(A1) + A.n_long_rows;
+  if (kap) A2.kappa_partial = A1.kappa_partial + launch_spmm_blocks(A1);
   HIP_TRY(c, launch_spmm(A2, ld, c->F.L.d, epi, c->stream));
-  return finish_long_rows(c, A1, ld, epi);
+  return CORA_OK;
 }
 
-// A product on a partitioned handle ends with its DISTRIBUTED long rows (format_build.cpp): the slots of partial sums
-// are added over the ranks -- on the device with the library's own communication, through the host with injected
-// callbacks -- and the owner copies its rows to the result; the rows' shares of kappa follow (EPI_HVP_K).
+// A product of a partitioned handle WITHOUT the library's own communication ends with its DISTRIBUTED long rows
+// (format_build.cpp): the slots of partial sums are added over the ranks through the injected all-reduce and the owner
+// copies its rows to the result; the rows' shares of kappa follow (EPI_HVP_K).
 static int launch_product(cora_ctx *c, SpmmArgs A, int ld, int epi, bool finish) {
   const int nl = static_cast<int>(c->F.long_rows.size());
   const bool dist = c->F.L.world > 1 && nl > 0;
@@ -1350,8 +1431,12 @@ static int finish_long_rows(cora_ctx *c, const SpmmArgs &A, int ld, int epi) {
     HIP_TRY(c, hipMemcpyAsync(c->d_long_out, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else {
-    const int rc = comm_missing(c);  // no communication: the caller adds the slots up itself (cora_long_row_slots)
-    if (rc) return rc;
+    // nobody can add the slots up: the landmark rows of the result would silently be PARTIAL sums (round-3 advice).
+    // A handle that is to run without communication keeps whole long rows: cora_ctx_create_part_opts(...,
+    // CORA_PART_WHOLE_LONG_ROWS).
+    return fail(c, CORA_ERR_NOT_READY,
+                "partitioned handle with distributed long rows and no communication: install cora_set_comm / cora_comm_create_*, "
+                "or create the handle with CORA_PART_WHOLE_LONG_ROWS");
   }
   const int kbase = launch_spmm_blocks(A);
   HIP_TRY(c, launch_long_finish(nl, ld, c->F.L.rank, c->d_long_rows, c->d_long_owner, c->d_long_out, A.X, A.out,
@@ -2469,6 +2554,8 @@ struct cora_native_comm {
   std::map<int, Buf> buf;           // per row stride
   double *d_scal = nullptr, *h_scal = nullptr;  // 1024 doubles each (device / pinned): all-reduce staging
   std::string err;
+  long n_allgather = 0, n_allreduce = 0;  // collectives issued on the data path (cora_comm_counters)
+  int n_long() const { return static_cast<int>(c->F.long_rows.size()); }
 
   int fail_(const std::string &m) {
     err = m;
@@ -2488,6 +2575,7 @@ struct cora_native_comm {
   // all-gather of `bytes` bytes per rank between DEVICE buffers, ordered on the handle's stream
   int allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
+    ++n_allgather;
     if (nccl) return nc(api->AllGather(send, recv, bytes, ncclChar, nccl, st), "ncclAllGather");
     if (hip(hipStreamSynchronize(st), "hipStreamSynchronize")) return 1;
     g->ptrs[rank] = send;
@@ -2501,7 +2589,10 @@ struct cora_native_comm {
   }
   // sum of n device doubles over the ranks, in place, ordered on the handle's stream (the same bits on every rank)
   int allreduce_dev(double *d, int n) {
-    if (nccl) return nc(api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce");
+    if (nccl) {
+      ++n_allreduce;
+      return nc(api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce");
+    }
     std::vector<double> h(static_cast<size_t>(n));
     if (hip(hipMemcpyAsync(h.data(), d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync")) return 1;
     if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
@@ -2510,6 +2601,7 @@ struct cora_native_comm {
     return hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
   }
   int allreduce_host(double *vals, int n) {
+    ++n_allreduce;
     if (nccl) {
       if (n > 1016) return fail_("all-reduce of more than 1016 doubles");
       std::memcpy(h_scal, vals, sizeof(double) * n);
@@ -2585,9 +2677,10 @@ struct cora_native_comm {
 
   int buffers(int ld, Buf **out) {
     Buf &b = buf[ld];
-    if (!b.send) {
-      if (hip(hipMalloc(reinterpret_cast<void **>(&b.send), sizeof(double) * e_max * ld), "hipMalloc")) return 1;
-      if (hip(hipMalloc(reinterpret_cast<void **>(&b.recv), sizeof(double) * e_max * ld * world), "hipMalloc")) return 1;
+    if (!b.send) {  // per rank: e_max rows + one slot per distributed long row
+      const size_t per = sizeof(double) * (static_cast<size_t>(e_max) + n_long()) * ld;
+      if (hip(hipMalloc(reinterpret_cast<void **>(&b.send), per), "hipMalloc")) return 1;
+      if (hip(hipMalloc(reinterpret_cast<void **>(&b.recv), per * world), "hipMalloc")) return 1;
     }
     *out = &b;
     return 0;
@@ -2603,7 +2696,23 @@ struct cora_native_comm {
     if (allgather_dev(b->send, b->recv, sizeof(double) * e_max * ld, st)) return 1;
     return hip(launch_move_rows(1, static_cast<int64_t>(world) * e_max, ld, d_recv_idx, b->recv, dX, st), "scatter");
   }
+  int product_pack(const double *dX, int ld, hipStream_t st, double **slots) {
+    if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
+    Buf *b;
+    if (buffers(ld, &b)) return 1;
+    *slots = b->send + static_cast<size_t>(e_max) * ld;
+    return hip(launch_exchange_pack(e_max, ld, d_export, static_cast<int64_t>(n_long()) * ld, dX, b->send, st), "pack");
+  }
+  int product_gather(double *dX, int ld, hipStream_t st, double *out, double *kappa, hipEvent_t after_collective = nullptr) {
+    Buf *b;
+    if (buffers(ld, &b)) return 1;
+    if (allgather_dev(b->send, b->recv, sizeof(double) * (static_cast<size_t>(e_max) + n_long()) * ld, st)) return 1;
+    if (after_collective) (void)hipEventRecord(after_collective, st);
+    return hip(launch_exchange_unpack(world, e_max, n_long(), ld, d_recv_idx, b->recv, dX, rank, c->d_long_rows, c->d_long_owner,
+                                      out, kappa, st), "unpack");
+  }
   int allgather(double *dX, int ld) {  // whole shards, in place
+    ++n_allgather;
     if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
     const Layout &L = c->F.L;
     const size_t n = static_cast<size_t>(L.shard_rows) * ld;
@@ -2635,6 +2744,11 @@ static void native_comm_destroy(cora_native_comm *nc) { delete nc; }
 static double *native_scalars(cora_native_comm *nc) { return nc->d_scal + 1016; }  // behind the host all-reduce's staging
 static int native_allreduce_dev(cora_native_comm *nc, double *d, int n) { return nc->allreduce_dev(d, n); }
 static int native_exchange_on(cora_native_comm *nc, double *dX, int ld, hipStream_t st) { return nc->exchange(dX, ld, st); }
+static int native_product_pack(cora_native_comm *nc, const double *dX, int ld, hipStream_t st, double **slots) { return nc->product_pack(dX, ld, st, slots); }
+static int native_product_gather(cora_native_comm *nc, double *dX, int ld, hipStream_t st, double *out, double *kappa,
+                                 hipEvent_t after_collective) {
+  return nc->product_gather(dX, ld, st, out, kappa, after_collective);
+}
 static const std::string &native_error(const cora_native_comm *nc) { return nc->err; }
 
 namespace {
@@ -2729,6 +2843,48 @@ int cora_comm_native_enable(cora_ctx *c, int on) {
   c->comm_allreduce = on ? native_allreduce_cb : nullptr;
   c->comm_allgather = on ? native_allgather_cb : nullptr;
   c->comm_user = on ? c->native_comm : nullptr;
+  return CORA_OK;
+}
+
+int cora_debug_local_products(cora_ctx *c, int on) {
+  if (!c) return CORA_ERR_ARG;
+  c->local_products = on != 0;
+  return CORA_OK;
+}
+
+int cora_debug_product_phases(cora_ctx *c, const double *dX, double *dOut, int epi, int reps, double us[5]) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!dX || !dOut || !us || reps < 1 || epi < EPI_NONE || epi > EPI_HVP) return fail(c, CORA_ERR_ARG, "bad arguments");
+  if (!product_one_collective(c) || product_overlaps_exchange(c))
+    return fail(c, CORA_ERR_NOT_READY, "phase timing needs the library's own communication, distributed long rows and the serial order");
+  while (c->phase_events.size() < 6) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    c->phase_events.push_back(e);
+  }
+  for (int k = 0; k < 5; ++k) us[k] = 0.0;
+  int rc = CORA_OK;
+  for (int it = 0; it < reps + 3 && !rc; ++it) {   // (three warm-up rounds)
+    c->phase_timing = true;
+    rc = apply_product(c, dX, c->ld, epi, dOut);
+    c->phase_timing = false;
+    if (rc) break;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (it < 3) continue;
+    for (int k = 0; k < 5; ++k) {
+      float ms = 0.f;
+      HIP_TRY(c, hipEventElapsedTime(&ms, c->phase_events[k], c->phase_events[k + 1]));
+      us[k] += ms * 1e3 / reps;
+    }
+  }
+  return rc;
+}
+
+int cora_comm_counters(const cora_ctx *c, long out[2]) {
+  if (!c || !out) return CORA_ERR_ARG;
+  out[0] = c->native_comm ? c->native_comm->n_allgather : 0;
+  out[1] = c->native_comm ? c->native_comm->n_allreduce : 0;
   return CORA_OK;
 }
 

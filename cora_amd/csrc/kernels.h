@@ -256,6 +256,11 @@ hipError_t launch_reduce_partials(const double *partial, int nblocks, int count,
 // row's share of <X, out> (0 on the other ranks)
 hipError_t launch_long_finish(int n_long, int ld, int rank, const int32_t *rows, const int32_t *owner, const double *slots,
                               const double *X, double *out, double *kappa, hipStream_t st);
+// the two ends of a partitioned product's exchange (kernels.hip, k_exchange_pack / k_exchange_unpack)
+hipError_t launch_exchange_pack(int64_t n, int ld, const int32_t *rows, int64_t ztail, const double *src, double *dst, hipStream_t st);
+hipError_t launch_exchange_unpack(int world, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, const double *recv, double *X,
+                                  int rank, const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa,
+                                  hipStream_t st);
 hipError_t launch_has_nan(int64_t n, const double *x, int *flag, hipStream_t st);
 // mode 0: dst[k] = src[rows[k]];  1: dst[rows[k]] = src[k];  2: dst[rows[k]] = src[rows[k]]  (rows of ld doubles)
 hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, const double *src, double *dst,

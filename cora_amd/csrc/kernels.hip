@@ -1836,6 +1836,54 @@ __global__ __launch_bounds__(256) void k_move_rows(int mode, int64_t n, int ld, 
   }
 }
 
+// The exchange of a partitioned handle's product, both ends (capi.hip, cora_native_comm::exchange_product):
+//   pack  : dst = [ the n exported rows of src | ztail zeros ] -- the zeros are the slots of the distributed long rows'
+//           partial sums, which the chunk launch that follows fills where this rank has a share
+//   unpack: the gathered buffers of all ranks, `stride` doubles each = [ e_max rows | n_long slots ]: rows go to
+//           X[recv_idx], and the owner of long row j adds slot j of every rank IN RANK ORDER (the same bits whatever the
+//           transport) into its row of the result; with kappa != nullptr every rank writes the row's kappa slot.
+__global__ __launch_bounds__(256) void k_exchange_pack(int64_t n, int ld, const int32_t *__restrict__ rows, int64_t ztail,
+                                                       const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t tot = n * ld;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < tot + ztail;
+       t += static_cast<int64_t>(gridDim.x) * 256) {
+    if (t >= tot) {
+      dst[t] = 0.0;
+      continue;
+    }
+    const int64_t k = t / ld, j = t - k * ld;
+    dst[t] = src[static_cast<int64_t>(rows[k]) * ld + j];
+  }
+}
+__global__ __launch_bounds__(256) void k_exchange_unpack(int world, int64_t e_max, int n_long, int ld, int64_t stride, int scatter_blocks,
+                                                         const int32_t *__restrict__ recv_idx, const double *__restrict__ recv,
+                                                         double *__restrict__ X, int rank, const int32_t *__restrict__ long_rows,
+                                                         const int32_t *__restrict__ long_owner, double *__restrict__ out,
+                                                         double *__restrict__ kappa) {
+  if (static_cast<int>(blockIdx.x) < scatter_blocks) {
+    const int64_t per = e_max * ld, tot = per * world;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < tot; t += static_cast<int64_t>(scatter_blocks) * 256) {
+      const int64_t r = t / per, w = t - r * per, k = t / ld, j = t - k * ld;
+      X[static_cast<int64_t>(recv_idx[k]) * ld + j] = recv[r * stride + w];
+    }
+    return;
+  }
+  const int j = static_cast<int>(blockIdx.x) - scatter_blocks, lane = threadIdx.x;
+  if (j >= n_long || lane >= 64) return;
+  double v = 0.0, k = 0.0;
+  if (lane < ld)
+    for (int r = 0; r < world; ++r) v += recv[r * stride + (e_max + j) * ld + lane];
+  if (long_owner[j] == rank && lane < ld) {
+    const size_t at = static_cast<size_t>(long_rows[j]) * ld + lane;
+    out[at] = v;
+    if (kappa) k = v * X[at];   // (a landmark's own row of X is this rank's: the scatter above does not write it)
+  }
+  if (kappa) {
+    k = wave_sum(k);
+    if (lane == 0) kappa[j] = k;
+  }
+}
+
 // Distributed long rows of a partitioned handle, after their partial sums have been added over the ranks: the owner of
 // long row j copies slot j to its row of the result; with kappa != nullptr EVERY rank writes the row's kappa slot
 // (<X[row], out[row]> on the owner, 0 elsewhere -- every slot of a launch is written).  One wavefront per row.
@@ -3176,6 +3224,20 @@ hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, co
                             hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * ld)), dim3(256), 0, st, mode, n, ld, rows, src, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_exchange_pack(int64_t n, int ld, const int32_t *rows, int64_t ztail, const double *src, double *dst, hipStream_t st) {
+  if (n * ld + ztail <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_exchange_pack, dim3(grid_for(n * ld + ztail)), dim3(256), 0, st, n, ld, rows, ztail, src, dst);
+  return hipGetLastError();
+}
+hipError_t launch_exchange_unpack(int world, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, const double *recv, double *X,
+                                  int rank, const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa,
+                                  hipStream_t st) {
+  const int sb = grid_for(static_cast<int64_t>(world) * e_max * ld);
+  hipLaunchKernelGGL(k_exchange_unpack, dim3(sb + n_long), dim3(256), 0, st, world, e_max, n_long, ld,
+                     (e_max + n_long) * static_cast<int64_t>(ld), sb, recv_idx, recv, X, rank, long_rows, long_owner, out, kappa);
   return hipGetLastError();
 }
 

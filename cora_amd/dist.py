@@ -362,6 +362,26 @@ class _NativeComm:
         self.ctx.L.cora_comm_native_enable.argtypes = [_C.c_void_p, _C.c_int]
         self.ctx._chk(self.ctx.L.cora_comm_native_enable(self.ctx.h, int(bool(on))))
 
+    def counters(self):
+        """(all-gathers, all-reduces) the library's own communication has issued on this handle so far."""
+        out = (_C.c_long * 2)()
+        self.ctx.L.cora_comm_counters.argtypes = [_C.c_void_p, _C.POINTER(_C.c_long)]
+        self.ctx._chk(self.ctx.L.cora_comm_counters(self.ctx.h, out))
+        return int(out[0]), int(out[1])
+
+    def product_phases(self, x_ptr, out_ptr, epi=2, reps=50):
+        """Microseconds per phase of a product: pack | long-row chunks | all-gather | unpack | slices (collective call)."""
+        us = (_C.c_double * 5)()
+        self.ctx.L.cora_debug_product_phases.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_int, _C.c_int,
+                                                         _C.POINTER(_C.c_double)]
+        self.ctx._chk(self.ctx.L.cora_debug_product_phases(self.ctx.h, _C.c_void_p(x_ptr), _C.c_void_p(out_ptr), int(epi), int(reps), us))
+        return dict(zip(["pack_us", "long_row_chunks_us", "allgather_us", "unpack_us", "slices_us"], [float(v) for v in us]))
+
+    def local_products(self, on=True):
+        """Timing hook: products without any collective step (the kernel alone)."""
+        self.ctx.L.cora_debug_local_products.argtypes = [_C.c_void_p, _C.c_int]
+        self.ctx._chk(self.ctx.L.cora_debug_local_products(self.ctx.h, int(bool(on))))
+
     def overlap(self, mode=1):
         """0: products run after the exchange of their operand; 1 (default): they overlap it with their interior slices
         when those are worth a launch of their own; 2: always."""

@@ -380,6 +380,22 @@ int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
 /* Measurement switch: on = 0 leaves the collective steps to the caller again (a product then runs on whatever the
  * remote rows hold: bench.py times the kernel alone this way), on = 1 re-installs the native communication. */
 int cora_comm_native_enable(cora_ctx *ctx, int on);
+/* Collectives the library's own communication has issued on this handle so far: out[0] all-gathers, out[1] all-reduces.
+ * A product is ONE all-gather (the exported rows of the operand and the distributed long rows' partial sums travel
+ * together; the owners add the sums up in rank order); an iteration of the device-resident STPCG is that plus two
+ * all-reduces (kappa; <r,r> and <r,v>): the two synchronisation points of preconditioned CG. */
+int cora_comm_counters(const cora_ctx *ctx, long out[2]);
+
+/* The phases of a partitioned handle's product, timed with HIP events on the handle's stream (library's own
+ * communication, serial order; collective: every rank calls it): us[0] pack of the exported rows, [1] the distributed
+ * long rows' chunks, [2] the all-gather, [3] unpack (rows scattered, long rows summed), [4] the slices.  epi: 0 Q X,
+ * 1 (Q - Lambda) X, 2 the Hessian-vector product.  What a first run on several GPUs is read with (bench.py --gpus N). */
+int cora_debug_product_phases(cora_ctx *ctx, const double *dX, double *dOut, int epi, int reps, double us[5]);
+
+/* Timing hook: with on != 0 the products of a partitioned handle skip every collective step (the operand's remote rows
+ * are whatever they are, the distributed long rows stay partial sums) -- the kernel alone, for bench.py's roofline leg. */
+int cora_debug_local_products(cora_ctx *ctx, int on);
+
 /* With the native communication a product of a partitioned handle overlaps the exchange of its operand with the
  * slices that read this rank's own rows only: exchange (pack, all-gather, scatter) on a second stream, interior
  * slices + long-row chunks at the same time on the handle's stream, boundary slices when the exchange has landed.

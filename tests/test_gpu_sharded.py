@@ -353,3 +353,92 @@ def test_block_jacobi_cholesky_on_partitions(world):
         assert abs(res["f"] - single["f"]) < 1e-5 * abs(single["f"])
     print("\nblock-Jacobi Cholesky, %d ranks: f=%.8f in %d products (one factor: f=%.8f in %d)"
           % (world, outs[0][3]["f"], outs[0][3]["hvps"], single["f"], single["hvps"]))
+
+
+@pytest.mark.parametrize("world,n", [(2, 900), (4, 3000)])
+def test_collectives_per_product_and_per_stpcg_iteration(world, n):
+    """What crosses the ranks, counted (cora_comm_counters): a product on a partitioned handle is ONE collective -- an
+    all-gather that carries the exported rows of the operand AND the distributed long rows' partial sums (the owners add
+    them in rank order; no memset, no all-reduce) -- and an iteration of the device-resident STPCG is that all-gather
+    plus two all-reduces (kappa | <r, r> and <r, v>), the two synchronisation points of preconditioned CG.
+    Call sites that run sharded this way: src/CORA.cpp:139-140, src/CORA_utils.cpp:83,113-119."""
+    p = 4
+    P1 = _problem(n, p)
+    dm = P1.dims()
+    rng = np.random.default_rng(3)
+    Y = P1.op("projectToManifold", rng.uniform(-1, 1, (dm["N"], p)))
+    V = P1.op("tangent_space_projection", Y, rng.uniform(-1, 1, (dm["N"], p)))
+    ref = P1.op("Riemannian_Hessian_vector_product", Y, P1.op("Euclidean_gradient", Y), V)
+
+    def body(r, group):
+        P = _problem(n, p)
+        comm = P.set_partition(r, world, lambda ctx: NativeLocalComm(ctx, group))
+        ctx = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+        assert len(ctx.long_rows()) > 0  # the landmark rows are distributed: their slots ride on the exchange
+        y, v, o = ctx.dev_alloc(p), ctx.dev_alloc(p), ctx.dev_alloc(p)
+        ctx.upload(Y, y)
+        ctx.set_point_dev(y)
+        ctx.upload(V, v)
+        ctx.sync()
+        a0 = comm.counters()
+        ctx.hvp_dev(v, o)
+        ctx.sync()
+        a1 = comm.counters()
+        H = ctx.download(o, p)   # (collective: one all-gather of whole shards)
+        a2 = comm.counters()
+        ctx.spmm_dev(v, p, o)
+        ctx.certificate_product_dev(v, p, o)
+        ctx.sync()
+        a3 = comm.counters()
+        # the device-resident STPCG: exactly `it` iterations, nothing else in between
+        s, rr, vv, pk, hp, g = (ctx.dev_alloc(p) for _ in range(6))
+        ctx.upload(V, g)
+        b0 = comm.counters()
+        it, _ = ctx.stpcg_dev(g, 1e9, s, rr, vv, pk, hp, max_iters=6)
+        ctx.sync()
+        b1 = comm.counters()
+        assert ctx.stpcg_path() == 1
+        ph = comm.product_phases(v, o, epi=2, reps=5)   # the bench's per-phase diagnostic (collective call)
+        assert len(ph) == 5 and all(t >= 0.0 for t in ph.values()) and ph["slices_us"] > 0.0
+        for q in (y, v, o, s, rr, vv, pk, hp, g):
+            ctx.dev_free(q)
+        return dict(product=(a1[0] - a0[0], a1[1] - a0[1]), download=(a2[0] - a1[0], a2[1] - a1[1]),
+                    two=(a3[0] - a2[0], a3[1] - a2[1]), stpcg=(b1[0] - b0[0], b1[1] - b0[1]), it=it, H=H)
+
+    outs = _run_ranks(world, body, "native")
+    for o in outs:
+        assert np.abs(o["H"] - ref).max() < 1e-10 * np.abs(ref).max()
+        assert o["product"] == (1, 0)
+        assert o["two"] == (2, 0)
+        it = o["it"]
+        assert it >= 1   # (at a random point the Hessian is indefinite: the solve stops on negative curvature early)
+        # per iteration 1 all-gather + 2 all-reduces; before the first one the solve applies the preconditioner to the
+        # gradient and takes <r, r>, <r, v> (one all-reduce); iterations enqueued past the stopping point (the host runs
+        # ahead by a batch of four) still communicate, neutralised by the state
+        ag, ar = o["stpcg"]
+        assert it <= ag <= it + 4 and ar == 2 * ag + 1, (it, ag, ar)
+    print("\nworld %d: product %s, STPCG of %d iterations %s (all-gathers, all-reduces)" % (
+        world, outs[0]["product"], outs[0]["it"], outs[0]["stpcg"]))
+
+
+def test_bench_two_ranks_runs_end_to_end_over_gloo(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here with both ranks
+    on the box's one GPU and CORA_BENCH_BACKEND=gloo: the N > 1 branch of the bench -- partitioned handles, the collective
+    set-up, the timed steps with their barrier, the gathered parity check, the multi_gpu block of the JSON line -- runs
+    end to end.  (RCCL itself needs one GPU per rank; its one-rank case is test_rccl_transport_at_world_one.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CORA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+           "--poses", "20000", "--pmc-traffic", "off"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0
+    assert d["parity_max_rel_err_vs_cpu"] < 1e-10
+    assert "multi_gpu" in d and d["multi_gpu"]["exchanged_rows_per_product"] > 0
