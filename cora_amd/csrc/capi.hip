@@ -2,7 +2,16 @@
 // device memory and stream; every compute entry point ends in a HIP kernel of
 // kernels.hip -- there is no CPU fallback.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>  // types and enums only: the entry points are resolved with dlsym (native communication, end of file)
+// RCCL's types and the few enumerators used, declared here (NCCL's public ABI: they have not changed since 2.0): the
+// entry points are resolved with dlsym at run time (native communication, end of file), so neither the build nor a
+// single-GPU user needs RCCL's headers or library.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclChar = 0, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -24,6 +33,7 @@
 #include "../../include/cora_hip.h"
 #include "cora_internal.h"
 #include "kernels.h"
+#include "parallel.h"
 
 using namespace cora;
 
@@ -1006,10 +1016,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
               for (int k = 0; k < nb; ++k) io[static_cast<size_t>(r0) + k] = make_int2(rows[r0 + ord[k]], ord[k]);
             }
           };
-          std::vector<std::thread> pool;
-          for (unsigned t = 1; t < nth; ++t) pool.emplace_back(part, t);
-          part(0);
-          for (std::thread &th : pool) th.join();
+          cora::parallel_parts(nth, part);
           io.back() = make_int2(0, 0);
           return io;
         };
@@ -1622,9 +1629,11 @@ int cora_dots_dev(cora_ctx *c, int count, const double *const *dA, const double 
 // vector -- allocations are zeroed and no kernel writes them -- and add nothing to an update or an inner product.
 static bool stpcg_device_ok(const cora_ctx *c) {
   if (c->F.L.world == 1) return true;
-  const bool chol = c->precond == CORA_PRECOND_BLOCK_CHOLESKY || c->precond == CORA_PRECOND_REGULARIZED_CHOLESKY;
-  return c->native_comm && !c->implicit && c->ld <= 12 &&
-         (c->precond == CORA_PRECOND_JACOBI || c->precond == CORA_PRECOND_NONE || (chol && c->precond_f.ready));
+  // the library's own communication must be the ACTIVE transport (after cora_comm_native_enable(0) or a later
+  // cora_set_comm the reductions would go one way and the operand's exchange another -- round-3 advice).  The answer must
+  // not depend on anything rank-local: the Cholesky case is decided by the preconditioner's KIND (a missing factor fails
+  // loudly in the solve, on every rank alike).
+  return c->native_comm && c->comm_user == c->native_comm && c->comm_exchange != nullptr && !c->implicit && c->ld <= 12;
 }
 
 // Steihaug-Toint truncated PCG for  min <g,s> + 1/2 <s,Hs>,  ||s||_M <= Delta, entirely on the device

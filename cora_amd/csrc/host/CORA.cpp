@@ -15,6 +15,7 @@
 
 #include "../../../include/cora_hip.h"
 #include "dense.h"
+#include "../parallel.h"
 
 namespace CORA {
 
@@ -288,10 +289,7 @@ Matrix projectSolution(const Problem &problem, const Matrix &Y, bool verbose) {
       for (int i = static_cast<int>(static_cast<int64_t>(n) * t / nth); i < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / nth); ++i)
         if (determinant(Yd.block(static_cast<Index>(i) * d, 0, d, d)) > 0) ++cnt[t];
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nth; ++t) pool.emplace_back(part, t);
-    part(0);
-    for (std::thread &th : pool) th.join();
+    cora::parallel_parts(nth, part);
     for (size_t c : cnt) ng0 += c;
   }
   printIfVerbose(verbose, "Out of " + std::to_string(n) + " blocks, " + std::to_string(ng0) +
@@ -306,10 +304,7 @@ Matrix projectSolution(const Problem &problem, const Matrix &Y, bool verbose) {
       for (int i = static_cast<int>(static_cast<int64_t>(n) * t / nth); i < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / nth); ++i)
         Yd.setBlock(static_cast<Index>(i) * d, 0, projectToSOd(Yd.block(static_cast<Index>(i) * d, 0, d, d)));
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nth; ++t) pool.emplace_back(part, t);
-    part(0);
-    for (std::thread &th : pool) th.join();
+    cora::parallel_parts(nth, part);
   }
   const Index rot = problem.numPosesDim();
   for (Index j = 0; j < r; ++j) {

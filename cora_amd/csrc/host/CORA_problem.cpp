@@ -14,6 +14,7 @@
 #include "../../../include/cora_hip.h"
 #include "dense.h"
 #include "sparse_cholesky.h"
+#include "../parallel.h"
 
 namespace CORA {
 
@@ -967,10 +968,7 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
             g(b, a) = sum;
           }
       };
-      std::vector<std::thread> pool;
-      for (unsigned t = 1; t < nth; ++t) pool.emplace_back(rows, t);
-      rows(0);
-      for (std::thread &th : pool) th.join();
+      cora::parallel_parts(nth, rows);
       for (unsigned t = 0; t < nth; ++t) G = G + part[t];
     }
     symmetricEigen(G, ev, V);

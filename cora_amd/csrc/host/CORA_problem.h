@@ -176,8 +176,10 @@ class Problem {
   // steps (cora_set_comm semantics; pass nullptr to install communication on the handle afterwards).  Every operator of
   // this class, TNT, LOBPCG, certify_solution and solveCORA then run on the partition, all ranks calling the same
   // sequence: the Lambda blocks of the certificate are gathered, every rank runs the PSD test (same decision), LOBPCG
-  // runs on the sharded operator.  Not sharded: the exact-Cholesky preconditioners and the implicit formulation (use
-  // Jacobi, explicit), the ILDL branch of fast_verification (skipped).  Call before the first operator.
+  // runs on the sharded operator.  The Cholesky preconditioners become block Jacobi over the ranks with exact
+  // blocks (every rank factorises the diagonal block of ITS rows of Q + lambda I: weaker than the reference's global
+  // factor, more inner iterations).  Not sharded: the implicit formulation (use explicit) and the ILDL branch of
+  // fast_verification (skipped).  Call before the first operator.
   void setPartition(int rank, int world, cora_exchange_fn exchange, cora_allreduce_fn allreduce,
                     cora_allgather_fn allgather, void *user) {
     part_rank_ = rank;

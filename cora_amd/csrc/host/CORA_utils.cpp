@@ -12,6 +12,7 @@
 #include "../../../include/cora_hip.h"
 #include "dense.h"
 #include "sparse_cholesky.h"
+#include "../parallel.h"
 
 namespace CORA {
 
@@ -34,10 +35,7 @@ Vector sparseTimesVector(const SparseMatrix &S, const Vector &x) {
     rows(0, n);
     return y;
   }
-  std::vector<std::thread> pool;
-  for (unsigned t = 0; t < nth; ++t)
-    pool.emplace_back(rows, n * static_cast<Index>(t) / nth, n * static_cast<Index>(t + 1) / nth);
-  for (std::thread &t : pool) t.join();
+  cora::parallel_parts(nth, [&](unsigned t) { rows(n * static_cast<Index>(t) / nth, n * static_cast<Index>(t + 1) / nth); });
   return y;
 }
 

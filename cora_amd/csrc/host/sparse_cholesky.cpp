@@ -14,6 +14,7 @@
 #include <functional>
 #include <numeric>
 #include <stdexcept>
+#include "../parallel.h"
 
 namespace CORA {
 
@@ -185,10 +186,7 @@ uint64_t hashWords(uint64_t h, const int32_t *p, size_t count) {
 // runs body(thread index) on nth threads
 template <class Body>
 void parallelRun(unsigned nth, Body body) {
-  std::vector<std::thread> pool;
-  for (unsigned th = 1; th < nth; ++th) pool.emplace_back([&body, th] { body(th); });
-  body(0u);
-  for (std::thread &t : pool) t.join();
+  cora::parallel_parts(nth, body);  // (joins everything and forwards the first exception: parallel.h)
 }
 
 

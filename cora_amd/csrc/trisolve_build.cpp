@@ -9,6 +9,7 @@
 #include <functional>
 #include <thread>
 #include <utility>
+#include "parallel.h"
 
 namespace cora {
 
@@ -119,10 +120,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   std::vector<const char *> bad(nt0, nullptr);
   std::vector<char> unsorted(nt0, 0);
   auto run0 = [&](auto body) {
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt0; ++t) pool.emplace_back(body, t);
-    body(0u);
-    for (std::thread &th : pool) th.join();
+    cora::parallel_parts(nt0, body);
   };
   run0([&](unsigned t) {
     std::vector<int32_t> &a = at[t];
@@ -719,19 +717,9 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
       size_t nth = std::min<size_t>(std::min<size_t>(hw, 48), std::max<size_t>(members.size() / 8, 1));
       if (const char *e = std::getenv("CORA_TRI_THREADS")) nth = std::max(1, std::atoi(e));
-      std::vector<std::thread> pool;
-      std::vector<std::exception_ptr> errs(nth);
-      for (size_t t = 0; t < nth; ++t)
-        pool.emplace_back([&, t] {
-          try {
-            for (size_t b = t; b < members.size(); b += nth) build_block(b);
-          } catch (...) {
-            errs[t] = std::current_exception();
-          }
-        });
-      for (std::thread &th : pool) th.join();
-      for (const std::exception_ptr &e : errs)
-        if (e) std::rethrow_exception(e);
+      cora::parallel_parts(static_cast<unsigned>(nth), [&](unsigned t) {
+        for (size_t b = t; b < members.size(); b += nth) build_block(b);
+      });
     }
     tick("blocks (threads)");
     SubBlockOpHost &S0 = SG;
@@ -761,9 +749,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
           [&] { S0.f_hdr.reserve(tot.fh + 8); S0.f_hdr.resize(tot.fh); S0.b_hdr.reserve(tot.bh + 8); S0.b_hdr.resize(tot.bh); },
           [&] { S0.c_idx.resize(tot.ci); S0.c_val.resize(tot.ci); S0.c_ptr.resize(tot.cp); S0.c_ptr[0] = 0; },
           [&] { S0.rows.resize(tot.rows); S0.b_rows.resize(tot.brows); S0.tgt_row.resize(tot.tgt); S0.tgt_slot.resize(tot.tgt); }};
-      std::vector<std::thread> pool;
-      for (auto &fn : sizing) pool.emplace_back(fn);
-      for (std::thread &th : pool) th.join();
+      cora::parallel_parts(static_cast<unsigned>(sizing.size()), [&](unsigned t) { sizing[t](); });
     }
     // small per-block records and the aux slots, in block order
     S0.row_begin.reserve(np), S0.nrows.reserve(np), S0.f_ent_begin.reserve(np), S0.b_ent_begin.reserve(np);
@@ -794,9 +780,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     {
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
       const size_t nth = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw, 32), np / 8));
-      std::vector<std::thread> pool;
-      for (size_t t = 0; t < nth; ++t)
-        pool.emplace_back([&, t] {
+      cora::parallel_parts(static_cast<unsigned>(nth), [&](unsigned t) {
           auto put = [](auto &dst, size_t at, const auto &src) { std::copy(src.begin(), src.end(), dst.begin() + static_cast<std::ptrdiff_t>(at)); };
           for (size_t b = np * t / nth; b < np * (t + 1) / nth; ++b) {
             SubBlockOpHost &Pc = pieces[b].S;
@@ -818,7 +802,6 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
             pieces[b] = Piece();
           }
         });
-      for (std::thread &th : pool) th.join();
     }
     S0.tgt_begin.push_back(static_cast<int32_t>(S0.tgt_slot.size()));
     S0.f_lev_begin.push_back(static_cast<int32_t>(S0.f_hdr.size() / 4));

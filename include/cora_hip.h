@@ -23,10 +23,10 @@
  *     the handle.  One handle = one HIP stream; a handle is not thread-safe,
  *     independent handles are.
  *   - `_dev` entry points take DEVICE pointers to the library's resident layout:
- *     row-major  rows x ld  doubles with ld = cora_ld(ctx) (= p up to 12 columns,
- *     the next multiple of 4 above; padding columns are zero) and rows = cora_rows(ctx) in the
- *     library's internal row order (identity for a 1-GPU handle).  Use
- *     cora_upload / cora_download to convert from / to the host layout.
+ *     row-major  rows x ld  doubles with ld = cora_ld(ctx) = cora_ld_for(k) = the number of
+ *     columns k itself for every k in 2..24 (no padding columns; ld = 2 for k = 1) -- ask, do not
+ *     assume -- and rows = cora_rows(ctx) in the library's internal row order (a permutation even
+ *     on one GPU: cora_row_map).  Use cora_upload / cora_download to convert from / to the host layout.
  *   - there is no CPU fallback: every compute entry point fails with
  *     CORA_ERR_HIP when no gfx950 device is usable.
  */
@@ -356,8 +356,11 @@ int cora_set_comm(cora_ctx *ctx, cora_exchange_fn exchange, cora_allreduce_fn al
  * partition, so that a rebuilt handle cannot silently compute per-rank partial results. */
 int cora_require_comm(cora_ctx *ctx, int on);
 /* 1 if cora_stpcg_dev / cora_stpcg_warm_dev can run on this handle: always on one GPU; on a partitioned handle with
- * the library's own communication (cora_comm_create_*: the inner products are all-reduced on the device, no host
- * round trip), the explicit formulation and a row-local preconditioner (Jacobi / none). */
+ * the library's own communication as the ACTIVE transport (cora_comm_create_*: the inner products are all-reduced on
+ * the device, no host round trip), the explicit formulation and up to 12 columns.  Preconditioners on a partitioned
+ * handle: none, Jacobi, or a Cholesky factor of the rank's OWN diagonal block of Q + lambda I installed with
+ * cora_precond_set_cholesky -- block Jacobi over the ranks with exact blocks, NOT the reference's one global factor
+ * (a sequential solve does not shard; expect more inner iterations than on one GPU). */
 int cora_stpcg_device_ok(const cora_ctx *ctx);
 /* The library's OWN communication for a partitioned handle: the three steps above implemented natively, so that no
  * callback (and no Python) sits on the data path.  Two transports:
