@@ -1018,10 +1018,51 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
           };
           cora::parallel_parts(nth, part);
           io.back() = make_int2(0, 0);
+          if (std::getenv("CORA_IO_STATS")) {  // lab: runs of consecutive rows per block
+            size_t tot = 0, mx = 0;
+            std::vector<size_t> hist(12, 0);
+            for (size_t b = 0; b < nblk; ++b) {
+              const int32_t r0 = desc[b].row_begin, nb = desc[b].nrows;
+              size_t runs = nb > 0;
+              for (int k = 1; k < nb; ++k) runs += io[static_cast<size_t>(r0) + k].x != io[static_cast<size_t>(r0) + k - 1].x + 1;
+              tot += runs; mx = std::max(mx, runs); hist[std::min<size_t>(runs, 11)]++;
+            }
+            std::fprintf(stderr, "io runs per block: mean %.2f max %zu, histogram", double(tot) / std::max<size_t>(nblk, 1), mx);
+            for (size_t h : hist) std::fprintf(stderr, " %zu", h);
+            std::fprintf(stderr, "\n");
+          }
           return io;
         };
-        HIP_TRY(c, up(&Q.fwd.io, io_of(H.rows)));
-        HIP_TRY(c, up(&Q.bwd.io, io_of(H.b_rows)));
+        // (the rows of a block in memory order are the same set for both sweeps: the runs are found once, from the
+        // forward list; only the tile positions differ)
+        {
+          const std::vector<int2> iof = io_of(H.rows), iob = io_of(H.b_rows);
+          bool runs_ok = std::getenv("CORA_SUB_IO_LISTS") == nullptr;  // (lab switch: the 8-byte index lists)
+          std::vector<uint16_t> tpf(iof.size() + 8, 0), tpb(iob.size() + 8, 0);
+          for (size_t b = 0; b < desc.size(); ++b) {
+            SubDesc &d = desc[b];
+            const int32_t r0 = d.row_begin, nb = d.nrows;
+            int nr = 0;
+            for (int q = 0; q < kSubMaxRuns; ++q) { d.run_off[q] = 0; d.run_end[q] = INT32_MAX; }
+            for (int k = 0; k < nb; ++k) {
+              const int2 a = iof[static_cast<size_t>(r0) + k], bb = iob[static_cast<size_t>(r0) + k];
+              if (a.x != bb.x || a.y > 0xffff || bb.y > 0xffff) runs_ok = false;
+              tpf[static_cast<size_t>(r0) + k] = static_cast<uint16_t>(a.y);
+              tpb[static_cast<size_t>(r0) + k] = static_cast<uint16_t>(bb.y);
+              if (k == 0 || a.x != iof[static_cast<size_t>(r0) + k - 1].x + 1) {  // a new run starts at k
+                if (nr > 0 && nr <= kSubMaxRuns) d.run_end[nr - 1] = k;
+                if (nr < kSubMaxRuns) d.run_off[nr] = a.x - k;
+                ++nr;
+              }
+            }
+            if (nr > kSubMaxRuns) runs_ok = false;
+          }
+          Q.io_runs = runs_ok ? 1 : 0;
+          HIP_TRY(c, up(&Q.fwd.io, iof));
+          HIP_TRY(c, up(&Q.bwd.io, iob));
+          HIP_TRY(c, up(&Q.fwd.tpos, tpf));
+          HIP_TRY(c, up(&Q.bwd.tpos, tpb));
+        }
         tick("  sub: io lists");
         // fused projection in the backward sweep: the first rotation row of a pose finds the others right behind it
         // in the tile, and a pose of the last stage has all its rows there.  Row units of a block: {tile position, row}

@@ -123,13 +123,20 @@ struct BlockOpDev {
   int nblocks;
 };
 // Device copy of a SubBlockOpHost (trisolve.h): stage 0 as workgroup blocks solved by substitution in LDS.
-struct SubDesc {  // 56 bytes per block
+struct SubDesc {  // 88 bytes per block
   int32_t row_begin, nrows;
   int32_t f_ent_begin, f_nent, b_ent_begin, b_nent;
   int32_t f_lev_begin, f_nlev, b_lev_begin, b_nlev;
   int32_t tgt_begin, ntgt;
   int32_t unit_begin, nunits;  // backward, fused projection: the block's row units in SubOpDev::b_unit
+  // The block's rows in MEMORY order are a few runs of consecutive rows (a chain block: its poses' rotation rows, their
+  // range rows, their translation rows): the k-th row in memory order is  k + run_off[r]  for the first r with
+  // k < run_end[r] (unused runs end at INT32_MAX).  With SubOpDev::io_runs the sweeps form their global addresses from
+  // these eight scalars -- the loads of a phase no longer wait for an index list -- and take the tile position of a row
+  // from a 16-bit list (SubSweep::tpos).
+  int32_t run_off[4], run_end[4];
 };
+constexpr int kSubMaxRuns = 4;
 struct SubSweep {  // one direction of the solve; rows are numbered by level within the block
   const int32_t *rows;      // [row_begin + k]: internal row
   const int32_t *hdr;       // [4 * (lev_begin + l)]: {first row, lanes per row g | entries per lane npl << 8, first coefficient (block-relative), first index (absolute)} of level l
@@ -139,6 +146,7 @@ struct SubSweep {  // one direction of the solve; rows are numbered by level wit
   // [row_begin + k]: {internal row, tile position} of the block's k-th row in MEMORY order: the tile is filled and
   // written back element by element in that order (a block is a few runs of consecutive rows: coalesced)
   const int2 *io;
+  const uint16_t *tpos;  // [row_begin + k]: the tile position alone (SubOpDev::io_runs)
 };
 struct SubOpDev {
   const SubDesc *desc;
@@ -152,6 +160,7 @@ struct SubOpDev {
                             // first rotation row -- the others follow it in the tile --, a range row, a translation row)
   int nblocks, ntop, max_rows, max_ent, max_lev, aux_base;
   int max_level_lanes, max_npl;  // widest level (rows x lanes per row) and most entries per lane of the plan
+  int io_runs;  // 1: every block has at most kSubMaxRuns runs of consecutive rows (SubDesc::run_off / run_end are valid)
 };
 // STPCG passes fused into the two sweeps (cora_stpcg_dev; one shard, explicit formulation):
 //   forward : the right-hand side IS the residual and is updated on the way in:  r += coef_r Hp; every row of the vector

@@ -2643,15 +2643,25 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   constexpr int kIoBatch = (FD == 1 && LD > 5) ? (LD <= 8 ? LD : 8) : (2 * LD <= 12 ? 2 * LD : 12);
   constexpr int kIoSub = (kIoBatch + 1) / 2;
   struct IoAt { int g, t; };  // offsets of an element in the vectors / in the tile
+  // (io_runs: the row of an element from the block's run table -- eight scalars of its descriptor --, so that the loads
+  // of a phase do not wait for an index list; the tile position from a 16-bit list, requested at the same time)
+  const uint16_t *__restrict__ tpos = Q.tpos + rb;
+  const bool io_runs = S.io_runs != 0;
   auto io_index = [&](int e0, IoAt (&at)[kIoBatch]) {
 #pragma unroll
     for (int u = 0; u < kIoBatch; ++u) {
       const int e = e0 + u * kSubThreads;
       const int ee = e < ne ? e : ne - 1;
       const int k = ee / LD, col = ee - k * LD;
-      const int2 rp = io[k];
-      at[u].g = rp.x * LD + col;
-      at[u].t = rp.y * LD + col;
+      if (io_runs) {
+        const int off = k < bd.run_end[0] ? bd.run_off[0] : (k < bd.run_end[1] ? bd.run_off[1] : (k < bd.run_end[2] ? bd.run_off[2] : bd.run_off[3]));
+        at[u].g = (k + off) * LD + col;
+        at[u].t = static_cast<int>(tpos[k]) * LD + col;
+      } else {
+        const int2 rp = io[k];
+        at[u].g = rp.x * LD + col;
+        at[u].t = rp.y * LD + col;
+      }
     }
   };
 
