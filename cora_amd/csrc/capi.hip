@@ -2896,6 +2896,12 @@ int cora_comm_native_enable(cora_ctx *c, int on) {
   return CORA_OK;
 }
 
+int cora_debug_spmm_window_min_slices(int min_slices) {
+  const int old = g_win_min_slices;
+  if (min_slices >= 0) g_win_min_slices = min_slices;
+  return old;
+}
+
 int cora_debug_local_products(cora_ctx *c, int on) {
   if (!c) return CORA_ERR_ARG;
   c->local_products = on != 0;

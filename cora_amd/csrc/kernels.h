@@ -54,6 +54,7 @@ struct SpmmArgs {
   int32_t n_local_poses = 0;  // poses of the shard (chain slices clamp their implied columns to them)
   int32_t win_on = 0;  // set by launch_spmm: X window + cooperative epilogue of the pose slices (n_slices >= kWinMinSlices)
 };
+extern int g_win_min_slices;  // launch_spmm: window form from this many slices on (kernels.hip)
 constexpr int kPoseFirstMaxLD = 6;
 constexpr int kWinMinSlices = 2048;  // = the wavefronts resident at once (256 CUs x 8)
 // number of blocks (= kappa partials) of a launch with these arguments

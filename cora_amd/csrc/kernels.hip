@@ -2960,8 +2960,7 @@ template <int LD, int D>
 static hipError_t launch_spmm_ld(const SpmmArgs &A_in, int epi, hipStream_t st) {
   SpmmArgs A = A_in;
   if (LD <= kPoseFirstMaxLD && A.slices_pose_first) A.slices = A.slices_pose_first;
-  static const int win_env = [] { const char *e = std::getenv("CORA_SPMM_WINDOW_MIN_SLICES"); return e ? std::atoi(e) : kWinMinSlices; }();
-  A.win_on = A.n_slices >= win_env ? 1 : 0;
+  A.win_on = A.n_slices >= g_win_min_slices ? 1 : 0;
   A.n_real_chunks = A.n_chunks;
   A.n_chunks = (A.n_chunks + 7) & ~7;
   A.n_slice_blocks = A.n_slices;
@@ -2998,6 +2997,9 @@ hipError_t launch_spmm_g3(const SpmmArgs &A, int ld, int d, int epi, hipStream_t
 hipError_t launch_spmm_g4(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
 hipError_t launch_spmm_g5(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);
 #if CORA_LDG & 1
+// slices from which the pose slices read X through their LDS windows (kWinMinSlices; CORA_SPMM_WINDOW_MIN_SLICES or
+// cora_debug_spmm_window_min_slices: the tests run the window form of every row stride on small problems)
+int g_win_min_slices = [] { const char *e = std::getenv("CORA_SPMM_WINDOW_MIN_SLICES"); return e ? std::atoi(e) : kWinMinSlices; }();
 SPMM_GROUP(0)
 hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st) {
   if (ld <= 5) return launch_spmm_g0(A, ld, d, epi, st);

@@ -395,6 +395,11 @@ int cora_comm_counters(const cora_ctx *ctx, long out[2]);
  * 1 (Q - Lambda) X, 2 the Hessian-vector product.  What a first run on several GPUs is read with (bench.py --gpus N). */
 int cora_debug_product_phases(cora_ctx *ctx, const double *dX, double *dOut, int epi, int reps, double us[5]);
 
+/* Test hook (process-wide): the pose slices of a product read X through their LDS windows from this many slices on
+ * (default 2 048 = the wavefronts resident at once; below, every wavefront is resident and gathers directly).  Returns
+ * the previous value; a negative argument only queries.  Results do not depend on it. */
+int cora_debug_spmm_window_min_slices(int min_slices);
+
 /* Timing hook: with on != 0 the products of a partitioned handle skip every collective step (the operand's remote rows
  * are whatever they are, the distributed long rows stay partial sums) -- the kernel alone, for bench.py's roofline leg. */
 int cora_debug_local_products(cora_ctx *ctx, int on);

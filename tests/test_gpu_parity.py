@@ -225,3 +225,89 @@ def test_rank_up_to_24():
     c = ctx_for(Q, dm, 3)
     with pytest.raises(capi.CoraError):
         c.set_rank(25)
+
+
+@pytest.fixture
+def window_form():
+    """Forces the LDS-window form of the pose slices (default: from 2 048 slices on) for the duration of a test."""
+    L = capi.load()
+    old = L.cora_debug_spmm_window_min_slices(0)
+    yield
+    L.cora_debug_spmm_window_min_slices(old)
+
+
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("p", list(range(2, 25)))
+def test_window_form_of_every_row_stride(d, p, window_form):
+    """The chain slices have two forms (X through LDS windows filled by LDS-DMA with staged stores / direct gathers) and,
+    by row stride, three ways to hold their work (translation row fused into the slots, translation row first, one
+    wavefront per SIMD).  Small problems take the gather form, so every stride's WINDOW form is run here on a small
+    problem -- Q X, (Q - Lambda) X, the Hvp, the Hvp with kappa (through one STPCG iteration's product) -- against the
+    oracle; ragged last slice (n not a multiple of 64), loop closures (general slots), several ranges per pose (tails)."""
+    if p < d:
+        pytest.skip("p >= d")
+    A, Q, dm = make_problem(d=d, n=333, n_landmarks=3, n_ranges=500, n_loops=7, seed=40 + p)
+    c = ctx_for(Q, dm, p)
+    rng = np.random.default_rng(p)
+    Y = orc.project_manifold(dm, rng.uniform(-1, 1, (dm.N, p)))
+    G = orc.egrad(Q, Y)
+    V = orc.tangent_proj(dm, Y, rng.uniform(-1, 1, (dm.N, p)))
+    X = rng.standard_normal((dm.N, p))
+    c.set_point(Y)
+    assert relerr(c.dataMatrixProduct(X), orc.spmm(Q, X)) < REL
+    st, ob = orc.lambda_blocks(Q, dm, Y)
+    assert relerr(c.certificate_product(X), orc.S_apply(Q, dm, st, ob, X)) < REL
+    ref = orc.hvp(Q, dm, Y, G, V)
+    assert relerr(c.Riemannian_Hessian_vector_product(Y, G, V), ref) < REL
+    if p <= 12:  # the product with the kappa slots: <V, H V> as the device STPCG's first iteration sees it
+        y, g, s, r, v, pk, hp = (c.dev_alloc(p) for _ in range(7))
+        c.upload(Y, y)
+        c.set_point_dev(y)
+        c.upload(V, g)
+        c.precond_setup(capi.PRECOND_NONE)
+        c.stpcg_dev(g, 1e-30, s, r, v, pk, hp, max_iters=1)   # radius ~ 0: one product, then the boundary step
+        Hp = c.download(hp, p)
+        Pk = c.download(pk, p)
+        assert relerr(Hp, orc.hvp(Q, dm, Y, G, Pk)) < REL
+    c.close()
+
+
+@pytest.mark.parametrize("p", [4, 5, 8])
+def test_heavy_tails_and_window_form(p, window_form):
+    """More than 64 pairs in a slice's tail (three range measurements per pose on average: the second and third round
+    of the wavefront's gather), in both forms of the kernel."""
+    A, Q, dm = make_problem(d=3, n=200, n_landmarks=6, n_ranges=650, seed=77)
+    L = capi.load()
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((dm.N, p))
+    Y = orc.project_manifold(dm, rng.uniform(-1, 1, (dm.N, p)))
+    G = orc.egrad(Q, Y)
+    V = orc.tangent_proj(dm, Y, rng.uniform(-1, 1, (dm.N, p)))
+    for win in (0, 1 << 30):
+        L.cora_debug_spmm_window_min_slices(win)
+        c = ctx_for(Q, dm, p)
+        assert relerr(c.dataMatrixProduct(X), orc.spmm(Q, X)) < REL
+        assert relerr(c.Riemannian_Hessian_vector_product(Y, G, V), orc.hvp(Q, dm, Y, G, V)) < REL
+        c.close()
+
+
+def test_matrix_without_the_symmetries_keeps_the_plain_layout(window_form):
+    """The chain layout relies on Q = Q^T in three places and checks each bit for bit when the format is built; a matrix
+    that breaks one (the data-matrix product accepts any CSR) keeps the plain layout for the slices concerned and the
+    product stays exact."""
+    import scipy.sparse as sp
+    A, Q, dm = make_problem(d=3, n=150, n_landmarks=2, n_ranges=100, seed=5)
+    S = Q.to_scipy().tolil()
+    tb = dm.dn + dm.r
+    S[tb + 70, 3 * 70 + 1] *= 1.5          # Q31 != Q13^T on pose 70's own block  -> its slice falls back
+    S[3 * 10 + 2, 3 * 9 + 1] += 0.25       # the block coupling poses 9 and 10 is no longer the transpose of its mirror
+    S = S.tocsr()
+    S.sort_indices()
+    Q2 = orc.CSR.from_scipy(S)
+    full = ctx_for(Q, dm, 5).format_stats()
+    c = ctx_for(Q2, dm, 5)
+    st = c.format_stats()
+    assert st["slices"] > full["slices"]   # translation-row slices are back for the slices that fell back
+    X = np.random.default_rng(2).standard_normal((dm.N, 5))
+    assert relerr(c.dataMatrixProduct(X), orc.spmm(Q2, X)) < REL
+    c.close()

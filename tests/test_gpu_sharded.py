@@ -442,3 +442,42 @@ def test_bench_two_ranks_runs_end_to_end_over_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0
     assert d["parity_max_rel_err_vs_cpu"] < 1e-10
     assert "multi_gpu" in d and d["multi_gpu"]["exchanged_rows_per_product"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_products_in_the_window_form(world):
+    """The LDS-window form of the chain slices on partitions (windows clipped to the shard's rows, a shard's first pose
+    with its predecessor on another rank, remote landmark rows in the tails), serial and overlapped: at the sizes of the
+    other tests every shard takes the gather form, so the window form is forced here."""
+    L = capi.load()
+    old = L.cora_debug_spmm_window_min_slices(0)
+    try:
+        n, p = 1000, 5
+        P1 = _problem(n, p)
+        dm = P1.dims()
+        _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
+        Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+        dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+        rng = np.random.default_rng(9)
+        Y = orc.project_manifold(dims, rng.uniform(-1, 1, (dm["N"], p)))
+        V = orc.tangent_proj(dims, Y, rng.uniform(-1, 1, (dm["N"], p)))
+        ref = orc.hvp(Q, dims, Y, orc.egrad(Q, Y), V)
+        ref_qx = orc.spmm(Q, V)
+
+        def body(r, group):
+            P = _problem(n, p)
+            comm = P.set_partition(r, world, lambda ctx: NativeLocalComm(ctx, group))
+            out = []
+            for mode in (0, 2):
+                comm.overlap(mode)
+                out.append((P.op("Riemannian_Hessian_vector_product", Y, P.op("Euclidean_gradient", Y), V),
+                            P.op("Euclidean_gradient", V)))   # (= Q V)
+            return out
+
+        for res in _run_ranks(world, body, "native"):
+            for H, QX in res:
+                assert np.abs(H - ref).max() < 1e-10 * np.abs(ref).max()
+                assert np.abs(QX - ref_qx).max() < 1e-10 * np.abs(ref_qx).max()
+            assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    finally:
+        L.cora_debug_spmm_window_min_slices(old)
