@@ -355,7 +355,7 @@ void Problem::fillImplicitFormulationMatrices() const {
   if (const char *env = std::getenv("CORA_ND_LEAF")) leaf = std::max(1, std::atoi(env));
   SparseMatrix none(nt, nt);
   const auto perm = coraOrdering(0, numPoses(), 0, static_cast<int>(nt), none, static_cast<int>(m), leaf);
-  const CholeskyFactor F = choleskyFactor(M, static_cast<int>(m), 0.0, perm);
+  const CholeskyFactor F = choleskyFactor(M, static_cast<int>(m), 0.0, perm, symbolic_cache_.get());
   if (!F.ok)
     throw std::runtime_error("Problem::fillImplicitFormulationMatrices: the reduced translation block of Q is "
                              "not positive definite (disconnected measurement graph?)");
@@ -484,10 +484,10 @@ void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
     // factorisation of the whole matrix, or of this rank's diagonal block (F.perm then holds API rows again)
     auto factorise = [&](const SparseMatrix &A, double shift) {
       wait_for_order();
-      if (!sharded) return choleskyFactor(A, m, shift, perm);
+      if (!sharded) return choleskyFactor(A, m, shift, perm, symbolic_cache_.get());
       const SparseMatrix B = local_block(A);
       const auto lperm = coraOrdering(dim_, n_loc, r_loc, nt_loc, B, m_fac, leaf);
-      CholeskyFactor Fl = choleskyFactor(B, m_fac, shift, lperm);
+      CholeskyFactor Fl = choleskyFactor(B, m_fac, shift, lperm, symbolic_cache_.get());
       for (int32_t &q : Fl.perm) q = own[static_cast<size_t>(q)];
       return Fl;
     };
@@ -1012,12 +1012,12 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
     if (cora_certificate_product_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
   };
   tick("start block + ordering");
-  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop);
+  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, nullptr, symbolic_cache_.get());
   tick("fast_verification");
   while (std::isnan(results.theta)) {  // :1076-1083
     std::cout << "NaN in theta -- result not certified" << std::endl;
     eta *= 2;
-    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop);
+    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, nullptr, symbolic_cache_.get());
   }
   if (!results.is_certified && formulation_ == Formulation::Implicit) {  // :1085-1100
     // leading (rotation + range) part of the direction, and its Rayleigh quotient with the

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "CORA_types.h"
+#include "sparse_cholesky.h"
 #include "Measurements.h"
 #include "Symbol.h"
 
@@ -76,6 +77,9 @@ class Problem {
   mutable Scalar precond_lambda_ = 0;   // regularisation actually used
   mutable long precond_nnz_ = 0;         // nnz(L)
   mutable int precond_levels_ = 0;       // height of the elimination tree
+  // symbolic analyses of this problem's factorisations (preconditioner block, certificate matrix): kept with the
+  // Problem and gone with it (shared between copies of one Problem: they factorise the same patterns)
+  mutable std::shared_ptr<SymbolicCache> symbolic_cache_ = std::make_shared<SymbolicCache>();
   mutable std::vector<int32_t> cert_perm_;  // elimination order of the full certificate matrix (pattern-only: kept per data matrix)
   // S = Q - Lambda(Y) kept between certifications: its pattern is Q's plus the Lambda blocks, only the entries under
   // Lambda change with Y.  cert_lambda_pos_: position in cert_S_.values of every Lambda entry (pose-block entries row
@@ -180,6 +184,7 @@ class Problem {
   // blocks (every rank factorises the diagonal block of ITS rows of Q + lambda I: weaker than the reference's global
   // factor, more inner iterations).  Not sharded: the implicit formulation (use explicit) and the ILDL branch of
   // fast_verification (skipped).  Call before the first operator.
+  SymbolicCache *symbolicCache() const { return symbolic_cache_.get(); }
   void setPartition(int rank, int world, cora_exchange_fn exchange, cora_allreduce_fn allreduce,
                     cora_allgather_fn allgather, void *user) {
     part_rank_ = rank;

@@ -45,17 +45,17 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
                               const std::vector<int32_t> &perm_in, cora_ctx *ctx,
                               const std::optional<DeviceOperator> &S_op,
                               const std::optional<DeviceOperator> &precond, Scalar max_fill_factor, Scalar drop_tol,
-                              const FastVerificationLab *lab) {
+                              const FastVerificationLab *lab, SymbolicCache *symbolic) {
   if (X0.rows() != S.rows()) throw std::invalid_argument("fast_verification: the start block has the wrong number of rows");
   return fast_verification(S, eta, std::vector<HostColumns>{HostColumns{X0.data(), static_cast<int>(X0.cols())}}, max_iters,
-                           perm_in, ctx, S_op, precond, max_fill_factor, drop_tol, lab);
+                           perm_in, ctx, S_op, precond, max_fill_factor, drop_tol, lab, symbolic);
 }
 
 CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vector<HostColumns> &X0, size_t max_iters,
                               const std::vector<int32_t> &perm_in, cora_ctx *ctx,
                               const std::optional<DeviceOperator> &S_op,
                               const std::optional<DeviceOperator> &precond, Scalar max_fill_factor, Scalar drop_tol,
-                              const FastVerificationLab *lab) {
+                              const FastVerificationLab *lab, SymbolicCache *symbolic) {
   const Index n = S.rows();
   int x0_cols = 0;
   for (const HostColumns &h : X0) x0_cols += h.cols;
@@ -75,7 +75,7 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
     if (timing) std::fprintf(stderr, "    [verify] %-24s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
-  const CholeskyFactor F = choleskyFactor(S, static_cast<int>(n), eta, perm);
+  const CholeskyFactor F = choleskyFactor(S, static_cast<int>(n), eta, perm, symbolic);
   tick("Cholesky of S + eta I");
   const bool PSD = F.ok;
   results.is_certified = PSD;

@@ -35,7 +35,8 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const Matrix &X
                               const std::vector<int32_t> &perm = {}, cora_ctx *ctx = nullptr,
                               const std::optional<DeviceOperator> &S_op = std::nullopt,
                               const std::optional<DeviceOperator> &precond = std::nullopt,
-                              Scalar max_fill_factor = 3, Scalar drop_tol = 1e-3, const FastVerificationLab *lab = nullptr);
+                              Scalar max_fill_factor = 3, Scalar drop_tol = 1e-3, const FastVerificationLab *lab = nullptr,
+                              SymbolicCache *symbolic = nullptr);
 
 /** The same with the start block given as pieces of host memory put side by side (columns of the previous level's
  * eigenvectors, cached random columns): nothing of size N x m is assembled on the host. */
@@ -43,7 +44,8 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
                               const std::vector<int32_t> &perm = {}, cora_ctx *ctx = nullptr,
                               const std::optional<DeviceOperator> &S_op = std::nullopt,
                               const std::optional<DeviceOperator> &precond = std::nullopt,
-                              Scalar max_fill_factor = 3, Scalar drop_tol = 1e-3, const FastVerificationLab *lab = nullptr);
+                              Scalar max_fill_factor = 3, Scalar drop_tol = 1e-3, const FastVerificationLab *lab = nullptr,
+                              SymbolicCache *symbolic = nullptr);
 
 inline CertResults fast_verification(const SparseMatrix &S, Scalar eta, size_t nx, size_t max_iters = 1000) {
   return fast_verification(S, eta, Matrix::Random(S.rows(), static_cast<Index>(nx)), max_iters);

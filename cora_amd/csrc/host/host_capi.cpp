@@ -434,7 +434,7 @@ int cora_problem_cholesky_solve(cora_problem *p, int m, double shift, int leaf_p
     const SparseMatrix &Q = q.getDataMatrix();
     const auto perm = coraOrdering(q.dim(), q.numPoses(), q.numRangeMeasurements(), q.numTranslationalStates(),
                                    Q, m, leaf_poses > 0 ? leaf_poses : 16);
-    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
+    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm, q.symbolicCache());
     info[0] = F.ok ? 1 : 0;
     info[1] = F.nnz();
     int height = 0;
@@ -473,7 +473,7 @@ int cora_problem_cholesky_probe_bumped(cora_problem *p, int m, double shift, int
       }
     }
     const SparseMatrix &Q = nbump > 0 ? bumped : Q0;
-    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
+    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm, q.symbolicCache());
     info[0] = F.ok ? 1 : 0;
     info[1] = F.nnz();
     info[2] = F.failed_column;
@@ -504,7 +504,7 @@ int cora_problem_plan_probe(cora_problem *p, double shift, int leaf_poses, int64
     const int N = static_cast<int>(Q.rows()), m = N - 1;
     const auto perm = coraOrdering(q.dim(), q.numPoses(), q.numRangeMeasurements(), q.numTranslationalStates(), Q, m,
                                    leaf_poses > 0 ? leaf_poses : 2);
-    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm);
+    const CholeskyFactor F = choleskyFactor(Q, m, shift, perm, q.symbolicCache());
     if (!F.ok) throw std::runtime_error("plan probe: the factorisation failed");
     // rows in API order stand in for the handle's internal order (the probe is about the builder's time and the
     // plan's shape, not about a particular handle); pose groups as capi.hip forms them

@@ -190,11 +190,19 @@ void parallelRun(unsigned nth, Body body) {
 }
 
 
-std::mutex g_sym_mutex;
-std::shared_ptr<const Symbolic> g_sym[2];  // the two most recent patterns (preconditioner block, certificate matrix)
+}  // namespace
+
+struct SymbolicCache::Impl {
+  std::mutex m;
+  std::shared_ptr<const Symbolic> slot[2];  // the two most recent patterns (preconditioner block, certificate matrix)
+};
+SymbolicCache::SymbolicCache() : impl(new Impl) {}
+SymbolicCache::~SymbolicCache() { delete impl; }
+
+namespace {
 
 std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const std::vector<int32_t> &perm,
-                                            const std::vector<int32_t> &iperm, bool *hit) {
+                                            const std::vector<int32_t> &iperm, bool *hit, SymbolicCache *cache) {
   *hit = false;
   // two independent 64-bit hashes of (outer, inner, perm) -- a stale hit would write a factor through the wrong column
   // counts, so the pair has to collide, not one word (round-2 advice).  The 17 M words are hashed in eight pieces on
@@ -223,14 +231,15 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
         key2 ^= key2 >> 31;
       }
   }
-  const bool use_cache = std::getenv("CORA_CHOL_NO_SYMBOLIC_CACHE") == nullptr;
+  const bool use_cache = cache != nullptr && std::getenv("CORA_CHOL_NO_SYMBOLIC_CACHE") == nullptr;
   if (use_cache) {
-    std::lock_guard<std::mutex> lock(g_sym_mutex);
+    std::lock_guard<std::mutex> lock(cache->impl->m);
+    auto &slot = cache->impl->slot;
     for (int e = 0; e < 2; ++e)
-      if (g_sym[e] && g_sym[e]->key == key && g_sym[e]->key2 == key2 && g_sym[e]->n == n && g_sym[e]->nnzA == A.inner.size()) {
-        if (e == 1) std::swap(g_sym[0], g_sym[1]);
+      if (slot[e] && slot[e]->key == key && slot[e]->key2 == key2 && slot[e]->n == n && slot[e]->nnzA == A.inner.size()) {
+        if (e == 1) std::swap(slot[0], slot[1]);
         *hit = true;
-        return g_sym[0];
+        return slot[0];
       }
   }
   const bool timing_ = std::getenv("CORA_TRI_TIMING") != nullptr;
@@ -341,9 +350,9 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   S->Lp[n] = static_cast<int32_t>(tot);
   S->tot = tot;
   if (use_cache) {
-    std::lock_guard<std::mutex> lock(g_sym_mutex);
-    g_sym[1] = g_sym[0];
-    g_sym[0] = S;
+    std::lock_guard<std::mutex> lock(cache->impl->m);
+    cache->impl->slot[1] = cache->impl->slot[0];
+    cache->impl->slot[0] = S;
   }
   return S;
 }
@@ -426,7 +435,8 @@ CholeskyFactor::~CholeskyFactor() {
   if (g_pool_i.size() < kStoragePoolMax) g_pool_i.push_back(std::move(Li));
 }
 
-CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm) {
+CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
+                              SymbolicCache *cache) {
   CholeskyFactor F;
   const int n = m;
   F.n = n;
@@ -446,7 +456,7 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
   // S + eta I is factorised up to three times per staircase on one pattern, like CHOLMOD's analyze / factorize split
   // behind Eigen's analyzePattern.
   bool sym_hit = false;
-  const std::shared_ptr<const Symbolic> sym = symbolicFor(A, n, perm, F.iperm, &sym_hit);
+  const std::shared_ptr<const Symbolic> sym = symbolicFor(A, n, perm, F.iperm, &sym_hit, cache);
   const std::vector<int32_t> &Cp = sym->Cp, &Ci = sym->Ci, &cnt = sym->cnt;
   const int64_t tot = sym->tot;
   std::vector<double> Cx(static_cast<size_t>(Cp[n]));

@@ -49,9 +49,25 @@ struct CholeskyFactor {
  * Q is only used to attach range rows to poses. Returns new -> old. */
 std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatrix &Q, int m, int leaf_poses = 16);
 
+/** The pattern-only part of a factorisation (permuted structure, elimination tree, column counts: CHOLMOD's analyze
+ * step), kept between factorisations of matrices with one pattern and order.  Owned by whoever owns the matrices -- a
+ * CORA::Problem keeps one for its preconditioner block and its certificate matrix -- and gone with it; holds the two most
+ * recent patterns, keyed by two independent hashes of (pattern, order).  Thread-safe. */
+class SymbolicCache {
+ public:
+  SymbolicCache();
+  ~SymbolicCache();
+  SymbolicCache(const SymbolicCache &) = delete;
+  SymbolicCache &operator=(const SymbolicCache &) = delete;
+  struct Impl;
+  Impl *impl;
+};
+
 /** LL^T of the leading m x m block of the symmetric matrix A (full pattern,
- * both triangles) plus shift * I, in the order perm (new -> old). */
-CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm);
+ * both triangles) plus shift * I, in the order perm (new -> old).  cache: where the symbolic analysis is looked up
+ * and left (nullptr: analysed afresh every time); the factor is the same bit for bit either way. */
+CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
+                              SymbolicCache *cache = nullptr);
 
 /** Incomplete L D L^T of the symmetric (possibly INDEFINITE) matrix A[0:m, 0:m] + shift * I in the order perm --
  * the stand-in for Preconditioners::ILDL (libs/Preconditioners, un-vendored submodule; reference call
