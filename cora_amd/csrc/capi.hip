@@ -987,11 +987,17 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       H.b_hdr.resize(H.b_hdr.size() + 8, 0);
       HIP_TRY(c, up(&Q.fwd.hdr, H.f_hdr));
       HIP_TRY(c, up(&Q.fwd.idx, H.f_idx));
+      static const bool f32 = std::getenv("CORA_SUB_F32") != nullptr;  // lab: with a -DCORA_SUB_F32=1 build of the sweeps
+      if (f32) {
+        std::vector<float> ff(H.f_val.begin(), H.f_val.end()), fb(H.b_val.begin(), H.b_val.end());
+        HIP_TRY(c, up(reinterpret_cast<float **>(const_cast<double **>(&Q.fwd.val)), ff));
+        HIP_TRY(c, up(reinterpret_cast<float **>(const_cast<double **>(&Q.bwd.val)), fb));
+      } else
       HIP_TRY(c, up(&Q.fwd.val, H.f_val));
       HIP_TRY(c, up(&Q.bwd.rows, H.b_rows));
       HIP_TRY(c, up(&Q.bwd.hdr, H.b_hdr));
       HIP_TRY(c, up(&Q.bwd.idx, H.b_idx));
-      HIP_TRY(c, up(&Q.bwd.val, H.b_val));
+      if (!f32) HIP_TRY(c, up(&Q.bwd.val, H.b_val));
       HIP_TRY(c, up(&Q.tgt_row, H.tgt_row));
       HIP_TRY(c, up(&Q.tgt_slot, H.tgt_slot));
       HIP_TRY(c, up(&Q.c_ptr, H.c_ptr));

@@ -1,10 +1,9 @@
 // HIP kernels for the CORA hot path on gfx950 (CDNA4, wave64).
 //
-// All resident vectors are row-major  rows x LD  doubles (LD even, padding
-// columns zero), so one row is LD*8 contiguous bytes and a d x LD pose block is
-// contiguous as well.  fp64 throughout (the reference's `typedef double Scalar`,
-// include/CORA/CORA_types.h:43).  No MFMA: the path is HBM/L2-bound
-// (0.49 flop/B at p = 5).
+// All resident vectors are row-major  rows x LD  doubles with LD = the number of columns (2..24, no padding
+// columns), so one row is LD*8 contiguous bytes and a d x LD pose block is contiguous as well.  fp64 throughout (the
+// reference's `typedef double Scalar`, include/CORA/CORA_types.h:43).  No MFMA in the products: the path is
+// HBM/L2-bound (0.49 flop/B at p = 5); the fp64 matrix cores serve the Gram / combine kernels of LOBPCG only.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -307,26 +306,8 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_COOP_EPI
 #define CORA_POSE_COOP_EPI 1
 #endif
-#ifndef CORA_POSE_PREFETCH
-#define CORA_POSE_PREFETCH 0
-#endif
-#ifndef CORA_POSE_PREFETCH_V
-#define CORA_POSE_PREFETCH_V 4  // value lines: 4 x 64 lines x 64 B = 16 KB, a pose slice of up to 10 slots at d = 3
-#endif
 #ifndef CORA_ROW_UNROLL
 #define CORA_ROW_UNROLL 4  // gathers in flight per lane of a row slice (translation / range rows)
-#endif
-#ifndef CORA_POSE_EARLY_SLOTS
-#define CORA_POSE_EARLY_SLOTS 0
-#endif
-#ifndef CORA_EPI_X2
-#define CORA_EPI_X2 1
-#endif
-#ifndef CORA_WIN_COPY_X2
-#define CORA_WIN_COPY_X2 1
-#endif
-#ifndef CORA_WIN_DMA
-#define CORA_WIN_DMA 1
 #endif
 #ifndef CORA_COOP_PREFETCH_LATE
 #define CORA_COOP_PREFETCH_LATE 1
@@ -441,7 +422,7 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   constexpr int kNeedEl = (kCoopT && kCoopEl > kStagedEl) ? kCoopEl : kStagedEl;
   constexpr int kSmemEl = !kWinLD ? 1 : (kNeedEl > kWinEl ? kNeedEl : kWinEl);
   __shared__ __attribute__((aligned(16))) double win[kSmemEl];
-  constexpr int kYIt = (D * LD + 1) / 2, kLIt = (D * D + 1) / 2;  // (CORA_EPI_X2: pairs of doubles per lane and access)
+  constexpr int kYIt = (D * LD + 1) / 2, kLIt = (D * D + 1) / 2;  // (pairs of doubles per lane and access)
   double ystage[kCoopT ? 2 * kYIt : 1], lstage[kCoopT ? 2 * kLIt : 1];
   // Chain layout (kSliceChainFlag, cora_internal.h): the lane owns the pose's translation row as well, the chain's columns
   // are implied, and what Q's symmetry gives comes from the lane before (lane 0: the slice's head block).
@@ -493,7 +474,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     if constexpr (kCoopT) {
       const double *__restrict__ Yp = A.Y + static_cast<size_t>(sd.row0) * LD;
       const double *__restrict__ Lq = A.lam_st + static_cast<size_t>(sd.aux0) * (D * D);
-#if CORA_EPI_X2
 #pragma unroll
       // ONE predicate per access (an odd count reads one double past the slice's rows: Y has the range rows behind
       // its rotation rows, the Lambda array is allocated with the slack).  The two-way form -- a pair, else a single
@@ -514,18 +494,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
         lstage[2 * i] = v.x;
         lstage[2 * i + 1] = v.y;
       }
-#else
-#pragma unroll
-      for (int i = 0; i < D * LD; ++i) {
-        const int e = i * kWave + lane;
-        ystage[i] = e < sd.nrows * D * LD ? Yp[e] : 0.0;
-      }
-#pragma unroll
-      for (int i = 0; i < D * D; ++i) {
-        const int e = i * kWave + lane;
-        lstage[i] = e < sd.nrows * D * D ? Lq[e] : 0.0;
-      }
-#endif
     }
   };
   if (kCoop && !(chain && CORA_COOP_PREFETCH_LATE)) coop_prefetch();
@@ -537,7 +505,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     ntr = kTrnRows ? max(min(A.win_trn_lo + sd.aux0 + kWave + 1, A.win_trn_hi) - t0, 0) : 0;
     const double *__restrict__ srot = X + static_cast<size_t>(w0) * LD;
     const double *__restrict__ strn = X + static_cast<size_t>(t0) * LD;
-#if CORA_WIN_DMA
     // LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight into the window -- wave-uniform LDS base + lane x 16,
     // per-lane source address --, no staging registers (44 at a row stride of 5: what kept the Hvp from holding its
     // other operands in flight) and no LDS-store pass.  Lanes past the end of the window's rows are masked off: LDS
@@ -565,64 +532,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       if ((nre & 1) && lane == 0) win[nre - 1] = srot[nre - 1];
       if ((nte & 1) && lane == 1) win[kRotEl + nte - 1] = strn[nte - 1];
     }
-#elif CORA_WIN_COPY_X2
-    // two doubles per lane and load (half the load and LDS-store instructions of the copy; rows are 8-byte aligned,
-    // which is all a dwordx4 access needs on this part)
-    constexpr int kRotEl = kRotRows * LD, kTrnEl = kTrnRows * LD;
-    constexpr int kRotIt = (kRotEl + 2 * kWave - 1) / (2 * kWave), kTrnIt = (kTrnEl + 2 * kWave - 1) / (2 * kWave);
-    Pair8 stage[kRotIt + kTrnIt + 1];
-#pragma unroll
-    for (int i = 0; i < kRotIt; ++i) {
-      const int e = 2 * (i * kWave + lane);
-      Pair8 v{0.0, 0.0};
-      if (e + 1 < nrot * LD) v = *reinterpret_cast<const Pair8 *>(srot + e);
-      else if (e < nrot * LD) v.x = srot[e];
-      stage[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < kTrnIt; ++i) {
-      const int e = 2 * (i * kWave + lane);
-      Pair8 v{0.0, 0.0};
-      if (e + 1 < ntr * LD) v = *reinterpret_cast<const Pair8 *>(strn + e);
-      else if (e < ntr * LD) v.x = strn[e];
-      stage[kRotIt + i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < kRotIt; ++i) {
-      const int e = 2 * (i * kWave + lane);
-      if (e < kRotEl) win[e] = stage[i].x;
-      if (e + 1 < kRotEl) win[e + 1] = stage[i].y;
-    }
-#pragma unroll
-    for (int i = 0; i < kTrnIt; ++i) {
-      const int e = 2 * (i * kWave + lane);
-      if (e < kTrnEl) win[kRotEl + e] = stage[kRotIt + i].x;
-      if (e + 1 < kTrnEl) win[kRotEl + e + 1] = stage[kRotIt + i].y;
-    }
-#else
-    constexpr int kRotIt = (kRotRows * LD + kWave - 1) / kWave, kTrnIt = (kTrnRows * LD + kWave - 1) / kWave;
-    double stage[kRotIt + kTrnIt + 1];
-#pragma unroll
-    for (int i = 0; i < kRotIt; ++i) {
-      const int e = i * kWave + lane;
-      stage[i] = e < nrot * LD ? srot[e] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < kTrnIt; ++i) {
-      const int e = i * kWave + lane;
-      stage[kRotIt + i] = e < ntr * LD ? strn[e] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < kRotIt; ++i) {
-      const int e = i * kWave + lane;
-      if (e < kRotRows * LD) win[e] = stage[i];
-    }
-#pragma unroll
-    for (int i = 0; i < kTrnIt; ++i) {
-      const int e = i * kWave + lane;
-      if (e < kTrnRows * LD) win[kRotRows * LD + e] = stage[kRotIt + i];
-    }
-#endif
     __syncthreads();
   }
   CORA_PHASE(0);  // the windows (and everything requested with them) have landed
@@ -630,24 +539,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   if (threadIdx.x == 0 && blockIdx.x < kSpmmTimesMax)  // where the wavefront runs: HW_ID (reg 4) | XCC_ID (reg 20) << 32
     g_spmm_phase[kSpmmPhases * blockIdx.x + 5] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
                                                  (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
-#endif
-#if CORA_POSE_PREFETCH
-  // every cache line of the slice's value and index streams is requested here, next to the window's loads: the slot
-  // loop below waits for its loads trip after trip (registers allow two slots in flight), and with the working set in
-  // HBM each of those waits was a full memory latency; now they are L2 / Infinity Cache hits.  One dword per 64-byte
-  // line and lane, results never used.
-  int pfv[CORA_POSE_PREFETCH_V + 1];
-  if (kWin) {
-    const char *vb = reinterpret_cast<const char *>(A.sval + sd.off);
-    const int vbytes = sd.width * D * kWave * 8, cbytes = sd.width * kWave * 4;
-#pragma unroll
-    for (int i = 0; i < CORA_POSE_PREFETCH_V; ++i) {
-      const int o = (i * kWave + lane) * 64;
-      pfv[i] = *reinterpret_cast<const int *>(vb + (o < vbytes ? o : 0));
-    }
-    const int o = lane * 64;
-    pfv[CORA_POSE_PREFETCH_V] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.scol + sd.coff) + (o < cbytes ? o : 0));
-  }
 #endif
   // the tail's first round: pair `lane` gathers its two rows of X now (the indices have arrived with the window's rows;
   // lanes past the tail read a valid row and multiply it by zero)
@@ -919,12 +810,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
   CORA_PHASE(2);  // general slots done
   if (kFuseT && chain) translation_tail();
   CORA_PHASE(3);  // tail done
-#if CORA_POSE_PREFETCH
-  if (kWin) {
-#pragma unroll
-    for (int i = 0; i <= CORA_POSE_PREFETCH_V; ++i) asm volatile("" ::"v"(pfv[i]));
-  }
-#endif
   // the slice's result rows leave through LDS: rotation rows and translation rows are runs of consecutive rows, stored as
   // full 512-byte pieces instead of 16-byte pieces of 64 different lines
   auto staged_store = [&] {
@@ -940,7 +825,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
     }
     __syncthreads();
     double *__restrict__ op = A.out + static_cast<size_t>(sd.row0) * LD;
-#if CORA_EPI_X2
 #pragma unroll
     for (int i = 0; i < kYIt; ++i) {
       const int e = 2 * (i * kWave + lane), n = sd.nrows * D * LD;
@@ -951,13 +835,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
         op[e] = win[e];
       }
     }
-#else
-#pragma unroll
-    for (int i = 0; i < D * LD; ++i) {
-      const int e = i * kWave + lane;
-      if (e < sd.nrows * D * LD) op[e] = win[e];
-    }
-#endif
     if (kFuseT && chain) {  // the slice's translation rows: consecutive rows as well
       double *__restrict__ ot = A.out + static_cast<size_t>(A.win_trn_lo + sd.aux0) * LD;
       constexpr int kTIt = (LD + 1) / 2;
@@ -982,7 +859,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       for (int j = 0; j < LD; ++j) xo[b][j] = win[l * LD + j];
     }
     __syncthreads();
-#if CORA_EPI_X2
 #pragma unroll
     for (int i = 0; i < kYIt; ++i) {
       const int e = 2 * (i * kWave + lane);
@@ -995,12 +871,6 @@ __device__ __forceinline__ double pose_slice(const SpmmArgs &A, const SliceDesc 
       if (e < kLEl) win[kYEl + e] = lstage[2 * i];
       if (e + 1 < kLEl) win[kYEl + e + 1] = lstage[2 * i + 1];
     }
-#else
-#pragma unroll
-    for (int i = 0; i < D * LD; ++i) win[i * kWave + lane] = ystage[i];
-#pragma unroll
-    for (int i = 0; i < D * D; ++i) win[kYEl + i * kWave + lane] = lstage[i];
-#endif
     __syncthreads();
     double y[D][LD];
 #pragma unroll
@@ -2461,8 +2331,16 @@ __device__ __forceinline__ void group_sum_all(double (&x)[N], int gs) {
   }
 }
 
+#ifndef CORA_SUB_F32
+#define CORA_SUB_F32 0  // lab: the substitution blocks' coefficients stored as fp32 (capi.hip uploads them so with CORA_SUB_F32=1)
+#endif
+#if CORA_SUB_F32
+typedef float SubCoef;
+#else
+typedef double SubCoef;
+#endif
 struct SubRegs {  // a lane's entries of one level: coefficients and (two per dword) local row indices
-  double v[kSubNpl];
+  SubCoef v[kSubNpl];
   uint32_t i[kSubNpl / 2];
 };
 // Pins a register set: the compiler waits HERE for whatever load still writes it (before the next level's loads are
@@ -2582,7 +2460,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   const SubDesc bd = S.desc[b];
   const int nb = bd.nrows, rb = bd.row_begin;
   const int nlev = BWD ? bd.b_nlev : bd.f_nlev;
-  const double *__restrict__ gv = Q.val + (BWD ? bd.b_ent_begin : bd.f_ent_begin);
+  const SubCoef *__restrict__ gv = reinterpret_cast<const SubCoef *>(Q.val) + (BWD ? bd.b_ent_begin : bd.f_ent_begin);
   const uint16_t *__restrict__ gi = Q.idx;
   const int4 *__restrict__ gh = reinterpret_cast<const int4 *>(Q.hdr) + (BWD ? bd.b_lev_begin : bd.f_lev_begin);
   const int wave_base = __builtin_amdgcn_readfirstlane(tid);
@@ -2616,14 +2494,14 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
       const u32x2 q = factor_load(reinterpret_cast<const u32x2 *>(gi + h.w + lane * 4));
       R.i[0] = q.x, R.i[1] = q.y;
     }
-    const double *__restrict__ pv = gv + h.z + lane;
+    const SubCoef *__restrict__ pv = gv + h.z + lane;
 #pragma unroll
     for (int u = 0; u < kSubNpl; ++u)
       if (u < npl) R.v[u] = factor_load(pv + u * nlane);
   };
   SubRegs RA, RB;
 #pragma unroll
-  for (int u = 0; u < kSubNpl; ++u) RA.v[u] = RB.v[u] = 0.0;
+  for (int u = 0; u < kSubNpl; ++u) RA.v[u] = RB.v[u] = 0;
 #pragma unroll
   for (int u = 0; u < kSubNpl / 2; ++u) RA.i[u] = RB.i[u] = 0;
   {
@@ -2740,7 +2618,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
             const double *__restrict__ t = reinterpret_cast<const double *>(smem + __umul24(li, LD * 8)) + c0;
 #pragma unroll
             for (int j = 0; j < CW; ++j)
-              if (c0 + j < LD) s[j] = fma(R.v[u], t[j], s[j]);
+              if (c0 + j < LD) s[j] = fma(static_cast<double>(R.v[u]), t[j], s[j]);
           }
         };
         switch (npl) {
