@@ -1074,7 +1074,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
         // in the tile, and a pose of the last stage has all its rows there.  Row units of a block: {tile position, row}
         const Layout &L = c->F.L;
         const int64_t rot0 = L.rot_base, rot1 = L.rot_base + static_cast<int64_t>(L.d) * L.nl_poses;
-        bool ok = group != nullptr && L.world == 1;
+        bool ok = group != nullptr;  // (a shard's rows are rotations | ranges | translations in this order too: the same tests on the row index)
         std::vector<int2> units;
         for (size_t b = 0; b < desc.size(); ++b) {
           const int32_t *rows = H.b_rows.data() + desc[b].row_begin;
@@ -1282,22 +1282,36 @@ static int chol_solve(cora_ctx *c, int ld, const double *dV, double *dOut) {
 // t = -M^-1 (B^T Y), and B^T Y = translation rows of Q [Y; 0].  Two explicit products and
 // one triangular solve on the translation block; vectors keep N rows, translation rows of the
 // input are ignored and translation rows of the output are zero.
+// Partitioned handle: the two products are the partitioned products (one exchange of the operand each); the translation
+// solve in between is a recurrence over the whole chain, so it is REPLICATED -- the right-hand side's rows are gathered
+// (whole shards in place: one collective) and every rank runs the same solve plan on the same numbers, then keeps its
+// own translations (and already holds the remote ones the second product reads).  Exact: the operator is the single
+// handle's, whatever the partition.
+static int64_t pinned_translation_row(const cora_ctx *c) { return c->F.api2int[static_cast<size_t>(c->F.L.N) - 1]; }
+
 static int implicit_lift(cora_ctx *c, const double *dX, int ld, double *w0, double *w1) {
   const Layout &L = c->F.L;
+  const bool sharded = L.world != 1;
   const size_t toff = static_cast<size_t>(L.trn_base) * ld;
   const size_t tbytes = static_cast<size_t>(L.nl_trans) * ld * sizeof(double);
   HIP_TRY(c, hipMemcpyAsync(w0, dX, vec_bytes(c, ld), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(w0 + toff, 0, tbytes, c->stream));
   SpmmArgs A = spmm_args(c, w0, w1);
-  HIP_TRY(c, launch_spmm(A, ld, L.d, EPI_NONE, c->stream));                      // w1[trans] = B^T X
-  const size_t last = static_cast<size_t>(L.trn_base) + L.nl_trans - 1;           // pinned translation
-  HIP_TRY(c, launch_zero_row(w1, last, ld, c->stream));
+  int rc;
+  if (sharded) {
+    if ((rc = exchange_and_product(c, A, ld, EPI_NONE))) return rc;               // (the exported translations are zero)
+  } else {
+    HIP_TRY(c, launch_spmm(A, ld, L.d, EPI_NONE, c->stream));                      // w1[trans] = B^T X
+  }
+  const int64_t last = pinned_translation_row(c);                                  // pinned translation (the API's last row)
+  const bool mine = last >= L.base && last < L.base + L.shard_rows;
+  if (mine) HIP_TRY(c, launch_zero_row(w1, static_cast<size_t>(last), ld, c->stream));
+  if (sharded && (rc = comm_allgather(c, w1, ld))) return rc;                       // every rank: all rows of B^T X
   double *w2;
-  int rc = get_scratch(c, 8, ld, &w2);
-  if (rc) return rc;
+  if ((rc = get_scratch(c, 8, ld, &w2))) return rc;
   if ((rc = factor_solve(c, c->implicit_f, ld, w1, w2))) return rc;                // w2[trans] = M^-1 B^T X
   HIP_TRY(c, launch_axpby(static_cast<int64_t>(L.nl_trans) * ld, -1.0, w2 + toff, 0.0, w0 + toff, c->stream));
-  HIP_TRY(c, launch_zero_row(w0, last, ld, c->stream));                            // w0 = [X; t; 0]
+  if (mine) HIP_TRY(c, launch_zero_row(w0, static_cast<size_t>(last), ld, c->stream));  // w0 = [X; t; 0]
   return CORA_OK;
 }
 
@@ -1310,7 +1324,11 @@ static int implicit_product(cora_ctx *c, const double *dX, int ld, int epi, doub
   if ((rc = get_scratch(c, 4, ld, &w1))) return rc;
   if ((rc = implicit_lift(c, dX, ld, w0, w1))) return rc;
   SpmmArgs A = spmm_args(c, w0, dOut);
-  HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
+  if (c->F.L.world != 1) {
+    if ((rc = exchange_and_product(c, A, ld, epi))) return rc;
+  } else {
+    HIP_TRY(c, launch_spmm(A, ld, c->F.L.d, epi, c->stream));
+  }
   const Layout &L = c->F.L;
   HIP_TRY(c, hipMemsetAsync(dOut + static_cast<size_t>(L.trn_base) * ld, 0,
                             static_cast<size_t>(L.nl_trans) * ld * sizeof(double), c->stream));
@@ -1502,7 +1520,6 @@ int cora_implicit_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int3
                                const int32_t *perm) {
   NEED_DEVICE(c);
   const Layout &L = c->F.L;
-  if (L.world != 1) return fail(c, CORA_ERR_ARG, "the implicit formulation is single-GPU");
   if (!Lp || !Li || !Lx || !perm || m != L.nt - 1) return fail(c, CORA_ERR_ARG, "factor must have n + l - 1 rows");
   const int64_t tb = static_cast<int64_t>(L.d) * L.n + L.r;
   std::vector<int32_t> row_of(static_cast<size_t>(m));
@@ -1518,15 +1535,22 @@ int cora_implicit_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int3
 int cora_aux_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
                           const int32_t *perm) {
   NEED_DEVICE(c);
-  const int64_t N = c->F.L.N;
-  if (c->F.L.world != 1) return fail(c, CORA_ERR_ARG, "triangular solves do not shard");
-  if (!Lp || !Li || !Lx || !perm || m != N) return fail(c, CORA_ERR_ARG, "factor must have N rows");
+  const Layout &Lo = c->F.L;
+  const int64_t N = Lo.N;
+  // Partitioned handle: the factor of THIS RANK'S rows (block Jacobi over the ranks, like cora_precond_set_cholesky);
+  // the solve then touches the rank's own rows of a vector and nothing else.
+  const bool sharded = Lo.world != 1;
+  const int64_t owned = sharded ? Lo.local_rows : N;
+  if (!Lp || !Li || !Lx || !perm || m != owned)
+    return fail(c, CORA_ERR_ARG, sharded ? "factor must cover the rank's own rows" : "factor must have N rows");
   std::vector<int32_t> row_of(static_cast<size_t>(m));
   std::vector<char> seen(static_cast<size_t>(N), 0);
   for (int i = 0; i < m; ++i) {
     if (perm[i] < 0 || perm[i] >= N || seen[perm[i]]) return fail(c, CORA_ERR_ARG, "perm is not a permutation");
     seen[perm[i]] = 1;
     row_of[i] = c->F.api2int[perm[i]];
+    if (sharded && (row_of[i] < Lo.base || row_of[i] >= Lo.base + Lo.shard_rows))
+      return fail(c, CORA_ERR_ARG, "the factor of a partitioned handle may only hold rows of its own shard");
   }
   return install_factor(c, c->aux_f, m, Lp, Li, Lx, row_of, -1);
 }
@@ -1774,7 +1798,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
     size_t need = std::max<size_t>(4 * 512, static_cast<size_t>((units + 255) / 256) + 8);
     const cora_ctx::DevFactor &f = c->precond_f;
-    sweep_fused = !sharded && chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
+    sweep_fused = !c->implicit && chol && f.ready && f.fuse_ok && !f.stages.empty() && f.stages[0].is_sub && c->ld * c->F.L.d <= 24 && c->ld <= 11 &&
                   !std::getenv("CORA_NO_SWEEP_FUSE");  // (row stride x d > 24: the fused backward sweep spills)
     // slots of the sweep-fused reductions: <r, r> per block of the forward sweep's launch, |y|^2 per solve block,
     // |row|^2 per row of the last stage's forward product
@@ -1920,6 +1944,28 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           HIP_TRY(c, launch_reduce_partials(kappa_partial, kappa_blocks, 1, ds, c->stream));
           if (native_allreduce_dev(c->native_comm, ds, 1)) return fail(c, CORA_ERR_HIP, "all-reduce step failed: " + native_error(c->native_comm));
           HIP_TRY(c, launch_stpcg_scalar_step(0, ds, c->d_stpcg, nullptr, nullptr, 0, c->stream));
+          if (sweep_fused) {
+            // the sweep-fused form on this rank's block-Jacobi factor: forward sweep (r += alpha Hp, slots of <r, r> and
+            // |y|^2) | last stage, whose tail block leaves this rank's <r, r> and <r, v> = |L_k^-1 r_k|^2 | ONE all-reduce
+            // for the two | scalar step | backward sweep (v = Proj_Y(x), s += alpha p, p = -v + beta p).  Three vector
+            // passes fewer than the form below, the same two all-reduces per iteration.
+            cora_ctx::DevFactor &f = c->precond_f;
+            double *t, *t2;
+            if ((rc = get_scratch(c, 6, c->ld, &t, f.aux_rows))) return rc;
+            if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
+            const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
+            HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
+            if (S1.aux_sum) HIP_TRY(c, launch_rowop(S1.fwd_a, c->ld, t, t, t, c->stream));
+            HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream, &sq));
+            tail.sums_out = ds + 2;
+            HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream, &tail));
+            if (native_allreduce_dev(c->native_comm, ds + 2, 2)) return fail(c, CORA_ERR_HIP, "all-reduce step failed: " + native_error(c->native_comm));
+            seq = ++c->dot_seq;
+            HIP_TRY(c, launch_stpcg_scalar_step(1, ds + 2, c->d_stpcg, &c->h_stpcg[0],
+                                                reinterpret_cast<unsigned long long *>(c->h_scalars + 7), seq, c->stream));
+            HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
+            return CORA_OK;
+          }
           DotArgs Ds = D;
           Ds.mode = DOTS_PLAIN;
           Ds.count = 1;

@@ -8,12 +8,16 @@
 // src/CORA_problem.cpp:625-712) with the variable layout of
 // include/CORA/CORA_problem.h:151-157.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 #include "cora_internal.h"
+#include "parallel.h"
 
 namespace cora {
 
@@ -79,6 +83,12 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
                   const int32_t *col, const double *val, int rank, int world,
                   HostFormat &F, bool distribute_long_rows) {
   const bool dist_long = distribute_long_rows && world > 1;
+  const bool timing = std::getenv("CORA_FORMAT_TIMING") != nullptr;
+  auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "  [format] %-28s %.4f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   if (d != 2 && d != 3) throw std::runtime_error("cora: dimension d must be 2 or 3");
   if (n < 0 || r < 0 || nt < n) throw std::runtime_error("cora: invalid problem sizes");
   if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("cora: invalid rank/world");
@@ -98,6 +108,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   }
   auto rowlen = [&](int64_t i) { return rowptr[i + 1] - rowptr[i]; };
 
+  tick("checks");
   // ---- 1. owner of every pose / range row / landmark -----------------------
   std::vector<int> pose_owner(n, 0), range_pose(r, -1), range_lm(r, -1), range_owner(r, 0), lm_owner(l, 0);
   const int64_t tb = dn + r;
@@ -218,6 +229,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     local_range_pose[li] = key;
   }
 
+  tick("owners + numbering");
   // ---- 3. local rows -> slices ---------------------------------------------
   std::vector<double> slice_key;  // position of each slice along the pose chain (work ordering)
   F.slices.clear(); F.sval.clear(); F.scol.clear(); F.perm.clear(); F.head_val.clear();
@@ -225,12 +237,12 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   F.padded_nnz = F.long_nnz = F.nnz_local = 0; F.max_width = 0; F.n_long_rows = 0;
   F.diag.assign(static_cast<size_t>(std::max<int64_t>(L.local_rows, 1)), 0.0);
 
-  auto local_row = [&](int64_t int_row) {
+  auto local_row = [&](int64_t int_row, int64_t *nnz_acc = nullptr) {  // (nnz_acc: a thread's own count, added up later)
     RowRef rr;
     rr.int_row = static_cast<int32_t>(int_row);
     rr.api_row = F.int2api[int_row];
     rr.len = rowlen(rr.api_row);
-    F.nnz_local += rr.len;
+    *(nnz_acc ? nnz_acc : &F.nnz_local) += rr.len;
     for (int32_t q = rowptr[rr.api_row]; q < rowptr[rr.api_row + 1]; ++q)
       if (col[q] == rr.api_row) F.diag[int_row - L.base] += val[q];
     return rr;
@@ -254,63 +266,90 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
   {
     struct PoseCols { std::vector<int32_t> c; std::vector<double> v; };  // v[k*d + a]
     struct RowEnt { std::vector<int32_t> c; std::vector<double> v; };
+    struct Ent { int32_t col, a, seq; double v; };  // one nonzero: internal column, row of the pose, position in the CSR
+    struct ChainLane {
+      double s0[4], s1[4], nxt[9], own[9], hq[3], ht, prev[9];
+      int nlocal = 0;  // pairs of the tail whose columns are rows of this shard (they come first)
+      std::vector<int32_t> gc, tc;
+      std::vector<double> gv, tv;
+    };
+    // a thread's scratch: kept from slice to slice so that the loop allocates nothing once it is warm
+    struct Scratch {
+      std::vector<PoseCols> pc;
+      std::vector<RowEnt> tr;
+      std::vector<ChainLane> cl;
+      std::vector<Ent> ent;
+      std::vector<int32_t> lc, rc;
+      std::vector<double> lv, rv;
+    };
     const int lanes = std::min(kWave, std::max(L.nl_poses, 1));
-    std::vector<PoseCols> pc(lanes);
-    std::vector<RowEnt> tr(lanes);
     const int FV = kChainFixed(d), HV = kChainHead(d);
-    for (int p0 = 0; p0 < L.nl_poses; p0 += kWave) {
+    // The slices are independent of each other: a few threads build them, each slice into buffers of its own, and
+    // they are put together in order afterwards (the same format whatever the thread count).
+    struct SliceOut {
+      SliceDesc sd{};
+      std::vector<double> v;
+      std::vector<int32_t> c;
+      int64_t padded = 0, nnz = 0;
+      int maxw = 0;
+    };
+    const int n_pose_slices = (L.nl_poses + kWave - 1) / kWave;
+    std::vector<SliceOut> outs(static_cast<size_t>(n_pose_slices));
+    F.head_val.assign(static_cast<size_t>(n_pose_slices) * HV, 0.0);
+    auto build_slice = [&](int p0, SliceOut &O, Scratch &W) {
+      std::vector<PoseCols> &pc = W.pc;
+      std::vector<RowEnt> &tr = W.tr;
+      std::vector<Ent> &ent = W.ent;
       const int cnt = std::min(kWave, L.nl_poses - p0);
       int width = 0;
       for (int q = 0; q < cnt; ++q) {
         PoseCols &P = pc[q];
         P.c.clear(); P.v.clear();
-        std::vector<std::pair<int32_t, std::pair<int, double>>> ent;  // (int col, (a, val))
+        ent.clear();
         for (int a = 0; a < d; ++a) {
-          const RowRef rr = local_row(L.rot_base + static_cast<int64_t>(p0 + q) * d + a);
+          const RowRef rr = local_row(L.rot_base + static_cast<int64_t>(p0 + q) * d + a, &O.nnz);
           for (int32_t t = rowptr[rr.api_row]; t < rowptr[rr.api_row + 1]; ++t)
-            ent.push_back({F.api2int[col[t]], {a, val[t]}});
+            ent.push_back({F.api2int[col[t]], a, static_cast<int32_t>(ent.size()), val[t]});
         }
-        std::stable_sort(ent.begin(), ent.end(),
-                         [](const auto &x, const auto &y) { return x.first < y.first; });
-        if (g_interleave) {
-          // keep equal columns adjacent (stable) but visit columns ordered by
-          // (col mod d, col / d): neighbouring poses then read one X row in
+        // by column, equal columns in the order the CSR holds them (they are summed in that order)
+        if (!g_interleave) {
+          std::sort(ent.begin(), ent.end(),
+                    [](const Ent &x, const Ent &y) { return x.col != y.col ? x.col < y.col : x.seq < y.seq; });
+        } else {
+          // columns visited ordered by (col mod d, col / d): neighbouring poses then read one X row in
           // consecutive slots, so it is still in L1 when re-referenced
-          std::stable_sort(ent.begin(), ent.end(), [d](const auto &x, const auto &y) {
-            const int xa = x.first % d, ya = y.first % d;
-            return xa != ya ? xa < ya : x.first < y.first;
+          std::sort(ent.begin(), ent.end(), [d](const Ent &x, const Ent &y) {
+            const int xa = x.col % d, ya = y.col % d;
+            return xa != ya ? xa < ya : x.col != y.col ? x.col < y.col : x.seq < y.seq;
           });
         }
-        for (const auto &e : ent) {
-          if (P.c.empty() || P.c.back() != e.first) {
-            P.c.push_back(e.first);
+        for (const Ent &e : ent) {
+          if (P.c.empty() || P.c.back() != e.col) {
+            P.c.push_back(e.col);
             P.v.resize(P.v.size() + d, 0.0);
           }
-          P.v[(P.c.size() - 1) * d + e.second.first] += e.second.second;
+          P.v[(P.c.size() - 1) * d + e.a] += e.v;
         }
         width = std::max(width, static_cast<int>(P.c.size()));
       }
       // ---- chain layout: gather what every lane stores and check what it does not store ----
       bool chain = g_chain_slices != 0;
-      struct ChainLane {
-        double s0[4], s1[4], nxt[9], own[9], hq[3], ht, prev[9];
-        int nlocal = 0;  // pairs of the tail whose columns are rows of this shard (they come first)
-        std::vector<int32_t> gc, tc;
-        std::vector<double> gv, tv;
-      };
-      std::vector<ChainLane> cl(chain ? cnt : 0);
+      std::vector<ChainLane> &cl = W.cl;
+      if (chain && cl.size() < static_cast<size_t>(cnt)) cl.resize(static_cast<size_t>(cnt));
       if (chain) {
         for (int q = 0; q < cnt; ++q) {  // the pose's translation row, internal columns in increasing order
           RowEnt &T = tr[q];
           T.c.clear(); T.v.clear();
           const int32_t api = F.int2api[L.trn_base + p0 + q];
           if (rowptr[api + 1] - rowptr[api] > kLongRow) chain = false;  // a long row stays on the chunked path
-          std::vector<std::pair<int32_t, double>> ent;
-          for (int32_t t = rowptr[api]; t < rowptr[api + 1]; ++t) ent.push_back({F.api2int[col[t]], val[t]});
-          std::stable_sort(ent.begin(), ent.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-          for (const auto &e : ent) {
-            if (!T.c.empty() && T.c.back() == e.first) T.v.back() += e.second;
-            else { T.c.push_back(e.first); T.v.push_back(e.second); }
+          ent.clear();
+          for (int32_t t = rowptr[api]; t < rowptr[api + 1]; ++t)
+            ent.push_back({F.api2int[col[t]], 0, static_cast<int32_t>(ent.size()), val[t]});
+          std::sort(ent.begin(), ent.end(),
+                    [](const Ent &x, const Ent &y) { return x.col != y.col ? x.col < y.col : x.seq < y.seq; });
+          for (const Ent &e : ent) {
+            if (!T.c.empty() && T.c.back() == e.col) T.v.back() += e.v;
+            else { T.c.push_back(e.col); T.v.push_back(e.v); }
           }
         }
         for (int q = 0; q < cnt; ++q) {
@@ -319,6 +358,8 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           std::memset(C.nxt, 0, sizeof C.nxt); std::memset(C.own, 0, sizeof C.own);
           std::memset(C.hq, 0, sizeof C.hq); std::memset(C.prev, 0, sizeof C.prev);
           C.ht = 0.0;
+          C.nlocal = 0;
+          C.gc.clear(); C.gv.clear(); C.tc.clear(); C.tv.clear();
           const int P = p0 + q;
           const int64_t me = L.rot_base + static_cast<int64_t>(P) * d, tme = L.trn_base + P;
           const bool has_next = P + 1 < L.nl_poses, has_prev = P > 0;
@@ -362,8 +403,9 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           ChainLane &C = cl[q];
           // columns of this shard first, rows of other ranks after them (each group padded to whole pairs): a
           // partitioned handle can run the local part before the exchange of the operand has landed
-          std::vector<int32_t> lc, rc;
-          std::vector<double> lv, rv;
+          std::vector<int32_t> &lc = W.lc, &rc = W.rc;
+          std::vector<double> &lv = W.lv, &rv = W.rv;
+          lc.clear(); rc.clear(); lv.clear(); rv.clear();
           for (size_t k = 0; k < C.tc.size(); ++k) {
             const bool local = C.tc[k] >= L.base && C.tc[k] < L.base + L.shard_rows;
             (local ? lc : rc).push_back(C.tc[k]);
@@ -372,19 +414,18 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           if (lc.size() & 1) { lc.push_back(lc.back()); lv.push_back(0.0); }
           if (rc.size() & 1) { rc.push_back(rc.back()); rv.push_back(0.0); }
           C.nlocal = static_cast<int>(lc.size() / 2);
-          C.tc = lc; C.tc.insert(C.tc.end(), rc.begin(), rc.end());
-          C.tv = lv; C.tv.insert(C.tv.end(), rv.begin(), rv.end());
+          C.tc.assign(lc.begin(), lc.end()); C.tc.insert(C.tc.end(), rc.begin(), rc.end());
+          C.tv.assign(lv.begin(), lv.end()); C.tv.insert(C.tv.end(), rv.begin(), rv.end());
           if (C.tc.size() / 2 > static_cast<size_t>(kSliceTailMaxMask)) chain = false;
           T += C.tc.size() / 2;
         }
         if (T > 0xffffu) chain = false;
       }
-      F.head_val.resize(static_cast<size_t>(p0 / kWave + 1) * HV, 0.0);
       SliceDesc sd{};
       sd.row0 = static_cast<int32_t>(L.rot_base + static_cast<int64_t>(p0) * d);
       sd.nrows = cnt;
-      sd.off = static_cast<int64_t>(F.sval.size());
-      sd.coff = static_cast<int32_t>(F.scol.size());
+      sd.off = 0;  // (placed when the slices are put together, below)
+      sd.coff = 0;
       sd.aux0 = p0;
       if (chain) {
         int gw = 0;
@@ -402,17 +443,16 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
         sd.width = gw;
         sd.type = kSliceStiefel | kSliceChainFlag | static_cast<int32_t>(mc << kSliceTailMaxShift) |
                   static_cast<int32_t>(static_cast<uint32_t>(T) << kSliceTailShift);
-        F.max_width = std::max(F.max_width, gw + 2 + 2 * d);
-        const size_t vb = F.sval.size(), cb = F.scol.size();
-        F.sval.resize(vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave + 2 * T, 0.0);
-        F.scol.resize(cb + (1 + static_cast<size_t>(gw)) * kWave + 2 * T, 0);
-        double *tv = &F.sval[vb + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave];
-        int32_t *tc = &F.scol[cb + (1 + static_cast<size_t>(gw)) * kWave];
+        O.maxw = gw + 2 + 2 * d;
+        O.v.assign((static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave + 2 * T, 0.0);
+        O.c.assign((1 + static_cast<size_t>(gw)) * kWave + 2 * T, 0);
+        double *tv = O.v.data() + (static_cast<size_t>(FV) + static_cast<size_t>(gw) * d) * kWave;
+        int32_t *tc = O.c.data() + (1 + static_cast<size_t>(gw)) * kWave;
         size_t te = 0;
         for (int lane = 0; lane < kWave; ++lane) {
           const bool active = lane < cnt;
           const ChainLane &C = cl[std::min(lane, cnt - 1)];
-          auto put = [&](int slot, double v) { F.sval[vb + static_cast<size_t>(slot) * kWave + lane] = active ? v : 0.0; };
+          auto put = [&](int slot, double v) { O.v[static_cast<size_t>(slot) * kWave + lane] = active ? v : 0.0; };
           for (int a = 0; a <= d; ++a) { put(a, C.s0[a]); put(d + 1 + a, C.s1[a]); }
           for (int k = 0; k < d * d; ++k) { put(2 * (d + 1) + k, C.nxt[k]); put(2 * (d + 1) + d * d + k, C.own[k]); }
           // general slots; padded slots repeat a column of the lane (or the lane's own first row) with zero values
@@ -420,7 +460,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           for (int k = 0; k < gw; ++k) {
             const bool have = k < static_cast<int>(C.gc.size());
             if (have) fill = C.gc[k];
-            F.scol[cb + (1 + static_cast<size_t>(k)) * kWave + lane] = fill;
+            O.c[(1 + static_cast<size_t>(k)) * kWave + lane] = fill;
             for (int a = 0; a < d; ++a) put(FV + k * d + a, have ? C.gv[static_cast<size_t>(k) * d + a] : 0.0);
           }
           uint32_t info = static_cast<uint32_t>(te);
@@ -433,16 +473,15 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
             }
             trn_owned[static_cast<size_t>(p0 + lane)] = 1;
           }
-          F.scol[cb + lane] = static_cast<int32_t>(info);
+          O.c[lane] = static_cast<int32_t>(info);
         }
-        F.padded_nnz += (static_cast<int64_t>(FV) + static_cast<int64_t>(gw) * d) * kWave + 2 * static_cast<int64_t>(T);
+        O.padded += (static_cast<int64_t>(FV) + static_cast<int64_t>(gw) * d) * kWave + 2 * static_cast<int64_t>(T);
       } else {
         sd.width = width;
         sd.type = kSliceStiefel;
-        F.max_width = std::max(F.max_width, width);
-        const size_t vb = F.sval.size(), cb = F.scol.size();
-        F.sval.resize(vb + static_cast<size_t>(width) * d * kWave, 0.0);
-        F.scol.resize(cb + static_cast<size_t>(width) * kWave, 0);
+        O.maxw = width;
+        O.v.assign(static_cast<size_t>(width) * d * kWave, 0.0);
+        O.c.assign(static_cast<size_t>(width) * kWave, 0);
         for (int lane = 0; lane < kWave; ++lane) {
           const PoseCols &P = pc[std::min(lane, cnt - 1)];
           const bool active = lane < cnt;
@@ -450,18 +489,48 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
           for (int k = 0; k < width; ++k) {
             const bool have = k < static_cast<int>(P.c.size());
             if (have) fill = P.c[k];
-            F.scol[cb + static_cast<size_t>(k) * kWave + lane] = fill;
+            O.c[static_cast<size_t>(k) * kWave + lane] = fill;
             for (int a = 0; a < d; ++a)
-              F.sval[vb + (static_cast<size_t>(k) * d + a) * kWave + lane] =
+              O.v[(static_cast<size_t>(k) * d + a) * kWave + lane] =
                   (have && active) ? P.v[static_cast<size_t>(k) * d + a] : 0.0;
           }
         }
-        F.padded_nnz += static_cast<int64_t>(width) * d * kWave;
+        O.padded += static_cast<int64_t>(width) * d * kWave;
       }
-      F.slices.push_back(sd);
-      slice_key.push_back(p0);
+      O.sd = sd;
+    };
+    {
+      unsigned nth = n_pose_slices < 64 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+      if (const char *e = std::getenv("CORA_FORMAT_THREADS")) nth = static_cast<unsigned>(std::max(1, std::atoi(e)));
+      parallel_parts(nth, [&](unsigned t) {
+        Scratch W;
+        W.pc.resize(static_cast<size_t>(lanes));
+        W.tr.resize(static_cast<size_t>(lanes));
+        const int s_begin = static_cast<int>(static_cast<int64_t>(n_pose_slices) * t / nth);
+        const int s_end = static_cast<int>(static_cast<int64_t>(n_pose_slices) * (t + 1) / nth);
+        for (int sl = s_begin; sl < s_end; ++sl) build_slice(sl * kWave, outs[static_cast<size_t>(sl)], W);
+      });
+    }
+    tick("pose slices: built");
+    size_t nv = F.sval.size(), nc = F.scol.size();
+    for (const SliceOut &O : outs) { nv += O.v.size(); nc += O.c.size(); }
+    F.sval.reserve(nv);
+    F.scol.reserve(nc);
+    for (SliceOut &O : outs) {
+      O.sd.off = static_cast<int64_t>(F.sval.size());
+      O.sd.coff = static_cast<int32_t>(F.scol.size());
+      F.sval.insert(F.sval.end(), O.v.begin(), O.v.end());
+      F.scol.insert(F.scol.end(), O.c.begin(), O.c.end());
+      F.padded_nnz += O.padded;
+      F.nnz_local += O.nnz;
+      F.max_width = std::max(F.max_width, O.maxw);
+      slice_key.push_back(O.sd.aux0);
+      F.slices.push_back(O.sd);
+      std::vector<double>().swap(O.v);
+      std::vector<int32_t>().swap(O.c);
     }
   }
+  tick("pose slices");
   // Oblique slices
   {
     std::vector<RowRef> rows;
@@ -475,6 +544,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       slice_key.push_back(local_range_pose[k0] + 0.25);
     }
   }
+  tick("range slices");
   // Translation rows: long rows -> chunked path; the rest sorted by length
   // inside windows of kSigma rows (keeps column locality) and sliced.
   {
@@ -573,6 +643,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     }
   }
 
+  tick("translation + long rows");
   // long-row chunks: launch order by the region of X they read
   F.chunk_order.resize(F.chunks.size());
   std::iota(F.chunk_order.begin(), F.chunk_order.end(), 0);
@@ -612,6 +683,7 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
       }
     }
   }
+  tick("work order");
 }
 
 void slice_columns(const HostFormat &F, const SliceDesc &sd, std::vector<int32_t> &out) {

@@ -1012,12 +1012,17 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
     if (cora_certificate_product_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
   };
   tick("start block + ordering");
-  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, nullptr, symbolic_cache_.get());
+  FastVerificationLab lab;
+  lab.seed_negative_direction = cert_lab_seed_;
+  lab.use_ildl = cert_lab_ildl_;
+  const FastVerificationLab *labp = cert_lab_on_ ? &lab : nullptr;
+  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, labp, symbolic_cache_.get());
+  cert_reached_step3_ = lab.reached_step3;
   tick("fast_verification");
   while (std::isnan(results.theta)) {  // :1076-1083
     std::cout << "NaN in theta -- result not certified" << std::endl;
     eta *= 2;
-    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, nullptr, symbolic_cache_.get());
+    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, labp, symbolic_cache_.get());
   }
   if (!results.is_certified && formulation_ == Formulation::Implicit) {  // :1085-1100
     // leading (rotation + range) part of the direction, and its Rayleigh quotient with the

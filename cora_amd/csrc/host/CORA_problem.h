@@ -87,6 +87,9 @@ class Problem {
   mutable SparseMatrix cert_S_;
   mutable std::vector<int32_t> cert_lambda_pos_, cert_lambda_q_;
   mutable Matrix cert_random_;  // the random start columns of the eigensolver (fixed seed: the same numbers every time)
+  // test switches of certify_solution's eigensolver stage (FastVerificationLab, CORA_utils.h) and what the last call did
+  bool cert_lab_on_ = false, cert_lab_seed_ = true, cert_lab_ildl_ = true;
+  mutable bool cert_reached_step3_ = false;
   const SparseMatrix &certificateMatrixCached(const Matrix &Y) const;
 
   void checkUpToDate() const;
@@ -213,6 +216,14 @@ class Problem {
   LambdaBlocks compute_Lambda_blocks(const Matrix &Y) const;
   SparseMatrix compute_Lambda_from_Lambda_blocks(const LambdaBlocks &Lambda_blocks, const int &Lambda_size) const;
   SparseMatrix get_certificate_matrix(const Matrix &Y) const;
+  /** Test switches of the eigensolver stage of certify_solution (see FastVerificationLab): without the seed of the failed
+   * factorisation and / or without the incomplete-LDL^T preconditioner; and whether the last call got as far as step 3. */
+  void setVerificationLab(bool seed_negative_direction, bool use_ildl) {
+    cert_lab_on_ = true;
+    cert_lab_seed_ = seed_negative_direction;
+    cert_lab_ildl_ = use_ildl;
+  }
+  bool lastCertificationReachedStep3() const { return cert_reached_step3_; }
   CertResults certify_solution(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap,
                                size_t max_LOBPCG_iters = 500) const;
 

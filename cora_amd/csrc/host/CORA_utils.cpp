@@ -164,11 +164,40 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
     }
     if (!done) {
       std::optional<DeviceOperator> T = precond;
-      // (partitioned handles: the incomplete factor is a sequential recurrence over the whole chain and does not shard --
-      // the remaining budget runs unpreconditioned, every rank in step)
-      if (!T && (!lab || lab->use_ildl) && cora_world(c) == 1) {
-        const CholeskyFactor I = incompleteLDLT(S, static_cast<int>(n), eta, perm, max_fill_factor, drop_tol);
-        if (cora_aux_set_cholesky(c, static_cast<int>(n), I.Lp.data(), I.Li.data(), I.Lx.data(), I.perm.data()) != CORA_OK)
+      // Partitioned handle: the incomplete factor is a sequential recurrence over the whole chain and does not shard,
+      // so the preconditioner becomes BLOCK JACOBI OVER THE RANKS like the Cholesky one (Problem::updatePreconditioner):
+      // every rank takes the diagonal block of M on its own rows, eliminates them in the order the global `perm` gives
+      // them, and applies the factor to its own rows with the same device solve plan.
+      if (!T && (!lab || lab->use_ildl)) {
+        CholeskyFactor I;
+        if (cora_world(c) == 1) {
+          I = incompleteLDLT(S, static_cast<int>(n), eta, perm, max_fill_factor, drop_tol);
+        } else {
+          std::vector<int32_t> map(static_cast<size_t>(n));
+          if (cora_row_map(c, map.data()) != CORA_OK) throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(c));
+          const int64_t lo = cora_shard_begin(c), hi = lo + cora_shard_rows(c);
+          std::vector<int32_t> to_local(static_cast<size_t>(n), -1), own;
+          for (Index i = 0; i < n; ++i)
+            if (map[static_cast<size_t>(i)] >= lo && map[static_cast<size_t>(i)] < hi) {
+              to_local[static_cast<size_t>(i)] = static_cast<int32_t>(own.size());
+              own.push_back(static_cast<int32_t>(i));
+            }
+          std::vector<Triplet> t;
+          for (size_t k = 0; k < own.size(); ++k)
+            for (int32_t q = S.outer[own[k]]; q < S.outer[own[k] + 1]; ++q) {
+              const int32_t j = to_local[static_cast<size_t>(S.inner[q])];
+              if (j >= 0) t.push_back({static_cast<Index>(k), static_cast<Index>(j), S.values[q]});
+            }
+          SparseMatrix B(static_cast<Index>(own.size()), static_cast<Index>(own.size()));
+          B.setFromTriplets(std::move(t));
+          std::vector<int32_t> lperm;
+          lperm.reserve(own.size());
+          for (int32_t g : perm)
+            if (to_local[static_cast<size_t>(g)] >= 0) lperm.push_back(to_local[static_cast<size_t>(g)]);
+          I = incompleteLDLT(B, static_cast<int>(own.size()), eta, lperm, max_fill_factor, drop_tol);
+          for (int32_t &q : I.perm) q = own[static_cast<size_t>(q)];
+        }
+        if (cora_aux_set_cholesky(c, I.n, I.Lp.data(), I.Li.data(), I.Lx.data(), I.perm.data()) != CORA_OK)
           throw std::runtime_error(std::string("fast_verification: ") + cora_last_error(c));
         T = [c](const double *dX, int k, double *dOut) {
           if (cora_aux_solve_dev(c, dX, k, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));

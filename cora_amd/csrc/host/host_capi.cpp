@@ -328,6 +328,17 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
   });
 }
 
+int cora_problem_set_verification_lab(cora_problem *p, int seed_negative_direction, int use_ildl) {
+  return guarded([&] { p->problem.setVerificationLab(seed_negative_direction != 0, use_ildl != 0); });
+}
+
+int cora_problem_certification_reached_step3(cora_problem *p, int *reached) {
+  return guarded([&] {
+    if (!reached) throw std::invalid_argument("reached is NULL");
+    *reached = p->problem.lastCertificationReachedStep3() ? 1 : 0;
+  });
+}
+
 int cora_host_fast_verification_lab(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                     double eta, const double *X0, int nx, int max_iters, const double opts[4],
                                     double out[4], double *x) {

@@ -183,6 +183,10 @@ struct RvTail {
   unsigned long long *seq_out;  // pinned: set to seq after the mirror is visible to the host
   unsigned long long seq;
   unsigned long long *seq_counter;  // non-null: seq = ++(*seq_counter), see DotArgs
+  // non-null (partitioned handle): the block leaves THIS RANK'S sums -- sums_out[0] = <r, r>, sums_out[1] = <r, v> -- and
+  // touches neither the state nor the mirror: the sums are added over the ranks first (one all-reduce), then
+  // k_stpcg_scalar_step runs the scalar step
+  double *sums_out;
 };
 struct SubFuse {
   DotArgs dot;                 // only dot.st (the coefficients of the state) is used

@@ -2004,7 +2004,7 @@ __device__ __forceinline__ void rowop_entries(const int32_t *__restrict__ col, c
 
 // The two reductions of a sweep-fused STPCG iteration (RvTail, kernels.h) in ONE block, fixed order: <r, r> from the
 // forward sweep's slots, then <r, v> = |L^-1 r|^2 from its |y|^2 slots and the squared norms of the last stage's rows.
-__device__ __forceinline__ double sum_slots_256(const double *__restrict__ x, int n, double *sm) {
+__device__ __forceinline__ double lane_sum_slots_256(const double *__restrict__ x, int n) {  // a lane's share (no barrier)
   double s[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) s[u] = 0.0;
@@ -2018,17 +2018,29 @@ __device__ __forceinline__ double sum_slots_256(const double *__restrict__ x, in
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] += (b0 + 256 * u < n) ? t[u] : 0.0;
   }
-  return block_sum_256(((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])), sm);
+  return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 __device__ __forceinline__ void rv_tail_block(const RvTail &T) {
   __shared__ double sm[12];
-  const double rr = sum_slots_256(T.rr_partial, T.n_rr, sm);
-  const double yy = sum_slots_256(T.yy_partial, T.n_yy, sm + 4);
-  const double tt = sum_slots_256(T.rowsq, T.n_rowsq, sm + 8);
+  StpcgState L = {};
+  if (threadIdx.x == 0 && !T.sums_out) L = *T.st;  // in flight while the slots are added up
+  // the three sets of slots are loaded together (one round trip, not three), then reduced one after the other
+  const double l_rr = lane_sum_slots_256(T.rr_partial, T.n_rr);
+  const double l_yy = lane_sum_slots_256(T.yy_partial, T.n_yy);
+  const double l_tt = lane_sum_slots_256(T.rowsq, T.n_rowsq);
+  const double rr = block_sum_256(l_rr, sm);
+  const double yy = block_sum_256(l_yy, sm + 4);
+  const double tt = block_sum_256(l_tt, sm + 8);
   if (threadIdx.x == 0) {
-    if (T.n_rr > 0) stpcg_after_rr(*T.st, rr);  // (n_rr == 0: <r, r> was finished by the residual pass)
-    stpcg_after_rv(*T.st, yy + tt);
-    *T.st_host = *T.st;  // pinned mirror for the host's (infrequent) look
+    if (T.sums_out) {  // partitioned: this rank's share of the two inner products
+      T.sums_out[0] = rr;
+      T.sums_out[1] = yy + tt;
+      return;
+    }
+    if (T.n_rr > 0) stpcg_after_rr(L, rr);  // (n_rr == 0: <r, r> was finished by the residual pass)
+    stpcg_after_rv(L, yy + tt);
+    *T.st = L;
+    *T.st_host = L;  // pinned mirror for the host's (infrequent) look
     if (T.seq_out) {
       unsigned long long seq = T.seq;
       if (T.seq_counter) *T.seq_counter = seq = *T.seq_counter + 1;
@@ -2791,6 +2803,8 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 // every wavefront a drain of its stores and an atomic round trip before it frees its slot: 29.8 us against 24.4 + 4.7.)
 __global__ __launch_bounds__(256) void k_kappa_finish(const double *__restrict__ partial, int n, StpcgState *st) {
   __shared__ double sm[4];
+  StpcgState L = {};
+  if (threadIdx.x == 0) L = *st;  // in flight while the partials are added up (after the barriers it would be a round trip of its own)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int b = threadIdx.x;
   // (10^6 poses: 40 k partials on one block -- keep 32 loads per lane in flight; the order of the sums is unchanged)
@@ -2803,7 +2817,10 @@ __global__ __launch_bounds__(256) void k_kappa_finish(const double *__restrict__
   }
   for (; b < n; b += 256) s0 += partial[b];
   const double t = block_sum_256((s0 + s1) + (s2 + s3), sm);
-  if (threadIdx.x == 0) stpcg_after_kappa(*st, t);
+  if (threadIdx.x == 0) {
+    stpcg_after_kappa(L, t);
+    *st = L;
+  }
 }
 
 __global__ void k_zero_row(double *x, size_t row, int ld) {

@@ -251,6 +251,15 @@ class Problem:
                                               out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
         return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
 
+    def set_verification_lab(self, seed=True, ildl=True):
+        """Test switches of certify()'s eigensolver stage (step 3 of fast_verification)."""
+        self._chk(self.L.cora_problem_set_verification_lab(self.h, int(bool(seed)), int(bool(ildl))))
+
+    def certification_reached_step3(self):
+        v = C.c_int(0)
+        self._chk(self.L.cora_problem_certification_reached_step3(self.h, C.byref(v)))
+        return bool(v.value)
+
     def solve(self, x0, max_rank=10, verbose=False, max_seconds=0, max_iterations=0):
         dm = self.dims()
         x0 = np.asfortranarray(np.asarray(x0, dtype=np.float64))

@@ -192,7 +192,9 @@ int cora_precond_stats(const cora_ctx *ctx, int64_t stats[4]);
  * translation rows of inputs are ignored, translation rows of outputs are zero (callers pass and
  * read the leading d*n + r rows).  cora_certificate_product* always applies the explicit S, like
  * the reference's certify_solution (:1054-1058).  cora_translation_explicit_dev =
- * getTranslationExplicitSolution (:1168-1197): out = [Y; -L^-1 B^T Y; 0]. */
+ * getTranslationExplicitSolution (:1168-1197): out = [Y; -L^-1 B^T Y; 0].
+ * Partitioned handle: every rank installs the WHOLE factor; the two products of an implicit product are partitioned
+ * products and the solve between them is replicated (the right-hand side is all-gathered, cora_allgather_fn). */
 int cora_implicit_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp, const int32_t *Li,
                                const double *Lx, const int32_t *perm);
 int cora_set_formulation(cora_ctx *ctx, int implicit);
@@ -326,7 +328,9 @@ int cora_sync(cora_ctx *ctx);
 /* A factor of the caller's own for the handle's vectors: (L L^T)^-1 with L (CSC, diagonal first) the Cholesky-form
  * factor of P A P^T, N rows, perm new -> old in API row order.  It may be INCOMPLETE (dropped entries).  Used by
  * fast_verification for the preconditioner of src/CORA_utils.cpp:140-156 (ILDL with pos_def_mod: L |D|^(1/2)).
- * cora_aux_solve_dev: dX = (P^T L L^T P)^-1 dB on k-column resident vectors, dB != dX. */
+ * cora_aux_solve_dev: dX = (P^T L L^T P)^-1 dB on k-column resident vectors, dB != dX.
+ * Partitioned handle: the factor of the RANK'S OWN rows (m = its row count, perm holds its API rows): the solve is
+ * block Jacobi over the ranks, like cora_precond_set_cholesky, and touches the rank's rows only. */
 int cora_aux_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
                           const int32_t *perm);
 int cora_aux_solve_dev(cora_ctx *ctx, const double *dB, int k, double *dX);

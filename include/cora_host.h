@@ -117,6 +117,12 @@ int cora_problem_tnt_step(cora_problem *p, const double *x, double Delta, int ho
  * out: [0] is_certified, [1] theta, [2] LOBPCG iterations; x: N (direction of negative curvature or 0). */
 int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, double out[3], double *x);
 
+/* Test switches of the eigensolver stage of certify_solution (src/CORA_utils.cpp:129-167): run step 3 without the seed
+ * that the failed factorisation yields and / or without the incomplete-LDL^T preconditioner; and whether the last
+ * cora_problem_certify got as far as step 3 (the preconditioned stage). */
+int cora_problem_set_verification_lab(cora_problem *p, int seed_negative_direction, int use_ildl);
+int cora_problem_certification_reached_step3(cora_problem *p, int *reached);
+
 /* fast_verification(S, eta, X0) (src/CORA_utils.cpp:17-186) for an arbitrary symmetric sparse S
  * (CSR, n x n).  X0: n x nx or NULL for a random block.  out: [0] is_certified, [1] theta,
  * [2] iterations; x: n. */

@@ -342,7 +342,7 @@ def test_block_jacobi_cholesky_on_partitions(world):
     outs = _run_ranks(world, body, "native")
     ref = np.zeros_like(V)
     for mine, lam_r, PV, res, path in outs:
-        assert abs(lam_r - lam) < 1e-9 * lam and path == 1
+        assert abs(lam_r - lam) < 1e-9 * lam and path in (1, 2)   # (2: the shard's plan is two-stage, sweep-fused form)
         idx = np.flatnonzero(mine)
         if mine[dm["N"] - 1]:
             idx = idx[idx != dm["N"] - 1]          # the pinned variable stays zero (src/CORA_preconditioners.cpp:78-79)
@@ -481,3 +481,172 @@ def test_sharded_products_in_the_window_form(world):
             assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     finally:
         L.cora_debug_spmm_window_min_slices(old)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sweep_fused_iteration_on_partitions(world):
+    """The sweep-fused STPCG iteration per shard (round-3 review: it only ran on one handle).  Every rank's block-Jacobi
+    factor is a two-stage solve plan of its own, so the iteration is: product with the partials of kappa | all-reduce,
+    scalar step | forward sweep with r += alpha Hp and the slots of <r, r> and |y|^2 | last stage, whose tail block leaves
+    the RANK'S <r, r> and <r, v> = |L_k^-1 r_k|^2 | ONE all-reduce for the two, scalar step | backward sweep with
+    v = Proj_Y(x), s += alpha p, p = -v + beta p.  Same iteration as the vector-pass form on the same partition
+    (CORA_NO_SWEEP_FUSE=1): same number of products, cost to 1e-9 after ten outer iterations; still two all-reduces
+    and one all-gather per iteration."""
+    import os
+    n, p = 30000 * world, 4
+
+    def make():
+        P, gt = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=6, n_ranges=n // 2, seed=5,
+                                       precond=capi.PRECOND_REGULARIZED_CHOLESKY, ground_truth=True)
+        P.update()
+        P.set_rank(p)
+        return P, gt
+    P0, gt = make()
+    # (a perturbed ground truth: the inner solves then run tens of iterations, not two)
+    Y0 = P0.op("projectToManifold", np.hstack([gt, np.zeros((gt.shape[0], p - gt.shape[1]))])
+               + 0.05 * np.random.default_rng(2).standard_normal((gt.shape[0], p)))
+    del P0
+
+    def body(r, group):
+        P, _ = make()
+        comm = P.set_partition(r, world, lambda ctx: NativeLocalComm(ctx, group))
+        dm = P.dims()
+        ctx = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+        P.precond_info()
+        c0 = comm.counters()
+        res = P.tnt(Y0, max_iterations=10)
+        c1 = comm.counters()
+        return res, ctx.stpcg_path(), (c1[0] - c0[0], c1[1] - c0[1])
+
+    out = {}
+    for mode, names in {"sweep": (), "passes": ("CORA_NO_SWEEP_FUSE",)}.items():
+        for var in names:
+            os.environ[var] = "1"
+        try:
+            out[mode] = _run_ranks(world, body, "native")
+        finally:
+            for var in names:
+                os.environ.pop(var, None)
+    for (a, pa, ca), (b, pb, cb) in zip(out["sweep"], out["passes"]):
+        assert pa == 2 and pb == 1
+        assert a["hvps"] == b["hvps"] and a["iterations"] == b["iterations"] and a["hvps"] >= 15
+        assert abs(a["f"] - b["f"]) < 1e-9 * abs(b["f"])
+        assert ca == cb   # the same collectives: the form changes what a rank does between them
+    print("\nsweep-fused on %d partitions: f=%.8f in %d products (vector passes: %.8f in %d)"
+          % (world, out["sweep"][0][0]["f"], out["sweep"][0][0]["hvps"], out["passes"][0][0]["f"], out["passes"][0][0]["hvps"]))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ildl_preconditioned_certification_on_partitions(world):
+    """Step 3 of fast_verification (src/CORA_utils.cpp:129-167) on a partitioned Problem (round-3 review: the remaining
+    budget ran unpreconditioned there).  The incomplete L D L^T is a recurrence over the whole chain, so it becomes block
+    Jacobi over the ranks like the Cholesky preconditioner: every rank factorises the diagonal block of S + eta I on ITS
+    rows and applies it with the device solve plan.  The point is a few TNT iterations from a slightly perturbed ground
+    truth: lambda_min(S) is negative and tiny, the unpreconditioned iteration does not find the direction within the
+    budget, the preconditioned one does -- on one handle and on the partitions (more iterations: the coupling between
+    the shards is not in the preconditioner), every rank with the same numbers."""
+    n, p, eta = 3000, 4, 1e-3
+
+    def make():
+        P, gt = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=4, n_ranges=n, seed=23, precond=capi.PRECOND_JACOBI,
+                                       ground_truth=True)
+        P.update()
+        P.set_rank(p)
+        return P, gt
+    P1, gt = make()
+    Y0 = P1.op("projectToManifold", np.hstack([gt, np.zeros((gt.shape[0], p - gt.shape[1]))])
+               + 0.02 * np.random.default_rng(1).standard_normal((gt.shape[0], p)))
+    Y = P1.tnt(Y0, max_iterations=12)["x"]
+    P1.set_verification_lab(seed=False, ildl=True)
+    one = P1.certify(Y, eta, nx=6)
+    assert not one["is_certified"] and P1.certification_reached_step3() and one["theta"] < -eta / 2
+    P1.set_verification_lab(seed=False, ildl=False)
+    plain = P1.certify(Y, eta, nx=6)
+    assert P1.certification_reached_step3() and plain["iters"] > 4 * one["iters"]
+
+    def body(r, group):
+        P, _ = make()
+        P.set_partition(r, world, lambda ctx: NativeLocalComm(ctx, group))
+        P.set_verification_lab(seed=False, ildl=True)
+        c = P.certify(Y, eta, nx=6)
+        return c, P.certification_reached_step3()
+
+    outs = _run_ranks(world, body, "native")
+    dm = P1.dims()
+    _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
+    from certhelp import certificate_matrix
+    Sd = certificate_matrix(orc.CSR(rowptr, colidx, vals, dm["N"]), orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"]), Y)
+    for c, step3 in outs:
+        assert step3 and not c["is_certified"]
+        assert c["theta"] < -eta / 2                       # the reference's stopping rule, reached ...
+        assert c["iters"] < plain["iters"] // 2            # ... well inside the budget the plain iteration exhausts
+        assert abs(np.linalg.norm(c["x"]) - 1) < 1e-8
+        assert abs(c["theta"] - c["x"] @ (Sd @ c["x"])) < 1e-8 * max(1.0, abs(c["theta"]))   # curvature by the oracle's S
+    for c, _ in outs[1:]:
+        assert c["iters"] == outs[0][0]["iters"] and np.array_equal(c["x"], outs[0][0]["x"])
+    print("\nILDL-preconditioned LOBPCG: one handle %d iterations, %d partitions %d, unpreconditioned %d (budget)"
+          % (one["iters"], world, outs[0][0]["iters"], plain["iters"]))
+
+
+@pytest.mark.parametrize("transport", ["callbacks", "native"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_implicit_formulation_on_partitions(world, transport):
+    """Formulation::Implicit (src/CORA_problem.cpp:714-753) on a partitioned Problem (round-3 review: it was single
+    handle only).  Q_impl Y = Q [Y; t; 0] with t = -M^-1 B^T Y: the two products are the partitioned products, the
+    translation solve -- a recurrence over the whole chain -- is replicated (the right-hand side is gathered, every rank
+    runs the same solve plan).  The operators against the oracle's Schur-complement restatement, TNT and the
+    certification against the single handle (cost to 1e-8, same decision)."""
+    n, p = 700, 4
+    Comm = TRANSPORTS[transport][1]
+
+    gt_box = []
+
+    def make():
+        P, gt = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=4, n_ranges=n // 2, n_loops=6, seed=19,
+                                       precond=capi.PRECOND_JACOBI, ground_truth=True)
+        P.update()
+        P.set_formulation(True)
+        P.set_rank(p)
+        gt_box.append(gt)
+        return P
+    P1 = make()
+    dm = P1.dims()
+    _, _, rowptr, colidx, vals = P1.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    I = orc.Implicit(Q, dims)
+    Y = P1.op("getRandomInitialGuess")
+    V = P1.op("tangent_space_projection", Y, np.random.default_rng(3).uniform(-1, 1, Y.shape))
+    G1 = P1.op("Euclidean_gradient", Y)
+    # TNT from where a front end would leave the problem (the generator's ground truth, rotations and ranges): converges
+    m = P1.variable_size()
+    Y0 = P1.op("projectToManifold", np.hstack([gt_box[0][:m], np.zeros((m, p - gt_box[0].shape[1]))]))
+    single = P1.tnt(Y0)
+    cert1 = P1.certify(single["x"], 1e-4)
+
+    def body(r, group):
+        P = make()
+        P.set_partition(r, world, lambda ctx: Comm(ctx, group))
+        f = P.op("evaluateObjective", Y)
+        G = P.op("Euclidean_gradient", Y)
+        H = P.op("Riemannian_Hessian_vector_product", Y, G, V)
+        X = P.op("getTranslationExplicitSolution", Y)
+        res = P.tnt(Y0)
+        cert = P.certify(res["x"], 1e-4)
+        return f, G, H, X, res, cert
+
+    outs = _run_ranks(world, body, transport)
+    Gref = I.product(Y)
+    scale = np.abs(Gref).max()
+    Xref = I.translation_explicit(Y)
+    for f, G, H, X, res, cert in outs:
+        assert abs(f - I.cost(Y)) < 1e-10 * max(1.0, abs(f))
+        assert np.abs(G - Gref).max() < 1e-10 * scale and np.abs(G - G1).max() < 1e-10 * scale
+        assert np.abs(H - I.hvp(Y, V)).max() < 1e-10 * scale
+        assert np.abs(X - Xref).max() < 1e-9 * max(1.0, np.abs(Xref).max())
+        assert abs(res["f"] - single["f"]) < 1e-8 * max(1.0, abs(single["f"]))
+        assert cert["is_certified"] == cert1["is_certified"]
+        if not cert["is_certified"]:
+            assert cert["theta"] < -0.5e-4
+    for o in outs[1:]:
+        assert np.array_equal(o[4]["x"], outs[0][4]["x"])
