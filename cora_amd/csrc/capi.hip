@@ -125,6 +125,10 @@ struct cora_ctx {
   size_t scratch_bytes[kScratchSlots] = {0};
   double *d_stage = nullptr;
   size_t stage_bytes = 0;
+  // two pinned buffers of kPinChunk bytes and their events: big downloads are pipelined through them (DMA into one
+  // while the host copies the other out) instead of hipMemcpy's own staging of pageable memory
+  char *h_pin[2] = {nullptr, nullptr};
+  hipEvent_t ev_pin[2] = {nullptr, nullptr};
   double *d_red = nullptr;      // reduction partials
   size_t red_doubles = 0;
   double *d_scalars = nullptr;  // 8 doubles
@@ -353,6 +357,38 @@ int download_impl(cora_ctx *c, const double *dptr, int k, double *host, int ldh)
     if (rc) return rc;
   }
   HIP_TRY(c, launch_download(N, k, ld, dptr, c->d_api2int, c->d_stage, c->stream));
+  constexpr size_t kPinChunk = size_t(8) << 20;
+  if (ldh == N && need >= 4 * kPinChunk) {
+    // One flat block of `need` bytes.  hipMemcpy into pageable memory stages through the runtime's own bounce buffer
+    // (measured 4.4 GB/s: 0.1 s for the 430 MB Ritz block of a 10^6-pose certification); here the DMA engine fills one
+    // pinned chunk while host threads copy the previous one out.
+    for (int i = 0; i < 2; ++i) {
+      if (!c->h_pin[i]) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_pin[i]), kPinChunk));
+      if (!c->ev_pin[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pin[i], hipEventDisableTiming));
+    }
+    const char *src = reinterpret_cast<const char *>(c->d_stage);
+    char *dst = reinterpret_cast<char *>(host);
+    const size_t nchunks = (need + kPinChunk - 1) / kPinChunk;
+    auto bytes_of = [&](size_t ch) { return std::min(kPinChunk, need - ch * kPinChunk); };
+    auto start = [&](size_t ch) -> hipError_t {
+      const hipError_t e = hipMemcpyAsync(c->h_pin[ch & 1], src + ch * kPinChunk, bytes_of(ch), hipMemcpyDeviceToHost, c->stream);
+      return e != hipSuccess ? e : hipEventRecord(c->ev_pin[ch & 1], c->stream);
+    };
+    HIP_TRY(c, start(0));
+    const unsigned nth = std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+    for (size_t ch = 0; ch < nchunks; ++ch) {
+      HIP_TRY(c, hipEventSynchronize(c->ev_pin[ch & 1]));
+      if (ch + 1 < nchunks) HIP_TRY(c, start(ch + 1));  // (the other buffer: its host copy finished in the round before)
+      const size_t nb = bytes_of(ch);
+      const char *from = c->h_pin[ch & 1];
+      char *to = dst + ch * kPinChunk;
+      cora::parallel_parts(nth, [&](unsigned t) {
+        const size_t a = nb * t / nth, b = nb * (t + 1) / nth;
+        std::memcpy(to + a, from + a, b - a);
+      });
+    }
+    return CORA_OK;
+  }
   HIP_TRY(c, hipMemcpy2DAsync(host, static_cast<size_t>(ldh) * sizeof(double), c->d_stage, N * sizeof(double),
                               N * sizeof(double), k, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -597,6 +633,10 @@ void cora_ctx_destroy(cora_ctx *c) {
     for (auto *f : {&c->precond_f, &c->implicit_f, &c->aux_f})
       for (void *p : f->allocs)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+      if (c->h_pin[i]) (void)hipHostFree(c->h_pin[i]);
+      if (c->ev_pin[i]) (void)hipEventDestroy(c->ev_pin[i]);
+    }
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_stpcg) (void)hipHostFree(c->h_stpcg);
     if (c->h_flag) (void)hipHostFree(c->h_flag);

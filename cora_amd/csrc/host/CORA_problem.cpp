@@ -932,6 +932,22 @@ Matrix Problem::alignEstimateToOrigin(const Matrix &Y) const {
 
 }  // namespace CORA
 
+namespace CORA {
+Matrix Matrix::RandomColumns(Index r, Index c, uint64_t seed) {
+  Matrix m(r, c);
+  const unsigned nth = r * c < 200000 ? 1u : static_cast<unsigned>(std::min<Index>(c, std::max(1u, std::thread::hardware_concurrency())));
+  cora::parallel_parts(nth, [&](unsigned t) {
+    for (Index j = c * t / nth; j < c * (t + 1) / nth; ++j) {
+      std::mt19937_64 g(seed + static_cast<uint64_t>(j));
+      std::uniform_real_distribution<Scalar> u(-1.0, 1.0);
+      Scalar *col = m.data() + static_cast<size_t>(j) * static_cast<size_t>(r);
+      for (Index i = 0; i < r; ++i) col[i] = u(g);
+    }
+  });
+  return m;
+}
+}  // namespace CORA
+
 // ---- certification: src/CORA_problem.cpp:1030-1103 ---------------------------
 #include "CORA_utils.h"
 #include "dense.h"
@@ -993,14 +1009,14 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   // exceeds it at ranks solveCORA rejects up front)
   const Index num_eigvecs = std::min<Index>(std::min<Index>(std::max<Index>(static_cast<Index>(nx), p + 2), N), 24);
   if (N < p) throw std::invalid_argument("The number of rows of S must be greater than or equal to the number of columns of Y");
-  // start block: the leading columns of the bootstrap block, the rest random (Matrix::Random(N, num_eigvecs) with a
+  // start block: the leading columns of the bootstrap block, the rest random (Matrix::RandomColumns(N, num_eigvecs) with a
   // fixed seed fills column after column, so a cached block with at least as many columns has the same numbers in
   // them); the two pieces go to the device as they are
   const Index from_bootstrap = eigvec_bootstrap.rows() == N ? std::min(eigvec_bootstrap.cols(), num_eigvecs) : 0;
   std::vector<HostColumns> X0;
   if (from_bootstrap > 0) X0.push_back(HostColumns{eigvec_bootstrap.data(), static_cast<int>(from_bootstrap)});
   if (from_bootstrap < num_eigvecs) {
-    if (cert_random_.rows() != N || cert_random_.cols() < num_eigvecs) cert_random_ = Matrix::Random(N, num_eigvecs, 0xC0FFEEull);
+    if (cert_random_.rows() != N || cert_random_.cols() < num_eigvecs) cert_random_ = Matrix::RandomColumns(N, num_eigvecs, 0xC0FFEEull);
     X0.push_back(HostColumns{cert_random_.data() + static_cast<size_t>(from_bootstrap) * static_cast<size_t>(N),
                              static_cast<int>(num_eigvecs - from_bootstrap)});
   }

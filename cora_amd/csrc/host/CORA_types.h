@@ -61,6 +61,9 @@ class Matrix {
     for (auto &v : m.a_) v = u(g);
     return m;
   }
+  /** The same distribution with a generator per column (seeded seed + column): column j holds the same numbers whatever
+   * the number of columns asked for, and the columns are filled by threads (10^6 poses: 54 M numbers, 0.3 s on one). */
+  static Matrix RandomColumns(Index r, Index c, uint64_t seed);
   Index rows() const { return rows_; }
   Index cols() const { return cols_; }
   Index size() const { return rows_ * cols_; }

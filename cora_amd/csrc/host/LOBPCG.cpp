@@ -114,7 +114,13 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
     B.chk(cora_upload(c, start[0].data, N, m, t1), "upload");
   } else {
     // pieces side by side: Out = sum_i piece_i [0 .. I .. 0]
-    std::vector<double *> dev;
+    struct Pieces {  // the pieces' device buffers go back whatever happens in the loop (round-3 advice)
+      cora_ctx *c;
+      std::vector<double *> v;
+      ~Pieces() {
+        for (double *d : v) cora_dev_free(c, d);
+      }
+    } dev{c, {}};
     std::vector<const double *> xs;
     std::vector<int> ks;
     std::vector<Matrix> sel;
@@ -122,7 +128,7 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
     for (const HostColumns &h : start) {
       double *d = nullptr;
       B.chk(cora_dev_alloc(c, h.cols, &d), "alloc");
-      dev.push_back(d);
+      dev.v.push_back(d);
       B.chk(cora_upload(c, h.data, N, h.cols, d), "upload");
       Matrix E(h.cols, m);
       for (int j = 0; j < h.cols; ++j) E(j, at + j) = 1.0;
@@ -133,9 +139,7 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
     }
     std::vector<const double *> cp;
     for (const Matrix &E : sel) cp.push_back(E.data());
-    const int rc = cora_combine_dev(c, static_cast<int>(xs.size()), xs.data(), ks.data(), cp.data(), m, t1);
-    for (double *d : dev) cora_dev_free(c, d);
-    B.chk(rc, "combine");
+    B.chk(cora_combine_dev(c, static_cast<int>(xs.size()), xs.data(), ks.data(), cp.data(), m, t1), "combine");
   }
   tick("upload of the block");
 

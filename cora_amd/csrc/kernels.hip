@@ -2095,6 +2095,11 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
   } else {  // one wavefront per chunk of a long row
     const int ch = ((b - nb8 - nb64) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
     if (ch >= op.nchunks) return;
+    // (what the hand-off below needs is requested with the chunk's bounds, not after its entries: three dependent round
+    // trips fewer at the end of the longest chain of the launch)
+    const int r = op.chunk_row[ch];
+    const int c0 = op.long_chunk_ptr[r], c1 = op.long_chunk_ptr[r + 1];
+    const size_t long_orow = static_cast<size_t>(op.long_out[r]);
     rowop_entries<LD>(op.col, op.val, src, op.chunk_begin[ch] + g, op.chunk_end[ch], 64, acc);
     double tot = 0.0;  // lane j < LD ends up with column j
 #pragma unroll
@@ -2104,8 +2109,6 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
     }
     // publish the partial write-through, take a ticket of the row; the last chunk to arrive adds the row's
     // partials in chunk order (deterministic) -- the hand-off of k_spmm's long rows
-    const int r = op.chunk_row[ch];
-    const int c0 = op.long_chunk_ptr[r], c1 = op.long_chunk_ptr[r + 1];
     if (g < LD)
       __hip_atomic_store(op.partial + static_cast<size_t>(ch) * kMaxLD + g, tot, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -2130,7 +2133,7 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
 #pragma unroll
       for (int j = 0; j < LD; ++j) part[j] = wave_sum(part[j]);
       if (g == 0) {
-        const size_t orow = static_cast<size_t>(op.long_out[r]);
+        const size_t orow = long_orow;
         if (src0) {
           double b0[LD];
           load_row<LD>(src0 + orow * LD, b0);

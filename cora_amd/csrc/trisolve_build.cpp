@@ -23,9 +23,9 @@ constexpr int kTopCap = 1536;        // stop cutting once this few rows are left
 int64_t kTopInverseNnz = 2500000;  // ... or once the inverse of what is left has this few entries:
                                              // a launch floor (~5 us) is worth ~25 MB of traffic, so small
                                              // factors are applied as ONE explicit inverse (2 products)
-constexpr int kShortRow = 64;        // entries: <= this -> 8 lanes per row
-constexpr int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
-constexpr int kChunk = 512;
+int kShortRow = 64;        // entries: <= this -> 8 lanes per row
+int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
+int kChunk = 512;
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
 int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
@@ -84,6 +84,9 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P,
                     const std::vector<int32_t> *group, int32_t aux_base) {
   if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
+  if (const char *e = std::getenv("CORA_TRI_SHORT_ROW")) kShortRow = std::max(8, std::atoi(e));
+  if (const char *e = std::getenv("CORA_TRI_WAVE_ROW")) kWaveRow = std::max(64, std::atoi(e));
+  if (const char *e = std::getenv("CORA_TRI_CHUNK")) kChunk = std::max(64, std::atoi(e));
   if (const char *e = std::getenv("CORA_TRI_SUB_ROWS")) kSubRows = std::min(512, std::max(32, std::atoi(e)));
   if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::min(8, std::max(1, std::atoi(e)));
   int kSnCap = kSnCapChain;  // (local: plans are built from several rank threads at once)
@@ -934,6 +937,22 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     wt_val[k] = std::vector<double>();
   }
   tick("b products");
+  if (timing)  // shape of every product: rows per length class and the longest row of each
+    for (int k = 0; k < K; ++k)
+      for (const auto &pr : {std::make_pair("fwd_a", &P.stages[k].fwd_a), std::make_pair("fwd_b", &P.stages[k].fwd_b),
+                             std::make_pair("bwd_a", &P.stages[k].bwd_a), std::make_pair("bwd_b", &P.stages[k].bwd_b)}) {
+        const RowOpHost &op = *pr.second;
+        if (op.empty()) continue;
+        int64_t e8 = 0, e64 = 0, m8 = 0, m64 = 0;
+        for (int r = 0; r < op.n8 + op.n64; ++r) {
+          const int64_t len = op.end[r] - op.begin[r];
+          (r < op.n8 ? e8 : e64) += len;
+          (r < op.n8 ? m8 : m64) = std::max(r < op.n8 ? m8 : m64, len);
+        }
+        std::fprintf(stderr, "  [tri plan] stage %d %s: %d rows of 8 lanes (%lld entries, longest %lld), %d wavefront rows (%lld, longest %lld), %zu long rows in %zu chunks\n",
+                     k, pr.first, op.n8, static_cast<long long>(e8), static_cast<long long>(m8), op.n64, static_cast<long long>(e64),
+                     static_cast<long long>(m64), op.long_out.size(), op.chunk_begin.size());
+      }
 }
 
 
