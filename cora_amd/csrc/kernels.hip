@@ -2399,6 +2399,17 @@ __device__ __forceinline__ void project_unit(const SubFuse &F, size_t row, RowOf
 #ifndef CORA_SUB_MIN_BLOCKS
 #define CORA_SUB_MIN_BLOCKS 4
 #endif
+#ifdef CORA_SUB_TIMES
+// measurement build: wall-clock stamps of a substitution block's phases, forward and backward sweep apart
+// (tools/sub_timeline.py): 0 start | 1 right-hand sides in the tile | 2 levels done | 3 end | 4 clocks spent waiting for
+// a level's entries (wave 0) | 5 levels
+constexpr unsigned kSubTimesMax = 8192;
+constexpr int kSubPhases = 6;
+__device__ unsigned long long g_sub_phase[2 * kSubPhases * kSubTimesMax];
+#define CORA_SUB_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kSubTimesMax) g_sub_phase[(BWD ? kSubPhases * kSubTimesMax : 0) + kSubPhases * blockIdx.x + (i)] = (v); } while (0)
+#else
+#define CORA_SUB_STAMP(i, v) do { } while (0)
+#endif
 // FD: 0 plain solve; 1 (forward) residual update fused into the prologue; 2 / 3 (backward) tangent projection for
 // d = FD fused into the epilogue -- see SubFuse (kernels.h).
 //
@@ -2471,6 +2482,8 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     }
     return;
   }
+  CORA_SUB_STAMP(0, wall_clock64());
+  [[maybe_unused]] unsigned long long dbg_wait = 0;
   const SubSweep &Q = BWD ? S.bwd : S.fwd;
   const SubDesc bd = S.desc[b];
   const int nb = bd.nrows, rb = bd.row_begin;
@@ -2603,11 +2616,18 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     }
   }
   __syncthreads();
+  CORA_SUB_STAMP(1, wall_clock64());
 
   // ---- the triangular solve, level by level
   constexpr int CW = LD <= 6 ? LD : (LD % 6 == 0 ? 6 : (LD % 5 == 0 ? 5 : 4));  // accumulators per column chunk
   auto level = [&](int l, const int4 h, const int4 hn, SubRegs &R, SubRegs &Rnext) {
+#ifdef CORA_SUB_TIMES
+    const unsigned long long dbg_w0 = wall_clock64();
+#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the level's entries have arrived ...
+#ifdef CORA_SUB_TIMES
+    dbg_wait += wall_clock64() - dbg_w0;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     fetch(hn, Rnext);  // ... the next level's are on their way while this one is computed
     __builtin_amdgcn_sched_barrier(0);
@@ -2672,6 +2692,17 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     }
   }
 
+  CORA_SUB_STAMP(2, wall_clock64());
+  CORA_SUB_STAMP(4, dbg_wait);
+  CORA_SUB_STAMP(5, static_cast<unsigned long long>(nlev));
+#ifdef CORA_SUB_TIMES
+  struct SubEnd {  // (the result paths return from several places)
+    unsigned bwd;
+    __device__ ~SubEnd() {
+      if (threadIdx.x == 0 && blockIdx.x < kSubTimesMax) g_sub_phase[(bwd ? kSubPhases * kSubTimesMax : 0) + kSubPhases * blockIdx.x + 3] = wall_clock64();
+    }
+  } dbg_end{BWD ? 1u : 0u};
+#endif
   // ---- results
   if (FD >= 2) {
     // v = Proj_Y(x) in the tile, a lane per row unit (a pose's rotation rows sit at consecutive positions) ...
@@ -3349,6 +3380,17 @@ hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double 
 #endif  // CORA_TU & 2
 }  // namespace cora
 
+#if defined(CORA_SUB_TIMES) && (CORA_TU & 4) && (CORA_LDG & 1)
+// measurement build only (-DCORA_SUB_TIMES, tools/sub_timeline.py): the block timestamps of the last forward and backward sweep
+extern "C" int cora_debug_sub_phases(unsigned long long *out, int n_blocks) {
+  if (n_blocks < 0 || static_cast<unsigned>(n_blocks) > cora::kSubTimesMax) return -1;
+  for (int w = 0; w < 2; ++w)
+    if (hipMemcpyFromSymbol(out + static_cast<size_t>(w) * cora::kSubPhases * n_blocks, HIP_SYMBOL(cora::g_sub_phase),
+                            sizeof(unsigned long long) * cora::kSubPhases * n_blocks,
+                            sizeof(unsigned long long) * w * cora::kSubPhases * cora::kSubTimesMax) != hipSuccess) return -2;
+  return 0;
+}
+#endif
 #if defined(CORA_SPMM_TIMES) && (CORA_TU & 1) && (CORA_LDG & 1)
 // measurement build only (-DCORA_SPMM_TIMES, tools/spmm_timeline.py): the wavefront timestamps of the last k_spmm launch
 extern "C" int cora_debug_spmm_times(unsigned long long *out, int n_blocks) {

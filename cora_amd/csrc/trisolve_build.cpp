@@ -814,6 +814,33 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     if (zero_row >= 0) P.top_rows.push_back(zero_row);
   }
   tick("merge / dense blocks");
+  if (timing && sub0) {  // shape of the substitution blocks: levels (= dependent steps of a sweep) and how full they are
+    const SubBlockOpHost &S0 = P.stages[0].sub_op;
+    const size_t nbk = S0.nrows.size();
+    int64_t fl = 0, bl = 0, lanes_f = 0, lanes_b = 0, rows = 0, ent_f = 0, ent_b = 0, slots_f = 0, slots_b = 0;
+    int fmax = 0, bmax = 0;
+    for (size_t b = 0; b < nbk; ++b) {
+      const int nf = S0.f_lev_begin[b + 1] - S0.f_lev_begin[b] - 1, nbw = S0.b_lev_begin[b + 1] - S0.b_lev_begin[b] - 1;
+      fl += nf; bl += nbw; fmax = std::max(fmax, nf); bmax = std::max(bmax, nbw);
+      rows += S0.nrows[b];
+      for (int l = 0; l < nf; ++l) {
+        const int32_t *h = &S0.f_hdr[4 * (static_cast<size_t>(S0.f_lev_begin[b]) + l)];
+        const int g = h[1] & 0xff, npl = (h[1] >> 8) & 0xf, nr = h[1] >> 12;
+        lanes_f += static_cast<int64_t>(nr) * g; slots_f += static_cast<int64_t>(nr) * g * npl;
+      }
+      for (int l = 0; l < nbw; ++l) {
+        const int32_t *h = &S0.b_hdr[4 * (static_cast<size_t>(S0.b_lev_begin[b]) + l)];
+        const int g = h[1] & 0xff, npl = (h[1] >> 8) & 0xf, nr = h[1] >> 12;
+        lanes_b += static_cast<int64_t>(nr) * g; slots_b += static_cast<int64_t>(nr) * g * npl;
+      }
+      ent_f += S0.f_nent[b]; ent_b += S0.b_nent[b];
+    }
+    std::fprintf(stderr, "  [tri plan] %zu substitution blocks, %.0f rows each: forward %.1f levels per block (max %d), %.0f lanes and %.0f entry slots per level; "
+                 "backward %.1f levels (max %d), %.0f lanes and %.0f slots per level; stored entries %lld + %lld\n",
+                 nbk, double(rows) / nbk, double(fl) / nbk, fmax, double(lanes_f) / std::max<int64_t>(fl, 1), double(slots_f) / std::max<int64_t>(fl, 1),
+                 double(bl) / nbk, bmax, double(lanes_b) / std::max<int64_t>(bl, 1), double(slots_b) / std::max<int64_t>(bl, 1),
+                 static_cast<long long>(ent_f), static_cast<long long>(ent_b));
+  }
   // ---- "a" products: the couplings between stages
   for (int k = 0; k < K && !sub0; ++k) {
     RowList fa, ba;
