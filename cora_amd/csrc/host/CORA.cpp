@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <thread>
 #include <cmath>
 #include <cstdint>
@@ -88,12 +89,21 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
   const auto t_begin = std::chrono::steady_clock::now();
   using clk = std::chrono::steady_clock;
   auto since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
+  // What the first certification needs and the point does not decide (order, pattern and symbolic analysis of the
+  // certificate matrix, storage of its factor, random start columns) is prepared on a thread of its own while the first
+  // TNT solve keeps the device busy.  (The future's destructor joins: an exception below cannot leave the thread behind.)
+  std::future<void> cert_prepared;
+  if (!std::getenv("CORA_NO_CERT_PREPARE"))
+    cert_prepared = std::async(std::launch::async, [&problem, LOBPCG_BLOCK_SIZE] {
+      problem.prepareCertification(std::max<Index>(LOBPCG_BLOCK_SIZE, static_cast<Index>(problem.getRelaxationRank()) + 2));
+    });
   while (static_cast<int>(problem.getRelaxationRank()) <= max_relaxation_rank) {
     ++levels;
     printIfVerbose(verbose, "\nSolving problem at rank " + std::to_string(problem.getRelaxationRank()));
     auto t0 = clk::now();
     result = TNT(problem, X, params);
     t_tnt += since(t0);
+    if (cert_prepared.valid()) cert_prepared.get();
     hvps += result.hessian_vector_products;
     traceBits("TNT", result.x, result.f, result.gradfx_norm, result.hessian_vector_products);
     printIfVerbose(verbose, "Obtained solution with objective value: " + std::to_string(result.f));

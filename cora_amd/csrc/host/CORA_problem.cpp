@@ -745,8 +745,21 @@ SparseMatrix Problem::compute_Lambda_from_Lambda_blocks(const LambdaBlocks &L, c
 
 SparseMatrix Problem::get_certificate_matrix(const Matrix &Y) const { return certificateMatrixCached(Y); }
 
-const SparseMatrix &Problem::certificateMatrixCached(const Matrix &Y) const {
-  const LambdaBlocks L = compute_Lambda_blocks(Y);
+const SparseMatrix &Problem::certificateMatrixCached(const Matrix &Y) const { return certificateMatrixFrom(compute_Lambda_blocks(Y)); }
+
+void Problem::prepareCertification(Index num_eigvecs) const {
+  const Index N = getDataMatrixSize();
+  if (static_cast<Index>(cert_perm_.size()) != N)
+    cert_perm_ = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_, static_cast<int>(N));
+  const size_t n_lambda = static_cast<size_t>(numPosesDim()) * dim_ + static_cast<size_t>(numRangeMeasurements());
+  if (cert_S_.rows() != N || cert_lambda_pos_.size() != n_lambda)  // the pattern, with Lambda = 0 for values
+    certificateMatrixFrom(LambdaBlocks(Matrix(dim_, numPosesDim()), Vector(numRangeMeasurements(), 1)));
+  choleskyAnalyze(cert_S_, static_cast<int>(N), cert_perm_, symbolic_cache_.get());
+  num_eigvecs = std::min<Index>(std::min<Index>(num_eigvecs, N), 24);
+  if (cert_random_.rows() != N || cert_random_.cols() < num_eigvecs) cert_random_ = Matrix::RandomColumns(N, num_eigvecs, 0xC0FFEEull);
+}
+
+const SparseMatrix &Problem::certificateMatrixFrom(const LambdaBlocks &L) const {
   // S = Q - Lambda.  Lambda lives on the d x d diagonal blocks of the rotation rows and on the diagonal of the range
   // rows.  The first call merges every row of Q (sorted by column) with its <= d entries of -Lambda in one pass
   // (entries of Lambda outside Q's pattern -- the off-diagonals of a pose without translation measurements -- are

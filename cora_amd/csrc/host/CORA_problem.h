@@ -91,6 +91,7 @@ class Problem {
   bool cert_lab_on_ = false, cert_lab_seed_ = true, cert_lab_ildl_ = true;
   mutable bool cert_reached_step3_ = false;
   const SparseMatrix &certificateMatrixCached(const Matrix &Y) const;
+  const SparseMatrix &certificateMatrixFrom(const std::pair<Matrix, Vector> &lambda_blocks) const;
 
   void checkUpToDate() const;
   void addOriginPose();
@@ -216,6 +217,12 @@ class Problem {
   LambdaBlocks compute_Lambda_blocks(const Matrix &Y) const;
   SparseMatrix compute_Lambda_from_Lambda_blocks(const LambdaBlocks &Lambda_blocks, const int &Lambda_size) const;
   SparseMatrix get_certificate_matrix(const Matrix &Y) const;
+  /** Everything a first certification needs that does not depend on the point: the elimination order of the certificate
+   * matrix, its pattern (Q's plus the Lambda blocks), the symbolic analysis of its factorisation with the factor's
+   * storage touched once, and the random start columns of the eigensolver.  solveCORA runs it on a thread of its own
+   * WHILE the first TNT solve keeps the device busy (none of it is read by TNT): at 10^5 poses 0.07 s of the first
+   * certification's 0.12 s, at 10^6 poses 0.8 of 1.4 s.  Calling it is optional; certify_solution does whatever is missing. */
+  void prepareCertification(Index num_eigvecs = 12) const;
   /** Test switches of the eigensolver stage of certify_solution (see FastVerificationLab): without the seed of the failed
    * factorisation and / or without the incomplete-LDL^T preconditioner; and whether the last call got as far as step 3. */
   void setVerificationLab(bool seed_negative_direction, bool use_ildl) {

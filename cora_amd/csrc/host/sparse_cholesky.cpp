@@ -461,6 +461,17 @@ CholeskyFactor::~CholeskyFactor() {
   }
 }
 
+void choleskyAnalyze(const SparseMatrix &A, int m, const std::vector<int32_t> &perm, SymbolicCache *cache) {
+  if (!cache || m <= 0) return;
+  std::vector<int32_t> iperm(static_cast<size_t>(A.rows()), -1);
+  for (int i = 0; i < m; ++i) iperm[perm[i]] = i;
+  bool hit = false;
+  const std::shared_ptr<const Symbolic> sym = symbolicFor(A, m, perm, iperm, &hit, cache);
+  CholeskyFactor F;  // (its destructor hands the storage to the pool)
+  F.Li = takeStorage(g_pool_i, static_cast<size_t>(sym->tot));
+  F.Lx = takeStorage(g_pool_x, static_cast<size_t>(sym->tot));
+}
+
 CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
                               SymbolicCache *cache) {
   CholeskyFactor F;

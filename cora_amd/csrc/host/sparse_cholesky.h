@@ -69,6 +69,11 @@ class SymbolicCache {
 CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
                               SymbolicCache *cache = nullptr);
 
+/** The part of choleskyFactor(A, m, *, perm, cache) that depends on the pattern and the order alone, done ahead of
+ * time: the symbolic analysis goes into `cache` and storage for the factor is touched once and left in the pool, so the
+ * factorisation that follows finds both (CORA::Problem::prepareCertification).  No-op without a cache. */
+void choleskyAnalyze(const SparseMatrix &A, int m, const std::vector<int32_t> &perm, SymbolicCache *cache);
+
 /** Incomplete L D L^T of the symmetric (possibly INDEFINITE) matrix A[0:m, 0:m] + shift * I in the order perm --
  * the stand-in for Preconditioners::ILDL (libs/Preconditioners, un-vendored submodule; reference call
  * src/CORA_utils.cpp:140-156 with ILDLOpts{max_fill_factor, drop_tol}).  Left-looking (Crout) elimination with
