@@ -1,5 +1,6 @@
 #include "CORA_utils.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -75,6 +76,47 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
     if (timing) std::fprintf(stderr, "    [verify] %-24s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
+  // The PSD test runs on the host and leaves the device idle; step 2 below -- the unpreconditioned eigensolver for 1 % of
+  // the budget -- needs nothing from it.  With the problem's own operator at hand (no handle to build) on one GPU it is
+  // started NOW on a thread of its own and joined after the factorisation: a failed certification no longer pays for it
+  // (10 ms of 55 at 10^5 poses), a successful one stops it at its next iteration and drops the result.  Same numbers
+  // either way.  (Partitioned handles: every rank would have to stop at the same iteration -- not speculated.)
+  const double unprecon_iter_frac = .01;
+  const int N = static_cast<int>(n);
+  LOBPCGStop stopfun = [eta](size_t, const std::vector<Scalar> &Theta, const double *, int) {
+    return (Theta[0] - eta) < -eta / 2;  // X orthonormal: x' S x = theta_M - eta
+  };
+  struct Speculation {
+    std::thread th;
+    std::atomic<bool> cancel{false};
+    std::unique_ptr<LOBPCGSolver> solver;
+    LOBPCGResult r;
+    std::exception_ptr err;
+    bool ran = false;
+    ~Speculation() {
+      cancel = true;
+      if (th.joinable()) th.join();
+    }
+  } spec;
+  if (S_op && ctx && n > 100 && cora_world(ctx) == 1 && std::getenv("CORA_NO_CERT_SPECULATION") == nullptr) {
+    spec.ran = true;
+    spec.th = std::thread([&, c = ctx] {
+      try {
+        const DeviceOperator Sop0 = *S_op;
+        DeviceOperator Mop0 = [&, c](const double *dX, int k, double *dOut) {
+          Sop0(dX, k, dOut);
+          if (eta != 0.0 && cora_axpby_cols_dev(c, k, eta, dX, 1.0, dOut) != CORA_OK) throw std::runtime_error(cora_last_error(c));
+        };
+        LOBPCGStop stop0 = [&](size_t it, const std::vector<Scalar> &Theta, const double *X, int m) {
+          return spec.cancel.load() || stopfun(it, Theta, X, m);
+        };
+        spec.solver = std::make_unique<LOBPCGSolver>(c, N);
+        spec.r = spec.solver->run(Mop0, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0, stop0, false);
+      } catch (...) {
+        spec.err = std::current_exception();
+      }
+    });
+  }
   const CholeskyFactor F = choleskyFactor(S, static_cast<int>(n), eta, perm, symbolic);
   tick("Cholesky of S + eta I");
   const bool PSD = F.ok;
@@ -82,8 +124,10 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
   if (PSD) {
     results.x = Vector::Zero(n, 1);
     results.all_eigvecs = Matrix();
-    return results;
+    return results;  // (the speculation, if any, is stopped and joined by its destructor)
   }
+  if (spec.th.joinable()) spec.th.join();
+  if (spec.err) std::rethrow_exception(spec.err);
   if (n <= 100) {  // dense path (:63-74)
     Matrix D(n, n);
     for (Index i = 0; i < n; ++i)
@@ -118,16 +162,17 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
     if (eta != 0.0 && cora_axpby_cols_dev(c, k, eta, dX, 1.0, dOut) != CORA_OK)
       throw std::runtime_error(cora_last_error(c));
   };
-  LOBPCGStop stopfun = [eta](size_t, const std::vector<Scalar> &Theta, const double *, int) {
-    return (Theta[0] - eta) < -eta / 2;  // X orthonormal: x' S x = theta_M - eta
-  };
   // STEP 2: unpreconditioned LOBPCG for 1 % of the iteration budget (:104-119).  The blocks of a run stay on the device;
   // what comes back to the host is the Ritz block of the run that ended the search, once.
-  const double unprecon_iter_frac = .01;
-  const int N = static_cast<int>(n);
-  auto solver = std::make_unique<LOBPCGSolver>(c, N);
-  LOBPCGResult r = solver->run(Mop, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0, stopfun,
-                               false);
+  std::unique_ptr<LOBPCGSolver> solver;
+  LOBPCGResult r;
+  if (spec.ran) {  // it ran beside the factorisation
+    solver = std::move(spec.solver);
+    r = std::move(spec.r);
+  } else {
+    solver = std::make_unique<LOBPCGSolver>(c, N);
+    r = solver->run(Mop, std::nullopt, X0, 1, static_cast<size_t>(unprecon_iter_frac * max_iters), 0.0, stopfun, false);
+  }
   size_t iters = r.num_iters;
   tick("LOBPCG, 1 % of the budget");
   if (!(r.Theta(0) - eta < -eta / 2)) {
