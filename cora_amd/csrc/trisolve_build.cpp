@@ -1,6 +1,7 @@
 #include "trisolve.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,8 @@ constexpr int kSnCapChain = 4;  // rows of a supernode of the substitution block
 int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
 int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
+
+std::atomic<int64_t> g_seg_waves{0}, g_seg_reads{0}, g_seg_real{0}, g_seg_levels{0}, g_seg_sublevels{0}, g_cur_reads{0}, g_cur_sublevels{0};  // (timing mode)
 
 struct RowList {  // rows of one product before they are sorted into length classes
   std::vector<int32_t> out, ptr{0}, col;
@@ -632,6 +635,24 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
           const int lev = lev_of_var[mem[order[t]]];
           int t1 = t;
           while (t1 < nb && lev_of_var[mem[order[t1]]] == lev) ++t1;
+          if (timing) {  // what a layout with a (g, npl) of its own per WAVEFRONT of a level would read: rows grouped by class
+            // rows by length, longest first; a wavefront takes rows while they fit its 64 lanes at the (g, npl) of its first row
+            std::vector<int> lens;
+            int64_t real = 0;
+            for (int q = t; q < t1; ++q) {
+              lens.push_back(std::max<int>(1, static_cast<int>(rows_ent[order[q]].size())));
+              real += lens.back();
+            }
+            std::sort(lens.begin(), lens.end(), std::greater<int>());
+            int64_t waves = 0, reads = 0;
+            for (size_t q = 0; q < lens.size();) {
+              const int g = lanes_for(lens[q]), npl = (lens[q] + g - 1) / g;
+              q += static_cast<size_t>(64 / g);
+              ++waves;
+              reads += 64 * npl;
+            }
+            g_seg_waves += waves; g_seg_reads += reads; g_seg_real += real; g_seg_levels += 1; g_seg_sublevels += (waves + 3) / 4;
+          }
           for (int c0 = t; c0 < t1;) {
             int max_len = 1;
             for (int q = c0; q < t1 && sn_id[order[q]] == sn_id[order[c0]]; ++q)
@@ -647,6 +668,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
             }
             // header {first row, g | npl << 8 | rows << 12, first coefficient (block-relative), first index (absolute in the idx array)}
             hdr.insert(hdr.end(), {c0, g | (npl << 8) | ((c1 - c0) << 12), static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
+            if (timing) { g_cur_reads += static_cast<int64_t>(((c1 - c0) * g + 63) / 64) * 64 * npl; g_cur_sublevels += 1; }
             // lane p of row k takes the row's entries p, p + g, ...  Coefficients of the level: slot-major,
             // [u][lane = (k - c0) * g + p] (the kernel streams them, one coalesced load per slot); local row indices:
             // lane-major, [lane][4 or 8] (one load per lane), the level padded to a multiple of 8 indices
@@ -814,7 +836,11 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     if (zero_row >= 0) P.top_rows.push_back(zero_row);
   }
   tick("merge / dense blocks");
-  if (timing && sub0) {  // shape of the substitution blocks: levels (= dependent steps of a sweep) and how full they are
+  if (timing && sub0) {
+    std::fprintf(stderr, "  [tri plan] tile reads per lane-slot, both sweeps: now %lld in %lld barrier levels; a (g, npl) per wavefront: %lld in %lld (tree levels %lld); real entries %lld\n",
+                 static_cast<long long>(g_cur_reads.load()), static_cast<long long>(g_cur_sublevels.load()), static_cast<long long>(g_seg_reads.load()),
+                 static_cast<long long>(g_seg_sublevels.load()), static_cast<long long>(g_seg_levels.load()), static_cast<long long>(g_seg_real.load()));
+    g_seg_waves = g_seg_reads = g_seg_real = g_seg_levels = g_seg_sublevels = g_cur_reads = g_cur_sublevels = 0;  // shape of the substitution blocks: levels (= dependent steps of a sweep) and how full they are
     const SubBlockOpHost &S0 = P.stages[0].sub_op;
     const size_t nbk = S0.nrows.size();
     int64_t fl = 0, bl = 0, lanes_f = 0, lanes_b = 0, rows = 0, ent_f = 0, ent_b = 0, slots_f = 0, slots_b = 0;
