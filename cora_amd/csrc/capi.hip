@@ -1908,6 +1908,17 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       tail.st = c->d_stpcg;
       tail.st_host = &c->h_stpcg[0];
       tail.seq_out = reinterpret_cast<unsigned long long *>(c->h_scalars + 7);
+      // kappa without a launch of its own (one GPU, mid-size problems): every block of the forward sweep adds the
+      // product's partials and runs the scalar step privately, the tail block of the last stage advances the state.
+      // Measured: with a few hundred partials (the reference's data sets: 288) an iteration loses the 4.5 us launch and
+      // the sweep does not notice (plaza1 69.0 -> 66.6 us per product end to end, tiers 88.5 -> 84.8, mrclam6 109 -> 104.5);
+      // with the 2 470 partials of 10^5 poses every block's sum costs the sweep the 5.2 us the launch took (1 060 blocks
+      // reading the same 20 KB through eight L2s): there, and above, the launch stays.
+      static const int fold_max = [] { const char *e = std::getenv("CORA_KAPPA_FOLD_MAX"); return e ? std::atoi(e) : 1024; }();
+      if (!sharded && kappa_blocks <= fold_max && !std::getenv("CORA_NO_KAPPA_FOLD")) {
+        FF.kappa_partial = tail.kappa_partial = kappa_partial;
+        FF.n_kappa = tail.n_kappa = kappa_blocks;
+      }
     }
   }
   c->stpcg_path = sweep_fused ? 2 : inverse_fused ? 3 : fused ? 1 : 0;
@@ -2035,7 +2046,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           return CORA_OK;
         }
         if (sweep_fused) {
-          HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
+          if (FF.n_kappa == 0) HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
           // Hp = H p | kappa | forward sweep: r += alpha Hp, <r, r>, |y|^2 | last stage, <r, v> in its second product |
           // backward sweep: v = Proj_Y(x), s += alpha p, p = -v + beta p   -- six launches
           cora_ctx::DevFactor &f = c->precond_f;

@@ -183,6 +183,10 @@ struct RvTail {
   unsigned long long *seq_out;  // pinned: set to seq after the mirror is visible to the host
   unsigned long long seq;
   unsigned long long *seq_counter;  // non-null: seq = ++(*seq_counter), see DotArgs
+  // n_kappa > 0: the iteration's kappa step has not run yet (SubFuse::n_kappa): the block adds the partials and runs it
+  // before the two steps of its own
+  const double *kappa_partial;
+  int n_kappa;
   // non-null (partitioned handle): the block leaves THIS RANK'S sums -- sums_out[0] = <r, r>, sums_out[1] = <r, v> -- and
   // touches neither the state nor the mirror: the sums are added over the ranks first (one all-reduce), then
   // k_stpcg_scalar_step runs the scalar step
@@ -202,6 +206,12 @@ struct SubFuse {
   double *p = nullptr, *s = nullptr;  // backward: s += coef_s p, then p = coef_v v + coef_beta p  (v = Proj_Y(x), not stored)
   int d = 0;
   int64_t rot_base = 0, rng_base = 0, trn_base = 0;  // internal rows: rotations | ranges | translations
+  // forward, n_kappa > 0: kappa = <p, Hp> has NOT been finished by a launch of its own -- every block adds the product's
+  // n_kappa partial sums itself (same order, same bits: kappa_sum_256) and runs the scalar step on a private copy of the
+  // state to get coef_r; the state itself is advanced later, by the tail block of the last stage (RvTail::n_kappa), which
+  // adds the same partials the same way.  One launch per iteration less; worth it while blocks x partials is small.
+  const double *kappa_partial = nullptr;
+  int n_kappa = 0;
 };
 inline int launch_subblock_blocks(const SubOpDev &S) { return S.nblocks + (S.ntop + 255) / 256; }
 hipError_t launch_subblock_fused(const SubOpDev &S, int ld, bool backward, const SubFuse &F, double *work, double *out,

@@ -123,6 +123,23 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm) {
   return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// Sum of the per-block partials of kappa = <p, Hp> by a block of 256 threads: ONE order of additions wherever it is
+// formed (k_kappa_finish, every block of a fused forward sweep, the tail block of the last stage), so the same bits.
+// (10^6 poses: 40 k partials on one block -- keep 32 loads per lane in flight.)
+__device__ __forceinline__ double kappa_sum_256(const double *__restrict__ partial, int n, double *sm) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = threadIdx.x;
+#pragma unroll 8
+  for (; b + 768 < n; b += 1024) {
+    s0 += partial[b];
+    s1 += partial[b + 256];
+    s2 += partial[b + 512];
+    s3 += partial[b + 768];
+  }
+  for (; b < n; b += 256) s0 += partial[b];
+  return block_sum_256((s0 + s1) + (s2 + s3), sm);
+}
+
 // Scalar recurrences of the device-resident Steihaug-Toint PCG (StpcgState, kernels.h), run by ONE thread of the
 // kernel that finished the inner product they need.
 __device__ __forceinline__ void stpcg_after_kappa(StpcgState &S, double kappa) {  // after Hp = H p:  kappa = <p, Hp>
@@ -2028,6 +2045,8 @@ __device__ __forceinline__ void rv_tail_block(const RvTail &T) {
   const double l_rr = lane_sum_slots_256(T.rr_partial, T.n_rr);
   const double l_yy = lane_sum_slots_256(T.yy_partial, T.n_yy);
   const double l_tt = lane_sum_slots_256(T.rowsq, T.n_rowsq);
+  __shared__ double ksm[4];
+  const double kappa = T.n_kappa > 0 ? kappa_sum_256(T.kappa_partial, T.n_kappa, ksm) : 0.0;  // (wave-uniform branch)
   const double rr = block_sum_256(l_rr, sm);
   const double yy = block_sum_256(l_yy, sm + 4);
   const double tt = block_sum_256(l_tt, sm + 8);
@@ -2037,6 +2056,7 @@ __device__ __forceinline__ void rv_tail_block(const RvTail &T) {
       T.sums_out[1] = yy + tt;
       return;
     }
+    if (T.n_kappa > 0) stpcg_after_kappa(L, kappa);  // the iteration's first scalar step, which no launch of its own ran
     if (T.n_rr > 0) stpcg_after_rr(L, rr);  // (n_rr == 0: <r, r> was finished by the residual pass)
     stpcg_after_rv(L, yy + tt);
     *T.st = L;
@@ -2427,7 +2447,18 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   const int tid = threadIdx.x;
   const int b = static_cast<int>(blockIdx.x);
   double dacc[4] = {0.0, 0.0, 0.0, 0.0};
-  const double cr = (FD == 1) ? F.dot.st->coef_r : 0.0;
+  double cr = 0.0;
+  if (FD == 1) {
+    if (F.n_kappa > 0) {  // kappa folded into this launch (SubFuse::n_kappa): private scalar step, the state is not written
+      const double kappa = kappa_sum_256(F.kappa_partial, F.n_kappa, dot_sm);
+      StpcgState L = *F.dot.st;
+      stpcg_after_kappa(L, kappa);
+      cr = L.coef_r;
+      __syncthreads();  // (dot_sm is used again below)
+    } else {
+      cr = F.dot.st->coef_r;
+    }
+  }
   // fused backward sweep: the step and the direction are updated on the way out (the scalars are final: the launch
   // before this one finished <r, v>)
   const double cs = (FD >= 2) ? F.dot.st->coef_s : 0.0, cv = (FD >= 2) ? F.dot.st->coef_v : 0.0,
@@ -2838,19 +2869,8 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 __global__ __launch_bounds__(256) void k_kappa_finish(const double *__restrict__ partial, int n, StpcgState *st) {
   __shared__ double sm[4];
   StpcgState L = {};
-  if (threadIdx.x == 0) L = *st;  // in flight while the partials are added up (after the barriers it would be a round trip of its own)
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = threadIdx.x;
-  // (10^6 poses: 40 k partials on one block -- keep 32 loads per lane in flight; the order of the sums is unchanged)
-#pragma unroll 8
-  for (; b + 768 < n; b += 1024) {
-    s0 += partial[b];
-    s1 += partial[b + 256];
-    s2 += partial[b + 512];
-    s3 += partial[b + 768];
-  }
-  for (; b < n; b += 256) s0 += partial[b];
-  const double t = block_sum_256((s0 + s1) + (s2 + s3), sm);
+  if (threadIdx.x == 0) L = *st;  // in flight while the partials are added up
+  const double t = kappa_sum_256(partial, n, sm);
   if (threadIdx.x == 0) {
     stpcg_after_kappa(L, t);
     *st = L;
