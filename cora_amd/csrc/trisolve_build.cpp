@@ -33,6 +33,10 @@ constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 colu
 constexpr int kSnCapChain = 4;  // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
 int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
 int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
+int kSplitMinRows = 1 << 20;  // a chunk of a level is closed early when the next rows are half as long, from this many rows on.
+                              // Never, since round 4: closing early saves padding (tile reads 15.4 M instead of 16.3 M at 10^5
+                              // poses) and costs barrier levels (25.0 k instead of 20.0 k); measured: 10^5 poses 117.6 / 118.4 us
+                              // per iteration (16 / never), 10^4 poses 62.9 / 58.4, tiers 83.1 / 78.6 us per product, mrclam3b 85.7 / 77.0
 constexpr int kMinBlock = 8;         // smaller subtrees are left to the next stage (a wavefront per block would idle)
 
 std::atomic<int64_t> g_seg_waves{0}, g_seg_reads{0}, g_seg_real{0}, g_seg_levels{0}, g_seg_sublevels{0}, g_cur_reads{0}, g_cur_sublevels{0};  // (timing mode)
@@ -95,6 +99,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
   int kSnCap = kSnCapChain;  // (local: plans are built from several rank threads at once)
   if (const char *e = std::getenv("CORA_TRI_SN_CAP")) kSnCap = std::min(32, std::max(1, std::atoi(e)));
   if (const char *e = std::getenv("CORA_TRI_LEVEL_LANES")) kLevelLanes = std::min(256, std::max(64, std::atoi(e)));
+  if (const char *e = std::getenv("CORA_TRI_SPLIT_MIN_ROWS")) kSplitMinRows = std::max(1, std::atoi(e));
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
   auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
     if (!timing) return;
@@ -663,7 +668,7 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
             while (c1 < t1 && c1 - c0 < cap_rows) {  // whole supernodes while they fit the width and are not much shorter
               int q = c1, sn_len = 0;
               while (q < t1 && sn_id[order[q]] == sn_id[order[c1]]) sn_len = std::max<int>(sn_len, static_cast<int>(rows_ent[order[q++]].size()));
-              if (c1 > c0 && (q - c0 > cap_rows || sn_len > w || (2 * sn_len <= w && c1 - c0 >= 16))) break;
+              if (c1 > c0 && (q - c0 > cap_rows || sn_len > w || (2 * sn_len <= w && c1 - c0 >= kSplitMinRows))) break;
               c1 = q;
             }
             // header {first row, g | npl << 8 | rows << 12, first coefficient (block-relative), first index (absolute in the idx array)}
