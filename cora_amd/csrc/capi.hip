@@ -1005,9 +1005,9 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
         d.b_ent_begin = H.b_ent_begin[b];
         d.b_nent = H.b_nent[b];
         d.f_lev_begin = H.f_lev_begin[b];
-        d.f_nlev = H.f_lev_begin[b + 1] - H.f_lev_begin[b] - 1;
+        d.f_nlev = (H.f_lev_begin[b + 1] - H.f_lev_begin[b]) / 4 - 1;  // barrier levels: one header per wavefront (4) each, + the closing one
         d.b_lev_begin = H.b_lev_begin[b];
-        d.b_nlev = H.b_lev_begin[b + 1] - H.b_lev_begin[b] - 1;
+        d.b_nlev = (H.b_lev_begin[b + 1] - H.b_lev_begin[b]) / 4 - 1;
         d.tgt_begin = H.tgt_begin[b];
         d.ntgt = H.tgt_begin[b + 1] - H.tgt_begin[b];
       }

@@ -2526,13 +2526,19 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   // level headers {first row, g | npl << 8 | rows << 12, first coefficient, first index}: staged in LDS behind the tile
   // (the loop below orders its loads with scheduling barriers, after which the compiler no longer reads global memory
   // through the scalar cache) and handed from level to level in scalar registers
+  // A barrier level is kSubWaves headers, one per WAVEFRONT of the workgroup: {first row, lanes per row | entries per
+  // lane << 8 | rows << 12, first coefficient, first index} of the rows that wavefront solves in the level (its own
+  // width: short rows do not pay for the level's longest); nlev levels + a closing one.
+  constexpr int kSubWaves = kSubThreads / 64;
+  const int wv = wave_base >> 6;
   int4 *hl = reinterpret_cast<int4 *>(smem + ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)));
-  if (tid <= nlev) hl[tid] = gh[tid];
+  for (int i = tid; i < (nlev + 1) * kSubWaves; i += kSubThreads) hl[i] = gh[i];
   auto header = [&](int l) {
-    const int4 h = hl[l < nlev ? l : nlev];  // the closing header has no rows
+    const int4 h = hl[(l < nlev ? l : nlev) * kSubWaves + wv];  // the closing level has no rows
     return make_int4(__builtin_amdgcn_readfirstlane(h.x), __builtin_amdgcn_readfirstlane(h.y),
                      __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w));
   };
+  const int wl = tid & 63;  // lane of the wavefront: a level's lanes are counted per wavefront
 
   // (Measured and dropped: entries of TWO levels ahead in a third register set.  The compiler only keeps loads in flight
   // across a first use when their number is branch-free, i.e. nine loads per lane and level whatever the level's width:
@@ -2542,8 +2548,8 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   // bounds a level once the latency is hidden: 16 unconditional loads per lane and level were 1.7 us per level).
   auto fetch = [&](const int4 h, SubRegs &R) {
     const int g = h.y & 0xff, npl = (h.y >> 8) & 0xf, nlane = (h.y >> 12) * g;
-    if (wave_base >= nlane) return;
-    const int lane = tid < nlane ? tid : nlane - 1;
+    if (nlane == 0) return;  // (wave-uniform: the header is the wavefront's own)
+    const int lane = wl < nlane ? wl : nlane - 1;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if (npl > 4) {
@@ -2564,7 +2570,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 #pragma unroll
   for (int u = 0; u < kSubNpl / 2; ++u) RA.i[u] = RB.i[u] = 0;
   {
-    const int4 h = gh[0];  // before anything is ordered: through the scalar cache
+    const int4 h = gh[wv];  // before anything is ordered
     fetch(make_int4(__builtin_amdgcn_readfirstlane(h.x), __builtin_amdgcn_readfirstlane(h.y),
                     __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w)), RA);
   }
@@ -2665,7 +2671,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     const int4 hnn = header(l + 2);
     const int r0 = h.x, g = h.y & 0xff, npl = (h.y >> 8) & 0xf;
     const int gs = 31 - __builtin_clz(g), nlane = (h.y >> 12) << gs;
-    const bool active = wave_base < nlane;  // wavefront-uniform: the others go straight to the barriers
+    const bool active = nlane > 0;  // wavefront-uniform: the others go straight to the barriers
     double res[LD];
     if (active) {
       // One jump on the (wave-uniform) number of entries per lane and one on the lanes per row, then straight-line code:
@@ -2704,8 +2710,8 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
       }
     }
     __syncthreads();  // every row of the level has read the tile ...
-    if (active && tid < nlane && (tid & (g - 1)) == 0) {
-      double *__restrict__ o = reinterpret_cast<double *>(smem + __mul24(r0 + (tid >> gs), LD * 8));
+    if (active && wl < nlane && (wl & (g - 1)) == 0) {
+      double *__restrict__ o = reinterpret_cast<double *>(smem + __mul24(r0 + (wl >> gs), LD * 8));
 #pragma unroll
       for (int j = 0; j < LD; ++j) o[j] = res[j];
     }
@@ -3260,7 +3266,11 @@ static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *sr
   const int grid = launch_subblock_blocks(S);
   if (grid <= 0) return hipSuccess;
   const size_t lds = ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(S.max_lev + 2) * 16;
-  if (S.max_level_lanes > kSubThreads || S.max_npl > kSubNpl || S.max_lev + 1 > kSubThreads || lds > 64 * 1024) return hipErrorInvalidValue;
+  if (S.max_level_lanes > kSubThreads || S.max_npl > kSubNpl || lds > 160 * 1024) return hipErrorInvalidValue;
+  // (wide rows: the tile of a 435-row block is 56 KB at 16 columns, 84 KB at 24 -- above the 64 KB a kernel gets without asking)
+  auto allow_lds = [&](const void *fn) {
+    return lds > 64 * 1024 ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) : hipSuccess;
+  };
   const dim3 g(grid), t(kSubThreads);
   if (F) {
     // the fused sweeps exist where cora_stpcg_dev dispatches them (row stride x d <= 24: above, the fused backward sweep
@@ -3280,8 +3290,13 @@ static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *sr
     return hipGetLastError();
   }
   const SubFuse none{};
-  if (backward) hipLaunchKernelGGL((k_subblock<LD, true, 0>), g, t, lds, st, S, src, work, dst, none);
-  else hipLaunchKernelGGL((k_subblock<LD, false, 0>), g, t, lds, st, S, src, work, dst, none);
+  if (backward) {
+    if (const hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_subblock<LD, true, 0>)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_subblock<LD, true, 0>), g, t, lds, st, S, src, work, dst, none);
+  } else {
+    if (const hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_subblock<LD, false, 0>)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_subblock<LD, false, 0>), g, t, lds, st, S, src, work, dst, none);
+  }
   return hipGetLastError();
 }
 

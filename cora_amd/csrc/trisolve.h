@@ -86,9 +86,13 @@ struct SubBlockOpHost {
   // the backward sweep numbers the block's rows by backward level (position k, stored at row_begin + k)
   std::vector<int32_t> b_rows;                    // internal row of backward position k
   std::vector<int32_t> tgt_row;                   // per target: its row in the vectors (the backward sweep stages x[tgt_row] in tile row nrows + k)
-  // per level: {first row of the level (block-relative), lanes per task g (power of two <= 64), entries per lane
-  // npl (<= 8), first entry (block-relative)}; every row of the level holds exactly g * npl entries (null padded);
-  // nlev + 1 headers per block, the last one closes the row range
+  // A BARRIER LEVEL of the kernel is 4 headers, one per wavefront of the workgroup: {first row the wavefront solves in
+  // the level (block-relative), lanes per row g (power of two <= 64) | entries per lane npl (<= 8) << 8 | rows << 12,
+  // first coefficient (block-relative), first index}; the rows of a wavefront hold exactly g * npl entries each (null
+  // padded) -- its own width, so short rows do not pay for the level's longest; a wavefront takes whole supernodes (their
+  // rows read each other's right-hand sides: one barrier level), rows = 0 marks a wavefront without work.  A level of the
+  // elimination tree that needs more than 4 wavefronts continues in the next barrier level.  nlev + 1 groups of 4
+  // headers per block, the last one closes the row range (f_lev_begin / b_lev_begin count headers).
   std::vector<int32_t> f_hdr, b_hdr;
   // in-block entries
   std::vector<uint16_t> f_idx, b_idx;             // local column (forward) / backward position of the row (backward)

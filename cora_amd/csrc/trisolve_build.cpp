@@ -33,6 +33,7 @@ constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 colu
 constexpr int kSnCapChain = 4;  // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
 int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
 int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
+constexpr int kSubWaves = 4, kWaveLanes = 64;  // wavefronts of a substitution block's workgroup (kSubThreads of the kernel / 64)
 int kSplitMinRows = 1 << 20;  // a chunk of a level is closed early when the next rows are half as long, from this many rows on.
                               // Never, since round 4: closing early saves padding (tile reads 15.4 M instead of 16.3 M at 10^5
                               // poses) and costs barrier levels (25.0 k instead of 20.0 k); measured: 10^5 poses 117.6 / 118.4 us
@@ -658,25 +659,59 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
             }
             g_seg_waves += waves; g_seg_reads += reads; g_seg_real += real; g_seg_levels += 1; g_seg_sublevels += (waves + 3) / 4;
           }
+          // One barrier level = kSubWaves wavefronts, each with a (lanes per row, entries per lane) pair of its own and
+          // a header of its own: a wavefront takes consecutive rows of the (longest-first) order while they fit its 64
+          // lanes at the width of its first row -- short rows no longer pay the width of the level's longest, and a level
+          // that needs more than kSubWaves wavefronts continues in the next barrier level.
+          // The rows of a SUPERNODE read each other's right-hand sides, so all of them sit in ONE barrier level: a wavefront
+          // takes whole supernodes; one that is too long for a wavefront (rows of 32 or 64 lanes) spreads over consecutive
+          // wavefronts of the same barrier level.
+          int nw = 0;
+          auto idle_wave = [&](int row) {
+            hdr.insert(hdr.end(), {row, 1, static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
+            ++nw;
+          };
+          auto sn_end = [&](int q) {  // one past the last row of the supernode that row q (of the order) belongs to
+            int e = q;
+            while (e < t1 && sn_id[order[e]] == sn_id[order[q]]) ++e;
+            return e;
+          };
           for (int c0 = t; c0 < t1;) {
+            // lanes per row: from the longest row of the first supernode (supernodes come longest first)
+            const int s1 = sn_end(c0);
             int max_len = 1;
-            for (int q = c0; q < t1 && sn_id[order[q]] == sn_id[order[c0]]; ++q)
-              max_len = std::max<int>(max_len, static_cast<int>(rows_ent[order[q]].size()));
-            const int g = lanes_for(max_len), npl = (max_len + g - 1) / g, w = g * npl;
-            const int cap_rows = std::max(kSnCap, kLevelLanes / g);
-            int c1 = c0;
-            while (c1 < t1 && c1 - c0 < cap_rows) {  // whole supernodes while they fit the width and are not much shorter
-              int q = c1, sn_len = 0;
-              while (q < t1 && sn_id[order[q]] == sn_id[order[c1]]) sn_len = std::max<int>(sn_len, static_cast<int>(rows_ent[order[q++]].size()));
-              if (c1 > c0 && (q - c0 > cap_rows || sn_len > w || (2 * sn_len <= w && c1 - c0 >= kSplitMinRows))) break;
-              c1 = q;
+            for (int q = c0; q < s1; ++q) max_len = std::max<int>(max_len, static_cast<int>(rows_ent[order[q]].size()));
+            const int g = lanes_for(max_len), cap = kWaveLanes / g;
+            int c1;
+            if (s1 - c0 > cap) {  // the supernode alone needs several wavefronts: all in this barrier level
+              const int need = (s1 - c0 + cap - 1) / cap;
+              if (need > kSubWaves) throw std::logic_error("cora: a supernode does not fit one barrier level");
+              if (nw % kSubWaves + need > kSubWaves)
+                while (nw % kSubWaves) idle_wave(c0);
+              c1 = c0 + cap;  // (the next turns of the loop take the rest: same g, same barrier level)
+            } else if (c0 > t && sn_id[order[c0 - 1]] == sn_id[order[c0]]) {
+              c1 = s1;  // the rest of a supernode that spreads over wavefronts: nothing else joins it (its rows may be shorter than the next supernode's)
+            } else {
+              c1 = s1;
+              while (c1 < t1) {  // whole supernodes while they fit
+                const int e = sn_end(c1);
+                if (e - c0 > cap) break;
+                c1 = e;
+              }
+            }
+            int npl = 1;
+            for (int q = c0; q < c1; ++q) {
+              const int len = std::max<int>(1, static_cast<int>(rows_ent[order[q]].size()));
+              if (lanes_for(len) > g) throw std::logic_error("cora: rows of a level are not ordered by length");
+              npl = std::max(npl, (len + g - 1) / g);
             }
             // header {first row, g | npl << 8 | rows << 12, first coefficient (block-relative), first index (absolute in the idx array)}
             hdr.insert(hdr.end(), {c0, g | (npl << 8) | ((c1 - c0) << 12), static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
-            if (timing) { g_cur_reads += static_cast<int64_t>(((c1 - c0) * g + 63) / 64) * 64 * npl; g_cur_sublevels += 1; }
-            // lane p of row k takes the row's entries p, p + g, ...  Coefficients of the level: slot-major,
+            ++nw;
+            if (timing) { g_cur_reads += static_cast<int64_t>(kWaveLanes) * npl; }
+            // lane p of row k takes the row's entries p, p + g, ...  Coefficients of the wavefront: slot-major,
             // [u][lane = (k - c0) * g + p] (the kernel streams them, one coalesced load per slot); local row indices:
-            // lane-major, [lane][4 or 8] (one load per lane), the level padded to a multiple of 8 indices
+            // lane-major, [lane][4 or 8] (one load per lane), padded to a multiple of 8 indices
             S0.max_level_lanes = std::max<int32_t>(S0.max_level_lanes, (c1 - c0) * g);
             S0.max_npl = std::max<int32_t>(S0.max_npl, npl);
             const int istride = npl <= 4 ? 4 : 8;
@@ -700,9 +735,12 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
             while (idx.size() % 8) idx.push_back(0);
             c0 = c1;
           }
+          while (nw % kSubWaves) idle_wave(t1);  // wavefronts without rows in the level's last barrier level
+          if (timing) g_cur_sublevels += nw / kSubWaves;
           t = t1;
         }
-        hdr.insert(hdr.end(), {nb, 1, static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
+        for (int w = 0; w < kSubWaves; ++w)  // the closing level: no rows
+          hdr.insert(hdr.end(), {nb, 1, static_cast<int32_t>(val.size()) - ent0, static_cast<int32_t>(idx.size())});
       };
       const int32_t fe0 = static_cast<int32_t>(S0.f_val.size()), be0 = static_cast<int32_t>(S0.b_val.size());
       S0.f_lev_begin.back() = static_cast<int32_t>(S0.f_hdr.size() / 4);
@@ -851,8 +889,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     int64_t fl = 0, bl = 0, lanes_f = 0, lanes_b = 0, rows = 0, ent_f = 0, ent_b = 0, slots_f = 0, slots_b = 0;
     int fmax = 0, bmax = 0;
     for (size_t b = 0; b < nbk; ++b) {
-      const int nf = S0.f_lev_begin[b + 1] - S0.f_lev_begin[b] - 1, nbw = S0.b_lev_begin[b + 1] - S0.b_lev_begin[b] - 1;
-      fl += nf; bl += nbw; fmax = std::max(fmax, nf); bmax = std::max(bmax, nbw);
+      const int nf = S0.f_lev_begin[b + 1] - S0.f_lev_begin[b] - kSubWaves, nbw = S0.b_lev_begin[b + 1] - S0.b_lev_begin[b] - kSubWaves;  // headers
+      fl += nf / kSubWaves; bl += nbw / kSubWaves; fmax = std::max(fmax, nf / kSubWaves); bmax = std::max(bmax, nbw / kSubWaves);
       rows += S0.nrows[b];
       for (int l = 0; l < nf; ++l) {
         const int32_t *h = &S0.f_hdr[4 * (static_cast<size_t>(S0.f_lev_begin[b]) + l)];
@@ -1059,23 +1097,27 @@ double lane_tree_sum(double *part, int g) {
     for (int p = 0; p + off < g; p += 2 * off) part[p] += part[p + off];
   return part[0];
 }
-void sub_levels(const int32_t *hdr, int nlev, const uint16_t *idx, const double *val, std::vector<double> &T) {
-  std::vector<double> res;
-  for (int l = 0; l < nlev; ++l) {
-    const int r0 = hdr[4 * l], g = hdr[4 * l + 1] & 0xff, npl = (hdr[4 * l + 1] >> 8) & 0xf, e0 = hdr[4 * l + 2], i0 = hdr[4 * l + 3],
-              r1 = r0 + (hdr[4 * l + 1] >> 12);
-    const int nlane = (r1 - r0) * g, istride = npl <= 4 ? 4 : 8;
-    res.assign(static_cast<size_t>(r1 - r0), 0.0);
-    for (int r = r0; r < r1; ++r) {  // every row of the level reads the tile before any of them writes it
-      double part[64];
-      for (int p = 0; p < g; ++p) {
-        const int lane = (r - r0) * g + p;
-        part[p] = 0.0;
-        for (int u = 0; u < npl; ++u) part[p] += val[e0 + u * nlane + lane] * T[idx[i0 + lane * istride + u]];
+void sub_levels(const int32_t *hdr, int nhdr, const uint16_t *idx, const double *val, std::vector<double> &T) {
+  // nhdr headers = barrier levels of kSubWaves wavefronts each (the closing level not counted): every row of a barrier
+  // level reads the tile before any of them writes it
+  std::vector<std::pair<int, double>> res;
+  for (int l0 = 0; l0 + kSubWaves <= nhdr; l0 += kSubWaves) {
+    res.clear();
+    for (int l = l0; l < l0 + kSubWaves; ++l) {
+      const int r0 = hdr[4 * l], g = hdr[4 * l + 1] & 0xff, npl = (hdr[4 * l + 1] >> 8) & 0xf, e0 = hdr[4 * l + 2], i0 = hdr[4 * l + 3],
+                r1 = r0 + (hdr[4 * l + 1] >> 12);
+      const int nlane = (r1 - r0) * g, istride = npl <= 4 ? 4 : 8;
+      for (int r = r0; r < r1; ++r) {
+        double part[64];
+        for (int p = 0; p < g; ++p) {
+          const int lane = (r - r0) * g + p;
+          part[p] = 0.0;
+          for (int u = 0; u < npl; ++u) part[p] += val[e0 + u * nlane + lane] * T[idx[i0 + lane * istride + u]];
+        }
+        res.push_back({r, lane_tree_sum(part, g)});
       }
-      res[r - r0] = lane_tree_sum(part, g);
     }
-    for (int r = r0; r < r1; ++r) T[r] = res[r - r0];
+    for (const auto &rv : res) T[rv.first] = rv.second;
   }
 }
 void apply_sub_forward(const SubBlockOpHost &S, const double *rhs, double *y, double *aux) {
@@ -1084,7 +1126,7 @@ void apply_sub_forward(const SubBlockOpHost &S, const double *rhs, double *y, do
     const int nb = S.nrows[b], rb = S.row_begin[b];
     T.assign(nb, 0.0);
     for (int l = 0; l < nb; ++l) T[l] = rhs[S.rows[rb + l]];
-    sub_levels(&S.f_hdr[4 * S.f_lev_begin[b]], S.f_lev_begin[b + 1] - S.f_lev_begin[b] - 1, S.f_idx.data(),
+    sub_levels(&S.f_hdr[4 * S.f_lev_begin[b]], S.f_lev_begin[b + 1] - S.f_lev_begin[b] - kSubWaves, S.f_idx.data(),
                &S.f_val[S.f_ent_begin[b]], T);
     for (int l = 0; l < nb; ++l) y[S.rows[rb + l]] = T[l];
     for (int32_t t = S.tgt_begin[b]; t < S.tgt_begin[b + 1]; ++t) {
@@ -1104,7 +1146,7 @@ void apply_sub_backward(const SubBlockOpHost &S, const double *y, const double *
     T.assign(nb + ntg, 0.0);
     for (int l = 0; l < nb; ++l) T[l] = y[S.b_rows[rb + l]];
     for (int k = 0; k < ntg; ++k) T[nb + k] = xlater[S.tgt_row[S.tgt_begin[b] + k]];  // the later stage's solution
-    sub_levels(&S.b_hdr[4 * S.b_lev_begin[b]], S.b_lev_begin[b + 1] - S.b_lev_begin[b] - 1, S.b_idx.data(),
+    sub_levels(&S.b_hdr[4 * S.b_lev_begin[b]], S.b_lev_begin[b + 1] - S.b_lev_begin[b] - kSubWaves, S.b_idx.data(),
                &S.b_val[S.b_ent_begin[b]], T);
     for (int l = 0; l < nb; ++l) x[S.b_rows[rb + l]] = T[l];
   }
