@@ -119,7 +119,9 @@ CoraResult solveCORA(Problem &problem, const Matrix &x0, int max_relaxation_rank
       eigvec_bootstrap = cert.all_eigvecs;
     }
     t0 = clk::now();
-    cert = problem.certify_solution(result.x, eta, LOBPCG_BLOCK_SIZE, eigvec_bootstrap);
+    // (the Ritz block stays on the device from one certification to the next: cert.all_eigvecs comes back empty, and
+    // an empty bootstrap tells the next call to start from the block where it is)
+    cert = problem.certify_solution_resident(result.x, eta, LOBPCG_BLOCK_SIZE, eigvec_bootstrap);
     t_cert += since(t0);
     traceBits("certify.x", cert.x, cert.theta, eta, static_cast<long>(cert.num_iters));
     traceBits("certify.block", cert.all_eigvecs, cert.theta, eta, cert.is_certified);

@@ -255,6 +255,7 @@ void Problem::updateProblemData() {  // src/CORA_problem.cpp:500-510
   tick("relative-pose submatrices");
   fillDataMatrix();
   tick("data matrix");
+  cert_block_.reset();  // (its device memory belongs to the handle)
   ctx_.reset();  // the device copy of Q is rebuilt lazily
   precond_ready_ = false;
   cert_perm_.clear();
@@ -969,6 +970,14 @@ namespace CORA {
 
 CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap,
                                       size_t max_LOBPCG_iters) const {
+  return certifyImpl(Y, eta, nx, eigvec_bootstrap, max_LOBPCG_iters, false);
+}
+CertResults Problem::certify_solution_resident(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap,
+                                               size_t max_LOBPCG_iters) const {
+  return certifyImpl(Y, eta, nx, eigvec_bootstrap, max_LOBPCG_iters, true);
+}
+CertResults Problem::certifyImpl(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap, size_t max_LOBPCG_iters,
+                                 bool resident) const {
   checkMatrixShape("Problem::certify_solution::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   const Index N = getDataMatrixSize(), p = Y.cols();
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
@@ -1025,9 +1034,21 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   // start block: the leading columns of the bootstrap block, the rest random (Matrix::RandomColumns(N, num_eigvecs) with a
   // fixed seed fills column after column, so a cached block with at least as many columns has the same numbers in
   // them); the two pieces go to the device as they are
-  const Index from_bootstrap = eigvec_bootstrap.rows() == N ? std::min(eigvec_bootstrap.cols(), num_eigvecs) : 0;
+  // (resident: an empty bootstrap means "the block the last certification left on the device")
+  const std::shared_ptr<LOBPCGSolver> prev = resident && eigvec_bootstrap.rows() == 0 ? cert_block_ : nullptr;
+  const bool from_device = prev && prev->deviceBlock() != nullptr;
+  const Index from_bootstrap = from_device ? std::min<Index>(prev->width(), num_eigvecs)
+                                           : (eigvec_bootstrap.rows() == N ? std::min(eigvec_bootstrap.cols(), num_eigvecs) : 0);
   std::vector<HostColumns> X0;
-  if (from_bootstrap > 0) X0.push_back(HostColumns{eigvec_bootstrap.data(), static_cast<int>(from_bootstrap)});
+  if (from_device) {
+    HostColumns h;
+    h.cols = static_cast<int>(from_bootstrap);
+    h.device = prev->deviceBlock();
+    h.device_width = prev->width();
+    X0.push_back(h);
+  } else if (from_bootstrap > 0) {
+    X0.push_back(HostColumns{eigvec_bootstrap.data(), static_cast<int>(from_bootstrap)});
+  }
   if (from_bootstrap < num_eigvecs) {
     if (cert_random_.rows() != N || cert_random_.cols() < num_eigvecs) cert_random_ = Matrix::RandomColumns(N, num_eigvecs, 0xC0FFEEull);
     X0.push_back(HostColumns{cert_random_.data() + static_cast<size_t>(from_bootstrap) * static_cast<size_t>(N),
@@ -1045,14 +1066,17 @@ CertResults Problem::certify_solution(const Matrix &Y, Scalar eta, size_t nx, co
   lab.seed_negative_direction = cert_lab_seed_;
   lab.use_ildl = cert_lab_ildl_;
   const FastVerificationLab *labp = cert_lab_on_ ? &lab : nullptr;
-  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, labp, symbolic_cache_.get());
+  std::shared_ptr<LOBPCGSolver> kept;
+  std::shared_ptr<LOBPCGSolver> *keep = resident ? &kept : nullptr;
+  CertResults results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, labp, symbolic_cache_.get(), keep);
   cert_reached_step3_ = lab.reached_step3;
   tick("fast_verification");
   while (std::isnan(results.theta)) {  // :1076-1083
     std::cout << "NaN in theta -- result not certified" << std::endl;
     eta *= 2;
-    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, labp, symbolic_cache_.get());
+    results = fast_verification(S, eta, X0, max_LOBPCG_iters, perm, c, Sop, std::nullopt, 3, 1e-3, labp, symbolic_cache_.get(), keep);
   }
+  if (resident) cert_block_ = kept;  // (the previous block goes now: the new one has been built from it)
   if (!results.is_certified && formulation_ == Formulation::Implicit) {  // :1085-1100
     // leading (rotation + range) part of the direction, and its Rayleigh quotient with the
     // simplified certificate Q_impl - Lambda

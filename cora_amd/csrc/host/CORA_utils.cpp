@@ -56,7 +56,8 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
                               const std::vector<int32_t> &perm_in, cora_ctx *ctx,
                               const std::optional<DeviceOperator> &S_op,
                               const std::optional<DeviceOperator> &precond, Scalar max_fill_factor, Scalar drop_tol,
-                              const FastVerificationLab *lab, SymbolicCache *symbolic) {
+                              const FastVerificationLab *lab, SymbolicCache *symbolic, std::shared_ptr<LOBPCGSolver> *keep_block) {
+  if (keep_block) keep_block->reset();
   const Index n = S.rows();
   int x0_cols = 0;
   for (const HostColumns &h : X0) x0_cols += h.cols;
@@ -253,9 +254,15 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
       iters += r.num_iters;
     }
   }
-  results.all_eigvecs = solver->block();
-  results.x = results.all_eigvecs.col(0);
-  tick("Ritz block to the host");
+  if (keep_block) {  // the block stays where it is (the next certification starts from it): one column over the bus
+    results.x = solver->column(0);
+    results.all_eigvecs = Matrix();
+    *keep_block = std::move(solver);
+  } else {
+    results.all_eigvecs = solver->block();
+    results.x = results.all_eigvecs.col(0);
+  }
+  tick(keep_block ? "first Ritz vector to the host" : "Ritz block to the host");
   // curvature along x, recomputed from S like the reference (:124-127)
   {
     const Vector Sx = sparseTimesVector(S, results.x);

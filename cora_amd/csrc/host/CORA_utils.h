@@ -2,6 +2,7 @@
 // src/CORA_utils.cpp:17-202).
 #pragma once
 
+#include <memory>
 #include <optional>
 #include <vector>
 
@@ -45,7 +46,11 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
                               const std::optional<DeviceOperator> &S_op = std::nullopt,
                               const std::optional<DeviceOperator> &precond = std::nullopt,
                               Scalar max_fill_factor = 3, Scalar drop_tol = 1e-3, const FastVerificationLab *lab = nullptr,
-                              SymbolicCache *symbolic = nullptr);
+                              SymbolicCache *symbolic = nullptr, std::shared_ptr<LOBPCGSolver> *keep_block = nullptr);
+/* keep_block != nullptr: the Ritz block of the eigensolver is NOT brought to the host (results.all_eigvecs stays empty,
+ * results.x is its first column): the solver that holds it on the device is handed over instead, to be the start block
+ * of the next certification (HostColumns::device) -- solveCORA needs nothing else from it.  nullptr is handed over when
+ * no eigensolver ran (certified, or the dense path of small matrices, which fills all_eigvecs as usual). */
 
 inline CertResults fast_verification(const SparseMatrix &S, Scalar eta, size_t nx, size_t max_iters = 1000) {
   return fast_verification(S, eta, Matrix::Random(S.rows(), static_cast<Index>(nx)), max_iters);

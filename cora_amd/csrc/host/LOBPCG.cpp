@@ -110,7 +110,7 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
   Blocks B(c, m);
   double *X = B.alloc(), *AX = B.alloc(), *W = B.alloc(), *AW = B.alloc(), *P = B.alloc(), *AP = B.alloc(),
          *t1 = B.alloc(), *t2 = B.alloc(), *t3 = B.alloc(), *t4 = B.alloc();
-  if (start.size() == 1) {
+  if (start.size() == 1 && !start[0].device) {
     B.chk(cora_upload(c, start[0].data, N, m, t1), "upload");
   } else {
     // pieces side by side: Out = sum_i piece_i [0 .. I .. 0]
@@ -126,6 +126,16 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
     std::vector<Matrix> sel;
     int at = 0;
     for (const HostColumns &h : start) {
+      if (h.device) {  // already resident: its leading columns are picked by the selection matrix
+        if (h.device_width < h.cols || h.device_width > 24) throw std::invalid_argument("LOBPCG: bad resident piece");
+        Matrix E(h.device_width, m);
+        for (int j = 0; j < h.cols; ++j) E(j, at + j) = 1.0;
+        sel.push_back(E);
+        xs.push_back(h.device);
+        ks.push_back(h.device_width);
+        at += h.cols;
+        continue;
+      }
       double *d = nullptr;
       B.chk(cora_dev_alloc(c, h.cols, &d), "alloc");
       dev.v.push_back(d);

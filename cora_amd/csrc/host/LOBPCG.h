@@ -37,6 +37,11 @@ struct LOBPCGResult {
 struct HostColumns {
   const double *data = nullptr;
   int cols = 0;
+  // non-null: the piece is the leading `cols` columns of a block that is ALREADY on the device (N rows, `device_width`
+  // columns, resident layout) -- e.g. the Ritz block the previous certification left there (LOBPCGSolver::deviceBlock):
+  // nothing is uploaded, the columns are picked up where they are
+  const double *device = nullptr;
+  int device_width = 0;
 };
 
 /** One LOBPCG run whose blocks stay on the device until they are asked for.  The start block is the concatenation of up
@@ -54,6 +59,8 @@ class LOBPCGSolver {
   Matrix block() const;
   Vector column(int j) const;
   int width() const { return m_; }
+  /** The Ritz block of the last run where it lives: N rows, width() columns, resident layout (nullptr before a run). */
+  const double *deviceBlock() const { return X_; }
 
  private:
   struct Impl;
