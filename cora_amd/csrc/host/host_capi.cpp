@@ -328,6 +328,29 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
   });
 }
 
+int cora_problem_certify_chain(cora_problem *p, const double *Y, double eta, int nx, int resident, double out[6], double *x) {
+  return guarded([&] {
+    // two certifications in a row at the same point, the second one started from the first one's Ritz block: handed over
+    // on the host (resident = 0: certify_solution with all_eigvecs as the bootstrap) or left on the device
+    // (resident = 1: certify_solution_resident with an empty bootstrap) -- the two ways must give the same numbers
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    const Matrix Ym = wrap(Y, N, r);
+    const Matrix boot = q.getFormulation() == Formulation::Implicit ? q.getTranslationExplicitSolution(Ym) : Ym;
+    const CertResults a = resident ? q.certify_solution_resident(Ym, eta, static_cast<size_t>(nx), boot)
+                                   : q.certify_solution(Ym, eta, static_cast<size_t>(nx), boot);
+    const CertResults b = resident ? q.certify_solution_resident(Ym, eta, static_cast<size_t>(nx), Matrix())
+                                   : q.certify_solution(Ym, eta, static_cast<size_t>(nx), a.all_eigvecs);
+    out[0] = a.is_certified ? 1.0 : 0.0;
+    out[1] = a.theta;
+    out[2] = static_cast<double>(a.num_iters);
+    out[3] = b.is_certified ? 1.0 : 0.0;
+    out[4] = b.theta;
+    out[5] = static_cast<double>(b.num_iters);
+    if (x) std::memcpy(x, b.x.data(), sizeof(double) * static_cast<size_t>(b.x.size()));
+  });
+}
+
 int cora_problem_set_verification_lab(cora_problem *p, int seed_negative_direction, int use_ildl) {
   return guarded([&] { p->problem.setVerificationLab(seed_negative_direction != 0, use_ildl != 0); });
 }

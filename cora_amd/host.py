@@ -251,6 +251,17 @@ class Problem:
                                               out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
         return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
 
+    def certify_chain(self, Y, eta, nx=10, resident=False):
+        """Two certifications in a row, the second started from the first one's Ritz block (host hand-over or resident)."""
+        dm = self.dims()
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        out = np.zeros(6)
+        x = np.zeros(dm["N"])
+        self._chk(self.L.cora_problem_certify_chain(self.h, Y.ctypes.data_as(_dp), C.c_double(eta), int(nx), int(bool(resident)),
+                                                    out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
+        return dict(first=dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2])),
+                    second=dict(is_certified=bool(out[3]), theta=out[4], iters=int(out[5]), x=x))
+
     def set_verification_lab(self, seed=True, ildl=True):
         """Test switches of certify()'s eigensolver stage (step 3 of fast_verification)."""
         self._chk(self.L.cora_problem_set_verification_lab(self.h, int(bool(seed)), int(bool(ildl))))

@@ -117,6 +117,12 @@ int cora_problem_tnt_step(cora_problem *p, const double *x, double Delta, int ho
  * out: [0] is_certified, [1] theta, [2] LOBPCG iterations; x: N (direction of negative curvature or 0). */
 int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, double out[3], double *x);
 
+/* Two certifications in a row at Y, the second started from the first one's Ritz block -- handed over through the host
+ * (resident = 0: Problem::certify_solution, all_eigvecs as the next bootstrap, the reference's flow src/CORA.cpp:158-170)
+ * or left on the device (resident = 1: Problem::certify_solution_resident, what this host's solveCORA does).
+ * out: [0..2] is_certified, theta, iterations of the first; [3..5] of the second; x: the second's direction. */
+int cora_problem_certify_chain(cora_problem *p, const double *Y, double eta, int nx, int resident, double out[6], double *x);
+
 /* Test switches of the eigensolver stage of certify_solution (src/CORA_utils.cpp:129-167): run step 3 without the seed
  * that the failed factorisation yields and / or without the incomplete-LDL^T preconditioner; and whether the last
  * cora_problem_certify got as far as step 3 (the preconditioned stage). */

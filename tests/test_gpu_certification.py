@@ -238,3 +238,24 @@ def test_start_block_with_columns_of_very_different_size():
     got = host.fast_verification(S, eta, X0=x0, max_iters=400, lab=dict())
     assert not got["is_certified"] and got["theta"] < -eta / 2 and got["theta"] >= lmin - 1e-12
     assert abs(np.linalg.norm(got["x"]) - 1.0) < 1e-9
+
+
+def test_ritz_block_left_on_the_device_gives_the_numbers_of_the_host_hand_over():
+    """solveCORA keeps the eigensolver's Ritz block on the device from one certification to the next
+    (Problem::certify_solution_resident: all_eigvecs stays empty, one column comes back, the next start block is picked
+    up where it is).  Same decision, theta, iteration counts and direction as handing all_eigvecs over through the host
+    (the reference's flow, src/CORA.cpp:158-170), bit for bit."""
+    P, gt = host.Problem.synthetic(dim=3, n_poses=4000, n_landmarks=5, n_ranges=2500, seed=12, precond=capi.PRECOND_JACOBI,
+                                   ground_truth=True)
+    P.update()
+    p = 4
+    P.set_rank(p)
+    Y = P.op("projectToManifold", np.hstack([gt, np.zeros((gt.shape[0], p - gt.shape[1]))])
+             + 0.05 * np.random.default_rng(4).standard_normal((gt.shape[0], p)))
+    a = P.certify_chain(Y, 1e-3, nx=8, resident=False)
+    b = P.certify_chain(Y, 1e-3, nx=8, resident=True)
+    assert not a["first"]["is_certified"] and a["first"]["theta"] < -0.5e-3
+    for k in ("first", "second"):
+        assert a[k]["is_certified"] == b[k]["is_certified"] and a[k]["iters"] == b[k]["iters"]
+        assert a[k]["theta"] == b[k]["theta"]
+    assert np.array_equal(a["second"]["x"], b["second"]["x"])
