@@ -35,44 +35,54 @@ def algorithmic_bytes(d, n, r, N, nnz, p):
 
 
 def pmc_traffic(args, ld, epi):
-    """HBM-side bytes per launch of the timed kernel, collected now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
+    """HBM-side bytes per launch of the timed kernels, collected now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
     separate passes, no trace domains, as MI355X_MICROARCH.md prescribes) of a short child run of this command that
-    stops after its timed region.  gfx950: FETCH_SIZE counts 128-byte fabric requests at 64 bytes, so reads = 2 x
-    FETCH_SIZE (calibrated with a streaming kernel, profiles/hvp_traffic.json); both counters are in KB.  Returns
-    (bytes, how) or (None, None) when rocprofv3 is missing, this run is itself under a profiler, or a pass fails."""
+    launches the back-to-back products and then the STPCG loop and stops.  gfx950: FETCH_SIZE counts 128-byte fabric
+    requests at 64 bytes, so reads = 2 x FETCH_SIZE (calibrated with a streaming kernel, profiles/hvp_traffic.json); both
+    counters are in KB.  Returns {kernel name: {"read", "write", "launches"}} (bytes per launch, averaged over the
+    launches of that kernel) or None when rocprofv3 is missing, this run is itself under a profiler, or a pass fails."""
     import csv, glob, shutil, subprocess, tempfile
     if os.environ.get("CORA_BENCH_CHILD") or shutil.which("rocprofv3") is None:
-        return None, None
+        return None
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
-        return None, None
-    kernel = "k_spmm<%d, 3, %d>" % (ld, epi)
+        return None
+    regex = "k_spmm<%d, 3, [0-3]>|k_subblock<%d|k_rowop<%d|k_kappa_finish" % (ld, ld, ld)
     env = dict(os.environ, CORA_BENCH_CHILD="1", TMPDIR="/tmp")
-    vals = {}
+    per = {}
     tmp = tempfile.mkdtemp(prefix="cora_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
-            cmd = ["rocprofv3", "--pmc", counter, "--kernel-include-regex", kernel, "--output-format", "csv", "-d", out,
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-include-regex", regex, "--output-format", "csv", "-d", out,
                    "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--kernel-only", "--steps", "60",
                    "--warmup", "5", "--poses", str(args.poses), "--rank", str(args.rank), "--op", args.op,
                    "--pmc-traffic", "off"]
-            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, None
-            xs = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                  if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]]
-            if len(xs) < 10:
-                return None, None
-            vals[counter] = sum(xs) / len(xs)
+                return None
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("cora::", "").strip()
+                t = acc.setdefault(name, [0.0, 0])
+                t[0] += float(row["Counter_Value"])
+                t[1] += 1
+            for name, (tot, cnt) in acc.items():
+                e = per.setdefault(name, {"launches": cnt})
+                kb = tot / cnt
+                e["read" if counter == "FETCH_SIZE" else "write"] = int(round((2.0 if counter == "FETCH_SIZE" else 1.0) * kb * 1024))
     except Exception:  # noqa: BLE001 -- a failed counter pass must not fail the bench: the committed figure is reported instead
-        return None, None
+        return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    pmc_traffic.last = {"read": int(round(2.0 * vals["FETCH_SIZE"] * 1024)), "write": int(round(vals["WRITE_SIZE"] * 1024))}
-    return int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), (
-        "collected by this run: two rocprofv3 --pmc passes (FETCH_SIZE %.0f KB x 2 on gfx950, WRITE_SIZE %.0f KB; per-launch "
-        "averages over the launches of %s in a short child run of this command)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], kernel))
+    per = {k: v for k, v in per.items() if "read" in v and "write" in v}
+    return per or None
+
+
+PMC_HOW = ("collected by this run: two rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950, WRITE_SIZE; separate passes, no trace "
+           "domains) of a short child run of this command, per-launch averages over the launches of each kernel")
 
 
 def cpu_quota():
@@ -128,11 +138,65 @@ def cpu_baseline(rowptr, colidx, vals, dm, p, budget_s, threads=1):
     return reps / dt, reps, (Y, V, ref)
 
 
+def stpcg_setup(P, dm, p, x_gt):
+    """The C++ host's own handle with the reference's default preconditioner (RegularizedCholesky) installed and the
+    generator's ground truth (padded to rank p) as the current point: there the Hessian is positive semidefinite up to
+    the noise, so the truncated CG is not cut short by negative curvature.  Returns (handle, six resident vectors)."""
+    from cora_amd import capi
+    P.set_rank(p)
+    t0 = time.perf_counter()
+    P.context_ptr()   # the Problem's own device handle (format of Q, uploads): not part of the preconditioner's set-up
+    t_handle = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
+    info = P.precond_info()
+    t_setup = time.perf_counter() - t0
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    v = [h.dev_alloc(p) for _ in range(6)]
+    Yh = np.zeros((dm["N"], p))
+    Yh[:, :dm["d"]] = x_gt
+    h.upload(Yh, v[5])
+    h.project_to_manifold_dev(v[5], v[5])
+    h.set_point_dev(v[5])
+    return h, v, info, t_handle, t_setup
+
+
+def stpcg_run(h, v, its):
+    """`its` iterations of the solver's own inner loop: cora_stpcg_dev from the Riemannian gradient at the current
+    point, tolerance out of reach and a huge radius so that it runs exactly `its` iterations (Hvp + update +
+    preconditioner + reductions + direction, scalars on the device).  Returns (iterations done, seconds)."""
+    s, r, z, pk, hp, _ = v
+    grad = h.point_ptrs()[2]
+    h.sync()
+    t0 = time.perf_counter()
+    done, _ = h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
+    h.sync()
+    return done, time.perf_counter() - t0
+
+
+def stpcg_bytes(dm, p, nnz_L, ent):
+    """Algorithmic bytes of one sweep-fused STPCG iteration (same convention as B_spmm: 12 bytes per
+    stored entry, every vector pass 8 N p): what each launch must move at least."""
+    N, d, n, r = dm["N"], dm["d"], dm["n"], dm["r"]
+    _, b_hvp = algorithmic_bytes(d, n, r, N, dm["nnz"], p)
+    vec = 8 * N * p
+    return {
+        "product": b_hvp,
+        "kappa": 0,
+        # forward: L once; r and Hp in, r and y out
+        "forward_sweep": 12 * nnz_L + 4 * vec,
+        # the last stage's two products: their stored entries (explicit inverse + folded aux sums), rows negligible
+        "top_forward": 12 * ent["top_forward"],
+        "top_backward": 12 * ent["top_backward"],
+        # backward: L once; y, p, s in, the point's rows (rotation + range rows) in, p and s out
+        "backward_sweep": 12 * nnz_L + 5 * vec + 8 * (d * n + r) * p,
+    }
+
+
 def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
     """SURVEY 8(d) timing protocol beside the headline number: percentiles of single launches, the plain
     Q.X product, and one full STPCG iteration (Hvp + preconditioner + inner products + updates,
     src/CORA.cpp:71-92,119-122) with the reference's default RegularizedCholesky preconditioner."""
-    from cora_amd import capi
     b_spmm, _ = algorithmic_bytes(dm["d"], dm["n"], dm["r"], dm["N"], dm["nnz"], p)
     one = []
     for _ in range(200):
@@ -152,51 +216,32 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
         "hvp_back_to_back_us": kernel_us,
     }
     # full STPCG iteration on the C++ host's own handle with the Cholesky preconditioner installed
-    P.set_rank(p)
-    t0 = time.perf_counter()
-    P.context_ptr()   # the Problem's own device handle (format of Q, uploads): not part of the preconditioner's set-up
-    ex["problem_handle_s"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    P.set_preconditioner(capi.PRECOND_REGULARIZED_CHOLESKY)
-    info = P.precond_info()
-    ex["preconditioner_setup_s"] = time.perf_counter() - t0
+    h, v, info, ex["problem_handle_s"], ex["preconditioner_setup_s"] = stpcg_setup(P, dm, p, x_gt)
     ex["preconditioner"] = {"kind": "RegularizedCholesky", "nnz_L": info["nnz"], "lambda": info["lam"]}
-    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
-    v = [h.dev_alloc(p) for _ in range(6)]
     s, r, z, pk, hp, y = v
-    # at the generator's ground truth (padded to rank p) the Hessian is positive semidefinite up to the noise,
-    # so the truncated CG is not cut short by negative curvature
-    Yh = np.zeros((dm["N"], p))
-    Yh[:, :dm["d"]] = x_gt
-    h.upload(Yh, y)
-    h.project_to_manifold_dev(y, y)
-    h.set_point_dev(y)
-
-    # the solver's own inner loop: cora_stpcg_dev from the Riemannian gradient at this point, tolerance out of
-    # reach and a huge radius so that it runs exactly `its` iterations (Hvp + update + preconditioner + two
-    # reductions + direction, scalars on the device)
-    grad = h.point_ptrs()[2]
     its = 60
-    h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=8)
-    h.sync()
-    t0 = time.perf_counter()
-    done, _ = h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
-    h.sync()
-    ex["stpcg_iteration_us"] = (time.perf_counter() - t0) / max(done, 1) * 1e6
+    stpcg_run(h, v, 8)
+    done, dt = stpcg_run(h, v, its)
+    ex["stpcg_iteration_us"] = dt / max(done, 1) * 1e6
     ex["stpcg_iterations_timed"] = done
     ex["stpcg_form"] = {0: "one pass per operation", 1: "fused vector passes (5 launches + the solve)",
-                        3: "one explicit inverse: 5 launches per iteration, <r,v> = |W r|^2",
+                        3: "one explicit inverse: product | kappa + residual | W | W^T | projection + step + direction",
                         2: "6 launches per iteration: product with the kappa partials | kappa | forward sweep (r += alpha Hp, "
                            "<r,r> and |L^-1 r|^2 slots) | last stage, two products (the second finishes <r,r> and "
                            "<r,v> = |L^-1 r|^2) | backward sweep (v = Proj_Y(x), s += alpha p, p = -v + beta p)"}.get(
                                h.stpcg_path(), "?")
-    # the Hessian-vector product as it runs INSIDE that loop (HIP events around it in every iteration).  Two sweeps
-    # over the factor (130 MB) pass between two products; their loads are non-temporal, so Q and the vectors stay in
-    # the Infinity Cache and the product runs close to its back-to-back rate (round 2 before that: 32.9 us)
-    h.profile_stpcg(True)
-    h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
+    # the launches of the iteration one by one (HIP events around every launch; the events cost the stream a little, so
+    # the sum is reported beside the clean iteration above, not instead of it).  The product's figure is the Hessian-
+    # vector product as it runs INSIDE the loop: two sweeps over the factor (130 MB, non-temporal loads) pass between
+    # two products
+    h.profile_stpcg(2)
+    stpcg_run(h, v, its)
+    ex["stpcg_phase_us"] = h.stpcg_phase_us()
+    h.profile_stpcg(1)   # events around the product only
+    stpcg_run(h, v, its)
     ex["hvp_in_stpcg_us"], ex["hvp_in_stpcg_samples"] = h.stpcg_hvp_us()
-    h.profile_stpcg(False)
+    h.profile_stpcg(0)
+    ex["_stpcg_entries"] = h.precond_entries()
     h.timer_start()
     for _ in range(50):
         h.precondition_projected_dev(r, z)
@@ -223,13 +268,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--poses", type=int, default=100000)
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank p")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--op", choices=["hvp", "cert"], default="hvp",
                     help="hvp: Riemannian Hessian-vector product (the headline metric); cert: certificate operator "
                          "(Q - Lambda) X with --rank columns (BASELINE config 5, use --rank 10)")
     ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
                     help="auto: HBM-side bytes of the timed kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) "
                          "of a short child run of this command, collected by this run (N = 1; skipped under a profiler)")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle's Hvp under OpenMP on every CPU the container may use (several thread "
+                         "counts, ~10 s of host time; off by default so that the run is not mostly host work)")
     ap.add_argument("--kernel-only", action="store_true", help=argparse.SUPPRESS)  # the child run of --pmc-traffic
     args = ap.parse_args()
 
@@ -297,6 +345,8 @@ def main():
             from cora_amd.dist import NativeRcclComm, TorchComm
             try:
                 comm = NativeRcclComm(ctx, device=dev)
+                # the library's communicator spans exactly the ranks of this launch (ncclCommCount; -1: an RCCL without it)
+                assert comm.nranks in (world, -1), "ncclCommCount = %d, WORLD_SIZE = %d" % (comm.nranks, world)
                 ok = 1.0
             except Exception as e:  # noqa: BLE001 -- reported, and the run goes on through torch.distributed's RCCL
                 sys.stderr.write("rank %d: native RCCL communicator failed (%s)\n" % (rank, e))
@@ -340,7 +390,11 @@ def main():
     torch.cuda.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
-    if args.kernel_only:   # child of --pmc-traffic: the launches above are all a counter pass needs
+    if args.kernel_only:   # child of --pmc-traffic: the launches above and the STPCG loop are all a counter pass needs
+        if world == 1 and args.op == "hvp":
+            h, v, _, _, _ = stpcg_setup(P, dm, p, x_gt)
+            stpcg_run(h, v, 8)
+            stpcg_run(h, v, 60)
         os.write(json_fd, b"{}\n")
         return
     if dist is not None:
@@ -385,9 +439,13 @@ def main():
     comp_write = 8 * rows_loc * k_cols
     local_frac = stats["local_nnz"] / max(dm["nnz"], 1)
     achieved = b_hvp * local_frac / kernel_us / 1e3  # GB/s, this rank's share of the bytes
+    epi = 2 if args.op == "hvp" else 1
+    k_b2b = "k_spmm<%d, 3, %d>" % (ld, epi)       # the back-to-back launches
+    k_loop = "k_spmm<%d, 3, 3>" % ld               # the same product inside the STPCG loop (EPI_HVP_K: + the kappa partials)
+    pmc = pmc_traffic(args, ld, epi) if (world == 1 and args.pmc_traffic == "auto") else None
     traffic, traffic_source = None, None
-    if world == 1 and args.pmc_traffic == "auto":
-        traffic, traffic_source = pmc_traffic(args, ld, 2 if args.op == "hvp" else 1)
+    if pmc and k_b2b in pmc:
+        traffic, traffic_source = pmc[k_b2b]["read"] + pmc[k_b2b]["write"], PMC_HOW
     tpath = os.path.join(ROOT, "profiles", "hvp_traffic.json")
     if traffic is None and world == 1 and n == 100000 and p == 5 and args.op == "hvp" and os.path.exists(tpath):
         try:
@@ -465,8 +523,38 @@ def main():
         gathered = ctx.download(out.data_ptr(), p)
         torch.cuda.synchronize()
 
+    # N = 1, the headline op: the solver's inner loop around the product (extras), timed before the result is put together
+    # because the roofline of the line is the product INSIDE that loop ("steady state inside the STPCG loop")
+    extras = None
+    if rank == 0 and world == 1 and args.op == "hvp":
+        extras = solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt)
+
     result = None
     if rank == 0:
+        kname = "cora::k_spmm<%d, 3, %d> (LD=%d, d=3, %s)" % (ld, epi, ld, "EPI_HVP" if args.op == "hvp" else "EPI_S")
+        b2b = {
+            "bound": "hbm",
+            "kernel": kname,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "compulsory_bytes": comp_read + comp_write,
+            "compulsory_read_bytes": comp_read,
+            "compulsory_write_bytes": comp_write,
+            "format_bytes": fb,
+            "traffic_read": pmc[k_b2b]["read"] if pmc and k_b2b in pmc else None,
+            "traffic_write": pmc[k_b2b]["write"] if pmc and k_b2b in pmc else None,
+            "kernel_us": kernel_us,
+            "bytes_per_launch": b_hvp * local_frac,
+            "how": "500 back-to-back launches between two HIP events on the handle's stream: Q and the three vectors stay in "
+                   "the 256 MiB Infinity Cache (see roofline_hbm for the same kernel with the working set rotated out of it)",
+        }
+        if b2b["traffic_read"]:
+            b2b["read_over_compulsory"] = b2b["traffic_read"] / comp_read
+            b2b["write_over_compulsory"] = b2b["traffic_write"] / comp_write
         result = {
             "metric": "riemannian_hessian_vector_products_per_sec" if args.op == "hvp" else
                       "certificate_operator_products_per_sec",
@@ -494,35 +582,75 @@ def main():
                 "algorithmic_bytes_per_hvp": b_hvp,
                 "algorithmic_bytes_per_spmm": b_spmm,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "cora::k_spmm<%d, 3, %d> (LD=%d, d=3, %s)" % (ld, 2 if args.op == "hvp" else 1, ld,
-                                                                        "EPI_HVP" if args.op == "hvp" else "EPI_S"),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_source,
-                "compulsory_bytes": comp_read + comp_write,
-                "compulsory_read_bytes": comp_read,
-                "compulsory_write_bytes": comp_write,
-                "format_bytes": fb,
-                "traffic_read": getattr(pmc_traffic, "last", {}).get("read") if traffic_source and "collected by this run" in traffic_source else None,
-                "traffic_write": getattr(pmc_traffic, "last", {}).get("write") if traffic_source and "collected by this run" in traffic_source else None,
-                "kernel_us": kernel_us,
-                "bytes_per_launch": b_hvp * local_frac,
-                "note": "back-to-back launches: Q and the three vectors stay in the 256 MiB Infinity Cache; "
-                        "see roofline_hbm for the same kernel with the working set rotated out of it",
-            },
+            "value_is": "steps / wall time of the timed region (K back-to-back products between two barriers + "
+                        "synchronisations, host clock); per-chunk statistics of the same launches: value_stats",
         }
-        rl = result["roofline"]
-        if rl["traffic_read"]:
-            rl["read_over_compulsory"] = rl["traffic_read"] / comp_read
-            rl["write_over_compulsory"] = rl["traffic_write"] / comp_write
+        if extras is not None and extras.get("hvp_in_stpcg_us"):
+            # the line's roofline: the product as the solver runs it -- inside the STPCG loop, the preconditioner's two
+            # sweeps over the factor between two products -- HIP events around it in every iteration
+            loop_us = extras["hvp_in_stpcg_us"]
+            rl = {
+                "bound": "hbm",
+                "kernel": "cora::k_spmm<%d, 3, 3> (LD=%d, d=3, EPI_HVP_K: the Hvp with the partial sums of <p, Hp>)" % (ld, ld),
+                "achieved": b_hvp / loop_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": b_hvp / loop_us / 1e3 / HBM_PEAK_GBS,
+                "traffic": (pmc[k_loop]["read"] + pmc[k_loop]["write"]) if pmc and k_loop in pmc else None,
+                "traffic_source": PMC_HOW if pmc and k_loop in pmc else None,
+                "traffic_read": pmc[k_loop]["read"] if pmc and k_loop in pmc else None,
+                "traffic_write": pmc[k_loop]["write"] if pmc and k_loop in pmc else None,
+                "kernel_us": loop_us, "bytes_per_launch": b_hvp, "samples": extras["hvp_in_stpcg_samples"],
+                "compulsory_bytes": comp_read + comp_write,
+                "how": "the Hessian-vector product INSIDE the device-resident STPCG loop (Cholesky preconditioner: two sweeps "
+                       "over the 58 MB factor and eleven vector passes between two products): HIP events around the launch in "
+                       "every iteration, mean over the iterations; the rocprofv3 average of k_spmm<%d, 3, 3> is this "
+                       "population (profiles/)" % ld,
+            }
+            result["roofline"] = rl
+            result["roofline_cache"] = b2b
+        else:
+            result["roofline"] = b2b
+        if extras is not None and extras.get("stpcg_phase_us") and extras["stpcg_phase_us"].get("forward_sweep"):
+            ent = extras.pop("_stpcg_entries")
+            ph = extras["stpcg_phase_us"]
+            ab = stpcg_bytes(dm, p, extras["preconditioner"]["nnz_L"], ent)
+            kmap = {"product": k_loop, "kappa": "k_kappa_finish", "forward_sweep": "k_subblock<%d, false, 1>" % ld,
+                    "top_forward": "k_rowop<%d>" % ld, "top_backward": "k_rowop<%d>" % ld,
+                    "backward_sweep": "k_subblock<%d, true, 3>" % ld}
+            kern = {}
+            for name in ("product", "kappa", "forward_sweep", "top_forward", "top_backward", "backward_sweep"):
+                e = {"kernel": kmap[name], "us": ph.get(name), "algorithmic_bytes": ab[name]}
+                if ph.get(name) and ab[name]:
+                    e["frac"] = ab[name] / ph[name] / 1e3 / HBM_PEAK_GBS
+                if pmc and kmap[name] in pmc and not name.startswith("top_"):
+                    e["pmc_bytes"] = pmc[kmap[name]]["read"] + pmc[kmap[name]]["write"]
+                    e["pmc_read"], e["pmc_write"] = pmc[kmap[name]]["read"], pmc[kmap[name]]["write"]
+                    if ab[name]:
+                        e["pmc_over_algorithmic"] = e["pmc_bytes"] / ab[name]
+                kern[name] = e
+            if pmc and kmap["top_forward"] in pmc:   # the two products of the last stage are launches of one kernel
+                t = pmc[kmap["top_forward"]]
+                kern["top_forward"]["pmc_bytes_both_products"] = 2 * (t["read"] + t["write"])
+            tot_b = sum(ab.values())
+            it_us = extras["stpcg_iteration_us"]
+            result["roofline_stpcg"] = {
+                "bound": "hbm", "what": "one sweep-fused STPCG iteration with the RegularizedCholesky preconditioner "
+                                         "(src/CORA.cpp:71-92,119-122; src/CORA_preconditioners.cpp:46-83), 6 launches",
+                "algorithmic_bytes": tot_b, "us": it_us, "achieved": tot_b / it_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": tot_b / it_us / 1e3 / HBM_PEAK_GBS,
+                "us_is": "host clock over %d iterations of cora_stpcg_dev (no events inside)" % extras["stpcg_iterations_timed"],
+                "sum_of_launches_us": sum(v for v in ph.values() if v),
+                "kernels": kern,
+                "entries": ent,
+                "bytes_are": "12 B per stored entry of L / of the last stage's products, 8 N p per vector pass: forward sweep L + 4 "
+                             "passes (r, Hp in; r, y out), backward sweep L + 5 passes (y, p, s in; p, s out) + the point's rows; "
+                             "kernels[*].us: HIP events around every launch in a separate run of the same loop",
+            }
+        elif extras is not None:
+            extras.pop("_stpcg_entries", None)
         if world > 1:
             result["multi_gpu"] = {
                 "transport": type(comm).__name__, "exchanged_rows_per_product": getattr(comm, "exchanged_rows", None),
+                "rccl_ranks": getattr(comm, "nranks", None),
                 "kernel_only_us": kernel_us, "step_us": elapsed / args.steps * 1e6,
                 "phases_us": phases, "collectives": comm_counts,
                 "note": "phases: HIP events on the handle's stream of rank 0, serial order (the interior / boundary overlap "
@@ -530,7 +658,7 @@ def main():
                         "collective step skipped (cora_debug_local_products)"}
         if hbm_us is not None:
             result["roofline_hbm"] = {
-                "bound": "hbm", "kernel": result["roofline"]["kernel"], "kernel_us": hbm_us,
+                "bound": "hbm", "kernel": kname, "kernel_us": hbm_us,
                 "achieved": b_hvp / hbm_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": b_hvp / hbm_us / 1e3 / HBM_PEAK_GBS,
                 "how": "five independent copies of the problem visited round-robin (working set ~750 MB)",
@@ -544,19 +672,11 @@ def main():
             }
         if chunk_us:
             n_c = len(chunk_us)
-            if args.steps < 200:
-                # a short timed region carries the launch ramp (+-5 %): the headline is then the median of the chunks
-                # measured right after it, the raw figure of the K timed steps stays beside it
-                result["value_timed_region"] = result["value"]
-                result["ms_per_step_timed_region"] = result["ms_per_step"]
-                result["value"] = 1e6 / chunk_us[n_c // 2]
-                result["ms_per_step"] = chunk_us[n_c // 2] / 1e3
-                result["value_is"] = ("median over 30 chunks of 100 back-to-back products (value_stats.p50); --steps < 200: "
-                                      "the K timed steps alone are value_timed_region")
             result["value_stats"] = {
                 "unit": result["unit"], "p10": 1e6 / chunk_us[int(0.9 * (n_c - 1))], "p50": 1e6 / chunk_us[n_c // 2],
                 "p90": 1e6 / chunk_us[int(0.1 * (n_c - 1))],
-                "how": "30 chunks of 100 back-to-back products after the timed region, HIP events per chunk"}
+                "how": "30 chunks of 100 back-to-back products after the timed region, HIP events per chunk (a short timed "
+                       "region carries the launch ramp; these do not)"}
         if world > 1 and args.op == "hvp":
             # parity of the sharded product against the CPU oracle on the same operands
             from oracle import oracle as orc
@@ -590,22 +710,22 @@ def main():
             ctx.hvp_dev(x.data_ptr(), out.data_ptr())
             got = ctx.download(out.data_ptr(), p)
             result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
-            result["extras"] = solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt)
-            # all-core column of BASELINE.md section 4: the same oracle loops under OpenMP.  A container may see
-            # more logical cores than it may use, so a few thread counts are tried and the best one is reported.
-            best = None
-            quota = cpu_quota()   # what the container may use (cgroup cpu.max), not what it sees
-            for th in sorted({max(1, min(t, cores, quota)) for t in (4, 8, 16, 32, 64, 128, cores)}):
-                hv, reps_th, _ = cpu_baseline(rowptr, colidx, vals, dm, p, 1.0, threads=th)
-                if best is None or hv > best[0]:
-                    best = (hv, th, reps_th)
-            result["extras"]["cpu_all_cores"] = {
-                "value": best[0], "unit": "Hvp/s", "cores": best[1],
-                "sample": "%d products, same oracle code with OpenMP row-parallel loops, threads bound to cores "
-                          "(spread over the sockets), Q and the vectors first touched by the threads that use them; best "
-                          "of several thread counts up to the container's CPU quota of %d (cgroup cpu.max; the host "
-                          "reports %d logical cores, a run on more threads than the quota is throttled: 128 threads "
-                          "reached 28 Hvp/s)" % (best[2], quota, cores)}
+            result["extras"] = extras
+            if args.cpu_all_cores:
+                # all-core column of BASELINE.md section 4: the same oracle loops under OpenMP.  A container may see
+                # more logical cores than it may use, so a few thread counts are tried and the best one is reported.
+                best = None
+                quota = cpu_quota()   # what the container may use (cgroup cpu.max), not what it sees
+                for th in sorted({max(1, min(t, cores, quota)) for t in (4, 8, 16, 32, 64, 128, cores)}):
+                    hv, reps_th, _ = cpu_baseline(rowptr, colidx, vals, dm, p, 1.0, threads=th)
+                    if best is None or hv > best[0]:
+                        best = (hv, th, reps_th)
+                result["extras"]["cpu_all_cores"] = {
+                    "value": best[0], "unit": "Hvp/s", "cores": best[1],
+                    "sample": "%d products, same oracle code with OpenMP row-parallel loops, threads bound to cores "
+                              "(spread over the sockets), Q and the vectors first touched by the threads that use them; best "
+                              "of several thread counts up to the container's CPU quota of %d (cgroup cpu.max; the host "
+                              "reports %d logical cores)" % (best[2], quota, cores)}
             result["cpu_baseline"] = {
                 "value": hv_s,
                 "unit": "Hvp/s",

@@ -189,6 +189,13 @@ class Context:
         self._chk(self.L.cora_format_bytes(self.h, b))
         return dict(zip(["values", "indices", "descriptors", "total"], [int(x) for x in b]))
 
+    def precond_entries(self):
+        """Entries the installed preconditioner's solve plan stores (cora_precond_entries)."""
+        s = (C.c_int64 * 6)()
+        self._chk(self.L.cora_precond_entries(self.h, s))
+        keys = ["top_forward", "top_backward", "sub_forward_slots", "sub_backward_slots", "sub_blocks", "aux_rows"]
+        return dict(zip(keys, [int(x) for x in s]))
+
     def set_stream(self, stream_ptr):
         self._chk(self.L.cora_set_stream(self.h, C.c_void_p(stream_ptr)))
 
@@ -398,6 +405,14 @@ class Context:
         us, cnt = C.c_double(), C.c_int()
         self._chk(self.L.cora_debug_stpcg_hvp_us(self.h, C.byref(us), C.byref(cnt)))
         return us.value, cnt.value
+
+    def stpcg_phase_us(self):
+        """Mean microseconds per launch of the sweep-fused iteration of the last stpcg_dev call (profile_stpcg(2)):
+        dict product | kappa | forward_sweep | top_forward | top_backward | backward_sweep; None where not recorded."""
+        us = (C.c_double * 6)()
+        self._chk(self.L.cora_debug_stpcg_phase_us(self.h, us))
+        names = ("product", "kappa", "forward_sweep", "top_forward", "top_backward", "backward_sweep")
+        return {k: (float(v) if v >= 0 else None) for k, v in zip(names, us)}
 
     def gram_dev(self, a, ka, b, kb):
         """G = A^T B (ka x kb) of two resident blocks."""

@@ -43,6 +43,7 @@ thread_local std::string g_create_error;
 constexpr int kScratchSlots = 9;
 }  // namespace
 
+constexpr size_t kProfMarks = 8;  // events per profiled STPCG iteration (cora_debug_profile_stpcg)
 struct cora_native_comm;
 static void native_comm_destroy(cora_native_comm *nc);
 static double *native_scalars(cora_native_comm *nc);                       // 8 device doubles of the sharded STPCG
@@ -112,6 +113,7 @@ struct cora_ctx {
     bool fuse_ok = false;  // substitution blocks whose tiles hold every pose's rotation rows at consecutive positions:
                            // the STPCG passes can be fused into the sweeps (SubFuse, kernels.h)
     bool ready = false;
+    int64_t entries[6] = {0, 0, 0, 0, 0, 0};  // cora_precond_entries (counted at install, before the host copy is dropped)
     unsigned long long generation = 0;  // counts installs: a captured STPCG graph carries the plan's arrays and sizes
   };
   DevFactor precond_f, implicit_f, aux_f;  // aux_f: the caller's own factor (cora_aux_set_cholesky)
@@ -153,10 +155,11 @@ struct cora_ctx {
   // cora_debug_product_phases: events at the phase boundaries of the one-collective product (serial order)
   std::vector<hipEvent_t> phase_events;
   bool phase_timing = false;
-  bool prof_stpcg = false;
-  std::vector<hipEvent_t> prof_events;
+  int prof_stpcg = 0;  // 0 off | 1 events around the product of every STPCG iteration | 2 around every launch of it
+  std::vector<hipEvent_t> prof_events;  // kProfMarks per iteration
   double prof_hvp_us = 0.0;
   int prof_hvp_count = 0;
+  double prof_phase_us[7] = {0, 0, 0, 0, 0, 0, 0};  // mean time between marks k and k + 1 (-1: not recorded)
   int stpcg_path = 0;  // iteration form of the last cora_stpcg_dev: 0 unfused, 1 fused vector passes, 2 sweep-fused
   // A batch of device-resident STPCG iterations as a hipGraph: the launches of an iteration have the same arguments
   // every time (the scalars live in device memory, the sequence number the host waits for is a device counter), so a
@@ -735,6 +738,15 @@ int cora_precond_stats(const cora_ctx *c, int64_t s[4]) {
   return CORA_OK;
 }
 
+// entries the solve plan of the preconditioner stores (bench.py's algorithmic bytes of the last stage; padding of the
+// substitution blocks): [0] last stage, forward product | [1] last stage, backward product | [2], [3] entry slots of the
+// substitution blocks' forward / backward sweep (null padding included) | [4] substitution blocks | [5] aux rows
+int cora_precond_entries(const cora_ctx *c, int64_t s[6]) {
+  if (!c || !s) return CORA_ERR_ARG;
+  for (int k = 0; k < 6; ++k) s[k] = c->precond_f.ready ? c->precond_f.entries[k] : 0;
+  return CORA_OK;
+}
+
 int cora_format_stats(const cora_ctx *c, int64_t s[8]) {
   if (!c || !s) return CORA_ERR_ARG;
   s[0] = static_cast<int64_t>(c->F.slices.size());
@@ -986,6 +998,19 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
   };
   const size_t K = f.plan.stages.size();
   f.stages.resize(K);
+  for (int64_t &e : f.entries) e = 0;
+  if (K > 0) {
+    const TriStage &top = f.plan.stages.back();
+    f.entries[0] = static_cast<int64_t>(top.fwd_b.val.size());
+    f.entries[1] = static_cast<int64_t>(top.bwd_b.val.size());
+    if (f.plan.stages[0].sub) {
+      const SubBlockOpHost &o = f.plan.stages[0].sub_op;
+      f.entries[2] = static_cast<int64_t>(o.f_val.size());
+      f.entries[3] = static_cast<int64_t>(o.b_val.size());
+      f.entries[4] = static_cast<int64_t>(o.nrows.size());
+      f.entries[5] = o.n_aux;
+    }
+  }
   for (size_t k = 0; k < K; ++k) {
     TriStage &S = f.plan.stages[k];
     cora_ctx::DevStage &D = f.stages[k];
@@ -1922,12 +1947,11 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     }
   }
   c->stpcg_path = sweep_fused ? 2 : inverse_fused ? 3 : fused ? 1 : 0;
-  // hipGraph replay of whole batches (one GPU, the fused forms; CORA_STPCG_GRAPH=0 switches it off)
-  // (opt-in, CORA_STPCG_GRAPH=1: measured on this part, replaying the batches does not bring the launches of an iteration
+  // hipGraph replay of whole batches (one GPU, the fused forms): OPT-IN, CORA_STPCG_GRAPH=1.  Measured on this part, replaying the batches does not bring the launches of an iteration
   // closer together -- a dependent kernel of 5 us and more already has its successor's packet waiting, what is left
   // between them is the dependency itself -- and a six-launch graph per iteration costs the host more than six launches:
   // iteration at 10^5 poses 116 -> 122 us, the reference's data sets unchanged.  tools/launch_lab.hip shows the gain only
-  // for kernels shorter than the launch rate, 3.5 -> 2.1 us each.  Kept: same bits, tested, one switch.)
+  // for kernels shorter than the launch rate, 3.5 -> 2.1 us each.  Kept: same bits, tested, one switch.
   const bool graphs_on = [] { const char *e = std::getenv("CORA_STPCG_GRAPH"); return e && e[0] == '1'; }();  // (read per solve: tests flip it)
   const bool use_graph = graphs_on && fused && !sharded && !c->prof_stpcg && max_iters >= batch;
   std::vector<uintptr_t> key;
@@ -1986,14 +2010,20 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     };
     // (the launches of one iteration; under capture an error must still close the capture: the caller does)
     auto one_iteration = [&]() -> int {
-      const bool prof = c->prof_stpcg && 2 * static_cast<size_t>(enqueued) + 1 < c->prof_events.size();
-      if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued], c->stream));
+      // measurement hook (cora_debug_profile_stpcg): mark 0 before the product, 1 after it; mode 2 also after every
+      // other launch of the sweep-fused form -- 2 kappa | 3 forward sweep | 4, 5 the last stage's two products | 6
+      // backward sweep (a mark is an event on the handle's stream: it does not reorder anything)
+      const bool prof = c->prof_stpcg && kProfMarks * (static_cast<size_t>(enqueued) + 1) <= c->prof_events.size();
+      auto mark = [&](int i) {
+        if (prof && (i <= 1 || c->prof_stpcg >= 2)) (void)hipEventRecord(c->prof_events[kProfMarks * enqueued + i], c->stream);
+      };
+      mark(0);
       if (fused) {
         // Hp = H p with the partials of kappa | kappa, alpha, r += alpha Hp with <r, r> | preconditioner | ...
         SpmmArgs A = spmm_args(c, dP, dHp);
         A.kappa_partial = kappa_partial;
         if ((rc = exchange_and_product(c, A, c->ld, EPI_HVP_K))) return rc;  // (one rank: the product alone)
-        if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
+        mark(1);
         if (sharded) {
           // kappa: local partials (fixed order) -> sum over the ranks -> scalar step;  then r += alpha Hp with <r, r>
           // and v = Proj_Y(D^-1 r) with <r, v>, both left on the device, one all-reduce for the two, scalar step
@@ -2047,6 +2077,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         }
         if (sweep_fused) {
           if (FF.n_kappa == 0) HIP_TRY(c, launch_kappa_finish(kappa_partial, kappa_blocks, c->d_stpcg, c->stream));
+          mark(2);
           // Hp = H p | kappa | forward sweep: r += alpha Hp, <r, r>, |y|^2 | last stage, <r, v> in its second product |
           // backward sweep: v = Proj_Y(x), s += alpha p, p = -v + beta p   -- six launches
           cora_ctx::DevFactor &f = c->precond_f;
@@ -2055,11 +2086,15 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           if ((rc = get_scratch(c, 7, c->ld, &t2))) return rc;
           const cora_ctx::DevStage &S0 = f.stages[0], &S1 = f.stages[1];
           HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, false, FF, t, dV, c->stream));
+          mark(3);
           if (S1.aux_sum) HIP_TRY(c, launch_rowop(S1.fwd_a, c->ld, t, t, t, c->stream));
           HIP_TRY(c, launch_rowop(S1.fwd_b, c->ld, nullptr, t, t2, c->stream, &sq));
+          mark(4);
           tail.seq = seq = ++c->dot_seq;
           HIP_TRY(c, launch_rowop(S1.bwd_b, c->ld, nullptr, t2, t, c->stream, &tail));
+          mark(5);
           HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
+          mark(6);
           return CORA_OK;
         }
         // kappa, the scalar step and r += alpha Hp with <r, r> in ONE launch (every block adds the partials: the plans
@@ -2097,7 +2132,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         return CORA_OK;
       }
       if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
-      if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[2 * enqueued + 1], c->stream));
+      mark(1);
       int nblocks = 0;
       D.count = 1;
       D.a[0] = dP;
@@ -2132,18 +2167,25 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // an iteration that starts at the limit only records the status: flush it so that the mirror is final
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(&H, c->d_stpcg, sizeof(StpcgState), hipMemcpyDeviceToHost));
-  if (c->prof_stpcg) {  // products of iterations that really ran (enqueued-ahead ones after the stop are neutral but timed)
-    double tot = 0.0;
-    int cnt = 0;
-    for (int i = 0; i < H.iters && 2 * static_cast<size_t>(i) + 1 < c->prof_events.size(); ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]) == hipSuccess) {
-        tot += ms * 1e3;
-        ++cnt;
+  if (c->prof_stpcg) {  // iterations that really ran (enqueued-ahead ones after the stop are neutral but timed)
+    const bool phases = c->prof_stpcg >= 2 && c->stpcg_path == 2 && !sharded;
+    for (int k = 0; k < 7; ++k) c->prof_phase_us[k] = -1.0;
+    for (int k = 0; k < (phases ? 6 : 1); ++k) {
+      double tot = 0.0;
+      int cnt = 0;
+      for (int i = 0; i < H.iters && kProfMarks * (static_cast<size_t>(i) + 1) <= c->prof_events.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->prof_events[kProfMarks * i + k], c->prof_events[kProfMarks * i + k + 1]) == hipSuccess) {
+          tot += ms * 1e3;
+          ++cnt;
+        }
+      }
+      c->prof_phase_us[k] = cnt ? tot / cnt : -1.0;
+      if (k == 0) {
+        c->prof_hvp_us = cnt ? tot / cnt : 0.0;
+        c->prof_hvp_count = cnt;
       }
     }
-    c->prof_hvp_us = cnt ? tot / cnt : 0.0;
-    c->prof_hvp_count = cnt;
   }
   *iters = H.iters;
   *step_M_norm = H.step_M_norm;
@@ -2215,11 +2257,17 @@ int cora_copy_shard_dev(cora_ctx *c, const double *dSrc, int ld, int shard, doub
 
 int cora_debug_profile_stpcg(cora_ctx *c, int on) {
   NEED_DEVICE(c);
-  c->prof_stpcg = on != 0;
+  c->prof_stpcg = on < 0 ? 0 : (on > 2 ? 2 : on);
   if (on && c->prof_events.empty()) {
-    c->prof_events.resize(2 * 256, nullptr);
+    c->prof_events.resize(kProfMarks * 256, nullptr);
     for (hipEvent_t &e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
   }
+  return CORA_OK;
+}
+
+int cora_debug_stpcg_phase_us(cora_ctx *c, double us[6]) {
+  if (!c || !us) return CORA_ERR_ARG;
+  for (int k = 0; k < 6; ++k) us[k] = c->prof_phase_us[k];
   return CORA_OK;
 }
 
@@ -2662,6 +2710,8 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // (optional: what the communicator itself reports)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 const RcclApi *rccl_api(std::string *err) {
@@ -2688,6 +2738,8 @@ const RcclApi *rccl_api(std::string *err) {
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
   });
   if (!load_error.empty()) {
     if (err) *err = load_error;
@@ -2966,7 +3018,27 @@ int cora_comm_create_rccl(cora_ctx *c, const void *id128) {
     delete nc;
     return fail(c, CORA_ERR_HIP, m);
   }
+  // the communicator must be what the partition assumes: world ranks, this rank's number (a launcher that hands the
+  // id to the wrong set of processes would otherwise gather shards in the wrong order, silently)
+  if (api->CommCount && api->CommUserRank) {
+    int cnt = -1, ur = -1;
+    if (api->CommCount(nc->nccl, &cnt) != ncclSuccess || api->CommUserRank(nc->nccl, &ur) != ncclSuccess || cnt != nc->world || ur != nc->rank) {
+      const std::string m = "RCCL communicator reports " + std::to_string(cnt) + " ranks / rank " + std::to_string(ur) +
+                            ", the handle was partitioned for " + std::to_string(nc->world) + " / " + std::to_string(nc->rank);
+      delete nc;
+      return fail(c, CORA_ERR_ARG, m);
+    }
+  }
   return native_finish(c, nc);
+}
+
+int cora_comm_rccl_ranks(const cora_ctx *c, int out[2]) {
+  if (!c || !out) return CORA_ERR_ARG;
+  out[0] = out[1] = -1;
+  const cora_native_comm *nc = c->native_comm;
+  if (!nc || !nc->nccl || !nc->api || !nc->api->CommCount || !nc->api->CommUserRank) return CORA_OK;
+  if (nc->api->CommCount(nc->nccl, &out[0]) != ncclSuccess || nc->api->CommUserRank(nc->nccl, &out[1]) != ncclSuccess) out[0] = out[1] = -1;
+  return CORA_OK;
 }
 
 cora_local_group *cora_local_group_create(int world) {
@@ -3021,28 +3093,35 @@ int cora_debug_product_phases(cora_ctx *c, const double *dX, double *dOut, int e
   NEED_DEVICE(c);
   NEED_RANK(c);
   if (!dX || !dOut || !us || reps < 1 || epi < EPI_NONE || epi > EPI_HVP) return fail(c, CORA_ERR_ARG, "bad arguments");
-  if (!product_one_collective(c) || product_overlaps_exchange(c))
-    return fail(c, CORA_ERR_NOT_READY, "phase timing needs the library's own communication, distributed long rows and the serial order");
+  // The call is collective (reps + 3 all-gathers), so whether it runs must not depend on anything rank-local (round-4
+  // advice): product_one_collective() is the same on every rank (world, transport, the common list of long rows), the
+  // interior / boundary overlap is not (it counts THIS rank's slices) -- the serial order is forced for the duration of
+  // the call instead of being required.
+  if (!product_one_collective(c))
+    return fail(c, CORA_ERR_NOT_READY, "phase timing needs the library's own communication and distributed long rows");
   while (c->phase_events.size() < 6) {
     hipEvent_t e;
     HIP_TRY(c, hipEventCreate(&e));
     c->phase_events.push_back(e);
   }
   for (int k = 0; k < 5; ++k) us[k] = 0.0;
+  const int overlap_saved = c->overlap_exchange;
+  c->overlap_exchange = 0;
   int rc = CORA_OK;
   for (int it = 0; it < reps + 3 && !rc; ++it) {   // (three warm-up rounds)
     c->phase_timing = true;
     rc = apply_product(c, dX, c->ld, epi, dOut);
     c->phase_timing = false;
     if (rc) break;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, CORA_ERR_HIP, "hipStreamSynchronize"); break; }
     if (it < 3) continue;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 5 && !rc; ++k) {
       float ms = 0.f;
-      HIP_TRY(c, hipEventElapsedTime(&ms, c->phase_events[k], c->phase_events[k + 1]));
+      if (hipEventElapsedTime(&ms, c->phase_events[k], c->phase_events[k + 1]) != hipSuccess) rc = fail(c, CORA_ERR_HIP, "hipEventElapsedTime");
       us[k] += ms * 1e3 / reps;
     }
   }
+  c->overlap_exchange = overlap_saved;
   return rc;
 }
 

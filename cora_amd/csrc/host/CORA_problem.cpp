@@ -1,6 +1,7 @@
 // Host side of CORA::Problem: registry + data-matrix assembly on the CPU (one
 // pass per problem), operators on the GPU through include/cora_hip.h.
 #include "CORA_problem.h"
+#include "LOBPCG.h"
 
 #include <chrono>
 #include <thread>
@@ -258,6 +259,7 @@ void Problem::updateProblemData() {  // src/CORA_problem.cpp:500-510
   cert_block_.reset();  // (its device memory belongs to the handle)
   ctx_.reset();  // the device copy of Q is rebuilt lazily
   precond_ready_ = false;
+  std::lock_guard<std::recursive_mutex> lock(*cert_mutex_);
   cert_perm_.clear();
   cert_S_ = SparseMatrix();
   cert_lambda_pos_.clear();
@@ -366,37 +368,21 @@ void Problem::fillImplicitFormulationMatrices() const {
   implicit_ready_ = true;
 }
 
-// ||Q||_2 = lambda_max(Q) by power iteration with the device SpMM.  The reference
-// estimates it with LOBPCG (block 4, <= 100 iterations, tolerance 1e-2,
-// src/CORA_problem.cpp:556-578); it only scales the regularisation lambda_reg.
+// ||Q||_2 = lambda_max(Q) = -lambda_min(-Q), estimated exactly as the reference does (src/CORA_problem.cpp:556-578):
+// LOBPCG on the operator X -> -(Q X), block min(4, N), one wanted pair, at most 100 iterations, tolerance 1e-2.  The
+// blocks stay on the device (LOBPCG.h), the operator is the device SpMM, so lambda_reg = ||Q||_2 / (kappa_max - 1) -- and
+// with it every STPCG iteration count -- is what the reference's call yields to the eigensolver's tolerance.  (Rounds 1-4
+// used a power iteration stopped at 1e-3: same converged results, a lambda_reg that differed in its third digit.)
+// Collective on partitioned handles (the Gram matrices are all-reduced), same number on every rank.
 static Scalar spectralNormEstimate(cora_ctx *c, Index N) {
-  double *x = nullptr, *y = nullptr;
-  auto chk = [&](int rc) {
-    if (rc != CORA_OK) throw std::runtime_error(std::string("spectral norm estimate: ") + cora_last_error(c));
+  const Index block = std::min<Index>(4, N);
+  DeviceOperator negQ = [c](const double *dX, int k, double *dOut) {
+    if (cora_spmm_dev(c, dX, k, dOut) != CORA_OK || cora_axpby_cols_dev(c, k, 0.0, dOut, -1.0, dOut) != CORA_OK)
+      throw std::runtime_error(std::string("spectral norm estimate: ") + cora_last_error(c));
   };
-  chk(cora_dev_alloc(c, 1, &x));
-  chk(cora_dev_alloc(c, 1, &y));
-  Matrix x0 = Matrix::Random(N, 1, 12345);
-  chk(cora_upload(c, x0.data(), static_cast<int>(N), 1, x));
-  double lambda = 0.0, prev = -1.0;
-  for (int it = 0; it < 100; ++it) {
-    chk(cora_spmm_dev(c, x, 1, y));
-    const double *A[2] = {x, y};
-    const double *B[2] = {y, y};
-    double xy, yy, xx;
-    chk(cora_dot_dev(c, x, y, 1, &xy));
-    chk(cora_dot_dev(c, y, y, 1, &yy));
-    chk(cora_dot_dev(c, x, x, 1, &xx));
-    (void)A; (void)B;
-    lambda = xy / xx;
-    if (!(yy > 0.0)) break;
-    chk(cora_axpby_cols_dev(c, 1, 1.0 / std::sqrt(yy), y, 0.0, x));
-    if (it > 5 && std::abs(lambda - prev) <= 1e-3 * std::abs(lambda)) break;
-    prev = lambda;
-  }
-  cora_dev_free(c, x);
-  cora_dev_free(c, y);
-  return lambda;
+  const Matrix X0 = Matrix::Random(N, block, 12345);
+  const LOBPCGResult r = LOBPCG(c, negQ, std::nullopt, X0, /*nev=*/1, /*max_iters=*/100, /*tau=*/1e-2);
+  return -r.Theta(0);
 }
 
 void Problem::ensurePreconditioner() const {  // src/CORA_problem.cpp:512-623
@@ -744,11 +730,15 @@ SparseMatrix Problem::compute_Lambda_from_Lambda_blocks(const LambdaBlocks &L, c
   return Lambda;
 }
 
-SparseMatrix Problem::get_certificate_matrix(const Matrix &Y) const { return certificateMatrixCached(Y); }
+SparseMatrix Problem::get_certificate_matrix(const Matrix &Y) const {
+  std::lock_guard<std::recursive_mutex> lock(*cert_mutex_);
+  return certificateMatrixCached(Y);
+}
 
 const SparseMatrix &Problem::certificateMatrixCached(const Matrix &Y) const { return certificateMatrixFrom(compute_Lambda_blocks(Y)); }
 
 void Problem::prepareCertification(Index num_eigvecs) const {
+  std::lock_guard<std::recursive_mutex> lock(*cert_mutex_);
   const Index N = getDataMatrixSize();
   if (static_cast<Index>(cert_perm_.size()) != N)
     cert_perm_ = coraOrdering(dim_, numPoses(), numRangeMeasurements(), numTranslationalStates(), data_matrix_, static_cast<int>(N));
@@ -978,6 +968,7 @@ CertResults Problem::certify_solution_resident(const Matrix &Y, Scalar eta, size
 }
 CertResults Problem::certifyImpl(const Matrix &Y, Scalar eta, size_t nx, const Matrix &eigvec_bootstrap, size_t max_LOBPCG_iters,
                                  bool resident) const {
+  std::lock_guard<std::recursive_mutex> lock(*cert_mutex_);
   checkMatrixShape("Problem::certify_solution::Y", getExpectedVariableSize(), relaxation_rank_, Y.rows(), Y.cols());
   const Index N = getDataMatrixSize(), p = Y.cols();
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;

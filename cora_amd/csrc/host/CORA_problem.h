@@ -8,6 +8,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <set>
 #include <utility>
@@ -84,6 +85,10 @@ class Problem {
   // symbolic analyses of this problem's factorisations (preconditioner block, certificate matrix): kept with the
   // Problem and gone with it (shared between copies of one Problem: they factorise the same patterns)
   mutable std::shared_ptr<SymbolicCache> symbolic_cache_ = std::make_shared<SymbolicCache>();
+  // cert_* below is written by prepareCertification(), which solveCORA runs on a thread of its own beside the first TNT
+  // solve, and read by certify_solution / get_certificate_matrix: every one of them holds this lock for its whole body
+  // (round-4 advice; shared between copies like the cache above so that Problem stays copyable)
+  mutable std::shared_ptr<std::recursive_mutex> cert_mutex_ = std::make_shared<std::recursive_mutex>();
   mutable std::vector<int32_t> cert_perm_;  // elimination order of the full certificate matrix (pattern-only: kept per data matrix)
   // S = Q - Lambda(Y) kept between certifications: its pattern is Q's plus the Lambda blocks, only the entries under
   // Lambda change with Y.  cert_lambda_pos_: position in cert_S_.values of every Lambda entry (pose-block entries row

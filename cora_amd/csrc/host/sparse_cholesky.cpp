@@ -194,7 +194,11 @@ void parallelRun(unsigned nth, Body body) {
 
 struct SymbolicCache::Impl {
   std::mutex m;
-  std::shared_ptr<const Symbolic> slot[2];  // the two most recent patterns (preconditioner block, certificate matrix)
+  // the most recent patterns, most recent first: preconditioner block, certificate matrix, the implicit formulation's M,
+  // a shard's block -- two slots were one too few once prepareCertification() ran beside the first TNT solve and the
+  // three patterns met in a nondeterministic order (round-4 advice)
+  static constexpr int kSlots = 4;
+  std::shared_ptr<const Symbolic> slot[kSlots];
 };
 SymbolicCache::SymbolicCache() : impl(new Impl) {}
 SymbolicCache::~SymbolicCache() { delete impl; }
@@ -235,9 +239,9 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   if (use_cache) {
     std::lock_guard<std::mutex> lock(cache->impl->m);
     auto &slot = cache->impl->slot;
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < SymbolicCache::Impl::kSlots; ++e)
       if (slot[e] && slot[e]->key == key && slot[e]->key2 == key2 && slot[e]->n == n && slot[e]->nnzA == A.inner.size()) {
-        if (e == 1) std::swap(slot[0], slot[1]);
+        std::rotate(slot, slot + e, slot + e + 1);  // to the front, the others keep their order
         *hit = true;
         return slot[0];
       }
@@ -351,8 +355,9 @@ std::shared_ptr<const Symbolic> symbolicFor(const SparseMatrix &A, int n, const 
   S->tot = tot;
   if (use_cache) {
     std::lock_guard<std::mutex> lock(cache->impl->m);
-    cache->impl->slot[1] = cache->impl->slot[0];
-    cache->impl->slot[0] = S;
+    auto &slot = cache->impl->slot;
+    std::rotate(slot, slot + SymbolicCache::Impl::kSlots - 1, slot + SymbolicCache::Impl::kSlots);  // the oldest falls out
+    slot[0] = S;
   }
   return S;
 }

@@ -15,26 +15,33 @@
 namespace cora {
 
 namespace {
+// Tunables below marked "env" are read ONCE, when the library is loaded (lab sweeps set them per process: tools/plan_sweep.sh).
+// They were process-wide variables that every build_tri_plan call rewrote from the environment -- a data race between the
+// rank threads that build their plans at the same time (round-4 advice).
+int64_t env_i64(const char *name, int64_t dflt, int64_t lo, int64_t hi) {
+  const char *e = std::getenv(name);
+  return e ? std::min(hi, std::max(lo, static_cast<int64_t>(std::atoll(e)))) : dflt;
+}
 constexpr int kBorderRowNnz = 4096;  // rows of L longer than this (landmarks) always belong to the last stage
 constexpr int kFirstCap = 64;        // rows of a stage-0 subtree: what one wavefront holds (a pair of
                                      // nested-dissection leaves, their separator and range rows); 32 / 40 / 48 /
                                      // 64 measured 154 / 155 / 162 / 151 us per apply at 10^5 poses
 constexpr int kCapGrowth = 16;       // stage k subtrees hold up to kFirstCap * kCapGrowth^k rows
 constexpr int kTopCap = 1536;        // stop cutting once this few rows are left: they form the last stage
-int64_t kTopInverseNnz = 2500000;  // ... or once the inverse of what is left has this few entries:
+const int64_t kTopInverseNnz = env_i64("CORA_TRI_TOP_INV", 2500000, 0, INT64_MAX);  // ... or once the inverse of what is left has this few entries:
                                              // a launch floor (~5 us) is worth ~25 MB of traffic, so small
                                              // factors are applied as ONE explicit inverse (2 products)
-int kShortRow = 64;        // entries: <= this -> 8 lanes per row
-int kWaveRow = 1024;       // entries: <= this -> one wavefront per row, else chunked
-int kChunk = 512;
+const int kShortRow = static_cast<int>(env_i64("CORA_TRI_SHORT_ROW", 64, 8, 1 << 30));  // entries: <= this -> 8 lanes per row
+const int kWaveRow = static_cast<int>(env_i64("CORA_TRI_WAVE_ROW", 1024, 64, 1 << 30));  // entries: <= this -> one wavefront per row, else chunked
+const int kChunk = static_cast<int>(env_i64("CORA_TRI_CHUNK", 512, 64, 1 << 30));
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
-int kSubRows = 512;        // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
+const int kSubRows = static_cast<int>(env_i64("CORA_TRI_SUB_ROWS", 512, 32, 512));  // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
 constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
 constexpr int kSnCapChain = 4;  // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
-int kLaneEntries = 8;       // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
-int kLevelLanes = 256;      // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
+const int kLaneEntries = static_cast<int>(env_i64("CORA_TRI_LANE_ENTRIES", 8, 1, 8));  // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
+const int kLevelLanes = static_cast<int>(env_i64("CORA_TRI_LEVEL_LANES", 256, 64, 256));  // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
 constexpr int kSubWaves = 4, kWaveLanes = 64;  // wavefronts of a substitution block's workgroup (kSubThreads of the kernel / 64)
-int kSplitMinRows = 1 << 20;  // a chunk of a level is closed early when the next rows are half as long, from this many rows on.
+const int kSplitMinRows = static_cast<int>(env_i64("CORA_TRI_SPLIT_MIN_ROWS", 1 << 20, 1, 1 << 30));  // a chunk of a level is closed early when the next rows are half as long, from this many rows on.
                               // Never, since round 4: closing early saves padding (tile reads 15.4 M instead of 16.3 M at 10^5
                               // poses) and costs barrier levels (25.0 k instead of 20.0 k); measured: 10^5 poses 117.6 / 118.4 us
                               // per iteration (16 / never), 10^4 poses 62.9 / 58.4, tiers 83.1 / 78.6 us per product, mrclam3b 85.7 / 77.0
@@ -91,16 +98,8 @@ void finalize(const RowList &R, RowOpHost &op) {
 void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *Lx,
                     const std::vector<int32_t> &row_of, int32_t zero_row, TriPlan &P,
                     const std::vector<int32_t> *group, int32_t aux_base) {
-  if (const char *e = std::getenv("CORA_TRI_TOP_INV")) kTopInverseNnz = std::atoll(e);
-  if (const char *e = std::getenv("CORA_TRI_SHORT_ROW")) kShortRow = std::max(8, std::atoi(e));
-  if (const char *e = std::getenv("CORA_TRI_WAVE_ROW")) kWaveRow = std::max(64, std::atoi(e));
-  if (const char *e = std::getenv("CORA_TRI_CHUNK")) kChunk = std::max(64, std::atoi(e));
-  if (const char *e = std::getenv("CORA_TRI_SUB_ROWS")) kSubRows = std::min(512, std::max(32, std::atoi(e)));
-  if (const char *e = std::getenv("CORA_TRI_LANE_ENTRIES")) kLaneEntries = std::min(8, std::max(1, std::atoi(e)));
   int kSnCap = kSnCapChain;  // (local: plans are built from several rank threads at once)
   if (const char *e = std::getenv("CORA_TRI_SN_CAP")) kSnCap = std::min(32, std::max(1, std::atoi(e)));
-  if (const char *e = std::getenv("CORA_TRI_LEVEL_LANES")) kLevelLanes = std::min(256, std::max(64, std::atoi(e)));
-  if (const char *e = std::getenv("CORA_TRI_SPLIT_MIN_ROWS")) kSplitMinRows = std::max(1, std::atoi(e));
   const bool timing = std::getenv("CORA_TRI_TIMING") != nullptr;
   auto tick = [t_prev = std::chrono::steady_clock::now(), timing](const char *what) mutable {
     if (!timing) return;

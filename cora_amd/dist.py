@@ -422,3 +422,7 @@ class NativeRcclComm(_NativeComm):
             buf = (_C.c_ubyte * 128).from_buffer_copy(raw)
         ctx._chk(L.cora_comm_create_rccl(ctx.h, buf))
         self._finish(ctx)
+        out = (_C.c_int * 2)()
+        L.cora_comm_rccl_ranks.argtypes = [_C.c_void_p, _C.POINTER(_C.c_int)]
+        ctx._chk(L.cora_comm_rccl_ranks(ctx.h, out))
+        self.nranks, self.user_rank = int(out[0]), int(out[1])   # ncclCommCount / ncclCommUserRank of the library's communicator

@@ -183,6 +183,10 @@ int cora_precond_set_cholesky(cora_ctx *ctx, int m, const int32_t *Lp,
 /* Device solve plan of the installed factor: [0] stages (a solve is 4*stages - 2 sparse products),
  * [1] entries of the explicit block inverses, [2] nnz(L), [3] rows of the last stage. */
 int cora_precond_stats(const cora_ctx *ctx, int64_t stats[4]);
+/* Entries the preconditioner's device solve plan stores: [0] / [1] the last stage's forward / backward product,
+ * [2] / [3] entry slots of the substitution blocks' forward / backward sweep (null padding included), [4] substitution
+ * blocks, [5] aux rows.  (Measurement: bench.py's bytes per STPCG iteration.) */
+int cora_precond_entries(const cora_ctx *ctx, int64_t s[6]);
 
 /* Translation-implicit formulation (Formulation::Implicit, src/CORA_problem.cpp:714-753):
  *   dataMatrixProduct(Y) = Qmain Y - B L^-1 B^T Y,  L L^T = Q33[0:nt-1, 0:nt-1].
@@ -384,6 +388,9 @@ void cora_local_group_destroy(cora_local_group *group);
 void cora_local_group_abort(cora_local_group *group); /* a rank failed outside the library: release the others */
 int cora_comm_create_local(cora_ctx *ctx, cora_local_group *group);
 int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
+/* What the handle's RCCL communicator itself reports: out[0] = ncclCommCount, out[1] = ncclCommUserRank (-1, -1 without an
+ * RCCL communicator).  cora_comm_create_rccl fails when they differ from the handle's partition. */
+int cora_comm_rccl_ranks(const cora_ctx *ctx, int out[2]);
 /* Measurement switch: on = 0 leaves the collective steps to the caller again (a product then runs on whatever the
  * remote rows hold: bench.py times the kernel alone this way), on = 1 re-installs the native communication. */
 int cora_comm_native_enable(cora_ctx *ctx, int on);
@@ -432,11 +439,16 @@ int cora_world(const cora_ctx *ctx);
  * two of them (the back-to-back figure keeps Q in the Infinity Cache). */
 int cora_debug_profile_stpcg(cora_ctx *ctx, int on);
 int cora_debug_stpcg_hvp_us(cora_ctx *ctx, double *mean_us, int *count);
+/* on = 2: events around EVERY launch of the sweep-fused iteration (one GPU).  us[k], mean over the iterations of the
+ * last cora_stpcg_dev that ran: 0 product with the kappa partials | 1 kappa | 2 forward sweep | 3, 4 the last stage's
+ * two products | 5 backward sweep; -1 where the form of the iteration has no such launch. */
+int cora_debug_stpcg_phase_us(cora_ctx *ctx, double us[6]);
 /* Form of the iteration the last cora_stpcg_dev ran: 0 one pass per operation, 1 fused vector passes, 2 vector passes
  * fused into the sweeps of the Cholesky solve (tests pin which form they compare). */
 int cora_debug_stpcg_path(const cora_ctx *ctx);
-/* Batches of device-resident STPCG iterations are captured once as a hipGraph and replayed (one GPU, fused forms;
- * CORA_STPCG_GRAPH=0 switches it off): out[0] = graphs captured so far, out[1] = batches replayed. */
+/* OPT-IN (CORA_STPCG_GRAPH=1; off by default -- measured slower on this part, see stpcg_run in capi.hip): batches of
+ * device-resident STPCG iterations captured once as a hipGraph and replayed (one GPU, fused forms).
+ * out[0] = graphs captured so far, out[1] = batches replayed (both 0 unless the switch is on). */
 int cora_debug_stpcg_graph(const cora_ctx *ctx, long out[2]);
 
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,

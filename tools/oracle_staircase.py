@@ -8,7 +8,7 @@ product code on the path (the C++ host only generates the graph, assembles Q and
 It answers the round-2 review's question "where does the reference-equivalent CPU path stop from this start?":
 every level ends on TNT's iteration limit far from stationarity, exactly like the GPU path.
 
-python tools/oracle_staircase.py [poses] [max_rank] [threads]   (10^4 poses: a few minutes per level on 8 cores)"""
+python tools/oracle_staircase.py [poses] [max_rank] [threads] [outer iterations per level]   (10^4 poses: a few minutes per level on 8 cores)"""
 import math, os, sys, time
 import numpy as np
 import scipy.sparse as sp
@@ -21,6 +21,7 @@ from oracle import oracle as orc, tnt as otnt
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10000
 max_rank = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 orc.set_threads(int(sys.argv[3]) if len(sys.argv) > 3 else min(8, orc.max_threads()))
+MAX_IT = int(sys.argv[4]) if len(sys.argv) > 4 else 250   # outer iterations per level (the reference: 250, src/CORA.cpp:97)
 
 P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42)
 P.update()
@@ -62,7 +63,7 @@ hvps = 0
 rank = x.shape[1]
 while rank <= max_rank:
     t0 = time.time()
-    res = otnt.tnt(Q, dims, x, precond="chol", lam=lam, perm=perm_pin)
+    res = otnt.tnt(Q, dims, x, precond="chol", lam=lam, perm=perm_pin, max_iterations=MAX_IT)
     hvps += res["hvps"]
     x = res["x"]
     eta = min(max(res["f"] * REL_ETA, MIN_ETA), MAX_ETA)
@@ -145,7 +146,7 @@ if x.shape[1] > dims.d:
     nr = np.linalg.norm(Yd[d * nn:d * nn + r], axis=1, keepdims=True)
     Yd[d * nn:d * nn + r] /= np.where(nr > 0, nr, 1.0)
     t0 = time.time()
-    res = otnt.tnt(Q, dims, np.asfortranarray(Yd), precond="chol", lam=lam, perm=perm_pin)
+    res = otnt.tnt(Q, dims, np.asfortranarray(Yd), precond="chol", lam=lam, perm=perm_pin, max_iterations=MAX_IT)
     print("rounded to rank %d: f=%.6f; refinement: TNT %s after %d outer iterations, %d Hvps, f=%.6f |g|=%.3e (%.0f s)"
           % (d, orc.cost(Q, Yd), res["status"], res["iterations"], res["hvps"], res["f"], res["grad_norm"], time.time() - t0),
           flush=True)
