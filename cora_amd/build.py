@@ -55,18 +55,35 @@ def needs_build():
 
 def build(force=False, verbose=False):
     """Compiles what is stale and links.  CORA_REBUILD_UNITS=<prefix,prefix> forces the objects whose names start
-    with one of the prefixes (variant builds of one kernel group: tools/variant.sh)."""
-    if not force and not needs_build() and not os.environ.get("CORA_REBUILD_UNITS"):
+    with one of the prefixes (variant builds of one kernel group: tools/variant.sh).  Lab: CORA_VARIANT=<name> builds
+    lib/variants/<name>/libcora_hip.so instead -- the units of CORA_REBUILD_UNITS compiled with CORA_EXTRA_HIPCC_FLAGS,
+    every other object taken from the main build -- which capi.load() picks up under CORA_LIB_VARIANT=<name>."""
+    variant = os.environ.get("CORA_VARIANT")
+    if not variant and not force and not needs_build() and not os.environ.get("CORA_REBUILD_UNITS"):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     only = [u for u in os.environ.get("CORA_REBUILD_UNITS", "").split(",") if u]
+    lib_out = LIB
+    vdir = None
+    if variant:
+        vdir = os.path.join(LIBDIR, "variants", variant)
+        os.makedirs(os.path.join(vdir, "obj"), exist_ok=True)
+        lib_out = os.path.join(vdir, "libcora_hip.so")
     objs = []
     jobs = []
     for s, oname, extra in units():
         o = os.path.join(objdir, oname)
+        if variant:
+            if any(oname.startswith(u) for u in only):
+                o = os.path.join(vdir, "obj", oname)
+                objs.append(o)
+                jobs.append((s, [HIPCC] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]))
+            else:
+                objs.append(o)   # the main build's object
+            continue
         objs.append(o)
         newest = max(os.path.getmtime(p) for p in _deps() if p.endswith(".h") or p == s)
         forced = force or any(oname.startswith(u) for u in only)
@@ -94,9 +111,9 @@ def build(force=False, verbose=False):
                 sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc failed on " + failed)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_out] + objs
     subprocess.check_call(cmd)
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":

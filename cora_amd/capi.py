@@ -47,7 +47,13 @@ def load():
         except ImportError:
             pass
         path = _build.LIB
-        if _build.needs_build():
+        # lab builds of one kernel group (cora_amd/build.py, CORA_VARIANT): never set outside measurement scripts
+        variant = os.environ.get("CORA_LIB_VARIANT")
+        if variant:
+            path = os.path.join(_build.LIBDIR, "variants", variant, "libcora_hip.so")
+            if not os.path.exists(path):
+                raise RuntimeError("CORA_LIB_VARIANT=%s: %s does not exist" % (variant, path))
+        elif _build.needs_build():
             try:
                 _build.build()
             except Exception as e:  # hipcc missing on a box that ships the prebuilt .so
@@ -409,10 +415,14 @@ class Context:
     def stpcg_phase_us(self):
         """Mean microseconds per launch of the sweep-fused iteration of the last stpcg_dev call (profile_stpcg(2)):
         dict product | kappa | forward_sweep | top_forward | top_backward | backward_sweep; None where not recorded."""
-        us = (C.c_double * 6)()
+        us = (C.c_double * 8)()
         self._chk(self.L.cora_debug_stpcg_phase_us(self.h, us))
-        names = ("product", "kappa", "forward_sweep", "top_forward", "top_backward", "backward_sweep")
-        return {k: (float(v) if v >= 0 else None) for k, v in zip(names, us)}
+        names = ("product", "kappa", "forward_sweep", "top_forward", "top_backward", "backward_sweep", "event_overhead")
+        out = {k: (float(v) if v >= 0 else None) for k, v in zip(names, us)}
+        out["kappa_folded"] = bool(us[7])
+        if out["kappa_folded"]:
+            out["kappa"] = None
+        return out
 
     def gram_dev(self, a, ka, b, kb):
         """G = A^T B (ka x kb) of two resident blocks."""

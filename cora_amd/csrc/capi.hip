@@ -159,7 +159,8 @@ struct cora_ctx {
   std::vector<hipEvent_t> prof_events;  // kProfMarks per iteration
   double prof_hvp_us = 0.0;
   int prof_hvp_count = 0;
-  double prof_phase_us[7] = {0, 0, 0, 0, 0, 0, 0};  // mean time between marks k and k + 1 (-1: not recorded)
+  double prof_phase_us[7] = {0, 0, 0, 0, 0, 0, 0};  // mean time between marks k and k + 1 (-1: not recorded); [6]: two marks in a row
+  bool prof_kappa_folded = false;  // the profiled iterations had no kappa launch (SubFuse::n_kappa)
   int stpcg_path = 0;  // iteration form of the last cora_stpcg_dev: 0 unfused, 1 fused vector passes, 2 sweep-fused
   // A batch of device-resident STPCG iterations as a hipGraph: the launches of an iteration have the same arguments
   // every time (the scalars live in device memory, the sequence number the host waits for is a device counter), so a
@@ -1939,7 +1940,10 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       // the sweep does not notice (plaza1 69.0 -> 66.6 us per product end to end, tiers 88.5 -> 84.8, mrclam6 109 -> 104.5);
       // with the 2 470 partials of 10^5 poses every block's sum costs the sweep the 5.2 us the launch took (1 060 blocks
       // reading the same 20 KB through eight L2s): there, and above, the launch stays.
-      static const int fold_max = [] { const char *e = std::getenv("CORA_KAPPA_FOLD_MAX"); return e ? std::atoi(e) : 1024; }();
+      // (round 5: a solve block adds the partials BEHIND the loads of its right-hand sides -- kernels.hip, late_kappa --, which
+      // moved the break-even up: at 10^5 poses the iteration goes from 111.8 to 110.6 us without the launch; 10^6 poses, 24 k
+      // partials, keep it)
+      static const int fold_max = [] { const char *e = std::getenv("CORA_KAPPA_FOLD_MAX"); return e ? std::atoi(e) : 4096; }();
       if (!sharded && kappa_blocks <= fold_max && !std::getenv("CORA_NO_KAPPA_FOLD")) {
         FF.kappa_partial = tail.kappa_partial = kappa_partial;
         FF.n_kappa = tail.n_kappa = kappa_blocks;
@@ -1947,6 +1951,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     }
   }
   c->stpcg_path = sweep_fused ? 2 : inverse_fused ? 3 : fused ? 1 : 0;
+  c->prof_kappa_folded = sweep_fused && FF.n_kappa > 0;
   // hipGraph replay of whole batches (one GPU, the fused forms): OPT-IN, CORA_STPCG_GRAPH=1.  Measured on this part, replaying the batches does not bring the launches of an iteration
   // closer together -- a dependent kernel of 5 us and more already has its successor's packet waiting, what is left
   // between them is the dependency itself -- and a six-launch graph per iteration costs the host more than six launches:
@@ -2095,6 +2100,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
           mark(5);
           HIP_TRY(c, launch_subblock_fused(S0.sub, c->ld, true, FB, t, dV, c->stream));
           mark(6);
+          mark(7);  // (two marks with nothing between them: what a mark itself costs the stream)
           return CORA_OK;
         }
         // kappa, the scalar step and r += alpha Hp with <r, r> in ONE launch (every block adds the partials: the plans
@@ -2170,7 +2176,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   if (c->prof_stpcg) {  // iterations that really ran (enqueued-ahead ones after the stop are neutral but timed)
     const bool phases = c->prof_stpcg >= 2 && c->stpcg_path == 2 && !sharded;
     for (int k = 0; k < 7; ++k) c->prof_phase_us[k] = -1.0;
-    for (int k = 0; k < (phases ? 6 : 1); ++k) {
+    for (int k = 0; k < (phases ? 7 : 1); ++k) {
       double tot = 0.0;
       int cnt = 0;
       for (int i = 0; i < H.iters && kProfMarks * (static_cast<size_t>(i) + 1) <= c->prof_events.size(); ++i) {
@@ -2265,9 +2271,10 @@ int cora_debug_profile_stpcg(cora_ctx *c, int on) {
   return CORA_OK;
 }
 
-int cora_debug_stpcg_phase_us(cora_ctx *c, double us[6]) {
+int cora_debug_stpcg_phase_us(cora_ctx *c, double us[8]) {
   if (!c || !us) return CORA_ERR_ARG;
-  for (int k = 0; k < 6; ++k) us[k] = c->prof_phase_us[k];
+  for (int k = 0; k < 7; ++k) us[k] = c->prof_phase_us[k];
+  us[7] = c->prof_kappa_folded ? 1.0 : 0.0;
   return CORA_OK;
 }
 

@@ -328,6 +328,36 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
   });
 }
 
+int cora_problem_saddle_escape(cora_problem *p, const double *Y, double theta, const double *v, double grad_tol,
+                               double pgrad_tol, double *y_out, double info[3]) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    if (r < 2) throw std::invalid_argument("saddle escape needs the incremented rank");
+    const Matrix Ym = wrap(Y, N, r - 1);
+    Vector vv(N, 1);
+    for (Index i = 0; i < N; ++i) vv(i) = v[i];
+    Matrix Yaug(N, r);
+    Yaug.setBlock(0, 0, Ym);
+    const Matrix out = saddleEscape(q, Ym, theta, vv, grad_tol, pgrad_tol);
+    std::memcpy(y_out, out.data(), sizeof(double) * static_cast<size_t>(out.size()));
+    info[0] = q.evaluateObjective(Yaug);
+    info[1] = q.evaluateObjective(out);
+    bool moved = false;
+    for (Index k = 0; k < out.size() && !moved; ++k) moved = out.data()[k] != Yaug.data()[k];
+    info[2] = moved ? 1.0 : 0.0;
+  });
+}
+
+int cora_problem_project_solution(cora_problem *p, const double *Y, double *y_out) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    const Matrix out = projectSolution(q, wrap(Y, N, r), false);
+    std::memcpy(y_out, out.data(), sizeof(double) * static_cast<size_t>(out.size()));
+  });
+}
+
 int cora_problem_certify_chain(cora_problem *p, const double *Y, double eta, int nx, int resident, double out[6], double *x) {
   return guarded([&] {
     // two certifications in a row at the same point, the second one started from the first one's Ritz block: handed over
@@ -359,6 +389,21 @@ int cora_problem_certification_reached_step3(cora_problem *p, int *reached) {
   return guarded([&] {
     if (!reached) throw std::invalid_argument("reached is NULL");
     *reached = p->problem.lastCertificationReachedStep3() ? 1 : 0;
+  });
+}
+
+int cora_host_cholesky_test(int d, int n_poses, int n_ranges, int n_trans, int n, const int32_t *rowptr, const int32_t *colidx,
+                            const double *vals, double shift, int leaf_poses, int64_t out[3]) {
+  return guarded([&] {
+    SparseMatrix S(n, n);
+    S.outer.assign(rowptr, rowptr + n + 1);
+    S.inner.assign(colidx, colidx + rowptr[n]);
+    S.values.assign(vals, vals + rowptr[n]);
+    const auto perm = coraOrdering(d, n_poses, n_ranges, n_trans, S, n, leaf_poses > 0 ? leaf_poses : 16);
+    const CholeskyFactor F = choleskyFactor(S, n, shift, perm, nullptr);
+    out[0] = F.ok ? 1 : 0;
+    out[1] = F.failed_column;
+    out[2] = F.nnz();
   });
 }
 

@@ -166,6 +166,14 @@ __device__ __forceinline__ void stpcg_after_kappa(StpcgState &S, double kappa) {
     S.step_M_norm = sqrt(sigma_next);
   }
 }
+// coef_r of the step above without touching the state: what a block of the fused forward sweep needs when kappa has no
+// launch of its own (the same expressions, so the same bits as stpcg_after_kappa leaves in S.coef_r)
+__device__ __forceinline__ double stpcg_coef_r_after_kappa(const StpcgState *__restrict__ S, double kappa) {
+  if (S->status != 0 || S->iters >= S->max_iters) return 0.0;
+  const double alpha = S->r_v / kappa;
+  const double sigma_next = S->sigma_M2 + 2 * alpha * S->s_Mp + alpha * alpha * S->p_M2;
+  return (!(kappa > 0.0) || sigma_next >= S->Delta2) ? 0.0 : alpha;
+}
 __device__ __forceinline__ void stpcg_after_rr(StpcgState &S, double rr) {  // after r += alpha Hp:  <r, r>
   if (S.status == 0) {
     S.rr = rr;
@@ -2377,6 +2385,7 @@ typedef double SubCoef;
 struct SubRegs {  // a lane's entries of one level: coefficients and (two per dword) local row indices
   SubCoef v[kSubNpl];
   uint32_t i[kSubNpl / 2];
+  int32_t row;  // forward sweeps that store a level's rows as they are solved (kDirect): the internal row of the lane's row
 };
 // Pins a register set: the compiler waits HERE for whatever load still writes it (before the next level's loads are
 // issued), and treats the values as opaque afterwards.
@@ -2385,6 +2394,7 @@ __device__ __forceinline__ void sub_touch(SubRegs &R) {
   for (int u = 0; u < kSubNpl; ++u) asm volatile("" : "+v"(R.v[u]));
 #pragma unroll
   for (int u = 0; u < kSubNpl / 2; ++u) asm volatile("" : "+v"(R.i[u]));
+  asm volatile("" : "+v"(R.row));
 }
 
 // v = Proj_Y(x) for the row unit that starts at `row` (a pose's d rotation rows: only its first row does the work;
@@ -2419,6 +2429,16 @@ __device__ __forceinline__ void project_unit(const SubFuse &F, size_t row, RowOf
 #ifndef CORA_SUB_MIN_BLOCKS
 #define CORA_SUB_MIN_BLOCKS 4
 #endif
+#ifndef CORA_SUB_FWD_DIRECT
+#define CORA_SUB_FWD_DIRECT 0  // 1: forward sweeps send a level's rows to memory when the level is solved (40-byte pieces from the
+                               // lanes that hold them) instead of an epilogue of their own.  Built and measured in round 5, not kept:
+                               // forward sweep at 10^5 poses 32.8 -> 35.4 us (with the folded kappa 35.8 -> 37.9) -- the level loop
+                               // streams the factor at 4.8 TB/s while it runs at the LDS's bandwidth and has no room for 435 more
+                               // stores and a row index per lane and level; the burst after the last level is the cheaper way
+#endif
+#ifndef CORA_SUB_LATE_FETCH
+#define CORA_SUB_LATE_FETCH 1  // fused forward sweep: the first level's entries are requested behind the prologue's loads
+#endif
 #ifdef CORA_SUB_TIMES
 // measurement build: wall-clock stamps of a substitution block's phases, forward and backward sweep apart
 // (tools/sub_timeline.py): 0 start | 1 right-hand sides in the tile | 2 levels done | 3 end | 4 clocks spent waiting for
@@ -2448,17 +2468,18 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   const int b = static_cast<int>(blockIdx.x);
   double dacc[4] = {0.0, 0.0, 0.0, 0.0};
   double cr = 0.0;
-  if (FD == 1) {
-    if (F.n_kappa > 0) {  // kappa folded into this launch (SubFuse::n_kappa): private scalar step, the state is not written
-      const double kappa = kappa_sum_256(F.kappa_partial, F.n_kappa, dot_sm);
-      StpcgState L = *F.dot.st;
-      stpcg_after_kappa(L, kappa);
-      cr = L.coef_r;
-      __syncthreads();  // (dot_sm is used again below)
-    } else {
-      cr = F.dot.st->coef_r;
-    }
-  }
+  // kappa folded into this launch (SubFuse::n_kappa): every block adds the product's partials itself and runs the scalar
+  // step on a private copy of the state (the state is not written).  A solve block does that INSIDE its prologue, behind
+  // the loads of its right-hand sides (kLateKappa below): the partials -- the same 20 KB for every block at 10^5 poses,
+  // L2 hits -- travel with the block's 35 KB of r and Hp instead of ahead of them.
+  auto folded_kappa = [&]() -> double {
+    const double kappa = kappa_sum_256(F.kappa_partial, F.n_kappa, dot_sm);
+    const double c = stpcg_coef_r_after_kappa(F.dot.st, kappa);
+    __syncthreads();  // (dot_sm is used again below)
+    return c;
+  };
+  const bool late_kappa = FD == 1 && F.n_kappa > 0 && b < S.nblocks;  // (block-uniform)
+  if (FD == 1 && !late_kappa) cr = F.n_kappa > 0 ? folded_kappa() : F.dot.st->coef_r;
   // fused backward sweep: the step and the direction are updated on the way out (the scalars are final: the launch
   // before this one finished <r, v>)
   const double cs = (FD >= 2) ? F.dot.st->coef_s : 0.0, cv = (FD >= 2) ? F.dot.st->coef_v : 0.0,
@@ -2539,6 +2560,11 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
                      __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w));
   };
   const int wl = tid & 63;  // lane of the wavefront: a level's lanes are counted per wavefront
+  // Forward sweeps store a level's rows the moment the level is solved (they are final): 40-byte pieces from the lanes
+  // that hold them, in flight while the next levels run (a barrier waits for LDS only), instead of a burst of its own
+  // after the last level with every block of the launch in the same phase.  |y|^2 is summed by the same lanes.
+  constexpr bool kDirect = CORA_SUB_FWD_DIRECT && !BWD;
+  const int32_t *__restrict__ grows = Q.rows + rb;  // internal row of every tile row (level order)
 
   // (Measured and dropped: entries of TWO levels ahead in a third register set.  The compiler only keeps loads in flight
   // across a first use when their number is branch-free, i.e. nine loads per lane and level whatever the level's width:
@@ -2563,17 +2589,31 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 #pragma unroll
     for (int u = 0; u < kSubNpl; ++u)
       if (u < npl) R.v[u] = factor_load(pv + u * nlane);
+    if constexpr (kDirect) R.row = grows[h.x + (lane >> (31 - __builtin_clz(g)))];  // (g: a power of two)
   };
   SubRegs RA, RB;
 #pragma unroll
   for (int u = 0; u < kSubNpl; ++u) RA.v[u] = RB.v[u] = 0;
 #pragma unroll
   for (int u = 0; u < kSubNpl / 2; ++u) RA.i[u] = RB.i[u] = 0;
-  {
-    const int4 h = gh[wv];  // before anything is ordered
-    fetch(make_int4(__builtin_amdgcn_readfirstlane(h.x), __builtin_amdgcn_readfirstlane(h.y),
-                    __builtin_amdgcn_readfirstlane(h.z), __builtin_amdgcn_readfirstlane(h.w)), RA);
-  }
+  RA.row = RB.row = 0;
+  // The first level's entries are requested before the prologue, so that they travel with the right-hand sides -- except
+  // in the fused forward sweep (two value streams in flight): there the twenty registers of the set did not fit beside
+  // the prologue's, the compiler WAITED for the entries in order to spill three of them (56 bytes of scratch per lane,
+  // written and read back by 267 k lanes: 25 MB per launch in the counters) and only then issued the prologue's first
+  // load.  The header is requested up front, the entries right behind the prologue's last load.
+  constexpr bool kLateFetch = CORA_SUB_LATE_FETCH && FD == 1;
+  // (a SCALAR load: the header is the wavefront's own, the plan's arrays are written by the host before any launch, and
+  // held in vector registers across the prologue it was the next thing to be waited for and spilled)
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(4))) const v4i_t *const_v4i_ptr;
+  const v4i_t h_first_v = *reinterpret_cast<const_v4i_ptr>(reinterpret_cast<uintptr_t>(gh + wv));  // before anything is ordered
+  const int4 h_first = make_int4(h_first_v.x, h_first_v.y, h_first_v.z, h_first_v.w);
+  auto fetch_first = [&] {
+    fetch(make_int4(__builtin_amdgcn_readfirstlane(h_first.x), __builtin_amdgcn_readfirstlane(h_first.y),
+                    __builtin_amdgcn_readfirstlane(h_first.z), __builtin_amdgcn_readfirstlane(h_first.w)), RA);
+  };
+  if (!kLateFetch) fetch_first();
 
   // element e of the block = column e % LD of its (e / LD)-th row in memory order.  Per pass a lane resolves kIoBatch
   // elements (all index loads in flight together; a block has <= 512 rows: ONE pass up to a row stride of 6) and moves
@@ -2585,12 +2625,21 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   // 52 us in two passes of 6 --, two passes of LD above, where one pass spills)
   constexpr int kIoBatch = (FD == 1 && LD > 5) ? (LD <= 8 ? LD : 8) : (2 * LD <= 12 ? 2 * LD : 12);
   constexpr int kIoSub = (kIoBatch + 1) / 2;
-  struct IoAt { int g, t; };  // offsets of an element in the vectors / in the tile
+  // offsets of a lane's kIoBatch elements in the vectors (g) and in the tile (t: below 2^16 -- 512 rows x 24 columns --, two
+  // per register: the fused forward sweep at a row stride of 5 was five registers short of holding them unpacked)
+  struct IoAt {
+    int g[kIoBatch];
+    uint32_t tp[(kIoBatch + 1) / 2];
+    __device__ __forceinline__ int t(int u) const { return static_cast<int>((u & 1) ? tp[u >> 1] >> 16 : tp[u >> 1] & 0xffffu); }
+    __device__ __forceinline__ void set_t(int u, int v) {
+      if (u & 1) tp[u >> 1] |= static_cast<uint32_t>(v) << 16; else tp[u >> 1] = static_cast<uint32_t>(v);
+    }
+  };
   // (io_runs: the row of an element from the block's run table -- eight scalars of its descriptor --, so that the loads
   // of a phase do not wait for an index list; the tile position from a 16-bit list, requested at the same time)
   const uint16_t *__restrict__ tpos = Q.tpos + rb;
   const bool io_runs = S.io_runs != 0;
-  auto io_index = [&](int e0, IoAt (&at)[kIoBatch]) {
+  auto io_index = [&](int e0, IoAt &at) {
 #pragma unroll
     for (int u = 0; u < kIoBatch; ++u) {
       const int e = e0 + u * kSubThreads;
@@ -2598,12 +2647,12 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
       const int k = ee / LD, col = ee - k * LD;
       if (io_runs) {
         const int off = k < bd.run_end[0] ? bd.run_off[0] : (k < bd.run_end[1] ? bd.run_off[1] : (k < bd.run_end[2] ? bd.run_off[2] : bd.run_off[3]));
-        at[u].g = (k + off) * LD + col;
-        at[u].t = static_cast<int>(tpos[k]) * LD + col;
+        at.g[u] = (k + off) * LD + col;
+        at.set_t(u, static_cast<int>(tpos[k]) * LD + col);
       } else {
         const int2 rp = io[k];
-        at[u].g = rp.x * LD + col;
-        at[u].t = rp.y * LD + col;
+        at.g[u] = rp.x * LD + col;
+        at.set_t(u, rp.y * LD + col);
       }
     }
   };
@@ -2615,8 +2664,11 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     const int ntg = BWD ? bd.ntgt : 0;
     int tgt_row = -1;
     if (BWD && tid < ntg) tgt_row = S.tgt_row[bd.tgt_begin + tid];
-    for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
-      IoAt at[kIoBatch];
+    // (the trip count is block-uniform -- lanes past the block's elements re-read its last one and store nothing --:
+    // the folded kappa below has barriers)
+    for (int base = 0; base < ne; base += kIoBatch * kSubThreads) {
+      const int e0 = base + tid;
+      IoAt at;
       io_index(e0, at);
 #pragma unroll
       for (int half = 0; half < kIoBatch; half += kIoSub) {
@@ -2624,9 +2676,10 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 #pragma unroll
         for (int u = 0; u < kIoSub; ++u) {
           if (half + u >= kIoBatch) continue;
-          x[u] = (FD == 1 ? F.r : src)[at[half + u].g];
-          if (FD == 1) h[FD == 1 ? u : 0] = F.Hp[at[half + u].g];
+          x[u] = (FD == 1 ? F.r : src)[at.g[half + u]];
+          if (FD == 1) h[FD == 1 ? u : 0] = F.Hp[at.g[half + u]];
         }
+        if (FD == 1 && half == 0 && base == 0 && late_kappa) cr = folded_kappa();  // behind the first loads of the block
 #pragma unroll
         for (int u = 0; u < kIoSub; ++u) {
           if (half + u >= kIoBatch) continue;
@@ -2634,14 +2687,15 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
           if (FD == 1) {
             if (cr != 0.0) {
               x[u] = fma(cr, h[FD == 1 ? u : 0], x[u]);
-              if (ok) F.r[at[half + u].g] = x[u];
+              if (ok) F.r[at.g[half + u]] = x[u];
             }
             if (ok) dacc[0] = fma(x[u], x[u], dacc[0]);
           }
-          if (ok) T[at[half + u].t] = x[u];
+          if (ok) T[at.t(half + u)] = x[u];
         }
       }
     }
+    if (kLateFetch) fetch_first();
     if (BWD) {
       for (int t = tid; t < ntg; t += kSubThreads) {
         if (t != tid) tgt_row = S.tgt_row[bd.tgt_begin + t];
@@ -2714,6 +2768,10 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
       double *__restrict__ o = reinterpret_cast<double *>(smem + __mul24(r0 + (wl >> gs), LD * 8));
 #pragma unroll
       for (int j = 0; j < LD; ++j) o[j] = res[j];
+      if constexpr (kDirect) {
+        store_row<LD>(dst + static_cast<size_t>(R.row) * LD, res);
+        if (FD == 1) dacc[1] += dot_row<LD>(res, res);
+      }
     }
     __syncthreads();  // ... before any of them is written
     return hnn;
@@ -2781,16 +2839,16 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     if (!upd) return;
     if (store_v) {
       for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
-        IoAt at[kIoBatch];
+        IoAt at;
         io_index(e0, at);
 #pragma unroll
         for (int u = 0; u < kIoBatch; ++u)
-          if (e0 + u * kSubThreads < ne) dst[at[u].g] = T[at[u].t];
+          if (e0 + u * kSubThreads < ne) dst[at.g[u]] = T[at.t(u)];
       }
       return;
     }
     for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
-      IoAt at[kIoBatch];
+      IoAt at;
       io_index(e0, at);
 #pragma unroll
       for (int half = 0; half < kIoBatch; half += kIoSub) {
@@ -2798,30 +2856,32 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 #pragma unroll
         for (int u = 0; u < kIoSub; ++u)
           if (half + u < kIoBatch) {
-            pv[u] = F.p[at[half + u].g];
-            sv[u] = F.s[at[half + u].g];
+            pv[u] = F.p[at.g[half + u]];
+            sv[u] = F.s[at.g[half + u]];
           }
 #pragma unroll
         for (int u = 0; u < kIoSub; ++u)
           if (half + u < kIoBatch && e0 + (half + u) * kSubThreads < ne) {
-            const double v = T[at[half + u].t];
-            F.s[at[half + u].g] = fma(cs, pv[u], sv[u]);
-            F.p[at[half + u].g] = fma(cv, v, cb * pv[u]);
+            const double v = T[at.t(half + u)];
+            F.s[at.g[half + u]] = fma(cs, pv[u], sv[u]);
+            F.p[at.g[half + u]] = fma(cv, v, cb * pv[u]);
           }
       }
     }
     return;
   }
-  for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
-    IoAt at[kIoBatch];
-    io_index(e0, at);
+  if constexpr (!kDirect) {
+    for (int e0 = tid; e0 < ne; e0 += kIoBatch * kSubThreads) {
+      IoAt at;
+      io_index(e0, at);
 #pragma unroll
-    for (int u = 0; u < kIoBatch; ++u)
-      if (e0 + u * kSubThreads < ne) {
-        const double v = T[at[u].t];
-        dst[at[u].g] = v;
-        if (FD == 1) dacc[1] = fma(v, v, dacc[1]);
-      }
+      for (int u = 0; u < kIoBatch; ++u)
+        if (e0 + u * kSubThreads < ne) {
+          const double v = T[at.t(u)];
+          dst[at.g[u]] = v;
+          if (FD == 1) dacc[1] = fma(v, v, dacc[1]);
+        }
+    }
   }
   if (FD == 1) {  // <r, r> and |y|^2 over the block's rows (RvTail adds the slots of all blocks in fixed order)
     const double rr = block_sum_256(dacc[0], dot_sm);

@@ -251,6 +251,29 @@ class Problem:
                                               out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
         return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
 
+    def saddle_escape(self, Y, theta, v, grad_tol=1e-4, pgrad_tol=1e-4):
+        """saddleEscape (src/CORA.cpp:245-350) from the saddle point Y (N x (rank - 1); set_rank(rank) first, as
+        solveCORA increments the rank before the call) along the certificate's direction v."""
+        dm = self.dims()
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        v = np.ascontiguousarray(np.asarray(v, dtype=np.float64))
+        assert Y.shape == (self.variable_size(), dm["rank"] - 1) and v.shape == (self.variable_size(),)
+        out = np.zeros((self.variable_size(), dm["rank"]), order="F")
+        info = np.zeros(3)
+        self._chk(self.L.cora_problem_saddle_escape(self.h, Y.ctypes.data_as(_dp), C.c_double(theta), v.ctypes.data_as(_dp),
+                                                    C.c_double(grad_tol), C.c_double(pgrad_tol), out.ctypes.data_as(_dp),
+                                                    info.ctypes.data_as(_dp)))
+        return dict(x=out, f_saddle=info[0], f=info[1], moved=bool(info[2]))
+
+    def project_solution(self, Y):
+        """projectSolution (src/CORA.cpp:352-441): N x rank -> N x d."""
+        dm = self.dims()
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        assert Y.shape == (self.variable_size(), dm["rank"])
+        out = np.zeros((self.variable_size(), dm["d"]), order="F")
+        self._chk(self.L.cora_problem_project_solution(self.h, Y.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+        return out
+
     def certify_chain(self, Y, eta, nx=10, resident=False):
         """Two certifications in a row, the second started from the first one's Ritz block (host hand-over or resident)."""
         dm = self.dims()

@@ -441,8 +441,10 @@ int cora_debug_profile_stpcg(cora_ctx *ctx, int on);
 int cora_debug_stpcg_hvp_us(cora_ctx *ctx, double *mean_us, int *count);
 /* on = 2: events around EVERY launch of the sweep-fused iteration (one GPU).  us[k], mean over the iterations of the
  * last cora_stpcg_dev that ran: 0 product with the kappa partials | 1 kappa | 2 forward sweep | 3, 4 the last stage's
- * two products | 5 backward sweep; -1 where the form of the iteration has no such launch. */
-int cora_debug_stpcg_phase_us(cora_ctx *ctx, double us[6]);
+ * two products | 5 backward sweep | 6 two events in a row with nothing between them (what an event costs the stream:
+ * every figure carries it); -1 where nothing was recorded.  us[7] = 1 when kappa had no launch of its own (folded into the
+ * forward sweep: us[1] is then another measurement of the event's cost). */
+int cora_debug_stpcg_phase_us(cora_ctx *ctx, double us[8]);
 /* Form of the iteration the last cora_stpcg_dev ran: 0 one pass per operation, 1 fused vector passes, 2 vector passes
  * fused into the sweeps of the Cholesky solve (tests pin which form they compare). */
 int cora_debug_stpcg_path(const cora_ctx *ctx);

@@ -129,6 +129,13 @@ int cora_problem_certify_chain(cora_problem *p, const double *Y, double eta, int
 int cora_problem_set_verification_lab(cora_problem *p, int seed_negative_direction, int use_ildl);
 int cora_problem_certification_reached_step3(cora_problem *p, int *reached);
 
+/* The PSD test of fast_verification alone (src/CORA_utils.cpp:36-51), on the host, no device needed: LL^T of S + shift I
+ * (S: CSR, n x n, the certificate matrix of a problem with d, n_poses, n_ranges, n_trans) in the elimination order
+ * certify_solution uses.  out: [0] 1 when the factorisation succeeded, [1] the permuted index of the first non-positive
+ * pivot (-1), [2] nnz(L). */
+int cora_host_cholesky_test(int d, int n_poses, int n_ranges, int n_trans, int n, const int32_t *rowptr, const int32_t *colidx,
+                            const double *vals, double shift, int leaf_poses, int64_t out[3]);
+
 /* fast_verification(S, eta, X0) (src/CORA_utils.cpp:17-186) for an arbitrary symmetric sparse S
  * (CSR, n x n).  X0: n x nx or NULL for a random block.  out: [0] is_certified, [1] theta,
  * [2] iterations; x: n. */
@@ -146,6 +153,15 @@ int cora_host_fast_verification_pieces(int n, const int32_t *rowptr, const int32
 int cora_host_fast_verification_lab(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals,
                                     double eta, const double *X0, int nx, int max_iters, const double opts[4],
                                     double out[4], double *x);
+
+/* saddleEscape (src/CORA.cpp:245-350): Y is N x (rank - 1), the problem's relaxation rank has been incremented by the
+ * caller (cora_problem_set_rank) as solveCORA does before the call; theta, v: the certificate's curvature and direction.
+ * y_out: N x rank.  info: [0] f at [Y 0], [1] f at y_out, [2] 1 when y_out differs from [Y 0] (a trial point was taken). */
+int cora_problem_saddle_escape(cora_problem *p, const double *Y, double theta, const double *v, double grad_tol,
+                               double pgrad_tol, double *y_out, double info[3]);
+
+/* projectSolution (src/CORA.cpp:352-441): Y is N x rank (the problem's current rank), y_out N x d. */
+int cora_problem_project_solution(cora_problem *p, const double *Y, double *y_out);
 
 /* solveCORA (src/CORA.cpp:26-243) from x0 (N x rank): Riemannian staircase up to max_rank, final
  * projection to rank d and refinement.  x_out: N x d.  opts[0..4] as in cora_problem_tnt (may be NULL).

@@ -54,15 +54,14 @@ def stpcg(hess, precon, g, Delta, prm):
     return s, math.sqrt(sig2), it
 
 
-def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
+def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, chol=None, **kw):
     """precond: "jacobi" | "none" | "chol" (RegularizedCholesky, src/CORA_problem.cpp:544-614, with
     the regularisation `lam` and the last translation pinned; `perm`: elimination order of the N - 1 rows -- the result
     of a solve does not depend on it, the fill does: natural order is hopeless beyond a few thousand poses)."""
     prm = dict(DEFAULTS)
     prm.update(kw)
     dinv = 1.0 / orc.diag(Q)
-    chol = None
-    if precond == "chol":
+    if precond == "chol" and chol is None:   # (chol: a factor of the same matrix the caller already holds)
         import scipy.sparse as sp
         M = (Q.to_scipy() + lam * sp.eye(dm.N)).tocsr()[:dm.N - 1, :dm.N - 1]
         chol = orc.Cholesky(orc.CSR.from_scipy(M), perm=perm)
@@ -86,7 +85,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
     hist = []
     status = "iteration_limit"
     hvps = 0
-    last = dict(inner=0, rho=0.0, accepted=False, h_norm=0.0, h_M_norm=0.0)
+    last = dict(inner=0, rho=0.0, accepted=False, h_norm=0.0, h_M_norm=0.0, df=0.0, dmod=0.0)
     for it in range(prm["max_iterations"] + 1):
         hist.append((f, gn, pgn))
         if gn < prm["gradient_tolerance"]:
@@ -109,7 +108,7 @@ def tnt(Q, dm, x0, precond="jacobi", lam=None, perm=None, **kw):
         rho = df / dmod if dmod != 0 else float("nan")
         rel = df / (math.sqrt(np.finfo(float).eps) + abs(f))
         accepted = (not math.isnan(rho)) and rho > prm["eta1"] and df > 0
-        last = dict(inner=inner, rho=rho, accepted=accepted, h_norm=hn, h_M_norm=hM)
+        last = dict(inner=inner, rho=rho, accepted=accepted, h_norm=hn, h_M_norm=hM, df=df, dmod=dmod)
         if accepted:
             x = xp
             G = orc.egrad(Q, x)

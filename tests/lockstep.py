@@ -1,0 +1,67 @@
+"""One outer iteration of the device's TNT against ONE iteration of the oracle's (oracle/tnt.py) from the same point and
+radius -- shared by tests/test_gpu_solver.py (random points, small graphs) and tests/test_gpu_staircase.py (every level of
+BASELINE config 3 and the final refinement of the reference's data sets)."""
+import os
+
+import numpy as np
+
+from oracle import tnt as otnt
+
+SHORT_SOLVE = 12  # inner iterations up to which an STPCG solve is numerically stable: two correct runs agree to 1e-8
+
+
+def lockstep(P, Q, dims, x0, steps, oracle_kw, host_stpcg=False, Delta0=5.0, return_state=False, long_inner_rel=0.0,
+             f_noise=None):
+    """Every outer iteration of the device solver against ONE iteration of the oracle from the SAME point and radius (the
+    device's), so that rounding differences cannot accumulate over the trajectory: the inner solve's length, the
+    acceptance decision, the radius update and the new cost of every iteration are pinned on their own.
+    Tolerances follow what truncated CG does to rounding: a SHORT inner solve (<= 12 iterations) is stable and the new
+    cost agrees to 1e-8; a long one on this indefinite, ill-conditioned Hessian loses orthogonality and amplifies the
+    rounding of its products (observed: 1e-12 .. 1e-7 typically, up to 2e-2 once in forty 15 .. 80-iteration solves) --
+    still the same number of inner iterations, the same decision and the same radius."""
+    x, Delta = np.asfortranarray(x0), Delta0
+    worst = dict(f_short=0.0, f_long=0.0, Delta=0.0, loose=0, long=0)
+    k = 0
+    for k in range(steps):
+        dev = P.tnt_step(x, Delta, host_stpcg=host_stpcg)
+        ref = otnt.tnt(Q, dims, x, max_iterations=1, Delta0=Delta, **oracle_kw)
+        if ref["status"] in ("gradient", "preconditioned_gradient"):
+            assert dev["status"] in (0, 1)
+            break
+        last = ref["last"]
+        if os.environ.get("CORA_LOCKSTEP_TRACE"):
+            print("  %2d inner %2d/%2d rho %.6f/%.6f f %.10e/%.10e Delta %.4e/%.4e acc %d" % (
+                k, dev["inner"], last["inner"], dev["rho"], last["rho"], dev["f"], ref["f"], dev["Delta"], ref["Delta"], dev["accepted"]))
+        # (long_inner_rel: near a critical point -- the later levels of a converged staircase -- a 50-iteration inner solve
+        # crosses its residual target a few iterations earlier or later; random points: the same count, give or take one)
+        slack = max(1, int(long_inner_rel * last["inner"])) if last["inner"] > SHORT_SOLVE else 1
+        assert abs(dev["inner"] - last["inner"]) <= slack, (k, dev["inner"], last["inner"])
+        # f_noise(x, f) -> what two correct evaluations of the cost at x may differ by.  Near a minimiser of an ill-
+        # conditioned problem the step's predicted and actual decrease fall BELOW that (1e-6 of a cost known to 1e-4): the
+        # gain ratio is then rounding noise on both sides and the iteration is not compared (the staircase's late levels)
+        noise = f_noise(x, ref["history"][0][0]) if f_noise is not None else 0.0
+        if f_noise is not None and max(abs(last["df"]), abs(last["dmod"])) < 8 * noise:
+            worst["below_noise"] = worst.get("below_noise", 0) + 1
+            x, Delta = dev["x"], dev["Delta"]
+            continue
+        assert dev["accepted"] == last["accepted"], (k, dev["rho"], last["rho"])
+        rel = max(abs(dev["f"] - ref["f"]) - noise, 0.0) / abs(ref["f"])   # (beyond what two evaluations of one point may differ by)
+        d_rel = abs(dev["Delta"] - ref["Delta"]) / ref["Delta"]
+        if dev["inner"] == last["inner"] and dev["inner"] <= SHORT_SOLVE:
+            assert rel <= 1e-8, (k, dev["inner"], dev["f"], ref["f"])
+            assert d_rel <= 1e-9, (k, dev["Delta"], ref["Delta"])
+            worst["f_short"] = max(worst["f_short"], rel)
+            worst["Delta"] = max(worst["Delta"], d_rel)
+        else:
+            # (the radius after a long solve: equal, unless the gain ratio or the step length sits on the threshold of
+            # the update rule -- rho against eta2 = 0.9, |h|_M against 0.99 Delta -- within the solve's own error)
+            assert rel <= 5e-2, (k, dev["inner"], dev["f"], ref["f"])
+            on_threshold = abs(last["rho"] - 0.9) < 0.05 or abs(last["h_M_norm"] / Delta - 0.99) < 0.02
+            assert d_rel <= 1e-4 or on_threshold, (k, dev["Delta"], ref["Delta"], last["rho"], last["h_M_norm"] / Delta)
+            worst["f_long"] = max(worst["f_long"], rel)
+            worst["long"] += 1
+            worst["loose"] += int(rel > 1e-6)
+        x, Delta = dev["x"], dev["Delta"]
+    if return_state:
+        return worst, k + 1, x, Delta
+    return worst, k + 1

@@ -76,50 +76,7 @@ def test_tnt_synthetic_noisy(d, n, p, loops, fused):
     assert abs(orc.cost(Q, got["x"]) - got["f"]) < 1e-10 * abs(got["f"])
 
 
-SHORT_SOLVE = 12  # inner iterations up to which an STPCG solve is numerically stable: two correct runs agree to 1e-8
-
-
-def _lockstep(P, Q, dims, x0, steps, oracle_kw, host_stpcg=False):
-    """Every outer iteration of the device solver against ONE iteration of the oracle from the SAME point and radius (the
-    device's), so that rounding differences cannot accumulate over the trajectory: the inner solve's length, the
-    acceptance decision, the radius update and the new cost of every iteration are pinned on their own.
-    Tolerances follow what truncated CG does to rounding: a SHORT inner solve (<= 12 iterations) is stable and the new
-    cost agrees to 1e-8; a long one on this indefinite, ill-conditioned Hessian loses orthogonality and amplifies the
-    rounding of its products (observed: 1e-12 .. 1e-7 typically, up to 2e-2 once in forty 15 .. 80-iteration solves) --
-    still the same number of inner iterations, the same decision and the same radius."""
-    x, Delta = np.asfortranarray(x0), 5.0
-    worst = dict(f_short=0.0, f_long=0.0, Delta=0.0, loose=0, long=0)
-    k = 0
-    for k in range(steps):
-        dev = P.tnt_step(x, Delta, host_stpcg=host_stpcg)
-        ref = otnt.tnt(Q, dims, x, max_iterations=1, Delta0=Delta, **oracle_kw)
-        if ref["status"] in ("gradient", "preconditioned_gradient"):
-            assert dev["status"] in (0, 1)
-            break
-        last = ref["last"]
-        if os.environ.get("CORA_LOCKSTEP_TRACE"):
-            print("  %2d inner %2d/%2d rho %.6f/%.6f f %.10e/%.10e Delta %.4e/%.4e acc %d" % (
-                k, dev["inner"], last["inner"], dev["rho"], last["rho"], dev["f"], ref["f"], dev["Delta"], ref["Delta"], dev["accepted"]))
-        assert abs(dev["inner"] - last["inner"]) <= 1, (k, dev["inner"], last["inner"])
-        assert dev["accepted"] == last["accepted"], (k, dev["rho"], last["rho"])
-        rel = abs(dev["f"] - ref["f"]) / abs(ref["f"])
-        d_rel = abs(dev["Delta"] - ref["Delta"]) / ref["Delta"]
-        if dev["inner"] == last["inner"] and dev["inner"] <= SHORT_SOLVE:
-            assert rel <= 1e-8, (k, dev["inner"], dev["f"], ref["f"])
-            assert d_rel <= 1e-9, (k, dev["Delta"], ref["Delta"])
-            worst["f_short"] = max(worst["f_short"], rel)
-            worst["Delta"] = max(worst["Delta"], d_rel)
-        else:
-            # (the radius after a long solve: equal, unless the gain ratio or the step length sits on the threshold of
-            # the update rule -- rho against eta2 = 0.9, |h|_M against 0.99 Delta -- within the solve's own error)
-            assert rel <= 5e-2, (k, dev["inner"], dev["f"], ref["f"])
-            on_threshold = abs(last["rho"] - 0.9) < 0.05 or abs(last["h_M_norm"] / Delta - 0.99) < 0.02
-            assert d_rel <= 1e-4 or on_threshold, (k, dev["Delta"], ref["Delta"], last["rho"], last["h_M_norm"] / Delta)
-            worst["f_long"] = max(worst["f_long"], rel)
-            worst["long"] += 1
-            worst["loose"] += int(rel > 1e-6)
-        x, Delta = dev["x"], dev["Delta"]
-    return worst, k + 1
+from lockstep import SHORT_SOLVE, lockstep as _lockstep  # noqa: E402,F401
 
 
 @pytest.mark.parametrize("fused", [False, True])
