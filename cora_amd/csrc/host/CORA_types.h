@@ -11,6 +11,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace CORA {
@@ -38,6 +39,8 @@ inline void checkMatrixShape(const std::string &func_name, Index exp_rows, Index
     throw MatrixShapeException(func_name, exp_rows, exp_cols, act_rows, act_cols);
 }
 
+class SparseMatrix;
+
 /** Column-major dense matrix of doubles (the storage order of Eigen::MatrixXd,
  * so data() can be handed to the C ABI with ld = rows()). */
 class Matrix {
@@ -64,6 +67,20 @@ class Matrix {
   /** The same distribution with a generator per column (seeded seed + column): column j holds the same numbers whatever
    * the number of columns asked for, and the columns are filled by threads (10^6 poses: 54 M numbers, 0.3 s on one). */
   static Matrix RandomColumns(Index r, Index c, uint64_t seed);
+  // The vector forms the reference's tests use on Eigen's VectorXd (tests/test_certification.cpp:21,52): n x 1.
+  static Matrix Zero(Index n) { return Matrix(n, 1); }
+  static Matrix Random(Index n) { return Random(n, 1); }
+  Matrix normalized() const {
+    const Scalar nrm = norm();
+    return nrm > 0 ? (*this) * (1.0 / nrm) : *this;
+  }
+  /** Sparse copy of the non-zero entries (Eigen's MatrixBase::sparseView()). */
+  SparseMatrix sparseView() const;
+  /** A 1 x 1 product read as a number, as Eigen allows (`Scalar theta = x.transpose() * S * x`). */
+  operator Scalar() const {
+    if (rows_ != 1 || cols_ != 1) throw std::logic_error("Matrix: only a 1 x 1 matrix converts to a scalar");
+    return a_[0];
+  }
   Index rows() const { return rows_; }
   Index cols() const { return cols_; }
   Index size() const { return rows_ * cols_; }
@@ -115,9 +132,11 @@ class Matrix {
     for (size_t i = 0; i < a_.size(); ++i) r.a_[i] -= o.a_[i];
     return r;
   }
-  Matrix operator*(Scalar s) const {
+  // (any arithmetic type, matched exactly: with the 1 x 1 conversion below `2 * M` would otherwise also read as int * double)
+  template <typename T, typename = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+  Matrix operator*(T s) const {
     Matrix r = *this;
-    for (auto &v : r.a_) v *= s;
+    for (auto &v : r.a_) v *= static_cast<Scalar>(s);
     return r;
   }
   Scalar dot(const Matrix &o) const {
@@ -138,7 +157,8 @@ class Matrix {
     return false;
   }
 };
-inline Matrix operator*(Scalar s, const Matrix &m) { return m * s; }
+template <typename T, typename = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+inline Matrix operator*(T s, const Matrix &m) { return m * s; }
 typedef Matrix Vector;  // N x 1
 
 /** Row-major CSR with int32 indices: the layout of the reference's
@@ -264,6 +284,13 @@ class SparseMatrix {
     r.setFromTriplets(std::move(t));
     return r;
   }
+  /** Dense copy (Eigen's SparseMatrix::toDense(): the reference's tests read their dense fixtures through it). */
+  Matrix toDense() const {
+    Matrix D(rows_, cols_);
+    for (Index i = 0; i < rows_; ++i)
+      for (int32_t q = outer[static_cast<size_t>(i)]; q < outer[static_cast<size_t>(i) + 1]; ++q) D(i, inner[q]) += values[q];
+    return D;
+  }
   Matrix operator*(const Matrix &X) const {  // CPU product for tiny host-side checks only
     Matrix r(rows_, X.cols());
     for (Index j = 0; j < X.cols(); ++j)
@@ -276,6 +303,24 @@ class SparseMatrix {
     return r;
   }
 };
+
+inline SparseMatrix Matrix::sparseView() const {
+  std::vector<Triplet> t;
+  for (Index i = 0; i < rows_; ++i)
+    for (Index j = 0; j < cols_; ++j)
+      if ((*this)(i, j) != 0.0) t.push_back({i, j, (*this)(i, j)});
+  SparseMatrix S(rows_, cols_);
+  S.setFromTriplets(std::move(t));
+  return S;
+}
+inline Matrix operator*(const Matrix &A, const SparseMatrix &S) { return (S.transpose() * A.transpose()).transpose(); }
+inline std::ostream &operator<<(std::ostream &os, const Matrix &M) {
+  for (Index i = 0; i < M.rows(); ++i) {
+    for (Index j = 0; j < M.cols(); ++j) os << (j ? " " : "") << M(i, j);
+    if (i + 1 < M.rows()) os << "\n";
+  }
+  return os;
+}
 
 enum class Formulation { Explicit, Implicit };  // include/CORA/CORA_types.h:50-55
 

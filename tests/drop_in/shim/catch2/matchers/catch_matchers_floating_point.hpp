@@ -1,0 +1,27 @@
+// Stand-in for <catch2/matchers/catch_matchers_floating_point.hpp> (see ../catch_test_macros.hpp): WithinAbs.
+#pragma once
+
+#include <cmath>
+#include <sstream>
+#include <string>
+
+#include "catch_matchers.hpp"
+
+namespace Catch {
+namespace Matchers {
+
+struct WithinAbsMatcher : MatcherBase<double> {
+  double target, margin;
+  WithinAbsMatcher(double t, double m) : target(t), margin(m) {}
+  bool match(const double &actual) const override { return std::fabs(actual - target) <= margin; }
+  std::string describe() const override {
+    std::ostringstream o;
+    o.precision(17);
+    o << "is within " << margin << " of " << target;
+    return o.str();
+  }
+};
+inline WithinAbsMatcher WithinAbs(double target, double margin) { return WithinAbsMatcher(target, margin); }
+
+}  // namespace Matchers
+}  // namespace Catch
