@@ -56,6 +56,7 @@ static int native_product_pack(cora_native_comm *nc, const double *dX, int ld, h
 static int native_product_gather(cora_native_comm *nc, double *dX, int ld, hipStream_t st, double *out, double *kappa,
                                  hipEvent_t after_collective = nullptr);
 static const std::string &native_error(const cora_native_comm *nc);
+static int native_allgather_rows(cora_native_comm *nc, double *dX, int ld, int64_t row0, int64_t nrows);  // one piece of every shard, packed
 struct cora_ctx {
   HostFormat F;
   cora_native_comm *native_comm = nullptr;  // owned: the library's own communication (cora_comm_create_*)
@@ -1378,7 +1379,15 @@ static int implicit_lift(cora_ctx *c, const double *dX, int ld, double *w0, doub
   const int64_t last = pinned_translation_row(c);                                  // pinned translation (the API's last row)
   const bool mine = last >= L.base && last < L.base + L.shard_rows;
   if (mine) HIP_TRY(c, launch_zero_row(w1, static_cast<size_t>(last), ld, c->stream));
-  if (sharded && (rc = comm_allgather(c, w1, ld))) return rc;                       // every rank: all rows of B^T X
+  if (sharded) {  // every rank: all translation rows of B^T X (the solve is replicated)
+    if (c->native_comm && c->comm_user == c->native_comm && !std::getenv("CORA_IMPLICIT_WHOLE_GATHER")) {
+      // the library's own communication gathers the translation rows alone, packed: 2 / 9 of a shard's rows at d = 3
+      if (native_allgather_rows(c->native_comm, w1, ld, L.trn_base - L.base, L.nl_trans))
+        return fail(c, CORA_ERR_HIP, "all-gather step failed: " + native_error(c->native_comm));
+    } else if ((rc = comm_allgather(c, w1, ld))) {
+      return rc;
+    }
+  }
   double *w2;
   if ((rc = get_scratch(c, 8, ld, &w2))) return rc;
   if ((rc = factor_solve(c, c->implicit_f, ld, w1, w2))) return rc;                // w2[trans] = M^-1 B^T X
@@ -2931,6 +2940,7 @@ struct cora_native_comm {
   }
   int allgather(double *dX, int ld) {  // whole shards, in place
     ++n_allgather;
+    rows_gathered += static_cast<long long>(c->F.L.shard_rows) * world;
     if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
     const Layout &L = c->F.L;
     const size_t n = static_cast<size_t>(L.shard_rows) * ld;
@@ -2944,8 +2954,58 @@ struct cora_native_comm {
     if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
     return g->barrier() ? 0 : fail_("local group broken");
   }
+  // All-gather of ONE contiguous piece of every shard -- rows [row0, row0 + nrows) of the caller's own shard, every rank
+  // its own piece (different offsets and lengths) -- into X in place: what the replicated translation solve of the
+  // implicit formulation needs (the translation rows: 2 / 9 of a shard's rows at d = 3) instead of whole shards.
+  // The pieces travel packed: own piece -> send buffer, one all-gather of the longest piece's size, one scatter kernel.
+  struct PackedRows {
+    int64_t row0 = -1, nrows = -1, maxn = 0;
+    std::vector<int64_t> meta;   // {row0, nrows} of every rank
+    int64_t *d_meta = nullptr;
+    std::map<int, Buf> buf;      // per row stride
+  } packed;
+  long long rows_gathered = 0;   // rows received by all-gathers of resident vectors so far (whole shards or packed pieces)
+  int allgather_rows(double *dX, int ld, int64_t row0, int64_t nrows) {
+    if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
+    const Layout &L = c->F.L;
+    if (packed.row0 != row0 || packed.nrows != nrows) {  // first call (the piece of a handle does not change): learn every rank's
+      const int64_t mine[2] = {row0, nrows};
+      packed.meta.assign(static_cast<size_t>(2 * world), 0);
+      if (allgather_host(mine, packed.meta.data(), sizeof(mine))) return 1;
+      --n_allgather;  // (planning, not the data path)
+      packed.maxn = 0;
+      for (int r = 0; r < world; ++r) packed.maxn = std::max(packed.maxn, packed.meta[static_cast<size_t>(2 * r + 1)]);
+      if (!packed.d_meta && hip(hipMalloc(&packed.d_meta, sizeof(int64_t) * 2 * world), "hipMalloc")) return 1;
+      if (hip(hipMemcpy(packed.d_meta, packed.meta.data(), sizeof(int64_t) * 2 * world, hipMemcpyHostToDevice), "hipMemcpy")) return 1;
+      for (auto &kv : packed.buf) {
+        if (kv.second.send) (void)hipFree(kv.second.send);
+        if (kv.second.recv) (void)hipFree(kv.second.recv);
+      }
+      packed.buf.clear();
+      packed.row0 = row0;
+      packed.nrows = nrows;
+    }
+    const size_t per = static_cast<size_t>(packed.maxn) * ld;
+    rows_gathered += packed.maxn * world;
+    if (per == 0) return 0;
+    // (one path for both transports: the in-process one runs the same staging, collective and scatter kernel as RCCL)
+    Buf &B = packed.buf[ld];
+    if (!B.send) {
+      if (hip(hipMalloc(&B.send, per * sizeof(double)), "hipMalloc") || hip(hipMalloc(&B.recv, per * world * sizeof(double)), "hipMalloc")) return 1;
+      if (hip(hipMemsetAsync(B.send, 0, per * sizeof(double), c->stream), "hipMemsetAsync")) return 1;
+    }
+    if (nrows > 0 && hip(hipMemcpyAsync(B.send, dX + static_cast<size_t>(rank * L.shard_rows + row0) * ld, static_cast<size_t>(nrows) * ld * sizeof(double),
+                                        hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync")) return 1;
+    if (allgather_dev(B.send, B.recv, per * sizeof(double))) return 1;
+    return hip(launch_scatter_shard_rows(world, rank, packed.maxn, ld, L.shard_rows, packed.d_meta, B.recv, dX, c->stream), "scatter");
+  }
   ~cora_native_comm() {
     if (c && c->has_device) (void)hipSetDevice(c->device);
+    for (auto &kv : packed.buf) {
+      if (kv.second.send) (void)hipFree(kv.second.send);
+      if (kv.second.recv) (void)hipFree(kv.second.recv);
+    }
+    if (packed.d_meta) (void)hipFree(packed.d_meta);
     for (auto &kv : buf) {
       if (kv.second.send) (void)hipFree(kv.second.send);
       if (kv.second.recv) (void)hipFree(kv.second.recv);
@@ -2968,6 +3028,7 @@ static int native_product_gather(cora_native_comm *nc, double *dX, int ld, hipSt
   return nc->product_gather(dX, ld, st, out, kappa, after_collective);
 }
 static const std::string &native_error(const cora_native_comm *nc) { return nc->err; }
+static int native_allgather_rows(cora_native_comm *nc, double *dX, int ld, int64_t row0, int64_t nrows) { return nc->allgather_rows(dX, ld, row0, nrows); }
 
 namespace {
 int native_exchange_cb(void *u, double *dX, int ld) { return static_cast<cora_native_comm *>(u)->exchange(dX, ld); }
@@ -3131,6 +3192,8 @@ int cora_debug_product_phases(cora_ctx *c, const double *dX, double *dOut, int e
   c->overlap_exchange = overlap_saved;
   return rc;
 }
+
+long long cora_comm_gathered_rows(const cora_ctx *c) { return (c && c->native_comm) ? c->native_comm->rows_gathered : 0; }
 
 int cora_comm_counters(const cora_ctx *c, long out[2]) {
   if (!c || !out) return CORA_ERR_ARG;

@@ -281,6 +281,8 @@ hipError_t launch_reduce_partials(const double *partial, int nblocks, int count,
 hipError_t launch_long_finish(int n_long, int ld, int rank, const int32_t *rows, const int32_t *owner, const double *slots,
                               const double *X, double *out, double *kappa, hipStream_t st);
 // the two ends of a partitioned product's exchange (kernels.hip, k_exchange_pack / k_exchange_unpack)
+hipError_t launch_scatter_shard_rows(int world, int rank, int64_t maxn, int ld, int64_t shard_rows, const int64_t *meta,
+                                     const double *recv, double *X, hipStream_t st);
 hipError_t launch_exchange_pack(int64_t n, int ld, const int32_t *rows, int64_t ztail, const double *src, double *dst, hipStream_t st);
 hipError_t launch_exchange_unpack(int world, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, const double *recv, double *X,
                                   int rank, const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa,

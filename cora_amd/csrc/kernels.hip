@@ -1750,6 +1750,19 @@ __global__ __launch_bounds__(256) void k_exchange_pack(int64_t n, int ld, const 
     dst[t] = src[static_cast<int64_t>(rows[k]) * ld + j];
   }
 }
+// Packed all-gather of one contiguous piece of every shard (the translation rows of the implicit formulation's solve):
+// recv holds `maxn` rows per rank; rank r's piece is meta[2 r + 1] rows that belong at row  r * shard_rows + meta[2 r]  of X.
+__global__ __launch_bounds__(256) void k_scatter_shard_rows(int world, int rank, int64_t maxn, int ld, int64_t shard_rows,
+                                                            const int64_t *__restrict__ meta, const double *__restrict__ recv,
+                                                            double *__restrict__ X) {
+  const int64_t per = maxn * ld, tot = per * world;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < tot; t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int r = static_cast<int>(t / per);
+    const int64_t k = t - r * per;
+    if (r == rank || k >= meta[2 * r + 1] * ld) continue;
+    X[(r * shard_rows + meta[2 * r]) * ld + k] = recv[t];
+  }
+}
 __global__ __launch_bounds__(256) void k_exchange_unpack(int world, int64_t e_max, int n_long, int ld, int64_t stride, int scatter_blocks,
                                                          const int32_t *__restrict__ recv_idx, const double *__restrict__ recv,
                                                          double *__restrict__ X, int rank, const int32_t *__restrict__ long_rows,
@@ -3257,6 +3270,12 @@ hipError_t launch_move_rows(int mode, int64_t n, int ld, const int32_t *rows, co
 hipError_t launch_exchange_pack(int64_t n, int ld, const int32_t *rows, int64_t ztail, const double *src, double *dst, hipStream_t st) {
   if (n * ld + ztail <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_exchange_pack, dim3(grid_for(n * ld + ztail)), dim3(256), 0, st, n, ld, rows, ztail, src, dst);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_shard_rows(int world, int rank, int64_t maxn, int ld, int64_t shard_rows, const int64_t *meta,
+                                     const double *recv, double *X, hipStream_t st) {
+  if (maxn * ld * world <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_shard_rows, dim3(grid_for(maxn * ld * world)), dim3(256), 0, st, world, rank, maxn, ld, shard_rows, meta, recv, X);
   return hipGetLastError();
 }
 hipError_t launch_exchange_unpack(int world, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, const double *recv, double *X,

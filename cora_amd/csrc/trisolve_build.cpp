@@ -1047,6 +1047,11 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         std::fprintf(stderr, "  [tri plan] stage %d %s: %d rows of 8 lanes (%lld entries, longest %lld), %d wavefront rows (%lld, longest %lld), %zu long rows in %zu chunks\n",
                      k, pr.first, op.n8, static_cast<long long>(e8), static_cast<long long>(m8), op.n64, static_cast<long long>(e64),
                      static_cast<long long>(m64), op.long_out.size(), op.chunk_begin.size());
+        if (!op.long_out.empty()) {  // chunks per long row
+          std::fprintf(stderr, "  [tri plan]   chunks per long row:");
+          for (size_t r = 0; r + 1 < op.long_chunk_ptr.size(); ++r) std::fprintf(stderr, " %d", op.long_chunk_ptr[r + 1] - op.long_chunk_ptr[r]);
+          std::fprintf(stderr, "\n");
+        }
       }
 }
 

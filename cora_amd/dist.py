@@ -369,6 +369,12 @@ class _NativeComm:
         self.ctx._chk(self.ctx.L.cora_comm_counters(self.ctx.h, out))
         return int(out[0]), int(out[1])
 
+    def gathered_rows(self):
+        """Rows of resident vectors received through all-gathers (whole shards or packed pieces) so far."""
+        self.ctx.L.cora_comm_gathered_rows.restype = _C.c_longlong
+        self.ctx.L.cora_comm_gathered_rows.argtypes = [_C.c_void_p]
+        return int(self.ctx.L.cora_comm_gathered_rows(self.ctx.h))
+
     def product_phases(self, x_ptr, out_ptr, epi=2, reps=50):
         """Microseconds per phase of a product: pack | long-row chunks | all-gather | unpack | slices (collective call)."""
         us = (_C.c_double * 5)()

@@ -388,6 +388,10 @@ void cora_local_group_destroy(cora_local_group *group);
 void cora_local_group_abort(cora_local_group *group); /* a rank failed outside the library: release the others */
 int cora_comm_create_local(cora_ctx *ctx, cora_local_group *group);
 int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
+/* Rows of resident vectors received through all-gathers of whole shards or of packed pieces so far (library's own
+ * communication): the implicit formulation's replicated translation solve gathers the translation rows alone
+ * (world x the longest shard's translation rows per product), not whole shards. */
+long long cora_comm_gathered_rows(const cora_ctx *ctx);
 /* What the handle's RCCL communicator itself reports: out[0] = ncclCommCount, out[1] = ncclCommUserRank (-1, -1 without an
  * RCCL communicator).  cora_comm_create_rccl fails when they differ from the handle's partition. */
 int cora_comm_rccl_ranks(const cora_ctx *ctx, int out[2]);

@@ -633,6 +633,17 @@ def test_implicit_formulation_on_partitions(world, transport):
         X = P.op("getTranslationExplicitSolution", Y)
         res = P.tnt(Y0)
         cert = P.certify(res["x"], 1e-4)
+        # the library's own communication gathers the TRANSLATION rows of the replicated solve's right-hand side, packed
+        # (world x the longest shard's translation rows), not whole shards
+        comm = getattr(P, "_comm", None)
+        if transport == "native" and comm is not None and hasattr(comm, "gathered_rows"):
+            h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+            r0 = comm.gathered_rows()
+            P.op("Euclidean_gradient", Y)
+            per_product = comm.gathered_rows() - r0   # the operator's one lift (+ whatever a download gathers: whole shards)
+            packed = per_product - world * h.shard_rows
+            assert (dm["n"] + dm["l"]) <= packed <= 2 * (dm["n"] + dm["l"]) and packed < world * h.shard_rows // 2, (
+                per_product, world, h.shard_rows)
         return f, G, H, X, res, cert
 
     outs = _run_ranks(world, body, transport)
