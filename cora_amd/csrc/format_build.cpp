@@ -536,7 +536,8 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     std::vector<RowRef> rows;
     rows.reserve(L.nl_ranges);
     for (int64_t i = 0; i < L.nl_ranges; ++i) rows.push_back(local_row(L.rng_base + i));
-    for (int64_t k0 = 0; k0 < L.nl_ranges; k0 += kWave) {
+    const bool lab_skip = std::getenv("CORA_LAB_SKIP_RANGE_SLICES") != nullptr;  // LAB (wrong range rows): what the range slices cost a launch
+    for (int64_t k0 = 0; k0 < L.nl_ranges && !lab_skip; k0 += kWave) {
       const int64_t cnt = std::min<int64_t>(kWave, L.nl_ranges - k0);
       emit_slice(F, rows, k0, k0 + cnt, kSliceOblique,
                  static_cast<int32_t>(L.rng_base + k0), static_cast<int32_t>(k0),

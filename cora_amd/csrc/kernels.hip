@@ -1050,7 +1050,7 @@ __device__ unsigned long long g_spmm_times[3 * kSpmmTimesMax];
 // 64 registers 31.3 us, 2 waves 20.4 us on the 10^5-pose graph).  With the X window the balance moved: what the memory
 // side sustains is requests in flight per CU, and three lighter wavefronts per SIMD (<= 168 registers, two slots per
 // trip) beat two heavier ones: Hvp 22.2 -> 21.4 us, HBM-resident 30.9 -> 29.2 us, inside the STPCG loop 27.8 -> 25.2 us;
-// four per SIMD are no better (tools/spmm_window_variants.sh, profiles/r03_kernel_evolution.md).
+// four per SIMD are no better (profiles/r03_kernel_evolution.md).
 template <int LD, int D, int EPI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LD <= CORA_SPMM_MIN2_MAX_LD ? CORA_SPMM_MIN_WAVES_PER_EU : 1, CORA_SPMM_WAVES_PER_EU)))
 void k_spmm(const SpmmArgs A) {
