@@ -2029,7 +2029,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       // backward sweep (a mark is an event on the handle's stream: it does not reorder anything)
       const bool prof = c->prof_stpcg && kProfMarks * (static_cast<size_t>(enqueued) + 1) <= c->prof_events.size();
       auto mark = [&](int i) {
-        if (prof && (i <= 1 || c->prof_stpcg >= 2)) (void)hipEventRecord(c->prof_events[kProfMarks * enqueued + i], c->stream);
+        // (mode 1: the product's two marks and the two marks in a row that measure what a mark costs)
+        if (prof && (i <= 1 || i >= 6 || c->prof_stpcg >= 2)) (void)hipEventRecord(c->prof_events[kProfMarks * enqueued + i], c->stream);
       };
       mark(0);
       if (fused) {
@@ -2185,7 +2186,9 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   if (c->prof_stpcg) {  // iterations that really ran (enqueued-ahead ones after the stop are neutral but timed)
     const bool phases = c->prof_stpcg >= 2 && c->stpcg_path == 2 && !sharded;
     for (int k = 0; k < 7; ++k) c->prof_phase_us[k] = -1.0;
-    for (int k = 0; k < (phases ? 7 : 1); ++k) {
+    const bool tail_marks = c->stpcg_path == 2 && !sharded;  // (marks 6 and 7 exist on the sweep-fused form)
+    for (int k = 0; k < 7; ++k) {
+      if (!(k == 0 || phases || (k == 6 && tail_marks))) continue;
       double tot = 0.0;
       int cnt = 0;
       for (int i = 0; i < H.iters && kProfMarks * (static_cast<size_t>(i) + 1) <= c->prof_events.size(); ++i) {

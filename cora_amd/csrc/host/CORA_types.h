@@ -151,6 +151,16 @@ class Matrix {
     for (Index i = 0; i < std::min(rows_, cols_); ++i) s += (*this)(i, i);
     return s;
   }
+  /** Eigen's isZero / isApprox (default precision 1e-12): |a_ij| <= prec for every entry; |a - b|_F <= prec min(|a|_F, |b|_F). */
+  bool isZero(Scalar prec = 1e-12) const {
+    for (Scalar v : a_)
+      if (std::fabs(v) > prec) return false;
+    return true;
+  }
+  bool isApprox(const Matrix &o, Scalar prec = 1e-12) const {
+    if (rows_ != o.rows_ || cols_ != o.cols_) return false;
+    return (*this - o).norm() <= prec * std::min(norm(), o.norm());
+  }
   bool hasNaN() const {
     for (Scalar v : a_)
       if (v != v) return true;

@@ -328,6 +328,21 @@ int cora_problem_certify(cora_problem *p, const double *Y, double eta, int nx, d
   });
 }
 
+int cora_problem_certify_resident(cora_problem *p, const double *Y, double eta, int nx, int first, double out[3], double *x) {
+  return guarded([&] {
+    Problem &q = p->problem;
+    const Index N = q.getExpectedVariableSize(), r = static_cast<Index>(q.getRelaxationRank());
+    const Matrix Ym = wrap(Y, N, r);
+    Matrix boot;  // empty: start from the Ritz block the previous certification left on the device (src/CORA.cpp:165-170)
+    if (first) boot = q.getFormulation() == Formulation::Implicit ? q.getTranslationExplicitSolution(Ym) : Ym;  // :158-164
+    const CertResults c = q.certify_solution_resident(Ym, eta, static_cast<size_t>(nx), boot);
+    out[0] = c.is_certified ? 1.0 : 0.0;
+    out[1] = c.theta;
+    out[2] = static_cast<double>(c.num_iters);
+    if (x) std::memcpy(x, c.x.data(), sizeof(double) * static_cast<size_t>(c.x.size()));
+  });
+}
+
 int cora_problem_saddle_escape(cora_problem *p, const double *Y, double theta, const double *v, double grad_tol,
                                double pgrad_tol, double *y_out, double info[3]) {
   return guarded([&] {

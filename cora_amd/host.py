@@ -251,6 +251,17 @@ class Problem:
                                               out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
         return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
 
+    def certify_resident(self, Y, eta, nx=10, first=True):
+        """The certification of solveCORA's own loop: the first level starts the eigensolver from the point, later levels
+        from the block the previous call left on the device (cora_problem_certify_resident)."""
+        dm = self.dims()
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+        out = np.zeros(3)
+        x = np.zeros(dm["N"])
+        self._chk(self.L.cora_problem_certify_resident(self.h, Y.ctypes.data_as(_dp), C.c_double(eta), int(nx), int(bool(first)),
+                                                       out.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
+        return dict(is_certified=bool(out[0]), theta=out[1], iters=int(out[2]), x=x)
+
     def saddle_escape(self, Y, theta, v, grad_tol=1e-4, pgrad_tol=1e-4):
         """saddleEscape (src/CORA.cpp:245-350) from the saddle point Y (N x (rank - 1); set_rank(rank) first, as
         solveCORA increments the rank before the call) along the certificate's direction v."""

@@ -154,6 +154,11 @@ int cora_host_fast_verification_lab(int n, const int32_t *rowptr, const int32_t 
                                     double eta, const double *X0, int nx, int max_iters, const double opts[4],
                                     double out[4], double *x);
 
+/* The certification call of solveCORA's loop (src/CORA.cpp:156-170): first != 0 -- the point itself is the eigensolver's
+ * bootstrap (first level); first == 0 -- it starts from the Ritz block the previous call left on the device (what this host's
+ * solveCORA does instead of handing all_eigvecs through the host).  out / x as cora_problem_certify. */
+int cora_problem_certify_resident(cora_problem *p, const double *Y, double eta, int nx, int first, double out[3], double *x);
+
 /* saddleEscape (src/CORA.cpp:245-350): Y is N x (rank - 1), the problem's relaxation rank has been incremented by the
  * caller (cora_problem_set_rank) as solveCORA does before the call; theta, v: the certificate's curvature and direction.
  * y_out: N x rank.  info: [0] f at [Y 0], [1] f at y_out, [2] 1 when y_out differs from [Y 0] (a trial point was taken). */

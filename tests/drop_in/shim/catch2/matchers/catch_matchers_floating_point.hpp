@@ -23,5 +23,21 @@ struct WithinAbsMatcher : MatcherBase<double> {
 };
 inline WithinAbsMatcher WithinAbs(double target, double margin) { return WithinAbsMatcher(target, margin); }
 
+// |actual - target| <= eps max(|actual|, |target|); Catch2's default eps: 100 machine epsilons
+struct WithinRelMatcher : MatcherBase<double> {
+  double target, eps;
+  WithinRelMatcher(double t, double e) : target(t), eps(e) {}
+  bool match(const double &actual) const override {
+    return std::fabs(actual - target) <= eps * std::fmax(std::fabs(actual), std::fabs(target));
+  }
+  std::string describe() const override {
+    std::ostringstream o;
+    o.precision(17);
+    o << "and " << target << " are within " << eps * 100 << "% of each other";
+    return o.str();
+  }
+};
+inline WithinRelMatcher WithinRel(double target, double eps = 100 * 2.220446049250313e-16) { return WithinRelMatcher(target, eps); }
+
 }  // namespace Matchers
 }  // namespace Catch

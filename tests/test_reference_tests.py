@@ -1,5 +1,5 @@
 """The reference's OWN test translation units -- tests/test_optimizer_helpers.cpp, tests/test_cora.cpp,
-tests/test_parse_pyfg.cpp, tests/test_certification.cpp -- compiled unmodified, from where they lie in the reference tree, against include/CORA/*.h and
+tests/test_parse_pyfg.cpp, tests/test_certification.cpp, tests/test_geometry.cpp -- compiled unmodified, from where they lie in the reference tree, against include/CORA/*.h and
 libcora_hip.so (oracle/build_ref_tests.py; Catch2 and the Eigen-based test helper replaced by the stand-ins under
 tests/drop_in/shim/), and RUN against the committed golden fixtures (byte-identical copies of the reference's tests/data).
 
@@ -73,6 +73,15 @@ def test_reference_certification_tests_pass(tmp_path):
     r = _run("test_certification", tmp_path)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "3 test cases, 0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_geometry_tests_pass(tmp_path):
+    """tests/test_geometry.cpp:10-81: ObliqueManifold -- random sample, projection to the manifold and to the tangent space,
+    retraction -- on one unit circle and on five unit spheres (the manifold classes run their geometry on the GPU)."""
+    r = _run("test_geometry", tmp_path)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "2 test cases, 0 failed" in r.stdout
 
 
 @pytest.mark.gpu
