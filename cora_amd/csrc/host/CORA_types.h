@@ -4,6 +4,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <iostream>  // the reference's headers bring it in (examples/main.cpp uses std::cout without including it)
@@ -56,8 +57,15 @@ class Matrix {
     for (Index i = 0; i < std::min(r, c); ++i) m(i, i) = 1.0;
     return m;
   }
-  /** Uniform in [-1, 1] like Eigen's Matrix::Random (src/CORA_problem.cpp:1026). */
-  static Matrix Random(Index r, Index c, uint64_t seed = 0x9E3779B97F4A7C15ull) {
+  /** Uniform in [-1, 1] like Eigen's Matrix::Random (src/CORA_problem.cpp:1026).  Without a seed successive calls return
+   * DIFFERENT matrices, as Eigen's do (it draws from rand()): the reference's tests/test_geometry.cpp:53-68 projects one
+   * random matrix onto the tangent space at the normalisation of another and requires a non-zero result.  The sequence is
+   * the same in every process (a counter, not a clock); everything inside the library passes an explicit seed. */
+  static Matrix Random(Index r, Index c) {
+    static std::atomic<uint64_t> calls{0};
+    return Random(r, c, 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * calls.fetch_add(1));
+  }
+  static Matrix Random(Index r, Index c, uint64_t seed) {
     Matrix m(r, c);
     std::mt19937_64 g(seed);
     std::uniform_real_distribution<Scalar> u(-1.0, 1.0);
