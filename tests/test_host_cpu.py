@@ -335,3 +335,68 @@ def test_cholesky_symbolic_cache_changes_nothing():
         assert np.array_equal(got["digest"], want["digest"])
         assert np.array_equal(got["negative_direction"], want["negative_direction"])
     assert ref[(N - 1, 2.0)]["ok"] and not ref[(N - 1, -1.0)]["ok"]
+
+
+def test_psd_test_of_the_certificate_agrees_with_the_oracle_and_the_spectrum():
+    """The PSD test of fast_verification alone (cora_host_cholesky_test: the host's sparse LL^T in the order certify_solution
+    uses, no device) on the certificate matrix of the golden RA-SLAM fixture at the random point: S + shift I has a factor
+    exactly when shift > -lambda_min(S) (dense spectrum), and the oracle's Cholesky says the same -- on both sides of the
+    threshold and close to it."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from mmio import read_mm
+    from oracle import oracle as orc
+    case = "small_ra_slam_problem"
+    S = sp.csr_matrix(read_mm(os.path.join(GOLDEN, case, "S_rand.mm")))
+    S = ((S + S.T) * 0.5).tocsr() if abs(S - S.T).max() > 0 else S.tocsr()
+    S.sort_indices()
+    P = host.Problem.from_pyfg(os.path.join(GOLDEN, case, "factor_graph.pyfg"))
+    P.update()
+    dm = P.dims()
+    lam_min = float(np.linalg.eigvalsh(S.toarray())[0])
+    assert lam_min < 0
+    L = capi.load()
+    rp, ci, v = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64)
+    for shift in (0.0, -0.5 * lam_min, -lam_min * (1 - 1e-6), -lam_min * (1 + 1e-6), -2 * lam_min, 10.0 - lam_min):
+        out = (C.c_int64 * 3)()
+        rc = L.cora_host_cholesky_test(dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"], dm["N"], rp.ctypes.data_as(C.c_void_p),
+                                       ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.c_double(shift), 2, out)
+        assert rc == 0
+        Ms = (S + shift * sp.identity(dm["N"])).tocsr()
+        Ms.sort_indices()
+        expect = shift > -lam_min
+        assert bool(out[0]) == expect, (shift, lam_min)
+        assert orc.Cholesky(orc.CSR.from_scipy(Ms)).ok == expect, (shift, lam_min)
+        assert (out[1] == -1) == expect
+
+
+def test_oracle_staircase_steps_on_the_golden_fixture():
+    """oracle/staircase.py on a case with known answers (noiseless fixture, ground truth X_gt, cost 0): rounding a lifted,
+    rotated copy of the ground truth gives the ground truth back up to one rotation; the certification threshold follows
+    src/CORA.cpp:111-116; a rank-deficient lift trips certify_solution's singular-value shortcut; the saddle escape from the
+    (certified) optimum along any direction finds no decrease and returns the lifted point."""
+    from mmio import read_mm
+    from oracle import oracle as orc
+    from oracle import staircase as ost
+    case = "small_ra_slam_problem"
+    P = host.Problem.from_pyfg(os.path.join(GOLDEN, case, "factor_graph.pyfg"))
+    P.update()
+    dm = P.dims()
+    _, _, rowptr, colidx, vals = P.matrix("DataMatrix")
+    Q = orc.CSR(rowptr, colidx, vals, dm["N"])
+    dims = orc.Dims(dm["d"], dm["n"], dm["r"], dm["N"])
+    Xgt = np.asfortranarray(read_mm(os.path.join(GOLDEN, case, "X_gt.mm")).toarray())
+    assert orc.cost(Q, Xgt) < 1e-9
+    rng = np.random.default_rng(4)
+    O, _ = np.linalg.qr(rng.standard_normal((4, 4)))
+    lifted = np.asfortranarray(np.hstack([Xgt, np.zeros((dm["N"], 2))]) @ O)      # rank 4, same cost
+    assert abs(orc.cost(Q, lifted)) < 1e-9
+    Yd = ost.project_solution(dims, lifted)
+    R = np.linalg.lstsq(Yd, Xgt, rcond=None)[0]
+    assert np.abs(R.T @ R - np.eye(dm["d"])).max() < 1e-9 and np.linalg.det(R) > 0 and np.abs(Yd @ R - Xgt).max() < 1e-9
+    assert ost.cert_eta(1e-12) == 1e-7 and ost.cert_eta(1e9) == 1e-1 and abs(ost.cert_eta(1000.0) - 5e-3) < 1e-15
+    assert ost.rank_deficient(lifted) and not ost.rank_deficient(Xgt)
+    v = rng.standard_normal(dm["N"])
+    v /= np.linalg.norm(v)
+    Yn, info = ost.saddle_escape(Q, dims, lambda Yt, V: orc.tangent_proj(dims, Yt, V), Xgt, -1e-3, v)
+    assert not info["accepted"] and not info["fallback"] and np.array_equal(Yn[:, :dm["d"]], Xgt) and np.all(Yn[:, dm["d"]] == 0)
