@@ -100,6 +100,42 @@ class Matrix {
   Scalar operator()(Index i) const { return a_[static_cast<size_t>(i)]; }
   void setZero() { std::fill(a_.begin(), a_.end(), 0.0); }
 
+  /** A writable view of a block (what Eigen's non-const block() / row() / col() give): `M.block(i, j, p, q) = B`,
+   * `M.row(i) = v` (a vector is accepted as a row, as Eigen does), and it reads as the Matrix it covers.  The reference's
+   * tests/test_construct_problem.cpp:53-60,118-120 builds its expected states this way. */
+  class BlockRef {
+    Matrix &m_;
+    Index r0_, c0_, nr_, nc_;
+
+   public:
+    BlockRef(Matrix &m, Index r0, Index c0, Index nr, Index nc) : m_(m), r0_(r0), c0_(c0), nr_(nr), nc_(nc) {}
+    operator Matrix() const { return static_cast<const Matrix &>(m_).block(r0_, c0_, nr_, nc_); }
+    BlockRef &operator=(const Matrix &b) {
+      if (b.rows() == nr_ && b.cols() == nc_) {
+        m_.setBlock(r0_, c0_, b);
+      } else if (b.rows() == nc_ && b.cols() == nr_ && (nr_ == 1 || nc_ == 1)) {
+        m_.setBlock(r0_, c0_, b.transpose());
+      } else {
+        throw MatrixShapeException("Matrix::block = ", nr_, nc_, b.rows(), b.cols());
+      }
+      return *this;
+    }
+    BlockRef &operator=(const BlockRef &o) { return *this = static_cast<Matrix>(o); }
+    Matrix operator+(const Matrix &o) const { return static_cast<Matrix>(*this) + o; }
+    Matrix operator-(const Matrix &o) const { return static_cast<Matrix>(*this) - o; }
+    Matrix operator*(const Matrix &o) const { return static_cast<Matrix>(*this) * o; }
+    Matrix transpose() const { return static_cast<Matrix>(*this).transpose(); }
+    Scalar norm() const { return static_cast<Matrix>(*this).norm(); }
+    Index rows() const { return nr_; }
+    Index cols() const { return nc_; }
+    Scalar operator()(Index i, Index j) const { return static_cast<const Matrix &>(m_)(r0_ + i, c0_ + j); }
+  };
+  BlockRef block(Index r0, Index c0, Index nr, Index nc) { return BlockRef(*this, r0, c0, nr, nc); }
+  BlockRef row(Index i) { return BlockRef(*this, i, 0, 1, cols_); }
+  BlockRef col(Index j) { return BlockRef(*this, 0, j, rows_, 1); }
+  Matrix row(Index i) const { return block(i, 0, 1, cols_); }
+  Matrix operator-() const { return (*this) * -1.0; }
+  void normalize() { *this = normalized(); }
   Matrix block(Index r0, Index c0, Index nr, Index nc) const {
     Matrix b(nr, nc);
     for (Index j = 0; j < nc; ++j)

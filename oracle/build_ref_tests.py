@@ -16,7 +16,7 @@ REF_TESTS = "/root/reference/tests"
 OUT = os.path.join(ROOT, "oracle", "_ref")
 SHIM = os.path.join(ROOT, "tests", "drop_in", "shim")
 # the reference's test files that use nothing but the Problem / solveCORA / parser API
-UNITS = ["test_optimizer_helpers", "test_cora", "test_parse_pyfg", "test_certification", "test_geometry"]
+UNITS = ["test_optimizer_helpers", "test_cora", "test_parse_pyfg", "test_certification", "test_geometry", "test_construct_problem"]
 
 
 def available():

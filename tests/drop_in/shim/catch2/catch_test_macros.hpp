@@ -26,6 +26,10 @@ inline std::vector<TestCase> &registry() {
 struct Registrar {
   Registrar(const char *name, const char *tags, void (*fn)()) { registry().push_back({name, tags, fn}); }
 };
+inline bool enter_section(const char *name) {
+  std::cout << "  section: " << name << std::endl;
+  return true;
+}
 struct Counters {
   int checks = 0, failed = 0;
 };
@@ -62,6 +66,9 @@ void check_that(const T &value, const M &matcher, bool fatal, const char *expr, 
 #define CATCH_SHIM_TEST2(name, tags) CATCH_SHIM_TEST(CATCH_SHIM_CAT(catch_shim_case_, __LINE__), name, tags)
 #define TEST_CASE(...) CATCH_SHIM_PICK(__VA_ARGS__, CATCH_SHIM_TEST2, CATCH_SHIM_TEST1)(__VA_ARGS__)
 
+// SECTION: Catch2 re-runs the test case once per leaf section; the sections of the reference's tests only READ what the case
+// set up, so here every section runs once, in order, inside one execution of the case.
+#define SECTION(name) if (CatchShim::enter_section(name))
 #define CHECK(expr) CatchShim::report(static_cast<bool>(expr), false, #expr, __FILE__, __LINE__)
 #define REQUIRE(expr) CatchShim::report(static_cast<bool>(expr), true, #expr, __FILE__, __LINE__)
 #define CHECK_FALSE(expr) CatchShim::report(!static_cast<bool>(expr), false, "!(" #expr ")", __FILE__, __LINE__)

@@ -84,6 +84,43 @@ EigenMatrixApproxMatcherUpToSign<MatrixType> IsApproximatelyEqualUpToSign(const 
   return EigenMatrixApproxMatcherUpToSign<MatrixType>(expected, epsilon);
 }
 
+// The one Eigen type the reference's tests name directly (tests/test_construct_problem.cpp:70-71: a random orthogonal matrix
+// from the left singular vectors of a small dense matrix).  Stand-in with the same spelling for the Eigen-free Matrix:
+// U = an orthonormal basis whose leading columns span range(A) (Gram-Schmidt, completed when A is rank deficient).
+namespace Eigen {
+enum { ComputeThinU = 1, ComputeThinV = 2, ComputeFullU = 4, ComputeFullV = 8 };
+template <typename MatrixType>
+class JacobiSVD {
+  MatrixType U_;
+
+ public:
+  JacobiSVD(const MatrixType &A, unsigned = 0) {
+    const CORA::Index n = A.rows();
+    U_ = MatrixType::Identity(n, n);
+    // Gram-Schmidt of [A | I]: an orthonormal basis whose leading columns span range(A) -- left singular vectors up to a
+    // rotation inside the singular subspaces, which is all the tests use (an orthogonal matrix)
+    MatrixType B(n, A.cols() + n);
+    for (CORA::Index j = 0; j < A.cols(); ++j)
+      for (CORA::Index i = 0; i < n; ++i) B(i, j) = A(i, j);
+    for (CORA::Index j = 0; j < n; ++j) B(j, A.cols() + j) = 1.0;
+    CORA::Index k = 0;
+    for (CORA::Index j = 0; j < B.cols() && k < n; ++j) {
+      MatrixType v = static_cast<const MatrixType &>(B).col(j);
+      for (CORA::Index q = 0; q < k; ++q) {
+        const MatrixType u = static_cast<const MatrixType &>(U_).col(q);
+        v = v - u * u.dot(v);
+      }
+      const double nv = v.norm();
+      if (nv > 1e-12) {
+        for (CORA::Index i = 0; i < n; ++i) U_(i, k) = v(i) / nv;
+        ++k;
+      }
+    }
+  }
+  const MatrixType &matrixU() const { return U_; }
+};
+}  // namespace Eigen
+
 namespace CORA {
 
 SparseMatrix readMatrixMarketFile(const std::string &filename);

@@ -1,5 +1,6 @@
 """The reference's OWN test translation units -- tests/test_optimizer_helpers.cpp, tests/test_cora.cpp,
-tests/test_parse_pyfg.cpp, tests/test_certification.cpp, tests/test_geometry.cpp -- compiled unmodified, from where they lie in the reference tree, against include/CORA/*.h and
+tests/test_parse_pyfg.cpp, tests/test_certification.cpp, tests/test_geometry.cpp,
+tests/test_construct_problem.cpp -- compiled unmodified, from where they lie in the reference tree, against include/CORA/*.h and
 libcora_hip.so (oracle/build_ref_tests.py; Catch2 and the Eigen-based test helper replaced by the stand-ins under
 tests/drop_in/shim/), and RUN against the committed golden fixtures (byte-identical copies of the reference's tests/data).
 
@@ -44,6 +45,15 @@ def test_reference_parse_pyfg_tests_pass(tmp_path):
     r = _run("test_parse_pyfg", tmp_path)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "3 test cases, 0 failed" in r.stdout
+
+
+def test_reference_construct_problem_tests_pass(tmp_path):
+    """tests/test_construct_problem.cpp:22-127: a problem built through the add* API (one odometry edge; one range edge between
+    landmarks) has the fixtures' sub-matrices, and the true state -- times any orthogonal matrix -- lies in the null space of
+    its data matrix.  Host code only, runs without a GPU."""
+    r = _run("test_construct_problem", tmp_path)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "2 test cases, 0 failed, 7 assertions" in r.stdout
 
 
 @pytest.mark.gpu
