@@ -99,20 +99,6 @@ def staircase_level_by_level(P, Q, dims, x0, max_rank, max_iterations, lock_iter
         # 1e6 apart count as certified; then the reference's criterion, a Cholesky factor of S + eta I)
         shortcut = ost.rank_deficient(X)
         ok = shortcut or orc.Cholesky(orc.CSR.from_scipy(Se), perm=perm_full if chain_order else minimum_degree_order(Se)).ok
-        if cert["is_certified"] != ok and os.environ.get("CORA_STAIRCASE_DEBUG"):
-            import scipy.sparse.linalg as spla
-            np.save("gpurun_out/staircase_debug_X.npy", X)
-            for sh in (eta, 2 * eta, 0.5 * eta):
-                try:
-                    w = spla.eigsh(S.tocsc(), k=3, sigma=-sh, which="LM", tol=1e-10, return_eigenvectors=False)
-                    print("    eigsh around %.4g:" % -sh, sorted(w))
-                except Exception as e:  # noqa: BLE001
-                    print("    eigsh around %.4g failed: %s" % (-sh, e))
-            for e2 in (eta * 0.9, eta, eta * 1.1, eta * 2):
-                S2 = (S + e2 * sp.identity(N)).tocsr(); S2.sort_indices()
-                print("    eta %.6g: oracle chain order %s, oracle min-degree %s, device %s" % (
-                    e2, orc.Cholesky(orc.CSR.from_scipy(S2), perm=perm_full).ok if chain_order else None,
-                    orc.Cholesky(orc.CSR.from_scipy(S2), perm=minimum_degree_order(S2)).ok, P.certify(X, e2)["is_certified"]))
         assert cert["is_certified"] == ok, (rank, eta, cert["theta"])
         lev = dict(rank=rank, lockstep=steps, worst=worst, f=res["f"], grad_norm=res["grad_norm"], iterations=res["iterations"],
                    hvps=res["hvps"], status=res["status"], eta=eta, certified=ok, theta=cert["theta"], shortcut=shortcut)
