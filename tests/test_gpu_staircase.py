@@ -78,7 +78,7 @@ def staircase_level_by_level(P, Q, dims, x0, max_rank, max_iterations, lock_iter
     while rank <= max_rank:
         P.set_rank(rank)
         # (1) the level's first outer iterations, one at a time against the oracle
-        worst, steps = lockstep(P, Q, dims, x, lock_iters, okw, long_inner_rel=0.15, f_noise=noise)
+        worst, steps = lockstep(P, Q, dims, x, lock_iters, okw, long_inner_rel=0.15, f_noise=noise, short_rel=1e-6)
         # (2) the level's TNT under the budget, on the device
         res = P.tnt(x, max_iterations=max_iterations)
         X = res["x"]
@@ -161,7 +161,7 @@ def staircase_level_by_level(P, Q, dims, x0, max_rank, max_iterations, lock_iter
         assert np.abs(R.T @ R - np.eye(d)).max() < 1e-6 and np.linalg.det(R) > 0
         assert np.abs(Yd @ R - Yr).max() < 1e-6
         P.set_rank(d)
-        worst, steps = lockstep(P, Q, dims, Yd, lock_iters, okw, long_inner_rel=0.15, f_noise=noise)
+        worst, steps = lockstep(P, Q, dims, Yd, lock_iters, okw, long_inner_rel=0.15, f_noise=noise, short_rel=1e-6)
         res = P.tnt(Yd, max_iterations=max_iterations)
         ref = otnt.tnt(Q, dims, Yd, max_iterations=max_iterations, **okw)
         rel = abs(res["f"] - ref["f"]) / abs(ref["f"])
@@ -222,7 +222,7 @@ def test_config3_converged_levels_match_the_oracle():
         prev = lev["f"]
 
 
-@pytest.mark.parametrize("name", ["tiers", "mrclam3b"])
+@pytest.mark.parametrize("name", ["tiers", "mrclam3b", "plaza2", "single_drone"])
 def test_dataset_refinement_against_the_oracle(name):
     """The two data sets of the reference that return with a large gradient (round 4: tiers |g| = 1.04, mrclam3b 0.16): the
     whole staircase level by level, and the final rank-d refinement against the oracle's TNT from the same rounded point --
