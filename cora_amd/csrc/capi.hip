@@ -1893,19 +1893,28 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     // one explicit inverse W = L^-1 and nothing else (two products per solve), no pinned-row stage in between
     inverse_fused = !sharded && !sweep_fused && chol && f.ready && f.stages.size() == 1 && !f.stages[0].dense && !f.stages[0].is_sub &&
                     !f.stages[0].has_fwd_a && !f.stages[0].has_bwd_a && !std::getenv("CORA_NO_INVERSE_FUSE");
+    static const bool residual_slots = !std::getenv("CORA_NO_RESIDUAL_SLOTS");
     if (inverse_fused) {
       const RowOpDev &fb = f.stages[0].fwd_b;
       sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
+      if (residual_slots) rr_slots = static_cast<size_t>(kappa_residual_slots_blocks(n)) + 8;
     }
     kappa_blocks = product_kappa_slots(c, spmm_args(c, dP, dHp));
     if ((rc = ensure_red(c, need + static_cast<size_t>(kappa_blocks) + rr_slots + yy_slots + sq_slots))) return rc;
     D.partial = c->d_red;
     kappa_partial = c->d_red + need;
     if (inverse_fused) {
-      double *rowsq = kappa_partial + kappa_blocks;
+      double *rr_partial = kappa_partial + kappa_blocks, *rowsq = rr_partial + rr_slots;
       sq.rowsq_out = rowsq;
-      tail.rr_partial = rowsq;  // unused (n_rr = 0)
-      tail.n_rr = 0;
+      // kappa and <r, r> are finished by the tail block too (k_kappa_residual_slots): the residual pass has no ticket and
+      // no last block, and the iteration's three scalar steps run in one place.  (CORA_NO_RESIDUAL_SLOTS: the residual
+      // pass finishes both itself, n_rr = n_kappa = 0 -- the form measured against in profiles/r05_kernel_evolution.md)
+      tail.rr_partial = rr_partial;
+      tail.n_rr = residual_slots ? kappa_residual_slots_blocks(n) : 0;
+      if (residual_slots) {
+        tail.kappa_partial = kappa_partial;
+        tail.n_kappa = kappa_blocks;
+      }
       tail.yy_partial = rowsq;
       tail.n_yy = 0;
       tail.rowsq = rowsq;
@@ -2115,7 +2124,11 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         }
         // kappa, the scalar step and r += alpha Hp with <r, r> in ONE launch (every block adds the partials: the plans
         // that come here are small, and a launch is what costs them)
-        HIP_TRY(c, launch_kappa_residual(D, kappa_partial, kappa_blocks, n, dHp + off, dR + off, c->stream));
+        if (inverse_fused && tail.n_rr > 0)
+          HIP_TRY(c, launch_kappa_residual_slots(c->d_stpcg, kappa_partial, kappa_blocks, n, dHp + off, dR + off,
+                                                 const_cast<double *>(tail.rr_partial), c->stream));
+        else
+          HIP_TRY(c, launch_kappa_residual(D, kappa_partial, kappa_blocks, n, dHp + off, dR + off, c->stream));
         if (inverse_fused) {
           // one explicit inverse (every data set of the reference): v = Proj_Y(W^T W r) and <r, v> = |W r|^2 -- the first
           // product leaves the squared norms of its rows, an extra block of the second adds them and runs the scalar step,

@@ -262,6 +262,11 @@ hipError_t launch_tangent_project_update(const RowArgs &R, const StpcgState *S, 
 // every block adds the partials itself (same order, same bits).  For the small plans, where a launch is what costs.
 hipError_t launch_kappa_residual(const DotArgs &D, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
                                  hipStream_t st);
+// The same pass without the scalar step: a block leaves its share of <r, r> in rr_slot[block] (kappa_residual_slots_blocks(n)
+// slots) and the state is advanced by the tail block of a later launch (RvTail::n_kappa, RvTail::n_rr) -- no ticket here.
+int kappa_residual_slots_blocks(int64_t n);
+hipError_t launch_kappa_residual_slots(const StpcgState *S, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
+                                       double *rr_slot, hipStream_t st);
 hipError_t launch_tangent_project_dot(const RowArgs &R, const DotArgs &D, int ld, const double *Y, const double *V,
                                       const double *scale, const double *r, double *out, hipStream_t st);
 // the scalar step of a partitioned handle's iteration, after the all-reduce of its inner products (k_stpcg_scalar_step)

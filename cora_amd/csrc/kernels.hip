@@ -1546,6 +1546,41 @@ __global__ __launch_bounds__(256) void k_kappa_residual(DotArgs D, const double 
   dots_finish(D, acc, sm, kappa);
 }
 
+// The same pass for the iterations whose reductions are finished by the tail block of a later launch (RvTail::n_kappa,
+// RvTail::n_rr: the one-explicit-inverse form): no ticket and no last block -- a block leaves its share of <r, r> in its
+// slot and is done, the state is not touched here.  Its first elements are requested BEFORE the partials are added, so
+// the launch is one round trip to memory and a block reduction, not three dependent ones.
+__global__ __launch_bounds__(256) void k_kappa_residual_slots(const StpcgState *__restrict__ st, const double *__restrict__ kpartial,
+                                                              int nk, int64_t n2, const double2 *__restrict__ Hp,
+                                                              double2 *__restrict__ r, double *__restrict__ rr_slot) {
+  __shared__ double sm[8];
+  __shared__ double ksm[4];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  double2 rv = make_double2(0.0, 0.0), h = make_double2(0.0, 0.0);
+  if (i < n2) {
+    rv = r[i];
+    h = Hp[i];
+  }
+  const double kappa = kappa_sum_256(kpartial, nk, ksm);
+  const double cr = stpcg_coef_r_after_kappa(st, kappa);
+  double acc = 0.0;
+  for (; i < n2; i += stride) {
+    if (cr != 0.0) {
+      rv.x = fma(cr, h.x, rv.x);
+      rv.y = fma(cr, h.y, rv.y);
+      r[i] = rv;
+    }
+    acc = fma(rv.x, rv.x, fma(rv.y, rv.y, acc));
+    if (i + stride < n2) {
+      rv = r[i + stride];
+      h = Hp[i + stride];
+    }
+  }
+  const double t = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) rr_slot[blockIdx.x] = t;
+}
+
 // s += coef_s p (the step of THIS iteration), then p = coef_v v + coef_beta p
 __global__ __launch_bounds__(256) void k_stpcg_step_direction(int64_t n2, const StpcgState *__restrict__ S,
                                                               const double2 *__restrict__ v, double2 *__restrict__ p,
@@ -3159,6 +3194,15 @@ hipError_t launch_kappa_residual(const DotArgs &D_in, const double *kpartial, in
   D.mode = DOTS_STPCG_KAPPA_RR;
   hipLaunchKernelGGL(k_kappa_residual, dim3(grid_for(n / 2, 256, 256)), dim3(256), 0, st, D, kpartial, nk,
                      reinterpret_cast<const double2 *>(Hp), reinterpret_cast<double2 *>(r));
+  return hipGetLastError();
+}
+int kappa_residual_slots_blocks(int64_t n) { return grid_for(n / 2, 256, 256); }
+// rr_slot: kappa_residual_slots_blocks(n) doubles, one per block of the launch (added by an RvTail block)
+hipError_t launch_kappa_residual_slots(const StpcgState *S, const double *kpartial, int nk, int64_t n, const double *Hp, double *r,
+                                       double *rr_slot, hipStream_t st) {
+  if (n <= 0 || n % 2 || reinterpret_cast<uintptr_t>(Hp) % 16 || reinterpret_cast<uintptr_t>(r) % 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_kappa_residual_slots, dim3(kappa_residual_slots_blocks(n)), dim3(256), 0, st, S, kpartial, nk, n / 2,
+                     reinterpret_cast<const double2 *>(Hp), reinterpret_cast<double2 *>(r), rr_slot);
   return hipGetLastError();
 }
 // D: mode / st / st_host / partial / ticket / seq fields set by the caller; n doubles, even, 16-byte aligned
