@@ -364,6 +364,24 @@ class Context:
     def retract_dev(self, v, alpha, out):
         self._chk(self.L.cora_retract_dev(self.h, C.c_void_p(v), C.c_double(alpha), C.c_void_p(out)))
 
+    def objective_dev(self, y):
+        """f(y) for a resident y without changing the current point."""
+        f = C.c_double()
+        self._chk(self.L.cora_objective_dev(self.h, C.c_void_p(y), C.byref(f)))
+        return f.value
+
+    def tnt_trial_dev(self, s, hs, xprop):
+        """hs = Hess(s), xprop = Retr_Y(s); returns [<grad, s>, <s, Hess s>, <s, s>, f(xprop)] in one wait."""
+        out = (C.c_double * 4)()
+        self._chk(self.L.cora_tnt_trial_dev(self.h, C.c_void_p(s), C.c_void_p(hs), C.c_void_p(xprop), out))
+        return [out[i] for i in range(4)]
+
+    def tnt_accept_dev(self, x, pg):
+        """x becomes the current point, pg = projected preconditioned gradient; returns [f, <g,g>, <Pg,Pg>, <g,Pg>]."""
+        out = (C.c_double * 4)()
+        self._chk(self.L.cora_tnt_accept_dev(self.h, C.c_void_p(x), C.c_void_p(pg), out))
+        return [out[i] for i in range(4)]
+
     def project_to_manifold_dev(self, a, out):
         self._chk(self.L.cora_project_to_manifold_dev(self.h, C.c_void_p(a), C.c_void_p(out)))
 

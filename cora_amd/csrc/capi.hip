@@ -29,6 +29,8 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <deque>
+#include <atomic>
 #include <vector>
 
 #include "../../include/cora_hip.h"
@@ -122,6 +124,11 @@ struct cora_ctx {
 
   bool have_point = false;
   double *d_Y = nullptr, *d_G = nullptr, *d_rgrad = nullptr;
+  // cora_tnt_trial_dev leaves Q X of its trial point here; cora_tnt_accept_dev of the same point takes it as the new
+  // point's Euclidean gradient (the two buffers change places) instead of forming the product again
+  double *d_G_trial = nullptr;
+  const double *trial_x = nullptr;  // the trial point d_G_trial belongs to (nullptr: none)
+  unsigned long long stpcg_pending_seq = 0;  // a neutral iteration of the last inner solve may still be in flight (stpcg_run)
   double f = 0.0;
   int precond = CORA_PRECOND_NONE;
 
@@ -403,7 +410,9 @@ int download_impl(cora_ctx *c, const double *dptr, int k, double *host, int ldh)
 }
 
 // Lambda, grad and f from (Y, G) already resident in d_Y / d_G.
-int point_finish(cora_ctx *c) {
+// wait == false (one GPU): nothing is waited for -- f arrives in h_scalars[4] (pinned) before whatever the caller enqueues
+// next on the stream finishes, and the caller stores it in c->f after its own wait.
+int point_finish(cora_ctx *c, bool wait = true) {
   const RowArgs R = row_args(c);
   const int64_t units = static_cast<int64_t>(R.nl_poses) + R.nl_ranges + R.nl_trans;
   const int nb = static_cast<int>((units + 255) / 256);
@@ -412,6 +421,12 @@ int point_finish(cora_ctx *c) {
   int nblocks = 0;
   HIP_TRY(c, launch_point_finish(R, c->ld, c->d_Y, c->d_G, c->d_rgrad, c->d_lam_st, c->d_lam_ob, c->d_red,
                                  &nblocks, c->stream));
+  if (!wait) {
+    c->h_scalars[4] = 0.0;
+    if (nblocks > 0) HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->h_scalars + 4, c->stream));
+    c->have_point = true;
+    return CORA_OK;
+  }
   if (nblocks > 0) {
     HIP_TRY(c, launch_reduce_partials(c->d_red, nblocks, 1, c->h_scalars, c->stream));  // pinned host memory
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -430,12 +445,13 @@ int point_finish(cora_ctx *c) {
 int wait_dots(cora_ctx *c, unsigned long long seq) {
   volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_scalars + 7);
   for (long spin = 0; spin < 20000000L; ++spin)
-    if (*flag == seq) return CORA_OK;
+    if (*flag >= seq) return CORA_OK;  // (numbers only grow on a handle; a later reduction may already have finished)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return *flag == seq ? CORA_OK : fail(c, CORA_ERR_HIP, "inner-product kernel did not complete");
+  return *flag >= seq ? CORA_OK : fail(c, CORA_ERR_HIP, "inner-product kernel did not complete");
 }
 
 int set_point_dev_impl(cora_ctx *c, const double *dY) {
+  c->trial_x = nullptr;
   if (dY != c->d_Y)
     HIP_TRY(c, hipMemcpyAsync(c->d_Y, dY, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
   const int rc = apply_product(c, c->d_Y, c->ld, EPI_NONE, c->d_G);
@@ -444,10 +460,11 @@ int set_point_dev_impl(cora_ctx *c, const double *dY) {
 }
 
 void free_rank_state(cora_ctx *c) {
-  for (double **p : {&c->d_Y, &c->d_G, &c->d_rgrad}) {
+  for (double **p : {&c->d_Y, &c->d_G, &c->d_rgrad, &c->d_G_trial}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
+  c->trial_x = nullptr;
   c->have_point = false;
 }
 
@@ -861,6 +878,59 @@ int cora_objective_dev(cora_ctx *c, const double *dY, double *f) {
   rc = cora_dots_dev(c, 1, a, b, &v);
   if (rc) return rc;
   *f = 0.5 * v;
+  return CORA_OK;
+}
+
+// One trust-region trial step in ONE wait (Optimization::Riemannian::TNT's outer iteration between two inner solves, as
+// called from src/CORA.cpp:139-140): H s for the model decrease, the retraction, Q X of the trial point for its cost, and
+// the four inner products in one reduction.  The same kernels, in the same order per vector, as cora_hvp_dev +
+// cora_dots_dev + cora_retract_dev + cora_objective_dev: the values are the same bits, two waits and a launch fewer.
+int cora_tnt_trial_dev(cora_ctx *c, const double *dS, double *dHs, double *dXprop, double out[4]) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
+  if (!dS || !dHs || !dXprop || !out || dHs == dS || dXprop == dS || dXprop == dHs) return fail(c, CORA_ERR_ARG, "bad arguments");
+  c->trial_x = nullptr;
+  int rc;
+  if (!c->d_G_trial) {
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_G_trial), vec_bytes(c, c->ld)));
+    HIP_TRY(c, hipMemsetAsync(c->d_G_trial, 0, vec_bytes(c, c->ld), c->stream));
+  }
+  if ((rc = apply_product(c, dS, c->ld, EPI_HVP, dHs))) return rc;
+  HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, c->d_Y, dS, 1.0, dXprop, c->stream));
+  if ((rc = apply_product(c, dXprop, c->ld, EPI_NONE, c->d_G_trial))) return rc;
+  const double *A[4] = {c->d_rgrad, dS, dS, dXprop};
+  const double *B[4] = {dS, dHs, dS, c->d_G_trial};
+  if ((rc = cora_dots_dev(c, 4, A, B, out))) return rc;
+  out[3] *= 0.5;
+  c->trial_x = dXprop;
+  return CORA_OK;
+}
+
+// The accepted trial point becomes the current point, and the preconditioned gradient with the norms TNT's stopping
+// tests need comes back in the same wait: out = f, <g, g>, <P g, P g>, <g, P g>.  After cora_tnt_trial_dev of the same
+// vector (one GPU) the product Q X is not formed again.  Otherwise: cora_set_point_dev + cora_precondition_projected_dev
+// + cora_dots_dev, call by call.
+int cora_tnt_accept_dev(cora_ctx *c, const double *dX, double *dPg, double out[4]) {
+  NEED_DEVICE(c);
+  NEED_RANK(c);
+  if (!dX || !dPg || !out || dX == dPg) return fail(c, CORA_ERR_ARG, "bad arguments");
+  int rc;
+  const bool fast = c->F.L.world == 1 && c->trial_x == dX && c->d_G_trial && !std::getenv("CORA_NO_TNT_FUSE");
+  if (fast) {
+    c->trial_x = nullptr;
+    if (dX != c->d_Y) HIP_TRY(c, hipMemcpyAsync(c->d_Y, dX, vec_bytes(c, c->ld), hipMemcpyDeviceToDevice, c->stream));
+    std::swap(c->d_G, c->d_G_trial);
+    if ((rc = point_finish(c, false))) return rc;
+  } else if ((rc = set_point_dev_impl(c, dX))) {
+    return rc;
+  }
+  if ((rc = cora_precondition_projected_dev(c, c->d_rgrad, dPg))) return rc;
+  const double *A[3] = {c->d_rgrad, dPg, c->d_rgrad};
+  const double *B[3] = {c->d_rgrad, dPg, dPg};
+  if ((rc = cora_dots_dev(c, 3, A, B, out + 1))) return rc;
+  if (fast) c->f = c->h_scalars[4];
+  out[0] = c->f;
   return CORA_OK;
 }
 
@@ -1650,6 +1720,7 @@ int cora_set_formulation(cora_ctx *c, int implicit) {
   if (c->implicit != (implicit != 0)) {
     c->implicit = implicit != 0;
     c->have_point = false;  // cached QY / Lambda belong to the other operator
+    c->trial_x = nullptr;
   }
   return CORA_OK;
 }
@@ -1828,6 +1899,10 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     if ((rc = cora_dots_dev(c, 2, A, B, rr_rv))) return rc;
   }
   const double r0 = std::sqrt(rr_rv[0]);
+  if (c->stpcg_pending_seq) {  // the last solve's neutral iteration writes the mirror too: it must be behind us before
+    if ((rc = wait_dots(c, c->stpcg_pending_seq))) return rc;  // the mirror is reset (long finished by now: no wait)
+    c->stpcg_pending_seq = 0;
+  }
   StpcgState &H = c->h_stpcg[1];  // staging copy for the upload; h_stpcg[0] is the mirror the kernels write
   H = StpcgState();
   H.r_v = rr_rv[1];
@@ -1852,9 +1927,12 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   D.out = c->d_scalars;
   D.st = c->d_stpcg;
   D.st_host = &c->h_stpcg[0];
-  // Iterations enqueued between two looks at the state: on small problems an iteration is a dozen launch
-  // floors and the host's wait is what costs, so it runs ahead by four (work enqueued past the stopping point is
-  // neutralised by the state); on large ones an iteration is worth 20 waits and running ahead would waste it.
+  // How far the host runs ahead of the state it has seen.  One GPU: ONE iteration on small problems (`depth`, below: the
+  // host waits for iteration k - 1 before it enqueues k + 1, so the GPU never waits for the host and exactly one
+  // iteration is enqueued past the stopping point, neutralised by the state), none on large ones (the reductions' block
+  // runs in the launch BEFORE the backward sweep, which covers the host's reaction).  Partitioned handles and graph replay:
+  // `batch` iterations between two looks, everything waited for (every rank must enqueue the same collective calls, so
+  // the decision may only depend on a state that no iteration in flight can have advanced).
   static const int batch_env = [] { const char *e = std::getenv("CORA_STPCG_BATCH"); return e ? std::atoi(e) : 0; }();
   const int batch = batch_env > 0 ? batch_env : (n > 1000000 ? 1 : 4);
   int enqueued = 0;
@@ -1999,6 +2077,17 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     tail.seq_counter = c->d_seq_counter;
     FF.dot.seq_counter = FB.dot.seq_counter = c->d_seq_counter;
   }
+  static const int depth_env = [] { const char *e = std::getenv("CORA_STPCG_DEPTH"); return e ? std::atoi(e) : -1; }();
+  const bool pipelined = !sharded && !use_graph && batch_env <= 0;
+  const int depth = depth_env >= 0 ? depth_env : (batch == 1 ? 0 : 1);
+  // Small problems, the default: the host runs ahead by the next iteration's PRODUCT only.  The reductions' block of
+  // iteration k runs in its second-to-last launch (or finishes it: the unfused forms); behind it the GPU still has the
+  // last launch of k and the product of k + 1, which is what the host needs to see the state and enqueue the rest of
+  // k + 1 -- the GPU does not wait for the host, and past the stopping point there is one product (its results are never
+  // read), not one whole neutral iteration.  CORA_STPCG_DEPTH=1 is the whole-iteration form.
+  const bool product_ahead = pipelined && depth == 1 && depth_env < 0 && !c->prof_stpcg;
+  bool have_product = false;
+  std::deque<unsigned long long> in_flight;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {
     unsigned long long seq = 0;
     const bool whole = use_graph && max_iters - enqueued >= batch;
@@ -2032,7 +2121,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       return CORA_OK;
     };
     // (the launches of one iteration; under capture an error must still close the capture: the caller does)
-    auto one_iteration = [&]() -> int {
+    // part: 0 the whole iteration | 1 its product alone (Hp = H p, with the partials of kappa) | 2 everything after the product
+    auto one_iteration = [&](int part = 0) -> int {
       // measurement hook (cora_debug_profile_stpcg): mark 0 before the product, 1 after it; mode 2 also after every
       // other launch of the sweep-fused form -- 2 kappa | 3 forward sweep | 4, 5 the last stage's two products | 6
       // backward sweep (a mark is an event on the handle's stream: it does not reorder anything)
@@ -2044,9 +2134,12 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       mark(0);
       if (fused) {
         // Hp = H p with the partials of kappa | kappa, alpha, r += alpha Hp with <r, r> | preconditioner | ...
-        SpmmArgs A = spmm_args(c, dP, dHp);
-        A.kappa_partial = kappa_partial;
-        if ((rc = exchange_and_product(c, A, c->ld, EPI_HVP_K))) return rc;  // (one rank: the product alone)
+        if (part != 2) {
+          SpmmArgs A = spmm_args(c, dP, dHp);
+          A.kappa_partial = kappa_partial;
+          if ((rc = exchange_and_product(c, A, c->ld, EPI_HVP_K))) return rc;  // (one rank: the product alone)
+        }
+        if (part == 1) return CORA_OK;
         mark(1);
         if (sharded) {
           // kappa: local partials (fixed order) -> sum over the ranks -> scalar step;  then r += alpha Hp with <r, r>
@@ -2160,7 +2253,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
         D.seq = 0;
         return CORA_OK;
       }
-      if ((rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
+      if (part != 2 && (rc = apply_product(c, dP, c->ld, EPI_HVP, dHp))) return rc;
+      if (part == 1) return CORA_OK;
       mark(1);
       int nblocks = 0;
       D.count = 1;
@@ -2184,6 +2278,27 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       HIP_TRY(c, launch_stpcg_direction(n, c->d_stpcg, dV, dP, c->stream));
       return CORA_OK;
     };
+    if (product_ahead) {
+      if (!have_product && (rc = one_iteration(1))) return rc;
+      if ((rc = one_iteration(2))) return rc;
+      ++enqueued;
+      have_product = enqueued < max_iters;
+      if (have_product && (rc = one_iteration(1))) return rc;
+      if ((rc = wait_dots(c, seq))) return rc;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      continue;
+    }
+    if (pipelined) {
+      if ((rc = one_iteration())) return rc;
+      ++enqueued;
+      in_flight.push_back(seq);
+      if (static_cast<int>(in_flight.size()) > depth) {
+        if ((rc = wait_dots(c, in_flight.front()))) return rc;
+        in_flight.pop_front();
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      continue;
+    }
     for (int b = 0; b < batch && enqueued < max_iters; ++b, ++enqueued) {
       if ((rc = one_iteration())) {
         (void)end_capture(false);
@@ -2193,9 +2308,24 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     if ((rc = end_capture(true))) return rc;
     if ((rc = wait_dots(c, seq))) return rc;
   }
-  // an iteration that starts at the limit only records the status: flush it so that the mirror is final
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(&H, c->d_stpcg, sizeof(StpcgState), hipMemcpyDeviceToHost));
+  if (c->h_stpcg[0].status == 0 || c->prof_stpcg) {  // the iteration limit ended the loop: what is in flight decides
+    while (!in_flight.empty()) {
+      if ((rc = wait_dots(c, in_flight.front()))) return rc;
+      in_flight.pop_front();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (c->h_stpcg[0].status != 0 && !c->prof_stpcg) {
+    // the mirror was written by the iteration that set the status (and only rewritten with the same iteration count,
+    // step norm and status by a neutral one after it): final, nothing to wait for.  What is still in flight is
+    // neutral and ordered before anything enqueued after this call; the next solve makes sure of it before it resets the mirror.
+    H = c->h_stpcg[0];
+    c->stpcg_pending_seq = in_flight.empty() ? 0 : in_flight.back();
+  } else {
+    // an iteration that starts at the limit only records the status: flush it so that the mirror is final
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(&H, c->d_stpcg, sizeof(StpcgState), hipMemcpyDeviceToHost));
+  }
   if (c->prof_stpcg) {  // iterations that really ran (enqueued-ahead ones after the stop are neutral but timed)
     const bool phases = c->prof_stpcg >= 2 && c->stpcg_path == 2 && !sharded;
     for (int k = 0; k < 7; ++k) c->prof_phase_us[k] = -1.0;
@@ -2493,6 +2623,7 @@ int cora_tangent_space_projection(cora_ctx *c, const double *Y, int ldy, const d
   if ((rc = get_scratch(c, 1, c->ld, &dO))) return rc;
   if ((rc = upload_impl(c, Y, ldy, c->p, c->d_Y))) return rc;
   c->have_point = false;  // Y replaced without refreshing the cached gradient
+  c->trial_x = nullptr;
   if ((rc = upload_impl(c, V, ldv, c->p, dV))) return rc;
   HIP_TRY(c, hipMemsetAsync(dO, 0, vec_bytes(c, c->ld), c->stream));
   HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, nullptr, dO, c->stream));

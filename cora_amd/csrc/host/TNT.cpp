@@ -179,17 +179,12 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
     double h_M_norm = 0.0;
     const int inner = STPCG(D, grad, Pg, g_g, g_Pg, Delta, prm, s, r, v, pk, Hp, h_M_norm);
     res.hessian_vector_products += inner + 1;
-    // model decrease  m(0) - m(h) = -<g,h> - 1/2 <h, H h>
-    D.chk(cora_hvp_dev(c, s, Hp), "cora_hvp_dev");
-    const double *A[3] = {grad, s, s};
-    const double *B[3] = {s, Hp, s};
-    double o[3];
-    D.chk(cora_dots_dev(c, 3, A, B, o), "cora_dots_dev");
+    // model decrease  m(0) - m(h) = -<g,h> - 1/2 <h, H h>,  the trial point and its cost: one wait for all of it
+    double o[4];
+    D.chk(cora_tnt_trial_dev(c, s, Hp, xprop, o), "cora_tnt_trial_dev");
     const double dm = -o[0] - 0.5 * o[1];
     const double h_norm = std::sqrt(o[2]);
-    D.chk(cora_retract_dev(c, s, 1.0, xprop), "cora_retract_dev");
-    double f_prop;
-    D.chk(cora_objective_dev(c, xprop, &f_prop), "cora_objective_dev");
+    const double f_prop = o[3];
     const double df = f - f_prop;
     const double rho = df / dm;
     const double rel_dec = df / (std::sqrt(std::numeric_limits<double>::epsilon()) + std::fabs(f));
@@ -202,10 +197,16 @@ TNTResult TNT(const Problem &problem, const Matrix &x0, const TNTParams &prm) {
     if (accepted) {
       ++res.accepted_steps;
       std::swap(x, xprop);
-      D.chk(cora_set_point_dev(c, x), "cora_set_point_dev");
-      D.chk(cora_point_cost(c, &f), "cora_point_cost");
+      // the trial point becomes the current one (its product Q X is kept, not formed again); f, P g and the three
+      // inner products of the stopping tests and of the next inner solve arrive in one wait
+      double a[4];
+      D.chk(cora_tnt_accept_dev(c, x, Pg, a), "cora_tnt_accept_dev");
+      f = a[0];
       grad = cora_point_rgrad_dev(c);
-      gradient_norms(grad_norm, pgrad_norm);
+      grad_norm = std::sqrt(a[1]);
+      pgrad_norm = std::sqrt(a[2]);
+      g_g = a[1];
+      g_Pg = a[3];
       if (prm.log_iterates) res.iterates.push_back(download(x));
     }
     // trust-region update

@@ -247,9 +247,19 @@ int cora_set_point_dev(cora_ctx *ctx, const double *dY);
  * Objective closure of src/CORA.cpp:52-55, used for trial points). Synchronises. */
 int cora_objective_dev(cora_ctx *ctx, const double *dY, double *f);
 
+/* One trust-region trial step of Optimization::Riemannian::TNT (the solver src/CORA.cpp:139-140 calls; its sources
+ * are a dependency absent from the reference tree) in ONE wait: dHs = Hess(s), dXprop = Retr_Y(s), and
+ * out = { <grad, s>, <s, Hess s>, <s, s>, f(Xprop) }.  Same kernels and values as cora_hvp_dev + cora_dots_dev +
+ * cora_retract_dev + cora_objective_dev; the product Q Xprop stays on the handle for cora_tnt_accept_dev. */
+int cora_tnt_trial_dev(cora_ctx *ctx, const double *dS, double *dHs, double *dXprop, double out[4]);
+/* Make dX the current point (cora_set_point_dev), dPg = precondition(grad) projected, and
+ * out = { f, <grad, grad>, <Pg, Pg>, <grad, Pg> } in one wait.  When dX is the vector the last cora_tnt_trial_dev
+ * filled (one GPU), Q X is taken from that call: the pointer cora_point_egrad_dev returns changes. */
+int cora_tnt_accept_dev(cora_ctx *ctx, const double *dX, double *dPg, double out[4]);
+
 /* f at the current point (local shard contribution when partitioned). */
 int cora_point_cost(cora_ctx *ctx, double *f);
-/* Device pointers to the cached point data (valid until the next set_point). */
+/* Device pointers to the cached point data (valid until the next point is set: cora_set_point*, cora_tnt_accept_dev). */
 const double *cora_point_Y_dev(const cora_ctx *ctx);
 const double *cora_point_egrad_dev(const cora_ctx *ctx);
 const double *cora_point_rgrad_dev(const cora_ctx *ctx);

@@ -251,6 +251,54 @@ def test_precondition_in_place_and_out_of_place_agree():
         h.dev_free(q)
 
 
+@pytest.mark.parametrize("precond", [capi.PRECOND_JACOBI, capi.PRECOND_REGULARIZED_CHOLESKY])
+def test_tnt_trial_and_accept_are_the_separate_calls_bit_for_bit(precond):
+    """cora_tnt_trial_dev / cora_tnt_accept_dev enqueue what cora_hvp_dev + cora_dots_dev + cora_retract_dev +
+    cora_objective_dev / cora_set_point_dev + cora_precondition_projected_dev + cora_dots_dev enqueue, and wait once:
+    every scalar and every vector they return is the same bits, with and without the product kept from the trial."""
+    P = host.Problem.synthetic(dim=3, n_poses=2500, n_landmarks=4, n_ranges=1200, n_loops=5, seed=5, precond=precond)
+    P.update()
+    p = 4
+    P.set_rank(p)
+    P.precond_info()
+    dm = P.dims()
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    y, s, hs, xp, pg, hs2, xp2, pg2 = [h.dev_alloc(p) for _ in range(8)]
+    rng = np.random.default_rng(3)
+    h.upload(rng.uniform(-1, 1, (dm["N"], p)), y)
+    h.project_to_manifold_dev(y, y)
+    h.set_point_dev(y)
+    grad = h.point_ptrs()[2]
+    h.upload(1e-2 * rng.uniform(-1, 1, (dm["N"], p)), s)
+    h.tangent_space_projection_dev(s, s)
+    # the separate calls
+    h.hvp_dev(s, hs2)
+    o_ref = h.dots_dev([(grad, s), (s, hs2), (s, s)])
+    h.retract_dev(s, 1.0, xp2)
+    f_ref = h.objective_dev(xp2)
+    o = h.tnt_trial_dev(s, hs, xp)
+    assert o[:3] == o_ref and o[3] == f_ref
+    assert np.array_equal(h.download(hs, p), h.download(hs2, p)) and np.array_equal(h.download(xp, p), h.download(xp2, p))
+    # accept: the product kept from the trial ...
+    a = h.tnt_accept_dev(xp, pg)
+    g_fast = h.download(h.point_ptrs()[2], p)
+    e_fast = h.download(h.point_ptrs()[1], p)
+    pg_fast = h.download(pg, p)
+    # ... against the separate calls at the same point, and against an accept that has no trial to take it from
+    h.set_point_dev(xp2)
+    grad = h.point_ptrs()[2]
+    f2 = h.point_cost()
+    h.precondition_projected_dev(grad, pg2)
+    n2 = h.dots_dev([(grad, grad), (pg2, pg2), (grad, pg2)])
+    assert a == [f2] + n2
+    assert np.array_equal(g_fast, h.download(grad, p)) and np.array_equal(e_fast, h.download(h.point_ptrs()[1], p))
+    assert np.array_equal(pg_fast, h.download(pg2, p))
+    b = h.tnt_accept_dev(xp2, pg)
+    assert b == a and np.array_equal(h.download(pg, p), pg_fast)
+    for q in (y, s, hs, xp, pg, hs2, xp2, pg2):
+        h.dev_free(q)
+
+
 @pytest.mark.parametrize("d,n,precond", [(3, 30000, capi.PRECOND_REGULARIZED_CHOLESKY), (2, 40000, capi.PRECOND_REGULARIZED_CHOLESKY),
                                           (3, 800, capi.PRECOND_REGULARIZED_CHOLESKY), (3, 800, capi.PRECOND_JACOBI)])
 @pytest.mark.parametrize("p", [5, 4])
