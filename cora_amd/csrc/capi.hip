@@ -1933,7 +1933,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // runs in the launch BEFORE the backward sweep, which covers the host's reaction).  Partitioned handles and graph replay:
   // `batch` iterations between two looks, everything waited for (every rank must enqueue the same collective calls, so
   // the decision may only depend on a state that no iteration in flight can have advanced).
-  static const int batch_env = [] { const char *e = std::getenv("CORA_STPCG_BATCH"); return e ? std::atoi(e) : 0; }();
+  // (the three switches of the host loop are read per solve: tests/test_gpu_solver.py runs one problem under each form)
+  const int batch_env = [] { const char *e = std::getenv("CORA_STPCG_BATCH"); return e ? std::atoi(e) : 0; }();
   const int batch = batch_env > 0 ? batch_env : (n > 1000000 ? 1 : 4);
   int enqueued = 0;
   // Fused iteration (explicit formulation, one shard, row strides up to 12): six passes instead of nine --
@@ -2077,7 +2078,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     tail.seq_counter = c->d_seq_counter;
     FF.dot.seq_counter = FB.dot.seq_counter = c->d_seq_counter;
   }
-  static const int depth_env = [] { const char *e = std::getenv("CORA_STPCG_DEPTH"); return e ? std::atoi(e) : -1; }();
+  const int depth_env = [] { const char *e = std::getenv("CORA_STPCG_DEPTH"); return e ? std::atoi(e) : -1; }();
   const bool pipelined = !sharded && !use_graph && batch_env <= 0;
   const int depth = depth_env >= 0 ? depth_env : (batch == 1 ? 0 : 1);
   // Small problems, the default: the host runs ahead by the next iteration's PRODUCT only.  The reductions' block of
@@ -2085,7 +2086,8 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   // last launch of k and the product of k + 1, which is what the host needs to see the state and enqueue the rest of
   // k + 1 -- the GPU does not wait for the host, and past the stopping point there is one product (its results are never
   // read), not one whole neutral iteration.  CORA_STPCG_DEPTH=1 is the whole-iteration form.
-  const bool product_ahead = pipelined && depth == 1 && depth_env < 0 && !c->prof_stpcg;
+  const int ahead_env = [] { const char *e = std::getenv("CORA_STPCG_AHEAD"); return e ? std::atoi(e) : -1; }();  // (lab)
+  const bool product_ahead = pipelined && !c->prof_stpcg && (ahead_env >= 0 ? ahead_env != 0 : (depth == 1 && depth_env < 0));
   bool have_product = false;
   std::deque<unsigned long long> in_flight;
   while (c->h_stpcg[0].status == 0 && enqueued < max_iters) {

@@ -251,6 +251,33 @@ def test_precondition_in_place_and_out_of_place_agree():
         h.dev_free(q)
 
 
+@pytest.mark.parametrize("n,precond", [(600, capi.PRECOND_REGULARIZED_CHOLESKY), (600, capi.PRECOND_JACOBI),
+                                        (12000, capi.PRECOND_REGULARIZED_CHOLESKY)])
+def test_host_loop_forms_take_the_same_path_bit_for_bit(n, precond):
+    """How far the host runs ahead of the inner solve's state (one product: the default; nothing; one iteration; batches of
+    four) and whether the outer iteration's calls are fused decide WHEN launches are enqueued, never what they compute: the
+    solver returns the same bits under every form (explicit-inverse, vector-pass and sweep-fused iterations)."""
+    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=4, n_ranges=n // 2, n_loops=6, seed=12, precond=precond)
+    P.update()
+    P.set_rank(4)
+    x0 = P.op("getRandomInitialGuess")
+    forms = [{}, {"CORA_STPCG_DEPTH": "0"}, {"CORA_STPCG_DEPTH": "1"}, {"CORA_STPCG_BATCH": "4"}, {"CORA_STPCG_BATCH": "1"},
+             {"CORA_NO_TNT_FUSE": "1"}, {"CORA_STPCG_AHEAD": "1", "CORA_STPCG_DEPTH": "0"}]
+    runs = []
+    for env in forms:
+        os.environ.update(env)
+        try:
+            runs.append(P.tnt(x0, max_iterations=15))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    a = runs[0]
+    assert a["hvps"] > 30
+    for env, b in zip(forms[1:], runs[1:]):
+        assert (a["iterations"], a["status"], a["hvps"], a["f"]) == (b["iterations"], b["status"], b["hvps"], b["f"]), env
+        assert np.array_equal(a["x"], b["x"]), env
+
+
 @pytest.mark.parametrize("precond", [capi.PRECOND_JACOBI, capi.PRECOND_REGULARIZED_CHOLESKY])
 def test_tnt_trial_and_accept_are_the_separate_calls_bit_for_bit(precond):
     """cora_tnt_trial_dev / cora_tnt_accept_dev enqueue what cora_hvp_dev + cora_dots_dev + cora_retract_dev +

@@ -25,7 +25,8 @@ h.set_point_dev(y)
 grad = h.point_ptrs()[2]
 h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=8)
 h.sync()
-t0 = time.perf_counter()
-done, _ = h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
-h.sync()
-print("stpcg path %d: %d iterations, %.1f us each" % (h.stpcg_path(), done, (time.perf_counter() - t0) / max(done, 1) * 1e6))
+for rep in range(int(os.environ.get("PROBE_REPEATS", "1"))):
+    t0 = time.perf_counter()
+    done, _ = h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
+    h.sync()
+    print("stpcg path %d: %d iterations, %.1f us each" % (h.stpcg_path(), done, (time.perf_counter() - t0) / max(done, 1) * 1e6))
