@@ -1070,6 +1070,7 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
   };
   const size_t K = f.plan.stages.size();
   f.stages.resize(K);
+  std::shared_ptr<SubBlockOpHost> dead_sub;
   for (int64_t &e : f.entries) e = 0;
   if (K > 0) {
     const TriStage &top = f.plan.stages.back();
@@ -1251,11 +1252,11 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       HIP_TRY(c, up(&Q.desc, desc));
       tick("  sub: units");
       // the host copy is not needed any more: 130 MB of vectors, 16 ms to hand back at 10^5 poses and 0.1 s at 10^6 -- on
-      // a thread of its own (joined before the next factor is installed and when the handle goes)
-      if (c->deferred_free.valid()) c->deferred_free.get();
-      c->deferred_free = std::async(std::launch::async, [dead = std::make_shared<SubBlockOpHost>(std::move(H))]() mutable { dead.reset(); });
+      // a thread of its own (joined before the next factor is installed and when the handle goes), started AFTER the
+      // last stage's uploads: a thread that unmaps 130 MB holds the address space's lock, and the next copy from pageable
+      // memory waited 12 ms for it (measured: a 2.3 MB copy, 0.0122 s)
+      dead_sub = std::make_shared<SubBlockOpHost>(std::move(H));
       H = SubBlockOpHost();
-      tick("  sub: host copy handed off");
       continue;
     }
     if (k == 1 && f.stages[0].is_sub) {  // the last stage of a two-stage plan: only its two explicit-inverse products
@@ -1307,6 +1308,10 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
     HIP_TRY(c, up_op(D.fwd_b, S.fwd_b));
     if (D.has_bwd_a) HIP_TRY(c, up_op(D.bwd_a, S.bwd_a));
     HIP_TRY(c, up_op(D.bwd_b, S.bwd_b));
+  }
+  if (dead_sub) {
+    if (c->deferred_free.valid()) c->deferred_free.get();
+    c->deferred_free = std::async(std::launch::async, [dead = std::move(dead_sub)]() mutable { dead.reset(); });
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   tick("upload");

@@ -8,6 +8,7 @@
 #include <exception>
 #include <stdexcept>
 #include <functional>
+#include <future>
 #include <thread>
 #include <utility>
 #include "parallel.h"
@@ -448,6 +449,57 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       }
   }
   tick("stages");
+  // ---- "b" products: explicit inverse of every diagonal block.  Column j of W = L_bb^-1 solves
+  // L_bb w = e_j and is non-zero only on the path from j to the root of its block.
+  // With substitution blocks only the last stage has one, and nothing it reads changes from here on: it is computed on
+  // a thread of its own while the blocks are built (12 ms of the plan at 10^5 poses).
+  std::vector<std::vector<int32_t>> wt_row(static_cast<size_t>(K)), wt_col(static_cast<size_t>(K));
+  std::vector<std::vector<double>> wt_val(static_cast<size_t>(K));
+  std::vector<RowList> bb(static_cast<size_t>(K));
+  auto explicit_inverses = [&]() {
+    std::vector<double> w(static_cast<size_t>(m), 0.0);
+    for (int j = 0; j < m; ++j) {
+      const int k = stage[j], b = blk[j];
+      if (k == 0 && sub0) continue;
+      const bool dense = k == 0 && dense0;
+      RowList &B = bb[k];
+      if (!dense) B.begin_row(row_of[j]);  // backward "b": x_j = sum_i W_ij t_i  (column j of W)
+      w[j] = 1.0;
+      for (int v = j; v >= 0 && stage[v] == k && blk[v] == b; v = parent[v]) {
+        const double wv = w[v] / Lx[Lp[v]];
+        w[v] = 0.0;
+        if (dense) {
+          const int lj = loc[j], li = loc[v];
+          const int64_t base = D0.w_off[blk_id[j]];
+          const size_t rb0 = static_cast<size_t>(D0.row_begin[blk_id[j]]);
+          D0.w_by_col[base + D0.off_col[rb0 + lj] + __builtin_popcountll(D0.mask_col[rb0 + lj] & ((1ull << li) - 1))] = wv;
+          D0.w_by_row[base + D0.off_row[rb0 + li] + __builtin_popcountll(D0.mask_row[rb0 + li] & ((1ull << lj) - 1))] = wv;
+          ++P.nnzW;
+        } else {
+          B.add(row_of[v], wv);
+          wt_row[k].push_back(v);
+          wt_col[k].push_back(j);
+          wt_val[k].push_back(wv);
+        }
+        for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q) {
+          const int i = Li[q];
+          if (stage[i] == k && blk[i] == b) w[i] -= Lx[q] * wv;
+          else if (sorted) break;  // ancestors outside the block are numbered after all of its rows
+        }
+      }
+      if (!dense) B.end_row();
+    }
+    if (zero_row >= 0) {  // the pinned row rides along as an empty row of the last stage's backward product
+      bb[K - 1].begin_row(zero_row);
+      bb[K - 1].end_row();
+    }
+  };
+  std::future<void> inverses_ready;
+  if (sub0) inverses_ready = std::async(std::launch::async, explicit_inverses);
+  struct JoinInverses {  // (an exception on the way must not leave the thread behind with references to this frame)
+    std::future<void> &f;
+    ~JoinInverses() { if (f.valid()) f.wait(); }
+  } join_inverses{inverses_ready};
   // ---- stage 0 as workgroup blocks solved by substitution (trisolve.h, SubBlockOpHost)
   std::vector<std::vector<int32_t>> aux_of(sub0 ? static_cast<size_t>(m) : 0);  // later-stage variable -> its aux rows
   if (sub0) {
@@ -933,47 +985,8 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
     if (k < K - 1 && !(k == 0 && dense0)) finalize(ba, P.stages[k].bwd_a);
   }
   tick("a products");
-  // ---- "b" products: explicit inverse of every diagonal block.  Column j of W = L_bb^-1 solves
-  // L_bb w = e_j and is non-zero only on the path from j to the root of its block.
-  std::vector<double> w(static_cast<size_t>(m), 0.0);
-  std::vector<std::vector<int32_t>> wt_row(static_cast<size_t>(K)), wt_col(static_cast<size_t>(K));
-  std::vector<std::vector<double>> wt_val(static_cast<size_t>(K));
-  std::vector<RowList> bb(static_cast<size_t>(K));
-  for (int j = 0; j < m; ++j) {
-    const int k = stage[j], b = blk[j];
-    if (k == 0 && sub0) continue;
-    const bool dense = k == 0 && dense0;
-    RowList &B = bb[k];
-    if (!dense) B.begin_row(row_of[j]);  // backward "b": x_j = sum_i W_ij t_i  (column j of W)
-    w[j] = 1.0;
-    for (int v = j; v >= 0 && stage[v] == k && blk[v] == b; v = parent[v]) {
-      const double wv = w[v] / Lx[Lp[v]];
-      w[v] = 0.0;
-      if (dense) {
-        const int lj = loc[j], li = loc[v];
-        const int64_t base = D0.w_off[blk_id[j]];
-        const size_t rb0 = static_cast<size_t>(D0.row_begin[blk_id[j]]);
-        D0.w_by_col[base + D0.off_col[rb0 + lj] + __builtin_popcountll(D0.mask_col[rb0 + lj] & ((1ull << li) - 1))] = wv;
-        D0.w_by_row[base + D0.off_row[rb0 + li] + __builtin_popcountll(D0.mask_row[rb0 + li] & ((1ull << lj) - 1))] = wv;
-        ++P.nnzW;
-      } else {
-        B.add(row_of[v], wv);
-        wt_row[k].push_back(v);
-        wt_col[k].push_back(j);
-        wt_val[k].push_back(wv);
-      }
-      for (int32_t q = Lp[v] + 1; q < Lp[v + 1]; ++q) {
-        const int i = Li[q];
-        if (stage[i] == k && blk[i] == b) w[i] -= Lx[q] * wv;
-        else if (sorted) break;  // ancestors outside the block are numbered after all of its rows
-      }
-    }
-    if (!dense) B.end_row();
-  }
-  if (zero_row >= 0) {  // the pinned row rides along as an empty row of the last stage's backward product
-    bb[K - 1].begin_row(zero_row);
-    bb[K - 1].end_row();
-  }
+  if (inverses_ready.valid()) inverses_ready.get();
+  else explicit_inverses();
   for (int k = 0; k < K; ++k) {
     if (k == 0 && (dense0 || sub0)) continue;
     finalize(bb[k], P.stages[k].bwd_b);
