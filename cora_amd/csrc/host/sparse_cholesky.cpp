@@ -21,8 +21,9 @@ namespace CORA {
 std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatrix &Q, int m, int leaf_poses) {
   const int64_t dn = static_cast<int64_t>(d) * n, tb = dn + r, N = dn + r + nt;
   if (m != N && m != N - 1) throw std::invalid_argument("coraOrdering: m must be N or N-1");
-  // range row k hangs off the first pose translation it touches
-  std::vector<std::vector<int32_t>> pose_ranges(static_cast<size_t>(n));
+  // range row k hangs off the first pose translation it touches (flat arrays, a counting sort by pose: a vector per pose
+  // was 2 x 10^5 allocations at 10^5 poses, and this function is on the set-up's critical path)
+  std::vector<int32_t> range_pose(static_cast<size_t>(r), -1), pose_cnt(static_cast<size_t>(n) + 1, 0);
   std::vector<int32_t> loose;
   for (int k = 0; k < r; ++k) {
     int pose = -1;
@@ -30,7 +31,8 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
       const int64_t c = Q.inner[q];
       if (c >= tb && c - tb < n) { pose = static_cast<int>(c - tb); break; }
     }
-    if (pose >= 0) pose_ranges[pose].push_back(static_cast<int32_t>(dn + k));
+    range_pose[static_cast<size_t>(k)] = pose;
+    if (pose >= 0) pose_cnt[static_cast<size_t>(pose) + 1]++;
     else loose.push_back(static_cast<int32_t>(dn + k));
   }
   std::vector<int32_t> perm;
@@ -39,8 +41,14 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
   // the elimination tree and eliminating it adds no fill (the t-t coupling is already in Q33).  With
   // the ranges out of the way every pose is a clean chain [rotation rows, translation] and
   // consecutive poses of a leaf merge into one supernode of the device triangular solves.
-  for (int i = 0; i < n; ++i)
-    for (int32_t row : pose_ranges[i]) perm.push_back(row);
+  {
+    for (int i = 0; i < n; ++i) pose_cnt[static_cast<size_t>(i) + 1] += pose_cnt[static_cast<size_t>(i)];
+    const size_t base = perm.size(), attached = static_cast<size_t>(pose_cnt[static_cast<size_t>(n)]);
+    perm.resize(base + attached);
+    std::vector<int32_t> at(pose_cnt.begin(), pose_cnt.end() - 1);
+    for (int k = 0; k < r; ++k)  // (ascending k within a pose, as before)
+      if (range_pose[static_cast<size_t>(k)] >= 0) perm[base + static_cast<size_t>(at[static_cast<size_t>(range_pose[static_cast<size_t>(k)])]++)] = static_cast<int32_t>(dn + k);
+  }
   for (int32_t row : loose) perm.push_back(row);
   auto emit_pose = [&](int i) {
     for (int a = 0; a < d; ++a) perm.push_back(static_cast<int32_t>(static_cast<int64_t>(i) * d + a));
@@ -52,15 +60,23 @@ std::vector<int32_t> coraOrdering(int d, int n, int r, int nt, const SparseMatri
   // chains follow each other in the index order and are tied together by inter-robot ranges: tiers, MR.CLAM) gets a
   // nested dissection by BFS level sets below: bisecting THEIR index range leaves every inter-robot edge across the
   // cut, and the fill (tiers: 22 s of factorisation, an explicit inverse of 134 s) is what the chain order avoids.
-  std::vector<std::vector<int32_t>> adj(static_cast<size_t>(n));
+  std::vector<std::vector<int32_t>> adj;
   bool index_chain = true;
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n && index_chain; ++i)
     for (int32_t q = Q.outer[tb + i]; q < Q.outer[tb + i + 1]; ++q) {
       const int64_t c = Q.inner[q] - tb;
       if (c < 0 || c >= n || c == i) continue;
-      adj[static_cast<size_t>(i)].push_back(static_cast<int32_t>(c));
-      if (c != i - 1 && c != i + 1) index_chain = false;
+      if (c != i - 1 && c != i + 1) { index_chain = false; break; }
     }
+  if (!index_chain) {  // (the adjacency lists are only walked by the level-set dissection)
+    adj.resize(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i)
+      for (int32_t q = Q.outer[tb + i]; q < Q.outer[tb + i + 1]; ++q) {
+        const int64_t c = Q.inner[q] - tb;
+        if (c < 0 || c >= n || c == i) continue;
+        adj[static_cast<size_t>(i)].push_back(static_cast<int32_t>(c));
+      }
+  }
   if (index_chain) {
     std::function<void(int, int)> nd = [&](int lo, int hi) {  // poses [lo, hi)
       if (hi - lo <= leaf_poses) {
@@ -473,8 +489,23 @@ void choleskyAnalyze(const SparseMatrix &A, int m, const std::vector<int32_t> &p
   bool hit = false;
   const std::shared_ptr<const Symbolic> sym = symbolicFor(A, m, perm, iperm, &hit, cache);
   CholeskyFactor F;  // (its destructor hands the storage to the pool)
-  F.Li = takeStorage(g_pool_i, static_cast<size_t>(sym->tot));
-  F.Lx = takeStorage(g_pool_x, static_cast<size_t>(sym->tot));
+  // first touch of 58 MB at 10^5 poses: the two arrays on a thread each (10 -> 6 ms)
+  std::exception_ptr idx_error;
+  std::thread idx([&] {
+    try {
+      F.Li = takeStorage(g_pool_i, static_cast<size_t>(sym->tot));
+    } catch (...) {
+      idx_error = std::current_exception();
+    }
+  });
+  try {
+    F.Lx = takeStorage(g_pool_x, static_cast<size_t>(sym->tot));
+  } catch (...) {
+    idx.join();
+    throw;
+  }
+  idx.join();
+  if (idx_error) std::rethrow_exception(idx_error);
 }
 
 CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const std::vector<int32_t> &perm,
