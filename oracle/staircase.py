@@ -28,7 +28,7 @@ def rank_deficient(Y):
     """src/CORA_problem.cpp:1037-1049: certify_solution treats a point whose extreme singular values differ by more than
     1e6 as certified without looking at S (a level the staircase entered along a short escape step and TNT left at once)."""
     sv = np.linalg.svd(np.asarray(Y), compute_uv=False)
-    return bool(sv[0] / sv[-1] > 1e6)
+    return bool(sv[-1] == 0.0 or sv[0] / sv[-1] > 1e6)  # (an exactly zero column: the ratio is infinite)
 
 
 def saddle_escape(Q, dims, precond, Y, theta, v, gradient_tolerance=1e-4, preconditioned_gradient_tolerance=1e-4):
