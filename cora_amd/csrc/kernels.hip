@@ -2490,9 +2490,11 @@ __device__ __forceinline__ void project_unit(const SubFuse &F, size_t row, RowOf
 #ifdef CORA_SUB_TIMES
 // measurement build: wall-clock stamps of a substitution block's phases, forward and backward sweep apart
 // (tools/sub_timeline.py): 0 start | 1 right-hand sides in the tile | 2 levels done | 3 end | 4 clocks spent waiting for
-// a level's entries (wave 0) | 5 levels
+// a level's entries (wave 0) | 5 levels | 6.. shader-clock cycles of wave 0 inside the level loop, summed over the levels:
+// 6 wait for the entries | 7 request of the next level's + header | 8 tile reads and products | 9 sums over a row's lanes |
+// 10 first barrier | 11 rows into the tile | 12 second barrier | 13 unused
 constexpr unsigned kSubTimesMax = 8192;
-constexpr int kSubPhases = 6;
+constexpr int kSubPhases = 14;
 __device__ unsigned long long g_sub_phase[2 * kSubPhases * kSubTimesMax];
 #define CORA_SUB_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kSubTimesMax) g_sub_phase[(BWD ? kSubPhases * kSubTimesMax : 0) + kSubPhases * blockIdx.x + (i)] = (v); } while (0)
 #else
@@ -2759,18 +2761,28 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 
   // ---- the triangular solve, level by level
   constexpr int CW = LD <= 6 ? LD : (LD % 6 == 0 ? 6 : (LD % 5 == 0 ? 5 : 4));  // accumulators per column chunk
+#ifdef CORA_SUB_TIMES
+  unsigned long long dbg_cyc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_c = 0;
+#define DBG_CYC(i) do { const unsigned long long c__ = __builtin_readcyclecounter(); dbg_cyc[i] += c__ - dbg_c; dbg_c = c__; } while (0)
+#else
+#define DBG_CYC(i) do { } while (0)
+#endif
   auto level = [&](int l, const int4 h, const int4 hn, SubRegs &R, SubRegs &Rnext) {
 #ifdef CORA_SUB_TIMES
     const unsigned long long dbg_w0 = wall_clock64();
+    dbg_c = __builtin_readcyclecounter();
 #endif
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the level's entries have arrived ...
 #ifdef CORA_SUB_TIMES
     dbg_wait += wall_clock64() - dbg_w0;
 #endif
+    DBG_CYC(0);
     __builtin_amdgcn_sched_barrier(0);
     fetch(hn, Rnext);  // ... the next level's are on their way while this one is computed
     __builtin_amdgcn_sched_barrier(0);
     const int4 hnn = header(l + 2);
+    DBG_CYC(1);
     const int r0 = h.x, g = h.y & 0xff, npl = (h.y >> 8) & 0xf;
     const int gs = 31 - __builtin_clz(g), nlane = (h.y >> 12) << gs;
     const bool active = nlane > 0;  // wavefront-uniform: the others go straight to the barriers
@@ -2805,13 +2817,16 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
           case 7: accumulate(std::integral_constant<int, 7>()); break;
           default: accumulate(std::integral_constant<int, 8>()); break;
         }
+        DBG_CYC(2);
         group_sum_all<CW>(s, gs);
+        DBG_CYC(3);
 #pragma unroll
         for (int j = 0; j < CW; ++j)
           if (c0 + j < LD) res[c0 + j] = s[j];
       }
     }
     __syncthreads();  // every row of the level has read the tile ...
+    DBG_CYC(4);
     if (active && wl < nlane && (wl & (g - 1)) == 0) {
       double *__restrict__ o = reinterpret_cast<double *>(smem + __mul24(r0 + (wl >> gs), LD * 8));
 #pragma unroll
@@ -2821,7 +2836,9 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
         if (FD == 1) dacc[1] += dot_row<LD>(res, res);
       }
     }
+    DBG_CYC(5);
     __syncthreads();  // ... before any of them is written
+    DBG_CYC(6);
     return hnn;
   };
   {
@@ -2838,6 +2855,9 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   CORA_SUB_STAMP(2, wall_clock64());
   CORA_SUB_STAMP(4, dbg_wait);
   CORA_SUB_STAMP(5, static_cast<unsigned long long>(nlev));
+#ifdef CORA_SUB_TIMES
+  for (int q = 0; q < 7; ++q) CORA_SUB_STAMP(6 + q, dbg_cyc[q]);
+#endif
 #ifdef CORA_SUB_TIMES
   struct SubEnd {  // (the result paths return from several places)
     unsigned bwd;

@@ -30,10 +30,11 @@ st = h.precond_stats() if hasattr(h, "precond_stats") else None
 fp = h.L.cora_debug_sub_phases
 fp.argtypes = [C.c_void_p, C.c_int]
 nb = 4096
-raw = np.zeros(2 * 6 * nb, dtype=np.uint64)
+NP = 14
+raw = np.zeros(2 * NP * nb, dtype=np.uint64)
 assert fp(raw.ctypes.data, nb) == 0
 for w, name in enumerate(("forward", "backward")):
-    ph = raw[w * 6 * nb:(w + 1) * 6 * nb].reshape(nb, 6).astype(np.int64)
+    ph = raw[w * NP * nb:(w + 1) * NP * nb].reshape(nb, NP).astype(np.int64)
     ok = (ph[:, 0] > 0) & (ph[:, 3] > 0) & (ph[:, 5] > 0)
     ph = ph[ok]
     t0 = ph[:, 0].min()
@@ -48,3 +49,6 @@ for w, name in enumerate(("forward", "backward")):
     print("    of it waiting for the level's entries (wave 0):", pc(wait), "| per level %.2f us" % (wait.sum() / nlev.sum()))
     print("  results (T->dst) ", pc(end))
     print("  whole block      ", pc(us(ph[:, 3] - ph[:, 0])))
+    cyc = ph[:, 6:13].sum(axis=0) / max(nlev.sum(), 1)
+    print("  shader-clock cycles per level (wave 0): wait %.0f | next level's request %.0f | tile reads + products %.0f | lane sums %.0f | "
+          "barrier %.0f | rows into the tile %.0f | barrier %.0f | all %.0f" % (*cyc, cyc.sum()))
