@@ -466,6 +466,12 @@ int cora_debug_stpcg_path(const cora_ctx *ctx);
  * device-resident STPCG iterations captured once as a hipGraph and replayed (one GPU, fused forms).
  * out[0] = graphs captured so far, out[1] = batches replayed (both 0 unless the switch is on). */
 int cora_debug_stpcg_graph(const cora_ctx *ctx, long out[2]);
+/* Measurement switches of cora_stpcg_dev's host loop (environment, read per solve; none changes what is computed --
+ * tests/test_gpu_solver.py runs one problem under each): CORA_STPCG_DEPTH=0|1 (the host waits for every iteration | runs one
+ * whole iteration ahead; default: the next iteration's product ahead on small problems, 0 at 10^5 poses and above),
+ * CORA_STPCG_BATCH=n (n iterations enqueued, all waited for: the form partitioned handles always use),
+ * CORA_NO_TNT_FUSE=1 (cora_tnt_accept_dev forms Q X again), CORA_NO_RESIDUAL_SLOTS=1 (the one-explicit-inverse iteration
+ * finishes <r, r> with a ticket in its residual pass). */
 
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
                                 int k, double *out, int ldo);
