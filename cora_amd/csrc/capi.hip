@@ -1972,7 +1972,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
       rr_slots = static_cast<size_t>(launch_subblock_blocks(f.stages[0].sub)) + 8;
       yy_slots = static_cast<size_t>(f.stages[0].sub.nblocks) + 8;
       const RowOpDev &fb = f.stages[1].fwd_b;
-      sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
+      sq_slots = static_cast<size_t>(rowop_rowsq_slots(fb)) + 8;
     }
     // one explicit inverse W = L^-1 and nothing else (two products per solve), no pinned-row stage in between
     inverse_fused = !sharded && !sweep_fused && chol && f.ready && f.stages.size() == 1 && !f.stages[0].dense && !f.stages[0].is_sub &&
@@ -1980,7 +1980,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
     static const bool residual_slots = !std::getenv("CORA_NO_RESIDUAL_SLOTS");
     if (inverse_fused) {
       const RowOpDev &fb = f.stages[0].fwd_b;
-      sq_slots = static_cast<size_t>(fb.n8) + fb.n64 + fb.nlong + 8;
+      sq_slots = static_cast<size_t>(rowop_rowsq_slots(fb)) + 8;
       if (residual_slots) rr_slots = static_cast<size_t>(kappa_residual_slots_blocks(n)) + 8;
     }
     kappa_blocks = product_kappa_slots(c, spmm_args(c, dP, dHp));
