@@ -176,7 +176,7 @@ struct RvTail {
   int n_rr;
   const double *yy_partial;  // [n_yy]  |y|^2 slots of the forward sweep's solve blocks
   int n_yy;
-  const double *rowsq;       // [n_rowsq] squared norms of the rows of t_1, a slot per block / long row (the last stage's first product leaves them)
+  const double *rowsq;       // [n_rowsq] squared norms of the rows of t_1, a slot per wavefront (the last stage's first product leaves them)
   int n_rowsq;
   StpcgState *st, *st_host;  // st == nullptr: no tail block in this launch ...
   double *rowsq_out;         // ... but, if set, the product leaves the squared norms of its rows in rowsq_out[rowop_rowsq_slots]
@@ -228,11 +228,11 @@ hipError_t launch_blockop(const BlockOpDev &B, int ld, bool backward, const doub
 // kappa = sum of the n partials of an EPI_HVP_K product (fixed order), then the scalar step that follows it
 hipError_t launch_kappa_finish(const double *partial, int n, StpcgState *state, hipStream_t st);
 // tail: optional RvTail (see SubFuse) -- per-row squared norms out, or one extra block that runs the reductions
-// slots a product leaves its rows' squared norms in (RvTail::rowsq_out): one per block of the two short-row classes, one per long row
+// slots a product leaves its rows' squared norms in (RvTail::rowsq_out): one per wavefront of the 8-lane class, one per row of the other two
 #ifdef CORA_ROWSQ_PER_ROW  // (lab: a slot per row, the form before)
 inline int rowop_rowsq_slots(const RowOpDev &op) { return op.n8 + op.n64 + op.nlong; }
 #else
-inline int rowop_rowsq_slots(const RowOpDev &op) { return ((op.n8 + 31) >> 5) + ((op.n64 + 3) >> 2) + op.nlong; }
+inline int rowop_rowsq_slots(const RowOpDev &op) { return 4 * ((op.n8 + 31) >> 5) + op.n64 + op.nlong; }
 #endif
 hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const double *src, double *dst,
                         hipStream_t st, const RvTail *tail = nullptr);

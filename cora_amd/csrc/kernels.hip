@@ -2135,12 +2135,12 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
     rv_tail_block(tail);
     return;
   }
-  // optional: the squared norms of the product's rows, ONE SLOT PER BLOCK of the short-row classes (the block adds its rows
-  // in a fixed order) and one per long row -- slot = block index | nb8 + nb64 + long row.  (A slot per row -- 14 k of them on
-  // plaza2, 9 k at 10^5 poses -- made the block that adds them up the longest chain of the NEXT launch: 7 dependent rounds of
-  // loads where the rows of that launch need three.)
+  // optional: the squared norms of the product's rows, ONE SLOT PER WAVEFRONT (the eight rows of a wavefront of the 8-lane
+  // class added in a fixed order; a row of the wavefront class; a long row) -- slot = 4 block + wavefront | 4 nb8 + row of
+  // its class | 4 nb8 + n64 + long row.  (A slot per row -- 14 k of them on plaza2, 9 k at 10^5 poses -- made the block that
+  // adds them up the longest chain of the NEXT launch: 7 dependent rounds of loads where the rows of that launch need
+  // three.  A slot per block needed a barrier here: first product 13.8 -> 15.0 us at 10^5 poses.)
   double *__restrict__ rowsq = tail.st ? nullptr : tail.rowsq_out;
-  __shared__ double sq_sm[4];
   double acc[LD];
 #pragma unroll
   for (int j = 0; j < LD; ++j) acc[j] = 0.0;
@@ -2166,34 +2166,26 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
     if (rowsq && ok && g == 0) rowsq[r] = sq;
 #else
     if (rowsq) {  // (block-uniform)
-      const double t = block_sum_256(sq, sq_sm);
-      if (threadIdx.x == 0) rowsq[b] = t;
+      const double t = wave_sum(sq);
+      if ((threadIdx.x & 63) == 0) rowsq[(b << 2) + (static_cast<int>(threadIdx.x) >> 6)] = t;
     }
 #endif
   } else if (b < nb8 + nb64) {  // one wavefront per row
     const int r = op.n8 + ((b - nb8) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
-    const bool ok = r < op.n8 + op.n64;  // (wave-uniform)
-    if (!ok && !rowsq) return;
-    double sq = 0.0;
-    if (ok) {
-      const int orow = op.out_row[r];
-      if (src0 && g == 0) load_row<LD>(src0 + static_cast<size_t>(orow) * LD, acc);
-      rowop_entries<LD>(op.col, op.val, src, op.begin[r] + g, op.end[r], 64, acc);
+    if (r >= op.n8 + op.n64) return;  // (wave-uniform)
+    const int orow = op.out_row[r];
+    if (src0 && g == 0) load_row<LD>(src0 + static_cast<size_t>(orow) * LD, acc);
+    rowop_entries<LD>(op.col, op.val, src, op.begin[r] + g, op.end[r], 64, acc);
 #pragma unroll
-      for (int j = 0; j < LD; ++j) acc[j] = wave_sum(acc[j]);
-      if (g == 0) {
-        store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
-        if (rowsq) sq = dot_row<LD>(acc, acc);
-      }
-    }
+    for (int j = 0; j < LD; ++j) acc[j] = wave_sum(acc[j]);
+    if (g == 0) {
+      store_row<LD>(dst + static_cast<size_t>(orow) * LD, acc);
 #ifdef CORA_ROWSQ_PER_ROW
-    if (rowsq && ok && g == 0) rowsq[r] = sq;
+      if (rowsq) rowsq[r] = dot_row<LD>(acc, acc);
 #else
-    if (rowsq) {
-      const double t = block_sum_256(sq, sq_sm);
-      if (threadIdx.x == 0) rowsq[b] = t;
-    }
+      if (rowsq) rowsq[(nb8 << 2) + (r - op.n8)] = dot_row<LD>(acc, acc);
 #endif
+    }
   } else {  // one wavefront per chunk of a long row
     const int ch = ((b - nb8 - nb64) << 2) + (static_cast<int>(threadIdx.x) >> 6), g = threadIdx.x & 63;
     if (ch >= op.nchunks) return;
@@ -2246,7 +2238,7 @@ __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__rest
 #ifdef CORA_ROWSQ_PER_ROW
         if (rowsq) rowsq[op.n8 + op.n64 + r] = dot_row<LD>(part, part);
 #else
-        if (rowsq) rowsq[nb8 + nb64 + r] = dot_row<LD>(part, part);
+        if (rowsq) rowsq[(nb8 << 2) + op.n64 + r] = dot_row<LD>(part, part);
 #endif
       }
     }
