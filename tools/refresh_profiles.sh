@@ -16,4 +16,6 @@ python tools/pmc_summary.py gpurun_out/r05_pmc > gpurun_out/r05_pmc/summary.txt;
 bash tools/stpcg_trace.sh 100000 5 40 > gpurun_out/r05_stpcg_iteration_trace.txt 2>&1; tail -9 gpurun_out/r05_stpcg_iteration_trace.txt
 python tools/rank_sweep.py > gpurun_out/r05_rank_sweep.md 2>gpurun_out/r05_rank_sweep.err; tail -12 gpurun_out/r05_rank_sweep.md
 bash tools/datasets_all.sh > gpurun_out/r05_datasets.txt 2>&1; cat gpurun_out/r05_datasets.txt
+python bench.py 2>/dev/null | grep '^{"metric' > gpurun_out/r05_bench.json                                  # -> profiles/r05_bench.json
+python bench.py --op cert --rank 10 2>/dev/null | grep '^{"metric' > gpurun_out/r05_bench_cert.json      # -> profiles/r05_bench_cert.json (BASELINE config 5: 10 columns)
 find $R -name "*kernel_stats.csv" | head; find $R gpurun_out/r05_pmc gpurun_out/stpcg_trace -name "*.csv" -size +2M -delete
