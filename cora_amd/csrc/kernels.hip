@@ -2130,10 +2130,17 @@ template <int LD>
 __global__ __launch_bounds__(256) void k_rowop(RowOpDev op, const double *__restrict__ src0,
                                                const double *__restrict__ src, double *__restrict__ dst, const RvTail tail) {
   const int nb8 = (op.n8 + 31) >> 5, nb64 = (op.n64 + 3) >> 2;
-  const int b = static_cast<int>(blockIdx.x);
-  if (tail.st && b == static_cast<int>(gridDim.x) - 1) {  // the extra block of a launch with a tail
+  if (tail.st && blockIdx.x == gridDim.x - 1) {  // the extra block of a launch with a tail
     rv_tail_block(tail);
     return;
+  }
+  // Blocks are dispatched in index order and the chunks of the long rows are the longest chain of the launch (entries,
+  // gathers, partial, ticket, the row's partials again): they take the first indices.  b below is the index in the order
+  // 8-lane rows | wavefront rows | chunks that the rest of the kernel (and the slots of the row squares) uses.
+  int b = static_cast<int>(blockIdx.x);
+  {
+    const int nbch = (op.nchunks + 3) >> 2;
+    b = b < nbch ? nb8 + nb64 + b : b - nbch;
   }
   // optional: the squared norms of the product's rows, ONE SLOT PER WAVEFRONT (the eight rows of a wavefront of the 8-lane
   // class added in a fixed order; a row of the wavefront class; a long row) -- slot = 4 block + wavefront | 4 nb8 + row of
