@@ -148,6 +148,7 @@ struct cora_ctx {
   unsigned long long dot_seq = 0;  // h_scalars[7] carries the sequence number of the last finished reduction
   unsigned *d_ticket = nullptr;  // last-block ticket of the inner-product kernels (zero between launches)
   double *h_scalars = nullptr;  // pinned, 8 doubles
+  double *h_gram = nullptr;     // pinned, 16 x 24 x 24 doubles: where the Gram products' reduction writes its results
   int *d_flag = nullptr;
   int *h_flag = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -662,6 +663,7 @@ void cora_ctx_destroy(cora_ctx *c) {
       if (c->ev_pin[i]) (void)hipEventDestroy(c->ev_pin[i]);
     }
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->h_gram) (void)hipHostFree(c->h_gram);
     if (c->h_stpcg) (void)hipHostFree(c->h_stpcg);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -2489,11 +2491,11 @@ int cora_gram_dev(cora_ctx *c, const double *dA, int ka, const double *dB, int k
   const int nblocks = 256, nel = ka * kb;
   int rc = ensure_red(c, static_cast<size_t>(nel) * nblocks + nel);
   if (rc) return rc;
-  double *dout = c->d_red + static_cast<size_t>(nel) * nblocks;
-  HIP_TRY(c, launch_gram(c->F.L.base, c->F.L.local_rows, dA, ka, dB, kb, c->d_red, nblocks, dout, c->stream));
-  std::vector<double> tmp(static_cast<size_t>(nel));
-  HIP_TRY(c, hipMemcpyAsync(tmp.data(), dout, nel * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (!c->h_gram) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_gram), 16 * kMaxLD * kMaxLD * sizeof(double)));
+  // (the reduction writes the results to pinned host memory itself: no copy, one wait)
+  HIP_TRY(c, launch_gram(c->F.L.base, c->F.L.local_rows, dA, ka, dB, kb, c->d_red, nblocks, c->h_gram, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double *tmp = c->h_gram;
   for (int a = 0; a < ka; ++a)  // device result is row-major ka x kb
     for (int b = 0; b < kb; ++b) G[static_cast<size_t>(b) * ka + a] = tmp[static_cast<size_t>(a) * kb + b];
   return comm_allreduce(c, G, nel);
@@ -2512,20 +2514,15 @@ int cora_gram_batch_dev(cora_ctx *c, int n, const double *const *dA, const int *
     need += nel * nblocks;
     nel_all += nel;
   }
-  // every product is the kernel of cora_gram_dev on its own piece of the reduction buffer: the numbers are those of n
-  // separate calls, the stream is synchronised once
-  int rc = ensure_red(c, need + nel_all);
+  // every product is the block of cora_gram_dev's kernel on its own piece of the reduction buffer: the numbers are those
+  // of n separate calls -- in TWO launches (all products | all reductions, which write the results to pinned host memory)
+  // and one wait, where a Rayleigh-Ritz step's twelve products were 24 launches, a copy and a wait
+  int rc = ensure_red(c, need);
   if (rc) return rc;
-  double *partial = c->d_red, *dout = c->d_red + need;
-  for (int e = 0; e < n; ++e) {
-    const size_t nel = static_cast<size_t>(ka[e]) * kb[e];
-    HIP_TRY(c, launch_gram(c->F.L.base, c->F.L.local_rows, dA[e], ka[e], dB[e], kb[e], partial, nblocks, dout, c->stream));
-    partial += nel * nblocks;
-    dout += nel;
-  }
-  std::vector<double> tmp(nel_all);
-  HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_red + need, nel_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (!c->h_gram) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_gram), 16 * kMaxLD * kMaxLD * sizeof(double)));
+  HIP_TRY(c, launch_gram_batch(c->F.L.base, c->F.L.local_rows, n, dA, ka, dB, kb, c->d_red, nblocks, c->h_gram, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double *tmp = c->h_gram;
   size_t off = 0;
   for (int e = 0; e < n; ++e) {
     for (int a = 0; a < ka[e]; ++a)  // device result is row-major ka x kb
@@ -2549,6 +2546,11 @@ int cora_combine_dev(cora_ctx *c, int n, const double *const *dX, const int *k, 
     coff[b] = static_cast<int>(coef.size());
     for (int i = 0; i < k[b]; ++i)
       for (int j = 0; j < kout; ++j) coef.push_back(C[b][static_cast<size_t>(j) * k[b] + i]);  // row-major on device
+  }
+  if (coef.size() <= static_cast<size_t>(kCombineKargMax)) {  // the coefficients ride in the kernel's arguments: nothing to wait for
+    HIP_TRY(c, launch_combine(c->F.L.base, c->F.L.local_rows, n, dX, k, coff, nullptr, static_cast<int>(coef.size()), kout, dOut,
+                              c->stream, coef.data()));
+    return CORA_OK;
   }
   int rc = ensure_red(c, coef.size() + 8);
   if (rc) return rc;

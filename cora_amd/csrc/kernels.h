@@ -238,8 +238,12 @@ hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const do
                         hipStream_t st, const RvTail *tail = nullptr);
 hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
                        double *partial, int nblocks, double *out, hipStream_t st);
+hipError_t launch_gram_batch(int64_t row0, int64_t rows, int n, const double *const *A, const int *ka, const double *const *B,
+                             const int *kb, double *partial, int nblocks, double *out, hipStream_t st);
+constexpr int kCombineKargMax = 400;  // coefficients that travel in the kernel's arguments (CombineCoef::kMax)
 hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double *const *x, const int *kx,
-                          const int *coff, const double *coef, int ncoef, int kout, double *out, hipStream_t st);
+                          const int *coff, const double *coef, int ncoef, int kout, double *out, hipStream_t st,
+                          const double *coef_host = nullptr);
 hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st);
 
 hipError_t launch_spmm(const SpmmArgs &A, int ld, int d, int epi, hipStream_t st);

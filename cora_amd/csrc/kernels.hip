@@ -1882,14 +1882,19 @@ __global__ __launch_bounds__(256) void k_download(int64_t N, int k, int ld, cons
   }
 }
 
+struct GramBatch {  // up to 16 products A_e^T B_e of one launch (k_gram_batch)
+  const double *A[16], *B[16];
+  double *partial[16];
+  int lda[16], ka[16], ldb[16], kb[16];
+};
 // ---------------------------------------------------------------------------
 // Tall-skinny block kernels for the eigensolver (LOBPCG Rayleigh-Ritz):
 //   Gram:    G = A^T B            (A: rows x ka, B: rows x kb; ka, kb <= 24)
 //   combine: Out = sum_i X_i C_i  (X_i: rows x k_i, C_i: k_i x kout, small, in `coef`)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gram(int64_t row0, int64_t rows, const double *__restrict__ A, int lda,
-                                              int ka, const double *__restrict__ B, int ldb, int kb,
-                                              double *__restrict__ partial) {
+__device__ __forceinline__ void gram_block(int64_t row0, int64_t rows, const double *__restrict__ A, int lda,
+                                           int ka, const double *__restrict__ B, int ldb, int kb,
+                                           double *__restrict__ partial) {
   // G = A^T B over the local rows is a GEMM with a long inner dimension (the rows) and a tiny output (ka x kb <= 24 x 24):
   // v_mfma_f64_16x16x4_f64 with the rows as k.  A wavefront walks its share of the rows four at a time; lane l feeds
   // A[row + l / 16][l % 16 (+ 16 per tile)] and B likewise -- one 8-byte load each, a wavefront covers four whole rows --
@@ -1950,6 +1955,17 @@ __global__ __launch_bounds__(256) void k_gram(int64_t row0, int64_t rows, const 
       }
     }
 }
+__global__ __launch_bounds__(256) void k_gram(int64_t row0, int64_t rows, const double *__restrict__ A, int lda,
+                                              int ka, const double *__restrict__ B, int ldb, int kb,
+                                              double *__restrict__ partial) {
+  gram_block(row0, rows, A, lda, ka, B, ldb, kb, partial);
+}
+// Up to 16 Gram products in ONE launch (blockIdx.y = product; blockIdx.x / gridDim.x as in k_gram: the same partial sums,
+// the same bits): the twelve blocks of a Rayleigh-Ritz step were 24 launches of a few microseconds each.
+__global__ __launch_bounds__(256) void k_gram_batch(int64_t row0, int64_t rows, const GramBatch G) {
+  const int e = blockIdx.y;
+  gram_block(row0, rows, G.A[e], G.lda[e], G.ka[e], G.B[e], G.ldb[e], G.kb[e], G.partial[e]);
+}
 
 // out[el] = sum over blocks of partial[el][block]: one block per element, fixed order
 __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ partial, int nblocks, int nel,
@@ -1963,22 +1979,27 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ 
   if (threadIdx.x == 0) out[el] = t;
 }
 
+struct CombineCoef {  // coefficient matrices passed by value (k_combine_karg)
+  static constexpr int kMax = 400;
+  double v[kMax];
+};
 struct CombineArgs {
   const double *x[4];
   int kx[4], ldx[4], coff[4];  // coff: offset of C_i in coef (row-major k_i x kout)
   int nblocks, kout, ldo;
 };
 
-__global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, CombineArgs A,
-                                                 const double *__restrict__ coef, int ncoef,
-                                                 double *__restrict__ out) {
+template <bool KARG>
+__device__ __forceinline__ void combine_block(int64_t row0, int64_t rows, const CombineArgs &A,
+                                              const double *__restrict__ coef, const CombineCoef *K, int ncoef,
+                                              double *__restrict__ out) {
   // Out = sum_b X_b C_b, 16 rows per wavefront and step, on v_mfma_f64_16x16x4_f64: the rows are the M dimension
   // (lane l feeds X[row + l % 16][4 s + l / 16]), the coefficient matrices the B operand (from LDS, zero padded), the
   // <= 2 column tiles of the output sit in 4 doubles per lane each: D[row = (l >> 4) + 4 reg][col = l & 15], so one
   // store instruction writes four whole consecutive rows.
   typedef double f64x4 __attribute__((ext_vector_type(4)));
   extern __shared__ double sc[];
-  for (int t = threadIdx.x; t < ncoef; t += 256) sc[t] = coef[t];
+  for (int t = threadIdx.x; t < ncoef; t += 256) sc[t] = KARG ? K->v[t] : coef[t];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
@@ -2030,6 +2051,17 @@ __global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, Com
         }
     }
   }
+}
+__global__ __launch_bounds__(256) void k_combine(int64_t row0, int64_t rows, CombineArgs A,
+                                                 const double *__restrict__ coef, int ncoef,
+                                                 double *__restrict__ out) {
+  combine_block<false>(row0, rows, A, coef, nullptr, ncoef, out);
+}
+// The coefficient matrices in the kernel's own arguments (up to CombineCoef::kMax doubles: every Rayleigh-Ritz step of the
+// eigensolver): no copy to the device and no wait for it in front of the launch.
+__global__ __launch_bounds__(256) void k_combine_karg(int64_t row0, int64_t rows, CombineArgs A, const CombineCoef K, int ncoef,
+                                                      double *__restrict__ out) {
+  combine_block<true>(row0, rows, A, nullptr, &K, ncoef, out);
 }
 
 #endif  // CORA_TU & 2
@@ -3570,8 +3602,32 @@ hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, cons
   return hipGetLastError();
 }
 
+// n products in one launch + one reduction over all their elements: partial = n consecutive pieces (ka_e kb_e nblocks
+// doubles each), out = the n results one after the other (row-major ka_e x kb_e) -- may be pinned host memory
+hipError_t launch_gram_batch(int64_t row0, int64_t rows, int n, const double *const *A, const int *ka, const double *const *B,
+                             const int *kb, double *partial, int nblocks, double *out, hipStream_t st) {
+  if (n < 1 || n > 16) return hipErrorInvalidValue;
+  GramBatch G{};
+  int nel_all = 0;
+  for (int e = 0; e < n; ++e) {
+    G.A[e] = A[e];
+    G.B[e] = B[e];
+    G.lda[e] = ld_for(ka[e]);
+    G.ka[e] = ka[e];
+    G.ldb[e] = ld_for(kb[e]);
+    G.kb[e] = kb[e];
+    G.partial[e] = partial + static_cast<size_t>(nel_all) * nblocks;
+    nel_all += ka[e] * kb[e];
+  }
+  hipLaunchKernelGGL(k_gram_batch, dim3(nblocks, n), dim3(256), 0, st, row0, rows, G);
+  hipLaunchKernelGGL(k_gram_reduce, dim3(nel_all), dim3(256), 0, st, partial, nblocks, nel_all, out);
+  return hipGetLastError();
+}
+
+// coef_host != nullptr and ncoef <= CombineCoef::kMax: the coefficients travel in the kernel's arguments (coef unused)
 hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double *const *x, const int *kx,
-                          const int *coff, const double *coef, int ncoef, int kout, double *out, hipStream_t st) {
+                          const int *coff, const double *coef, int ncoef, int kout, double *out, hipStream_t st,
+                          const double *coef_host) {
   CombineArgs A;
   for (int b = 0; b < 4; ++b) { A.x[b] = nullptr; A.kx[b] = 0; A.ldx[b] = 0; A.coff[b] = 0; }
   for (int b = 0; b < nblocks; ++b) { A.x[b] = x[b]; A.kx[b] = kx[b]; A.ldx[b] = ld_for(kx[b]); A.coff[b] = coff[b]; }
@@ -3579,6 +3635,12 @@ hipError_t launch_combine(int64_t row0, int64_t rows, int nblocks, const double 
   A.kout = kout;
   A.ldo = ld_for(kout);
   const int grid = static_cast<int>(std::min<int64_t>((rows + 63) / 64, 2048));  // 4 wavefronts x 16 rows per block and step
+  if (coef_host && ncoef <= CombineCoef::kMax) {
+    CombineCoef K;
+    for (int t = 0; t < ncoef; ++t) K.v[t] = coef_host[t];
+    hipLaunchKernelGGL(k_combine_karg, dim3(std::max(grid, 1)), dim3(256), ncoef * sizeof(double), st, row0, rows, A, K, ncoef, out);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_combine, dim3(std::max(grid, 1)), dim3(256), ncoef * sizeof(double), st, row0, rows, A, coef,
                      ncoef, out);
   return hipGetLastError();
