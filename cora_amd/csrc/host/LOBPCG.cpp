@@ -201,8 +201,18 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
     Matrix D(m, m), I = Matrix::Identity(m, m);
     for (int i = 0; i < m; ++i) D(i, i) = -theta[i];
     B.combine({AX, X}, {I, D}, t1);
-    // residual norms of the wanted pairs
-    const Matrix RR = B.gram(t1, t1);
+    // residual norms of the wanted pairs (without a preconditioner W is R itself: X' W is asked for in the same trip
+    // -- the same kernels on the same operands, one wait fewer per iteration)
+    Matrix RR(m, m), XtW_early(m, m);
+    const bool early = !T;
+    if (early) {
+      const double *ga[2] = {t1, X}, *gb[2] = {t1, t1};
+      const int km[2] = {m, m};
+      double *out[2] = {RR.data(), XtW_early.data()};
+      B.chk(cora_gram_batch_dev(c, 2, ga, km, gb, km, out), "gram batch");
+    } else {
+      RR = B.gram(t1, t1);
+    }
     size_t nconv = 0;
     for (size_t k = 0; k < nev; ++k)
       if (std::sqrt(std::max(RR(k, k), 0.0)) <= tau * std::max(std::abs(theta[k]), 1e-300)) ++nconv;
@@ -212,7 +222,7 @@ LOBPCGResult LOBPCGSolver::run(const DeviceOperator &A, const std::optional<Devi
     else std::swap(W, t1);
     // W <- (I - X X^T) W, then orthonormalise W
     {
-      Matrix XtW = B.gram(X, W);
+      Matrix XtW = early ? XtW_early : B.gram(X, W);
       for (Index i = 0; i < XtW.size(); ++i) XtW.data()[i] = -XtW.data()[i];
       B.combine({W, X}, {I, XtW}, t1);
       Matrix G = B.gram(t1, t1);  // columns scaled to unit length, as above (a vanished column stays out)
