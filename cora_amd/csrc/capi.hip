@@ -1808,6 +1808,13 @@ int cora_axpy2_dev(cora_ctx *c, double a1, const double *dX1, double *dY1, doubl
   return CORA_OK;
 }
 
+int cora_fill_random_dev(cora_ctx *c, int k, unsigned long long seed, double *dX) {
+  NEED_DEVICE(c);
+  if (k <= 0 || k > kMaxLD || !dX) return fail(c, CORA_ERR_ARG, "bad arguments");
+  HIP_TRY(c, launch_fill_random(c->F.L.N, k, seed, c->d_api2int, dX, c->stream));
+  return CORA_OK;
+}
+
 int cora_axpby_cols_dev(cora_ctx *c, int k, double a, const double *dX, double b, double *dY) {
   NEED_DEVICE(c);
   if (k <= 0 || k > kMaxLD || !dX || !dY) return fail(c, CORA_ERR_ARG, "bad arguments");

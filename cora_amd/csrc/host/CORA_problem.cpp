@@ -380,11 +380,20 @@ static Scalar spectralNormEstimate(cora_ctx *c, Index N) {
     if (cora_spmm_dev(c, dX, k, dOut) != CORA_OK || cora_axpby_cols_dev(c, k, 0.0, dOut, -1.0, dOut) != CORA_OK)
       throw std::runtime_error(std::string("spectral norm estimate: ") + cora_last_error(c));
   };
-  const Matrix X0 = Matrix::Random(N, block, 12345);
-  // (only the Ritz value is wanted: the block stays on the device and goes with the solver)
+  // the random start block is drawn on the device (cora_fill_random_dev: the reference draws Matrix::Random on the host;
+  // which numbers they are does not matter to an estimate with tolerance 1e-2, and 450 k x 4 of them cost 3 ms to draw and
+  // 6 ms to upload).  Only the Ritz value is wanted: the block stays on the device and goes with the solver.
+  struct Start {
+    cora_ctx *c;
+    double *d = nullptr;
+    ~Start() { if (d) cora_dev_free(c, d); }
+  } start{c};
+  if (cora_dev_alloc(c, static_cast<int>(block), &start.d) != CORA_OK ||
+      cora_fill_random_dev(c, static_cast<int>(block), 12345ull, start.d) != CORA_OK)
+    throw std::runtime_error(std::string("spectral norm estimate: ") + cora_last_error(c));
   LOBPCGSolver solver(c, static_cast<int>(N));
-  const LOBPCGResult r = solver.run(negQ, std::nullopt, {HostColumns{X0.data(), static_cast<int>(block)}}, /*nev=*/1,
-                                    /*max_iters=*/100, /*tau=*/1e-2, std::nullopt, /*download=*/false);
+  const LOBPCGResult r = solver.run(negQ, std::nullopt, {HostColumns{nullptr, static_cast<int>(block), start.d, static_cast<int>(block)}},
+                                    /*nev=*/1, /*max_iters=*/100, /*tau=*/1e-2, std::nullopt, /*download=*/false);
   return -r.Theta(0);
 }
 

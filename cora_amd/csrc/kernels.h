@@ -238,6 +238,7 @@ hipError_t launch_rowop(const RowOpDev &op, int ld, const double *src0, const do
                         hipStream_t st, const RvTail *tail = nullptr);
 hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
                        double *partial, int nblocks, double *out, hipStream_t st);
+hipError_t launch_fill_random(int64_t N, int k, unsigned long long seed, const int32_t *api2int, double *x, hipStream_t st);
 hipError_t launch_gram_batch(int64_t row0, int64_t rows, int n, const double *const *A, const int *ka, const double *const *B,
                              const int *kb, double *partial, int nblocks, double *out, hipStream_t st);
 constexpr int kCombineKargMax = 400;  // coefficients that travel in the kernel's arguments (CombineCoef::kMax)

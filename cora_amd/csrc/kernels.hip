@@ -1394,6 +1394,24 @@ __global__ __launch_bounds__(256) void k_stpcg_direction(int64_t n, const StpcgS
     p[i] = fma(cv, v[i], cb * p[i]);
 }
 
+// x[row of API variable i][col] = a number in (-1, 1) that depends on (seed, i, col) only (splitmix64 of the triple) -- what an
+// upload of a host-drawn N x k block would leave, whatever the partition: the start block of an eigensolver run, made
+// where it is used (450 k x 4 doubles from the host were 3 ms to draw and 6 ms to upload)
+__global__ __launch_bounds__(256) void k_fill_random(int64_t N, int ld, int k, unsigned long long seed,
+                                                     const int32_t *__restrict__ api2int, double *__restrict__ x) {
+  const int64_t n = N * ld;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n; t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = t / ld;
+    const int col = static_cast<int>(t - i * ld);
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (static_cast<unsigned long long>(i) * 32ull + static_cast<unsigned long long>(col) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const double u = static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+    x[static_cast<size_t>(api2int[i]) * ld + col] = col < k ? 2.0 * u - 1.0 : 0.0;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_scale_rows(int64_t rows, int ld, const double *__restrict__ scale,
                                                     const double *__restrict__ x, double *__restrict__ y) {
   const int64_t n = rows * ld;
@@ -3593,6 +3611,13 @@ hipError_t launch_zero_row(double *x, size_t row, int ld, hipStream_t st) {
 
 namespace cora {
 #if CORA_TU & 2
+
+hipError_t launch_fill_random(int64_t N, int k, unsigned long long seed, const int32_t *api2int, double *x, hipStream_t st) {
+  if (N <= 0) return hipSuccess;
+  const int ld = ld_for(k);
+  hipLaunchKernelGGL(k_fill_random, dim3(grid_for(N * ld)), dim3(256), 0, st, N, ld, k, seed, api2int, x);
+  return hipGetLastError();
+}
 
 hipError_t launch_gram(int64_t row0, int64_t rows, const double *A, int ka, const double *B, int kb,
                        double *partial, int nblocks, double *out, hipStream_t st) {

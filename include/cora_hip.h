@@ -310,6 +310,9 @@ int cora_stpcg_warm_dev(cora_ctx *ctx, const double *dGrad, const double *dPg, d
                         double *dHp, int *iters, double *step_M_norm);
 /* Same for vectors allocated with k columns (cora_dev_alloc(ctx, k, ..)). */
 int cora_axpby_cols_dev(cora_ctx *ctx, int k, double a, const double *dX, double b, double *dY);
+/* dX (k columns, resident layout) = numbers in (-1, 1) that depend on (seed, variable, column) only -- the same block on
+ * every partition of the problem --: a start block for the eigensolver made on the device (the norm estimate of src/CORA_problem.cpp:556-578 starts from Matrix::Random). */
+int cora_fill_random_dev(cora_ctx *ctx, int k, unsigned long long seed, double *dX);
 int cora_copy_dev(cora_ctx *ctx, const double *dX, int k, double *dY);
 int cora_dot_dev(cora_ctx *ctx, const double *dA, const double *dB, int k,
                  double *out); /* synchronises the stream */
