@@ -482,6 +482,22 @@ CholeskyFactor::~CholeskyFactor() {
   }
 }
 
+void choleskyReserveStorage(size_t entries) {
+  if (entries < (1u << 20)) return;  // (small factors are not pooled)
+  CholeskyFactor F;  // (its destructor hands the storage to the pool, where choleskyAnalyze / choleskyFactor find it)
+  std::thread idx([&] {
+    try {
+      F.Li = takeStorage(g_pool_i, entries);
+    } catch (...) {  // (a reservation that fails is no reservation)
+    }
+  });
+  try {
+    F.Lx = takeStorage(g_pool_x, entries);
+  } catch (...) {
+  }
+  idx.join();
+}
+
 void choleskyAnalyze(const SparseMatrix &A, int m, const std::vector<int32_t> &perm, SymbolicCache *cache) {
   if (!cache || m <= 0) return;
   std::vector<int32_t> iperm(static_cast<size_t>(A.rows()), -1);

@@ -73,6 +73,10 @@ CholeskyFactor choleskyFactor(const SparseMatrix &A, int m, double shift, const 
  * time: the symbolic analysis goes into `cache` and storage for the factor is touched once and left in the pool, so the
  * factorisation that follows finds both (CORA::Problem::prepareCertification).  No-op without a cache. */
 void choleskyAnalyze(const SparseMatrix &A, int m, const std::vector<int32_t> &perm, SymbolicCache *cache);
+/** First touch of storage for a factor of up to `entries` entries, left in the pool the factorisation draws from: a guess
+ * made before the symbolic analysis knows the count (run beside it: the touch of 58 MB was 6 ms at the end of the chain
+ * the first factorisation waits for).  Too small a guess costs nothing but the touch. */
+void choleskyReserveStorage(size_t entries);
 
 /** Incomplete L D L^T of the symmetric (possibly INDEFINITE) matrix A[0:m, 0:m] + shift * I in the order perm --
  * the stand-in for Preconditioners::ILDL (libs/Preconditioners, un-vendored submodule; reference call

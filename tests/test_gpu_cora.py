@@ -61,7 +61,7 @@ def test_config3_staircase_on_the_10k_pose_graph():
 
     Where such a run ends is decided by rounding: every level runs TNT into its iteration limit on a chaotic trajectory
     from f0 = 2e12, and builds of rounds 2-5 have ended on 2 410.00 (the chi-square sized optimum; also the CPU oracle's own
-    staircase, profiles/r03_config3_cpu_oracle.txt), 9 049, 28 959, 30 146 and 39 333 -- all of them outcomes of the
+    staircase, profiles/r03_config3_cpu_oracle.txt), 9 049, 28 959, 30 146, 32 842 and 39 333 -- all of them outcomes of the
     reference's algorithm under the reference's limits.  So the end value is not compared with a number; it is PINNED
     STEP BY STEP: the same sequence of calls solveCORA makes is driven through the C ABI one step at a time
     (tests/test_gpu_staircase.py: TNT of every level in lockstep with the oracle, the certificate's decision against the
