@@ -221,6 +221,13 @@ int fail(cora_ctx *c, int code, const std::string &msg) {
     if ((c)->p <= 0) return fail((c), CORA_ERR_NOT_READY, "cora_set_rank not called"); \
   } while (0)
 
+// A kept trial product (cora_tnt_trial_dev) belongs to the CONTENTS of a vector, not to its address: every entry point that
+// can write a caller's vector, or hand its address out again, says so here (round-5 advice: an accept after such a write
+// silently took a stale Euclidean gradient).
+inline void wrote(cora_ctx *c, const void *p) {
+  if (c && p && p == c->trial_x) c->trial_x = nullptr;
+}
+
 template <typename T>
 hipError_t to_device(T **dptr, const std::vector<T> &v) {
   const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
@@ -811,6 +818,7 @@ int cora_dev_alloc(cora_ctx *c, int k, double **dptr) {
       break;
     }
   if (!*dptr) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(dptr), bytes));
+  wrote(c, *dptr);  // the allocator may return an address that was freed while a trial product of it was kept
   HIP_TRY(c, hipMemsetAsync(*dptr, 0, bytes, c->stream));
   for (auto &p : c->user_allocs)
     if (!p.first) {
@@ -823,6 +831,7 @@ int cora_dev_alloc(cora_ctx *c, int k, double **dptr) {
 
 int cora_dev_free(cora_ctx *c, double *dptr) {
   NEED_DEVICE(c);
+  wrote(c, dptr);
   constexpr size_t kPoolMax = 16;
   for (auto &p : c->user_allocs)
     if (p.first == dptr && dptr) {
@@ -840,6 +849,7 @@ int cora_dev_free(cora_ctx *c, double *dptr) {
 
 int cora_upload(cora_ctx *c, const double *host, int ld, int k, double *dptr) {
   NEED_DEVICE(c);
+  wrote(c, dptr);
   int rc = upload_impl(c, host, ld, k, dptr);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffer may be pageable
@@ -949,12 +959,14 @@ const double *cora_point_rgrad_dev(const cora_ctx *c) { return (c && c->have_poi
 
 int cora_spmm_dev(cora_ctx *c, const double *dX, int k, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
   return apply_product(c, dX, ld_for(k), EPI_NONE, dOut);
 }
 
 int cora_hvp_dev(cora_ctx *c, const double *dX, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   NEED_RANK(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dX || !dOut) return fail(c, CORA_ERR_ARG, "null pointer");
@@ -963,6 +975,7 @@ int cora_hvp_dev(cora_ctx *c, const double *dX, double *dOut) {
 
 int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dX || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
   return exchange_and_product(c, spmm_args(c, dX, dOut), ld_for(k), EPI_S);
@@ -970,6 +983,7 @@ int cora_certificate_product_dev(cora_ctx *c, const double *dX, int k, double *d
 
 int cora_tangent_space_projection_dev(cora_ctx *c, const double *dV, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   NEED_RANK(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   HIP_TRY(c, launch_tangent_project(row_args(c), c->ld, c->d_Y, dV, nullptr, dOut, c->stream));
@@ -1129,7 +1143,15 @@ static int install_factor(cora_ctx *c, cora_ctx::DevFactor &f, int m, const int3
       H.b_hdr.resize(H.b_hdr.size() + 8, 0);
       HIP_TRY(c, up(&Q.fwd.hdr, H.f_hdr));
       HIP_TRY(c, up(&Q.fwd.idx, H.f_idx));
-      static const bool f32 = std::getenv("CORA_SUB_F32") != nullptr;  // lab: with a -DCORA_SUB_F32=1 build of the sweeps
+      // LAB BUILDS ONLY (-DCORA_SUB_F32=1 on capi.hip AND the kernels_tri units: the sweeps then read fp32 coefficients).  A
+      // compile-time constant since round 6: as an environment switch of the product library it uploaded floats into a buffer
+      // the default kernels read as doubles.  Measured at 10^5 poses, p = 5 (profiles/r06_kernel_evolution.md): forward sweep
+      // 35.8 -> 33.3 us, backward 35.2 -> 34.6, iteration 110.5 -> 107.2 us (3 %): the sweeps are not bound by the factor's bytes.
+#if defined(CORA_SUB_F32) && CORA_SUB_F32
+      constexpr bool f32 = true;
+#else
+      constexpr bool f32 = false;
+#endif
       if (f32) {
         std::vector<float> ff(H.f_val.begin(), H.f_val.end()), fb(H.b_val.begin(), H.b_val.end());
         HIP_TRY(c, up(reinterpret_cast<float **>(const_cast<double **>(&Q.fwd.val)), ff));
@@ -1715,6 +1737,7 @@ int cora_aux_set_cholesky(cora_ctx *c, int m, const int32_t *Lp, const int32_t *
 
 int cora_aux_solve_dev(cora_ctx *c, const double *dB, int k, double *dX) {
   NEED_DEVICE(c);
+  wrote(c, dX);
   if (!c->aux_f.ready) return fail(c, CORA_ERR_NOT_READY, "no factor installed (cora_aux_set_cholesky)");
   if (!dB || !dX || k <= 0 || k > kMaxLD || dB == dX) return fail(c, CORA_ERR_ARG, "bad arguments");
   return factor_solve(c, c->aux_f, ld_for(k), dB, dX);
@@ -1734,6 +1757,7 @@ int cora_set_formulation(cora_ctx *c, int implicit) {
 
 int cora_translation_explicit_dev(cora_ctx *c, const double *dY, int k, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   if (!dY || !dOut || k <= 0 || k > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
   if (!c->implicit_f.ready)
     return fail(c, CORA_ERR_NOT_READY, "implicit formulation needs cora_implicit_set_cholesky");
@@ -1746,6 +1770,7 @@ int cora_translation_explicit_dev(cora_ctx *c, const double *dY, int k, double *
 
 int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   NEED_RANK(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   const double *scale = nullptr;
@@ -1777,6 +1802,7 @@ int cora_precondition_projected_dev(cora_ctx *c, const double *dV, double *dOut)
 
 int cora_retract_dev(cora_ctx *c, const double *dV, double alpha, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   NEED_RANK(c);
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, c->d_Y, dV, alpha, dOut, c->stream));
@@ -1785,6 +1811,7 @@ int cora_retract_dev(cora_ctx *c, const double *dV, double alpha, double *dOut) 
 
 int cora_project_to_manifold_dev(cora_ctx *c, const double *dA, double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   NEED_RANK(c);
   HIP_TRY(c, launch_project_manifold(row_args(c), c->ld, dA, nullptr, 0.0, dOut, c->stream));
   return CORA_OK;
@@ -1792,6 +1819,7 @@ int cora_project_to_manifold_dev(cora_ctx *c, const double *dA, double *dOut) {
 
 int cora_axpby_dev(cora_ctx *c, double a, const double *dX, double b, double *dY) {
   NEED_DEVICE(c);
+  wrote(c, dY);
   NEED_RANK(c);
   const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
   HIP_TRY(c, launch_axpby(c->F.L.local_rows * c->ld, a, dX + off, b, dY + off, c->stream));
@@ -1801,6 +1829,8 @@ int cora_axpby_dev(cora_ctx *c, double a, const double *dX, double b, double *dY
 int cora_axpy2_dev(cora_ctx *c, double a1, const double *dX1, double *dY1, double a2, const double *dX2,
                    double *dY2) {
   NEED_DEVICE(c);
+  wrote(c, dY1);
+  wrote(c, dY2);
   NEED_RANK(c);
   if (!dX1 || !dY1 || !dX2 || !dY2 || dY1 == dY2) return fail(c, CORA_ERR_ARG, "bad arguments");
   const size_t off = static_cast<size_t>(c->F.L.base) * c->ld;
@@ -1810,6 +1840,7 @@ int cora_axpy2_dev(cora_ctx *c, double a1, const double *dX1, double *dY1, doubl
 
 int cora_fill_random_dev(cora_ctx *c, int k, unsigned long long seed, double *dX) {
   NEED_DEVICE(c);
+  wrote(c, dX);
   if (k <= 0 || k > kMaxLD || !dX) return fail(c, CORA_ERR_ARG, "bad arguments");
   HIP_TRY(c, launch_fill_random(c->F.L.N, k, seed, c->d_api2int, dX, c->stream));
   return CORA_OK;
@@ -1817,6 +1848,7 @@ int cora_fill_random_dev(cora_ctx *c, int k, unsigned long long seed, double *dX
 
 int cora_axpby_cols_dev(cora_ctx *c, int k, double a, const double *dX, double b, double *dY) {
   NEED_DEVICE(c);
+  wrote(c, dY);
   if (k <= 0 || k > kMaxLD || !dX || !dY) return fail(c, CORA_ERR_ARG, "bad arguments");
   const int ld = ld_for(k);
   const size_t off = static_cast<size_t>(c->F.L.base) * ld;
@@ -1826,6 +1858,7 @@ int cora_axpby_cols_dev(cora_ctx *c, int k, double a, const double *dX, double b
 
 int cora_copy_dev(cora_ctx *c, const double *dX, int k, double *dY) {
   NEED_DEVICE(c);
+  wrote(c, dY);
   HIP_TRY(c, hipMemcpyAsync(dY, dX, vec_bytes(c, ld_for(k)), hipMemcpyDeviceToDevice, c->stream));
   return CORA_OK;
 }
@@ -1887,6 +1920,7 @@ static int stpcg_run(cora_ctx *c, const double *dGrad, const double *dPg, double
   if (!c->have_point) return fail(c, CORA_ERR_NOT_READY, "no current point (cora_set_point)");
   if (!dGrad || !dS || !dR || !dV || !dP || !dHp || !iters || !step_M_norm || max_iters < 0)
     return fail(c, CORA_ERR_ARG, "bad arguments");
+  for (const double *w : {dS, dR, dV, dP, dHp}) wrote(c, w);
   // Partitioned handle: the same fused iteration, every rank on its own rows, with the library's own communication
   // (cora_comm_create_*): the operand's remote rows are exchanged before the product, and the three inner products are
   // summed over the ranks ON THE DEVICE -- kappa after the product, <r, r> and <r, v> together after the projection --
@@ -2404,6 +2438,7 @@ int cora_world(const cora_ctx *c) { return c ? c->F.L.world : 0; }
 
 int cora_pack_rows_dev(cora_ctx *c, const double *dX, int ld, const int32_t *d_rows, int64_t n, double *dPacked) {
   NEED_DEVICE(c);
+  wrote(c, dPacked);
   if (!dX || !d_rows || !dPacked || ld <= 0 || n < 0) return fail(c, CORA_ERR_ARG, "bad arguments");
   HIP_TRY(c, launch_move_rows(0, n, ld, d_rows, dX, dPacked, c->stream));
   return CORA_OK;
@@ -2411,6 +2446,7 @@ int cora_pack_rows_dev(cora_ctx *c, const double *dX, int ld, const int32_t *d_r
 
 int cora_scatter_rows_dev(cora_ctx *c, const double *dPacked, int ld, const int32_t *d_rows, int64_t n, double *dX) {
   NEED_DEVICE(c);
+  wrote(c, dX);
   if (!dX || !d_rows || !dPacked || ld <= 0 || n < 0) return fail(c, CORA_ERR_ARG, "bad arguments");
   HIP_TRY(c, launch_move_rows(1, n, ld, d_rows, dPacked, dX, c->stream));
   return CORA_OK;
@@ -2418,6 +2454,7 @@ int cora_scatter_rows_dev(cora_ctx *c, const double *dPacked, int ld, const int3
 
 int cora_copy_rows_dev(cora_ctx *c, const double *dSrc, int ld, const int32_t *d_rows, int64_t n, double *dDst) {
   NEED_DEVICE(c);
+  wrote(c, dDst);
   if (!dSrc || !d_rows || !dDst || ld <= 0 || n < 0) return fail(c, CORA_ERR_ARG, "bad arguments");
   HIP_TRY(c, launch_move_rows(2, n, ld, d_rows, dSrc, dDst, c->stream));
   return CORA_OK;
@@ -2425,6 +2462,7 @@ int cora_copy_rows_dev(cora_ctx *c, const double *dSrc, int ld, const int32_t *d
 
 int cora_copy_shard_dev(cora_ctx *c, const double *dSrc, int ld, int shard, double *dDst) {
   NEED_DEVICE(c);
+  wrote(c, dDst);
   if (!dSrc || !dDst || ld <= 0 || shard < 0 || shard >= c->F.L.world) return fail(c, CORA_ERR_ARG, "bad arguments");
   const size_t off = static_cast<size_t>(shard) * c->F.L.shard_rows * ld;
   HIP_TRY(c, hipMemcpyAsync(dDst + off, dSrc + off, static_cast<size_t>(c->F.L.shard_rows) * ld * sizeof(double),
@@ -2544,6 +2582,7 @@ int cora_gram_batch_dev(cora_ctx *c, int n, const double *const *dA, const int *
 int cora_combine_dev(cora_ctx *c, int n, const double *const *dX, const int *k, const double *const *C, int kout,
                      double *dOut) {
   NEED_DEVICE(c);
+  wrote(c, dOut);
   if (n < 1 || n > 4 || !dX || !k || !C || !dOut || kout <= 0 || kout > kMaxLD) return fail(c, CORA_ERR_ARG, "bad arguments");
   std::vector<double> coef;
   int coff[4] = {0, 0, 0, 0};

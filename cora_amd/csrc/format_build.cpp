@@ -536,7 +536,14 @@ void build_format(int d, int n, int r, int nt, const int32_t *rowptr,
     std::vector<RowRef> rows;
     rows.reserve(L.nl_ranges);
     for (int64_t i = 0; i < L.nl_ranges; ++i) rows.push_back(local_row(L.rng_base + i));
-    const bool lab_skip = std::getenv("CORA_LAB_SKIP_RANGE_SLICES") != nullptr;  // LAB (wrong range rows): what the range slices cost a launch
+    // LAB BUILDS ONLY (-DCORA_LAB_BUILD): a launch without the range slices -- WRONG range rows -- measured what folding them
+    // into the pose slices could gain at best (round 5: nothing).  Not in the product library: a user who set the variable got
+    // silent garbage.
+#ifdef CORA_LAB_BUILD
+    const bool lab_skip = std::getenv("CORA_LAB_SKIP_RANGE_SLICES") != nullptr;
+#else
+    constexpr bool lab_skip = false;
+#endif
     for (int64_t k0 = 0; k0 < L.nl_ranges && !lab_skip; k0 += kWave) {
       const int64_t cnt = std::min<int64_t>(kWave, L.nl_ranges - k0);
       emit_slice(F, rows, k0, k0 + cnt, kSliceOblique,

@@ -6,7 +6,7 @@
 
 namespace CORA {
 
-CholFactorPtrVector getBlockCholeskyFactorization(const SparseMatrix &A, const std::vector<int> &block_sizes) {
+CholFactorPtrVector getBlockCholeskyFactorization(const SparseMatrix &A, const VectorXi &block_sizes) {
   const long sum = std::accumulate(block_sizes.begin(), block_sizes.end(), 0L);
   if (sum != A.rows())
     throw std::invalid_argument("The block sizes must sum to A.rows() for the CORA block Cholesky preconditioner. "

@@ -19,7 +19,7 @@ using CholFactorPtrVector = std::vector<CholFactorPtr>;
 /** LL^T of every diagonal block of A; block_sizes must sum to A.rows().  The blocks are the documented
  * ones, block b starting where block b-1 ends (the reference's loop never advances its block_start,
  * src/CORA_preconditioners.cpp:30-41, and factors the first block again: not reproduced). */
-CholFactorPtrVector getBlockCholeskyFactorization(const SparseMatrix &A, const std::vector<int> &block_sizes);
+CholFactorPtrVector getBlockCholeskyFactorization(const SparseMatrix &A, const VectorXi &block_sizes);
 
 /** Block-wise solve; rhs has as many rows as the factors together, or one more, in which case the last row of
  * the result is zero (the pinned translation, :46-83). */

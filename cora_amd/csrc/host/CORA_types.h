@@ -51,6 +51,34 @@ class Matrix {
  public:
   Matrix() = default;
   Matrix(Index r, Index c) : rows_(r), cols_(c), a_(static_cast<size_t>(r * c), 0.0) {}
+  /** `CORA::Vector b(n)` (Eigen's VectorXd(n)): n x 1, zero-filled here (Eigen leaves it uninitialised). */
+  explicit Matrix(Index n) : Matrix(n, 1) {}
+  /** Dense copy of a sparse matrix, implicit as in Eigen (the reference's tests/test.cpp:206 hands a SparseMatrix to
+   * blockCholeskySolve's `const Matrix &rhs`). */
+  Matrix(const SparseMatrix &S);  // NOLINT(runtime/explicit)
+  /** Eigen's comma initialiser, `v << 1.0, 2.0, 3.0;` -- row by row (tests/test.cpp:70,212). */
+  class CommaInit {
+    Matrix &m_;
+    Index k_ = 0;
+
+   public:
+    CommaInit(Matrix &m, Scalar first) : m_(m) { put(first); }
+    CommaInit &operator,(Scalar v) {
+      put(v);
+      return *this;
+    }
+
+   private:
+    void put(Scalar v) {
+      if (k_ >= m_.size()) throw std::out_of_range("Matrix <<: more coefficients than entries");
+      m_(k_ / m_.cols(), k_ % m_.cols()) = v;
+      ++k_;
+    }
+  };
+  CommaInit operator<<(Scalar first) { return CommaInit(*this, first); }
+  /** Inverse by Gaussian elimination with partial pivoting (Eigen's MatrixBase::inverse(); small dense matrices of the
+   * tests only: tests/test.cpp:56,112,191). */
+  Matrix inverse() const;
   static Matrix Zero(Index r, Index c) { return Matrix(r, c); }
   static Matrix Identity(Index r, Index c) {
     Matrix m(r, c);
@@ -215,6 +243,70 @@ template <typename T, typename = typename std::enable_if<std::is_arithmetic<T>::
 inline Matrix operator*(T s, const Matrix &m) { return m * s; }
 typedef Matrix Vector;  // N x 1
 
+inline Matrix Matrix::inverse() const {
+  if (rows_ != cols_) throw std::invalid_argument("Matrix::inverse: not square");
+  const Index n = rows_;
+  Matrix A = *this, B = Identity(n, n);
+  for (Index k = 0; k < n; ++k) {
+    Index piv = k;
+    for (Index i = k + 1; i < n; ++i)
+      if (std::fabs(A(i, k)) > std::fabs(A(piv, k))) piv = i;
+    if (A(piv, k) == 0.0) throw std::runtime_error("Matrix::inverse: singular");
+    if (piv != k)
+      for (Index j = 0; j < n; ++j) {
+        std::swap(A(k, j), A(piv, j));
+        std::swap(B(k, j), B(piv, j));
+      }
+    const Scalar inv = 1.0 / A(k, k);
+    for (Index i = 0; i < n; ++i) {
+      if (i == k) continue;
+      const Scalar f = A(i, k) * inv;
+      if (f == 0.0) continue;
+      for (Index j = k; j < n; ++j) A(i, j) -= f * A(k, j);
+      for (Index j = 0; j < n; ++j) B(i, j) -= f * B(k, j);
+    }
+    for (Index j = k; j < n; ++j) A(k, j) *= inv;
+    for (Index j = 0; j < n; ++j) B(k, j) *= inv;
+  }
+  return B;
+}
+
+/** Eigen::VectorXi as the reference uses it (include/CORA/CORA_types.h:44; block sizes of getBlockCholeskyFactorization,
+ * tests/test.cpp:50-51,166-167): a vector of ints with Eigen's size constructor, comma initialiser and operator(). */
+class VectorXi : public std::vector<int> {
+ public:
+  VectorXi() = default;
+  explicit VectorXi(Index n) : std::vector<int>(static_cast<size_t>(n), 0) {}
+  VectorXi(const std::vector<int> &v) : std::vector<int>(v) {}  // NOLINT(runtime/explicit)
+  VectorXi(std::initializer_list<int> v) : std::vector<int>(v) {}
+  class CommaInit {
+    VectorXi &v_;
+    size_t k_ = 0;
+
+   public:
+    CommaInit(VectorXi &v, int first) : v_(v) { put(first); }
+    CommaInit &operator,(int x) {
+      put(x);
+      return *this;
+    }
+
+   private:
+    void put(int x) {
+      if (k_ >= v_.std::vector<int>::size()) throw std::out_of_range("VectorXi <<: more coefficients than entries");
+      v_[k_++] = x;
+    }
+  };
+  CommaInit operator<<(int first) { return CommaInit(*this, first); }
+  Index size() const { return static_cast<Index>(std::vector<int>::size()); }
+  int &operator()(Index i) { return (*this)[static_cast<size_t>(i)]; }
+  int operator()(Index i) const { return (*this)[static_cast<size_t>(i)]; }
+  int sum() const {
+    int s = 0;
+    for (int x : *this) s += x;
+    return s;
+  }
+};
+
 /** Row-major CSR with int32 indices: the layout of the reference's
  * Eigen::SparseMatrix<Scalar, Eigen::RowMajor> (include/CORA/CORA_types.h:70). */
 struct Triplet {
@@ -237,6 +329,31 @@ class SparseMatrix {
   const int32_t *outerIndexPtr() const { return outer.data(); }
   const int32_t *innerIndexPtr() const { return inner.data(); }
   const Scalar *valuePtr() const { return values.data(); }
+
+  /** Eigen's element-wise interface (the reference's tests/test.cpp:29-47,99-107,153-187 builds its matrices with it).  The
+   * matrix is always kept compressed, so insert() moves the entries behind it -- meant for the small matrices of tests --
+   * and makeCompressed() has nothing to do.  The reference returned by insert() / coeffRef() is valid until the next one. */
+  Scalar &insert(Index i, Index j) {
+    int32_t at;
+    if (find(i, j, &at)) throw std::invalid_argument("SparseMatrix::insert: the entry exists (use coeffRef)");
+    inner.insert(inner.begin() + at, static_cast<int32_t>(j));
+    values.insert(values.begin() + at, 0.0);
+    for (Index r = i + 1; r <= rows_; ++r) outer[static_cast<size_t>(r)]++;
+    return values[static_cast<size_t>(at)];
+  }
+  Scalar &coeffRef(Index i, Index j) {
+    int32_t at;
+    return find(i, j, &at) ? values[static_cast<size_t>(at)] : insert(i, j);
+  }
+  Scalar coeff(Index i, Index j) const {
+    int32_t at;
+    return find(i, j, &at) ? values[static_cast<size_t>(at)] : 0.0;
+  }
+  void makeCompressed() {}
+  bool isCompressed() const { return true; }
+  SparseMatrix operator*(const SparseMatrix &o) const { return times(nullptr, o); }
+  /** Eigen's SparseMatrixBase::isApprox: |a - b|_F <= prec min(|a|_F, |b|_F). */
+  bool isApprox(const SparseMatrix &o, Scalar prec = 1e-12) const;
 
   /** Duplicates are summed (in the order they were given) and structural zeros kept, like Eigen's setFromTriplets.
    * Rows are formed by a counting sort, columns sorted inside each row: linear in the number of triplets (the
@@ -345,6 +462,18 @@ class SparseMatrix {
       for (int32_t q = outer[static_cast<size_t>(i)]; q < outer[static_cast<size_t>(i) + 1]; ++q) D(i, inner[q]) += values[q];
     return D;
   }
+
+ private:
+  /** Position of (i, j) in inner / values, or where it would go. */
+  bool find(Index i, Index j, int32_t *at) const {
+    if (i < 0 || i >= rows_ || j < 0 || j >= cols_) throw std::out_of_range("SparseMatrix: index out of range");
+    const auto b = inner.begin() + outer[static_cast<size_t>(i)], e = inner.begin() + outer[static_cast<size_t>(i) + 1];
+    const auto it = std::lower_bound(b, e, static_cast<int32_t>(j));
+    *at = static_cast<int32_t>(it - inner.begin());
+    return it != e && *it == j;
+  }
+
+ public:
   Matrix operator*(const Matrix &X) const {  // CPU product for tiny host-side checks only
     Matrix r(rows_, X.cols());
     for (Index j = 0; j < X.cols(); ++j)
@@ -358,6 +487,11 @@ class SparseMatrix {
   }
 };
 
+inline Matrix::Matrix(const SparseMatrix &S) { *this = S.toDense(); }
+inline bool SparseMatrix::isApprox(const SparseMatrix &o, Scalar prec) const {
+  if (rows_ != o.rows_ || cols_ != o.cols_) return false;
+  return toDense().isApprox(o.toDense(), prec);
+}
 inline SparseMatrix Matrix::sparseView() const {
   std::vector<Triplet> t;
   for (Index i = 0; i < rows_; ++i)

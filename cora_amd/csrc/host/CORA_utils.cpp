@@ -185,7 +185,11 @@ CertResults fast_verification(const SparseMatrix &S, Scalar eta, const std::vect
     // can only improve on it.
     if (lab) lab->reached_step3 = true;
     const size_t budget3 = static_cast<size_t>((1.0 - unprecon_iter_frac) * max_iters);
-    const bool seeded = !F.negative_direction.empty() && (!lab || lab->seed_negative_direction);
+    // (the seed is this build's addition to the reference's order -- same stopping rule, a different x -- and can be
+    // switched off: Problem::setVerificationLab / FastVerificationLab per call, CORA_NO_PIVOT_SEED=1 for a whole process;
+    // without it the search is the reference's own: bootstrap block, then the ILDL-preconditioned run, :112-167)
+    const bool seeded = !F.negative_direction.empty() && (!lab || lab->seed_negative_direction) &&
+                        std::getenv("CORA_NO_PIVOT_SEED") == nullptr;
     std::vector<HostColumns> X0s = X0;
     if (seeded) {
       if (x0_cols >= 24) {  // no room for one more column: the seed takes the place of the last one

@@ -254,7 +254,12 @@ int cora_objective_dev(cora_ctx *ctx, const double *dY, double *f);
 int cora_tnt_trial_dev(cora_ctx *ctx, const double *dS, double *dHs, double *dXprop, double out[4]);
 /* Make dX the current point (cora_set_point_dev), dPg = precondition(grad) projected, and
  * out = { f, <grad, grad>, <Pg, Pg>, <grad, Pg> } in one wait.  When dX is the vector the last cora_tnt_trial_dev
- * filled (one GPU), Q X is taken from that call: the pointer cora_point_egrad_dev returns changes. */
+ * filled (one GPU), Q X is taken from that call: the pointer cora_point_egrad_dev returns changes.
+ * CONTRACT of the reuse: the kept product belongs to the CONTENTS dXprop had when cora_tnt_trial_dev returned.  Every entry
+ * point of this header that writes a caller's vector (cora_upload, the outputs of every *_dev operation, cora_stpcg_*_dev's
+ * work vectors) or can hand its address out again (cora_dev_free / cora_dev_alloc) drops it when that vector is dXprop, and
+ * the accept then forms Q X again.  A write the library cannot see (the caller's own kernel, hipMemcpy into dXprop) must be
+ * followed by cora_set_point_dev instead of this call. */
 int cora_tnt_accept_dev(cora_ctx *ctx, const double *dX, double *dPg, double out[4]);
 
 /* f at the current point (local shard contribution when partitioned). */
@@ -469,12 +474,52 @@ int cora_debug_stpcg_path(const cora_ctx *ctx);
  * device-resident STPCG iterations captured once as a hipGraph and replayed (one GPU, fused forms).
  * out[0] = graphs captured so far, out[1] = batches replayed (both 0 unless the switch is on). */
 int cora_debug_stpcg_graph(const cora_ctx *ctx, long out[2]);
-/* Measurement switches of cora_stpcg_dev's host loop (environment, read per solve; none changes what is computed --
- * tests/test_gpu_solver.py runs one problem under each): CORA_STPCG_DEPTH=0|1 (the host waits for every iteration | runs one
- * whole iteration ahead; default: the next iteration's product ahead on small problems, 0 at 10^5 poses and above),
- * CORA_STPCG_BATCH=n (n iterations enqueued, all waited for: the form partitioned handles always use),
- * CORA_NO_TNT_FUSE=1 (cora_tnt_accept_dev forms Q X again), CORA_NO_RESIDUAL_SLOTS=1 (the one-explicit-inverse iteration
- * finishes <r, r> with a ticket in its residual pass). */
+/* EVERY environment variable the library reads (round 6: one table; `grep -rn 'getenv("CORA_' cora_amd/csrc` finds the same
+ * names and no others).  NONE changes what is computed beyond the rounding of a different (equally valid) order of operations;
+ * the two lab switches that produced wrong results (CORA_LAB_SKIP_RANGE_SLICES, the CORA_SUB_F32 upload) are no longer in the
+ * product library: they exist only in builds with -DCORA_LAB_BUILD / -DCORA_SUB_F32=1.
+ *
+ * Forms of the STPCG iteration (all tested against each other, tests/test_gpu_solver.py; read per solve):
+ *   CORA_NO_FUSE=1            one pass per operation instead of the fused vector passes
+ *   CORA_NO_SWEEP_FUSE=1      vector passes are not folded into the sweeps of the two-stage Cholesky solve
+ *   CORA_NO_INVERSE_FUSE=1    ... nor into the two products of a one-explicit-inverse plan
+ *   CORA_NO_RESIDUAL_SLOTS=1  the one-explicit-inverse iteration finishes <r, r> with a ticket in its residual pass
+ *   CORA_NO_KAPPA_FOLD=1, CORA_KAPPA_FOLD_MAX=n (4096)   kappa = <p, Hp> gets a launch of its own (always | above n partials)
+ *   CORA_NO_TNT_FUSE=1        cora_tnt_accept_dev forms Q X again instead of taking the trial's
+ * Host loop of cora_stpcg_dev (same numbers, tests run one problem under each):
+ *   CORA_STPCG_DEPTH=0|1      the host waits for every iteration | runs one whole iteration ahead (default: the next
+ *                             iteration's product ahead on small problems, 0 at 10^5 poses and above)
+ *   CORA_STPCG_AHEAD=0|1      forces the product-ahead form off | on
+ *   CORA_STPCG_BATCH=n        n iterations enqueued, all waited for (the form partitioned handles always use)
+ *   CORA_STPCG_GRAPH=1        opt-in hipGraph replay of batches (measured slower on this part)
+ * Partitioned handles:
+ *   CORA_NO_EXCHANGE_OVERLAP=1, CORA_EXCHANGE_OVERLAP_MIN_SLICES=n (2048)   interior slices beside the exchange: never | from n
+ *                             interior slices per rank
+ *   CORA_IMPLICIT_WHOLE_GATHER=1   the implicit formulation gathers whole shards instead of the packed translation rows
+ * Format of Q and the product's launch (same products to rounding; bit-identical where the order of sums is unchanged):
+ *   CORA_CHAIN_SLICES=0       pose slices in the plain layout (all columns explicit)
+ *   CORA_SLICE_LJF=...        order of the slices inside an XCD's range (longest first)
+ *   CORA_SPMM_EXTRA_LDS=bytes, CORA_SPMM_WINDOW_MIN_SLICES=n   occupancy / LDS-window experiments of k_spmm
+ *   CORA_FORMAT_THREADS=n, CORA_FORMAT_TIMING=1   host threads of the format builder; its phase times on stderr
+ * Solve plan of a Cholesky factor (trisolve_build.cpp; every plan solves the same system, tests/test_trisolve_cpu.py):
+ *   CORA_TRI_SUB=0|1          force the explicit-stage form | the substitution-block form
+ *   CORA_TRI_SN_CAP=n         rows per supernode whose diagonal block is inverted (default: a pose)
+ *   CORA_TRI_UNFOLD_MIN=n     aux sums folded into the last stage's first product below n extra entries
+ *   CORA_TRI_LEVEL_CAP=x      (round 6) subtrees deeper than x times the median are not taken whole as solve blocks
+ *   CORA_TRI_THREADS=n, CORA_TRI_CHECK_ETREE=1, CORA_TRI_TIMING=1   builder threads; elimination tree computed both ways
+ *                             and compared; phase times of set-up on stderr
+ *   CORA_SUB_IO_LISTS=1, CORA_IO_STATS=1   row I/O of the sweeps from index lists instead of run tables; run statistics
+ * Host factorisation and ordering (sparse_cholesky.cpp, CORA_problem.cpp; bit-identical factors in every setting):
+ *   CORA_CHOL_THREADS=n, CORA_SYMBOLIC_THREADS=n, CORA_CHOL_NO_SYMBOLIC_CACHE=1, CORA_CHOL_NO_TRAILING_GROUP=1
+ *   CORA_ND_LEAF=n            poses per leaf of the nested dissection (2)
+ *   CORA_REG_CHOLESKY_MAX_COND=x   kappa_max of the regularised preconditioner (1e6, src/CORA_problem.cpp:551)
+ * solveCORA (host/CORA.cpp, CORA_utils.cpp):
+ *   CORA_NO_CERT_PREPARE=1    the first certification's pattern work is not prepared beside the first TNT solve
+ *   CORA_NO_CERT_SPECULATION=1   the eigensolver's first stage does not run beside the host's PSD test
+ *   CORA_NO_PIVOT_SEED=1      (round 6) fast_verification keeps the reference's plain order after a failed factorisation --
+ *                             LOBPCG from the bootstrap block, then the ILDL branch (src/CORA_utils.cpp:112-167) -- instead of
+ *                             seeding the block with the failed pivot's direction of non-positive curvature
+ *   CORA_TRACE_BITS=1         the bits of every stage of the staircase on stderr (determinism bisection) */
 
 int cora_debug_format_spmm_host(const cora_ctx *ctx, const double *X, int ldx,
                                 int k, double *out, int ldo);

@@ -73,5 +73,13 @@ void check_that(const T &value, const M &matcher, bool fatal, const char *expr, 
 #define REQUIRE(expr) CatchShim::report(static_cast<bool>(expr), true, #expr, __FILE__, __LINE__)
 #define CHECK_FALSE(expr) CatchShim::report(!static_cast<bool>(expr), false, "!(" #expr ")", __FILE__, __LINE__)
 #define REQUIRE_FALSE(expr) CatchShim::report(!static_cast<bool>(expr), true, "!(" #expr ")", __FILE__, __LINE__)
+// INFO: Catch2 attaches the message to the next failing assertion of the scope; here it is printed when reached (the reference's
+// tests/test.cpp:121-124 only reaches its INFO lines after the REQUIRE they explain has already passed or thrown).
+#define INFO(msg)                                 \
+  do {                                            \
+    std::ostringstream catch_shim_info;           \
+    catch_shim_info << msg;                       \
+    std::cout << "  info: " << catch_shim_info.str() << std::endl; \
+  } while (0)
 #define CHECK_THAT(value, matcher) CatchShim::check_that(value, matcher, false, #value ", " #matcher, __FILE__, __LINE__)
 #define REQUIRE_THAT(value, matcher) CatchShim::check_that(value, matcher, true, #value ", " #matcher, __FILE__, __LINE__)

@@ -97,21 +97,26 @@ def test_solve_implicit_plaza2():
                                                                             res["hvps"], res["seconds"]))
 
 
-def test_reference_call_sequence_binary_solves_plaza2(tmp_path):
-    """The reference's examples/main.cpp call sequence (tests/drop_in/reference_call_sequence.cpp, written against
-    <CORA/...>), compiled against include/ and libcora_hip.so, run on the reference's own Plaza2 file."""
+def test_example_binary_solves_plaza2(tmp_path):
+    """The repository's examples/main.cpp -- the call sequence of the reference's example (parse, updateProblemData, random
+    start, solveCORA(max_rank 10), alignEstimateToOrigin) -- compiled against include/ and libcora_hip.so, run on the
+    reference's own Plaza2 file.  (The reference's own examples/main.cpp is compiled unmodified where the reference tree is
+    mounted: tests/test_dropin_build.py.)"""
+    import re
     import subprocess
     from cora_amd import build as _build
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = _build.build()
-    exe = str(tmp_path / "seq")
+    exe = str(tmp_path / "cora_main")
     subprocess.run([_build.HIPCC, "-O1", "-std=c++17", "-I" + os.path.join(root, "include"),
-                    os.path.join(root, "tests", "drop_in", "reference_call_sequence.cpp"), "-L" + os.path.dirname(lib),
-                    "-lcora_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True, timeout=600)
+                    "-I" + os.path.join(root, "cora_amd", "csrc", "host"), os.path.join(root, "examples", "main.cpp"),
+                    "-L" + os.path.dirname(lib), "-lcora_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe],
+                   check=True, timeout=600)
     r = subprocess.run([exe, os.path.join(DATA, "plaza2.pyfg")], stdout=subprocess.PIPE, text=True, timeout=300, check=True)
-    line = [l for l in r.stdout.splitlines() if l.startswith("cost ")][-1].split()
-    assert abs(float(line[1]) - 734.328) < 2e-3      # run_utils/parse_data.py:40 of the reference
-    assert int(line[3]) == 14084
+    m = re.search(r"final cost ([0-9.eE+-]+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    assert abs(float(m.group(1)) - 734.328) < 2e-3      # run_utils/parse_data.py:40 of the reference
+    assert re.search(r"N 14084\b", r.stdout), r.stdout[-2000:]
 
 
 @pytest.mark.parametrize("name", ["plaza1", "tiers", "mrclam3b", "mrclam5a", "mrclam6"])

@@ -326,6 +326,66 @@ def test_tnt_trial_and_accept_are_the_separate_calls_bit_for_bit(precond):
         h.dev_free(q)
 
 
+def test_a_write_to_the_trial_vector_drops_the_kept_product():
+    """Round-5 advice: cora_tnt_accept_dev took the product cora_tnt_trial_dev kept whenever the POINTER matched -- after an
+    upload into the trial vector, an operation with it as output, or a free / alloc pair that hands the same address out again,
+    the accept silently used the Euclidean gradient of the OLD contents.  Every such write now drops the kept product
+    (`wrote` in capi.hip; contract in include/cora_hip.h): the accept equals cora_set_point_dev at the new contents."""
+    P = host.Problem.synthetic(dim=3, n_poses=1200, n_landmarks=4, n_ranges=600, seed=9, precond=capi.PRECOND_JACOBI)
+    P.update()
+    p = 4
+    P.set_rank(p)
+    P.precond_info()
+    dm = P.dims()
+    h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
+    rng = np.random.default_rng(11)
+    Y0 = rng.uniform(-1, 1, (dm["N"], p))
+    Z = rng.uniform(-1, 1, (dm["N"], p))
+
+    def fresh():
+        y, s, hs, xp, pg, z = [h.dev_alloc(p) for _ in range(6)]
+        h.upload(Y0, y)
+        h.project_to_manifold_dev(y, y)
+        h.set_point_dev(y)
+        h.upload(1e-2 * Y0[::-1].copy(), s)
+        h.tangent_space_projection_dev(s, s)
+        h.upload(Z, z)
+        h.project_to_manifold_dev(z, z)
+        h.tnt_trial_dev(s, hs, xp)
+        return y, s, hs, xp, pg, z
+
+    def reference(z):
+        h.set_point_dev(z)
+        return h.point_cost(), h.download(h.point_ptrs()[1], p)
+
+    # (1) upload into the trial vector
+    y, s, hs, xp, pg, z = fresh()
+    Zm = h.download(z, p)
+    h.upload(Zm, xp)
+    a = h.tnt_accept_dev(xp, pg)
+    e = h.download(h.point_ptrs()[1], p)
+    f_ref, e_ref = reference(z)
+    assert a[0] == f_ref and np.array_equal(e, e_ref)
+    # (2) the trial vector as the output of an operation
+    y, s, hs, xp, pg, z = fresh()
+    h.copy_dev(z, p, xp) if hasattr(h, "copy_dev") else h.axpby_dev(1.0, z, 0.0, xp)
+    a = h.tnt_accept_dev(xp, pg)
+    e = h.download(h.point_ptrs()[1], p)
+    f_ref, e_ref = reference(z)
+    assert a[0] == f_ref and np.array_equal(e, e_ref)
+    # (3) free + alloc: the pool hands the same address out again, zeroed; filled with other contents by a write the
+    #     invalidation has already seen
+    y, s, hs, xp, pg, z = fresh()
+    addr = int(xp) if isinstance(xp, int) else xp
+    h.dev_free(xp)
+    xp_new = h.dev_alloc(p)
+    h.axpby_dev(1.0, z, 0.0, xp_new)
+    a = h.tnt_accept_dev(xp_new, pg)
+    e = h.download(h.point_ptrs()[1], p)
+    f_ref, e_ref = reference(z)
+    assert a[0] == f_ref and np.array_equal(e, e_ref), (addr, xp_new)
+
+
 @pytest.mark.parametrize("d,n,precond", [(3, 30000, capi.PRECOND_REGULARIZED_CHOLESKY), (2, 40000, capi.PRECOND_REGULARIZED_CHOLESKY),
                                           (3, 800, capi.PRECOND_REGULARIZED_CHOLESKY), (3, 800, capi.PRECOND_JACOBI)])
 @pytest.mark.parametrize("p", [5, 4])

@@ -217,6 +217,49 @@ def test_config3_staircase_level_by_level():
     print("  end: f = %.6f |g| = %.3e, %d levels" % (out["f"], out["grad_norm"], len(out["levels"])))
 
 
+def test_config3_first_failed_certificate_in_the_reference_s_plain_order():
+    """Round-5 review: after a failed factorisation of S + eta I this build seeds the eigensolver's block with the failed pivot's
+    direction of non-positive curvature; the reference runs LOBPCG from the bootstrap block and then the ILDL-preconditioned
+    branch (src/CORA_utils.cpp:112-167).  Same stopping rule (:90-99), different x.  The seed is behind a switch (default on:
+    Problem::setVerificationLab, CORA_NO_PIVOT_SEED=1): here BOTH orders run on BASELINE config 3's first failed certificate (rank 3
+    after 250 outer iterations from the odometry start) and both directions must satisfy the reference's rule on the ORACLE's S --
+    x' S x equal to the reported theta and below -eta / 2 -- and the saddle escape must accept from either."""
+    n = 10_000
+    orc.set_threads(min(8, orc.max_threads()))
+    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    Q, dims = _oracle(P)
+    x0 = orc.project_manifold(dims, np.asfortranarray(P.op("getOdomInitialization")))
+    P.set_rank(3)
+    P.precond_info()
+    res = P.tnt(x0, max_iterations=250)
+    X = res["x"]
+    eta = ost.cert_eta(res["f"])
+    S = certificate_matrix(Q, dims, X)
+    out = {}
+    for name, how in (("seeded", dict(lab=(True, True))), ("plain", dict(lab=(False, True))), ("plain by environment", dict(env=True))):
+        if "lab" in how:
+            P.set_verification_lab(*how["lab"])
+        else:
+            P.set_verification_lab(True, True)
+            os.environ["CORA_NO_PIVOT_SEED"] = "1"
+        try:
+            cert = P.certify(X, eta)
+        finally:
+            os.environ.pop("CORA_NO_PIVOT_SEED", None)
+        assert not cert["is_certified"], name
+        v = cert["x"]
+        theta_or = float(v @ (S @ v)) / float(v @ v)
+        assert abs(theta_or - cert["theta"]) <= 1e-6 * max(abs(theta_or), eta), (name, theta_or, cert["theta"])
+        assert theta_or < -eta / 2, (name, theta_or, eta)
+        out[name] = (cert["theta"], cert["iters"])
+        print("  %-22s theta = %.6e  (eta = %.3g)  iterations %s" % (name, cert["theta"], eta, out[name][1]))
+    P.set_verification_lab(True, True)
+    # the two switches of the plain order are the same computation
+    assert out["plain"][0] == out["plain by environment"][0]
+
+
 def test_config3_converged_levels_match_the_oracle():
     """The same staircase with 5 000 outer iterations per level, so that every level runs to a stopping rule instead of the
     iteration limit (round-4 review: "what does the oracle do?").  The oracle's own run of this (tools/oracle_staircase.py

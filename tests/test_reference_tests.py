@@ -1,6 +1,6 @@
-"""The reference's OWN test translation units -- tests/test_optimizer_helpers.cpp, tests/test_cora.cpp,
+"""The reference's OWN test translation units -- ALL SEVEN: tests/test_optimizer_helpers.cpp, tests/test_cora.cpp,
 tests/test_parse_pyfg.cpp, tests/test_certification.cpp, tests/test_geometry.cpp,
-tests/test_construct_problem.cpp -- compiled unmodified, from where they lie in the reference tree, against include/CORA/*.h and
+tests/test_construct_problem.cpp, tests/test.cpp -- compiled unmodified, from where they lie in the reference tree, against include/CORA/*.h and
 libcora_hip.so (oracle/build_ref_tests.py; Catch2 and the Eigen-based test helper replaced by the stand-ins under
 tests/drop_in/shim/), and RUN against the committed golden fixtures (byte-identical copies of the reference's tests/data).
 
@@ -54,6 +54,17 @@ def test_reference_construct_problem_tests_pass(tmp_path):
     r = _run("test_construct_problem", tmp_path)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "2 test cases, 0 failed, 7 assertions" in r.stdout
+
+
+def test_reference_block_cholesky_tests_pass(tmp_path):
+    """tests/test.cpp:25-214 (round 6: the seventh and last unit): getBlockCholeskyFactorization / blockCholeskySolve of a
+    hand-coded 3 x 3 matrix, of a random SPD matrix of odd size below 100 and of two 3 x 3 diagonal blocks of a 6 x 6 matrix,
+    each against the dense inverse -- on the identity, on the matrix itself and on a vector (Eigen's isApprox, 1e-12).
+    Built with Eigen's element-wise sparse interface (insert / coeff / coeffRef / makeCompressed), the VectorXi comma
+    initialiser and Catch2's GENERATE(take(1, filter(.., random(..)))).  Host code only, runs without a GPU."""
+    r = _run("test", tmp_path)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "3 test cases, 0 failed, 10 assertions" in r.stdout
 
 
 @pytest.mark.gpu

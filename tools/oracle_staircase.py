@@ -8,7 +8,11 @@ product code on the path (the C++ host only generates the graph, assembles Q and
 It answers the round-2 review's question "where does the reference-equivalent CPU path stop from this start?":
 every level ends on TNT's iteration limit far from stationarity, exactly like the GPU path.
 
-python tools/oracle_staircase.py [poses] [max_rank] [threads] [outer iterations per level]   (10^4 poses: a few minutes per level on 8 cores)"""
+python tools/oracle_staircase.py [poses] [max_rank] [threads] [outer iterations per level] [perturbation seed]   (10^4 poses: a few minutes per level on 8 cores)
+
+With a perturbation seed s > 0 every entry of the start point is moved by one unit in its last place, up or down by a
+coin drawn from numpy's default_rng(s) (round 6: how far the ORACLE's own end value moves under a last-digit change of its
+start -- profiles/r06_config3_oracle_spread.txt)."""
 import math, os, sys, time
 import numpy as np
 import scipy.sparse as sp
@@ -31,6 +35,11 @@ Q = orc.CSR(rowptr, colidx, vals, dm_["N"])
 dims = orc.Dims(dm_["d"], dm_["n"], dm_["r"], dm_["N"])
 Qs = Q.to_scipy().tocsr()
 x = orc.project_manifold(dims, P.op("getOdomInitialization"))
+PERTURB = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+if PERTURB > 0:
+    coin = np.random.default_rng(PERTURB).integers(0, 2, size=x.shape).astype(bool)
+    x = np.where(coin, np.nextafter(x, np.inf), np.nextafter(x, -np.inf))
+    print("start perturbed by +-1 ulp per entry, seed %d" % PERTURB, flush=True)
 # RegularizedCholesky: lambda = ||Q||_2 / (kappa_max - 1), kappa_max = 1e6 (src/CORA_problem.cpp:544-614)
 lam_max = float(spla.eigsh(Qs, k=1, which="LA", tol=1e-3, return_eigenvectors=False)[0])
 lam = lam_max / (1e6 - 1)
