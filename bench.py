@@ -313,8 +313,9 @@ def main():
                     help="auto: HBM-side bytes of the timed kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) "
                          "of a short child run of this command, collected by this run (N = 1; skipped under a profiler)")
     ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time the oracle's Hvp under OpenMP on every CPU the container may use (several thread "
-                         "counts, ~10 s of host time; off by default so that the run is not mostly host work)")
+                    help="the all-core column with a sweep over several thread counts (~10 s of host time); by default only "
+                         "two thread counts are tried (the container's CPU quota and half of it, ~1 s each)")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-core column altogether")
     ap.add_argument("--kernel-only", action="store_true", help=argparse.SUPPRESS)  # the child run of --pmc-traffic
     args = ap.parse_args()
 
@@ -593,6 +594,12 @@ def main():
         if b2b["traffic_read"]:
             b2b["read_over_compulsory"] = b2b["traffic_read"] / comp_read
             b2b["write_over_compulsory"] = b2b["traffic_write"] / comp_write
+        # `frac` is quoted on the ALGORITHMIC bytes (the reference's CSR, 12 B per entry), which the device format
+        # does not move (25.6 MB instead of 56.4 MB at 10^5 poses).  Beside it, the same kernel time against what the kernel
+        # really moved (PMC) and against the least the format could move (round-5 review: "report the Hvp against what it moves")
+        if traffic:
+            b2b["frac_traffic"] = traffic / kernel_us / 1e3 / HBM_PEAK_GBS
+        b2b["frac_compulsory"] = (comp_read + comp_write) / kernel_us / 1e3 / HBM_PEAK_GBS
         result = {
             "metric": "riemannian_hessian_vector_products_per_sec" if args.op == "hvp" else
                       "certificate_operator_products_per_sec",
@@ -656,6 +663,14 @@ def main():
                        "(profiles/r05_bench_kernel_stats.csv holds the same population), the event figures stay in "
                        "kernel_us_events",
             }
+            if rl["traffic"]:
+                rl["frac_traffic"] = rl["traffic"] / loop_us / 1e3 / HBM_PEAK_GBS
+                rl["read_over_compulsory"] = rl["traffic_read"] / comp_read
+                rl["write_over_compulsory"] = rl["traffic_write"] / comp_write
+            rl["frac_compulsory"] = (comp_read + comp_write) / loop_us / 1e3 / HBM_PEAK_GBS
+            rl["frac_is"] = ("frac: algorithmic bytes (the reference's CSR, SURVEY 8d) / kernel time / peak; frac_traffic: PMC bytes of "
+                             "the same kernel / time / peak -- what the kernel really moved; frac_compulsory: the least the device "
+                             "format can move (its own bytes once + every vector row once) / time / peak")
             result["roofline"] = rl
             result["roofline_cache"] = b2b
         else:
@@ -780,16 +795,20 @@ def main():
             got = ctx.download(out.data_ptr(), p)
             result["parity_max_rel_err_vs_cpu"] = float(np.abs(got - ref).max() / np.abs(ref).max())
             result["extras"] = extras
-            if args.cpu_all_cores:
+            all_cores = None
+            if not args.no_cpu_all_cores:
                 # all-core column of BASELINE.md section 4: the same oracle loops under OpenMP.  A container may see
                 # more logical cores than it may use, so a few thread counts are tried and the best one is reported.
+                # (round 6: in the default run too -- two thread counts, about a second each -- so that the driver's record
+                # carries the column; --cpu-all-cores sweeps more counts)
                 best = None
                 quota = cpu_quota()   # what the container may use (cgroup cpu.max), not what it sees
-                for th in sorted({max(1, min(t, cores, quota)) for t in (4, 8, 16, 32, 64, 128, cores)}):
+                counts = (4, 8, 16, 32, 64, 128, cores) if args.cpu_all_cores else (min(cores, quota), max(1, min(cores, quota) // 2))
+                for th in sorted({max(1, min(t, cores, quota)) for t in counts}):
                     hv, reps_th, _ = cpu_baseline(rowptr, colidx, vals, dm, p, 1.0, threads=th)
                     if best is None or hv > best[0]:
                         best = (hv, th, reps_th)
-                result["extras"]["cpu_all_cores"] = {
+                all_cores = result["extras"]["cpu_all_cores"] = {
                     "value": best[0], "unit": "Hvp/s", "cores": best[1],
                     "sample": "%d products, same oracle code with OpenMP row-parallel loops, threads bound to cores "
                               "(spread over the sockets), Q and the vectors first touched by the threads that use them; best "
@@ -803,6 +822,8 @@ def main():
                 "sample": "%d Hessian-vector products of the same 10^5-pose workload with oracle/cora_oracle.c "
                           "(single thread, like the reference; host has %s logical cores)" % (reps_cpu, cores),
             }
+            if all_cores:   # BASELINE.md section 4's second column beside the reference-equivalent single thread
+                result["cpu_baseline"]["all_cores"] = {k: all_cores[k] for k in ("value", "unit", "cores")}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:

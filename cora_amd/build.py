@@ -1,7 +1,8 @@
 """Builds cora_amd/lib/libcora_hip.so with hipcc for gfx950 (no GPU needed).
 
 Sources: csrc/format_build.cpp (host format builder), csrc/kernels.hip (CDNA4
-kernels), csrc/capi.hip (C ABI, include/cora_hip.h) and csrc/host/*.cpp (the
+kernels), csrc/capi.hip (C ABI, include/cora_hip.h), csrc/p2p.hip (device-side
+collectives over peer-mapped mailboxes) and csrc/host/*.cpp (the
 C++ host mirroring the reference's CORA::Problem / solveCORA interface)."""
 import glob
 import os
@@ -24,7 +25,7 @@ KERNEL_PARTS = [("spmm_g0", 1, 1), ("spmm_g1", 1, 2), ("spmm_g2", 1, 4), ("spmm_
 
 
 def sources():
-    srcs = [os.path.join(CSRC, f) for f in ("format_build.cpp", "trisolve_build.cpp", "kernels.hip", "capi.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("format_build.cpp", "trisolve_build.cpp", "kernels.hip", "capi.hip", "p2p.hip")]
     srcs += sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
     return srcs
 

@@ -36,6 +36,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include "../../include/cora_hip.h"
 #include "cora_internal.h"
 #include "kernels.h"
+#include "p2p.h"
 #include "parallel.h"
 
 using namespace cora;
@@ -62,6 +63,7 @@ static int native_allgather_rows(cora_native_comm *nc, double *dX, int ld, int64
 struct cora_ctx {
   HostFormat F;
   cora_native_comm *native_comm = nullptr;  // owned: the library's own communication (cora_comm_create_*)
+  cora::P2PState *p2p_pending = nullptr;    // a mailbox exported by cora_comm_p2p_handle, not yet connected
   int device = -1;
   bool has_device = false;
   hipStream_t stream = nullptr;
@@ -646,6 +648,8 @@ void cora_ctx_destroy(cora_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     native_comm_destroy(c->native_comm);
     c->native_comm = nullptr;
+    if (c->p2p_pending) cora::p2p_destroy(c->p2p_pending);
+    c->p2p_pending = nullptr;
     free_rank_state(c);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->ev_operand) (void)hipEventDestroy(c->ev_operand);
@@ -2974,6 +2978,8 @@ struct cora_native_comm {
   cora_local_group *g = nullptr;  // local transport
   const RcclApi *api = nullptr;   // RCCL transport
   ncclComm_t nccl = nullptr;
+  cora::P2PState *p2p = nullptr;  // device-side transport over peer-mapped mailboxes (p2p.h): no RCCL, no host on the data path
+  long n_p2p_gather = 0, n_p2p_reduce = 0;
   // exchange plan
   int e_max = 0;
   int64_t exchanged_rows = 0;       // rows received per exchange (world * e_max)
@@ -3004,6 +3010,10 @@ struct cora_native_comm {
   // all-gather of `bytes` bytes per rank between DEVICE buffers, ordered on the handle's stream
   int allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
+    if (p2p) {  // one kernel: push into the peers' mailboxes, wait for theirs, copy out (counted apart: not a library collective)
+      ++n_p2p_gather;
+      return cora::p2p_allgather(p2p, send, recv, bytes, st, &err) ? fail_(err) : 0;
+    }
     ++n_allgather;
     if (nccl) return nc(api->AllGather(send, recv, bytes, ncclChar, nccl, st), "ncclAllGather");
     if (hip(hipStreamSynchronize(st), "hipStreamSynchronize")) return 1;
@@ -3018,6 +3028,10 @@ struct cora_native_comm {
   }
   // sum of n device doubles over the ranks, in place, ordered on the handle's stream (the same bits on every rank)
   int allreduce_dev(double *d, int n) {
+    if (p2p) {
+      ++n_p2p_reduce;
+      return cora::p2p_allreduce(p2p, d, n, c->stream, &err) ? fail_(err) : 0;
+    }
     if (nccl) {
       ++n_allreduce;
       return nc(api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce");
@@ -3030,12 +3044,14 @@ struct cora_native_comm {
     return hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
   }
   int allreduce_host(double *vals, int n) {
-    ++n_allreduce;
-    if (nccl) {
+    if (!p2p) ++n_allreduce;
+    if (nccl || p2p) {
       if (n > 1016) return fail_("all-reduce of more than 1016 doubles");
       std::memcpy(h_scal, vals, sizeof(double) * n);
       if (hip(hipMemcpyAsync(d_scal, h_scal, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync")) return 1;
-      if (nc(api->AllReduce(d_scal, d_scal, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce")) return 1;
+      if (p2p) {
+        if (allreduce_dev(d_scal, n)) return 1;
+      } else if (nc(api->AllReduce(d_scal, d_scal, static_cast<size_t>(n), ncclDouble, ncclSum, nccl, c->stream), "ncclAllReduce")) return 1;
       if (hip(hipMemcpyAsync(h_scal, d_scal, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync")) return 1;
       if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
       std::memcpy(vals, h_scal, sizeof(double) * n);
@@ -3146,6 +3162,10 @@ struct cora_native_comm {
     if (hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
     const Layout &L = c->F.L;
     const size_t n = static_cast<size_t>(L.shard_rows) * ld;
+    if (p2p) {
+      --n_allgather;
+      return allgather_dev(dX + n * rank, dX, n * sizeof(double));  // in place: a rank's own piece is delivered onto itself
+    }
     if (nccl) return nc(api->AllGather(dX + n * rank, dX, n, ncclDouble, nccl, c->stream), "ncclAllGather");
     if (hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return 1;
     g->ptrs[rank] = dX;
@@ -3174,7 +3194,7 @@ struct cora_native_comm {
       const int64_t mine[2] = {row0, nrows};
       packed.meta.assign(static_cast<size_t>(2 * world), 0);
       if (allgather_host(mine, packed.meta.data(), sizeof(mine))) return 1;
-      --n_allgather;  // (planning, not the data path)
+      if (!p2p) --n_allgather;  // (planning, not the data path)
       packed.maxn = 0;
       for (int r = 0; r < world; ++r) packed.maxn = std::max(packed.maxn, packed.meta[static_cast<size_t>(2 * r + 1)]);
       if (!packed.d_meta && hip(hipMalloc(&packed.d_meta, sizeof(int64_t) * 2 * world), "hipMalloc")) return 1;
@@ -3217,6 +3237,7 @@ struct cora_native_comm {
     if (d_scal) (void)hipFree(d_scal);
     if (h_scal) (void)hipHostFree(h_scal);
     if (nccl && api) (void)api->CommDestroy(nccl);
+    if (p2p) cora::p2p_destroy(p2p);
   }
 };
 
@@ -3336,6 +3357,49 @@ int cora_comm_create_local(cora_ctx *c, cora_local_group *g) {
   nc->world = c->F.L.world;
   nc->g = g;
   return native_finish(c, nc);
+}
+
+// Device-side transport (p2p.h).  Two steps, because the peers' mailboxes must exist before anybody can map them:
+//   cora_comm_p2p_handle  -> this rank's mailbox and its 128-byte export blob;
+//   (the launcher gathers the blobs of all ranks in rank order: torch.distributed, MPI, a file -- like the RCCL id)
+//   cora_comm_create_p2p  -> maps the peers and plans the exchange (the planning all-gathers already run on the mailboxes).
+int cora_comm_p2p_handle(cora_ctx *c, void *blob128) {
+  NEED_DEVICE(c);
+  if (!blob128) return fail(c, CORA_ERR_ARG, "bad arguments");
+  if (c->p2p_pending) {
+    cora::p2p_destroy(c->p2p_pending);
+    c->p2p_pending = nullptr;
+  }
+  std::string err;
+  if (cora::p2p_create(c->device, c->F.L.rank, c->F.L.world, &c->p2p_pending, blob128, &err)) return fail(c, CORA_ERR_HIP, err);
+  return CORA_OK;
+}
+
+int cora_comm_create_p2p(cora_ctx *c, const void *blobs) {
+  NEED_DEVICE(c);
+  if (!blobs) return fail(c, CORA_ERR_ARG, "bad arguments");
+  if (!c->p2p_pending) return fail(c, CORA_ERR_NOT_READY, "cora_comm_p2p_handle was not called on this handle");
+  std::string err;
+  if (cora::p2p_connect(c->p2p_pending, blobs, &err)) return fail(c, CORA_ERR_HIP, err);
+  auto *nc = new cora_native_comm;
+  nc->c = c;
+  nc->rank = c->F.L.rank;
+  nc->world = c->F.L.world;
+  nc->p2p = c->p2p_pending;
+  c->p2p_pending = nullptr;
+  return native_finish(c, nc);
+}
+
+int cora_comm_p2p_status(const cora_ctx *c, long out[6]) {
+  if (!c || !out) return CORA_ERR_ARG;
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  out[3] = -1;
+  const cora_native_comm *nc = c->native_comm;
+  if (!nc || !nc->p2p) return CORA_OK;
+  cora::p2p_status(nc->p2p, out);
+  out[4] = nc->n_p2p_gather;
+  out[5] = nc->n_p2p_reduce;
+  return CORA_OK;
 }
 
 int cora_comm_native_enable(cora_ctx *c, int on) {

@@ -409,6 +409,39 @@ class NativeLocalComm(_NativeComm):
         self._finish(ctx)
 
 
+class NativeP2PComm(_NativeComm):
+    """Device-side collectives over peer-mapped mailboxes (cora_comm_create_p2p): no RCCL, no host on the data path.
+    `gather_blobs(my_blob: bytes) -> list of every rank's blob in rank order` is the launcher's part: torch.distributed's
+    all_gather_object by default (any backend), or whatever the caller passes (threads of one process: a shared list)."""
+
+    BLOB = 128
+
+    def __init__(self, ctx, group=None, gather_blobs=None):
+        L = ctx.L
+        L.cora_comm_p2p_handle.argtypes = [_C.c_void_p, _C.c_void_p]
+        L.cora_comm_create_p2p.argtypes = [_C.c_void_p, _C.c_void_p]
+        buf = (_C.c_ubyte * self.BLOB)()
+        ctx._chk(L.cora_comm_p2p_handle(ctx.h, buf))
+        mine = bytes(buf)
+        if gather_blobs is not None:
+            blobs = gather_blobs(mine)
+        elif ctx.world > 1:
+            blobs = [None] * ctx.world
+            dist.all_gather_object(blobs, mine, group=group)
+        else:
+            blobs = [mine]
+        assert len(blobs) == ctx.world and all(len(b) == self.BLOB for b in blobs)
+        raw = b"".join(blobs)
+        ctx._chk(L.cora_comm_create_p2p(ctx.h, (_C.c_ubyte * len(raw)).from_buffer_copy(raw)))
+        self._finish(ctx)
+
+    def status(self):
+        out = (_C.c_long * 6)()
+        self.ctx.L.cora_comm_p2p_status.argtypes = [_C.c_void_p, _C.POINTER(_C.c_long)]
+        self.ctx._chk(self.ctx.L.cora_comm_p2p_status(self.ctx.h, out))
+        return dict(zip(["collectives", "kernels", "timeouts", "memory_kind", "allgathers", "allreduces"], [int(v) for v in out]))
+
+
 class NativeRcclComm(_NativeComm):
     """One rank per process and GPU: RCCL called by the library itself (cora_comm_create_rccl).  The 128-byte id is
     made on rank 0 and broadcast with torch.distributed (any backend); after that torch is not on the data path."""

@@ -405,6 +405,24 @@ cora_local_group *cora_local_group_create(int world);
 void cora_local_group_destroy(cora_local_group *group);
 void cora_local_group_abort(cora_local_group *group); /* a rank failed outside the library: release the others */
 int cora_comm_create_local(cora_ctx *ctx, cora_local_group *group);
+/* Third transport (round 6; SURVEY 8e mitigation 3: "one-shot direct all-gather"): DEVICE-SIDE collectives over peer-mapped
+ * mailboxes, no RCCL and no host on the data path (cora_amd/csrc/p2p.h).  The exchange of a product is under 1 KB per rank
+ * and the reductions of an STPCG iteration are 1-3 doubles, so a collective is ONE small kernel on the handle's stream: it
+ * writes its payload into every peer's mailbox (stores over xGMI; the mailbox is exported with hipIpcGetMemHandle and mapped
+ * by the peers, or shared by pointer between threads of one process), sets a per-(receiver, sender) sequence flag with
+ * release at system scope, spins on the flags of its OWN mailbox (with a wall-clock timeout, CORA_P2P_TIMEOUT_S, default 60:
+ * a dead peer raises an error count instead of hanging the GPU) and delivers -- all-reduces add in rank order, the same bits
+ * as the other transports.  Ranks: one process per GPU, several processes sharing a GPU (tests), or threads.
+ *   cora_comm_p2p_handle(ctx, blob)   -> creates this rank's mailbox, blob = CORA_P2P_HANDLE_BYTES to hand to the peers
+ *   (launcher: all-gather of the blobs in rank order -- torch.distributed, MPI, a file; like the RCCL id)
+ *   cora_comm_create_p2p(ctx, blobs)  -> collective: maps the peers, plans the exchange
+ * cora_comm_counters stays at 0 + 0 on this transport (no library collective is issued); cora_comm_p2p_status:
+ * out[0] collectives, [1] kernels launched for them, [2] timeouts raised, [3] mailbox memory (0 uncached, 1 fine-grained,
+ * 2 ordinary; -1 no p2p transport), [4] all-gathers, [5] all-reduces. */
+#define CORA_P2P_HANDLE_BYTES 128
+int cora_comm_p2p_handle(cora_ctx *ctx, void *blob);
+int cora_comm_create_p2p(cora_ctx *ctx, const void *blobs);
+int cora_comm_p2p_status(const cora_ctx *ctx, long out[6]);
 int64_t cora_comm_exchanged_rows(const cora_ctx *ctx);
 /* Rows of resident vectors received through all-gathers of whole shards or of packed pieces so far (library's own
  * communication): the implicit formulation's replicated translation solve gathers the translation rows alone
