@@ -3151,6 +3151,12 @@ struct cora_native_comm {
   int product_gather(double *dX, int ld, hipStream_t st, double *out, double *kappa, hipEvent_t after_collective = nullptr) {
     Buf *b;
     if (buffers(ld, &b)) return 1;
+    if (p2p && cora::p2p_exchange_unpack_fits(p2p, e_max, n_long(), ld)) {  // hand-over, wait and unpack in ONE kernel, from the mailbox
+      ++n_p2p_gather;
+      if (after_collective) (void)hipEventRecord(after_collective, st);
+      return cora::p2p_exchange_unpack(p2p, b->send, e_max, n_long(), ld, d_recv_idx, dX, c->d_long_rows, c->d_long_owner, out, kappa, st, &err)
+                 ? fail_(err) : 0;
+    }
     if (allgather_dev(b->send, b->recv, sizeof(double) * (static_cast<size_t>(e_max) + n_long()) * ld, st)) return 1;
     if (after_collective) (void)hipEventRecord(after_collective, st);
     return hip(launch_exchange_unpack(world, e_max, n_long(), ld, d_recv_idx, b->recv, dX, rank, c->d_long_rows, c->d_long_owner,

@@ -104,6 +104,55 @@ __global__ __launch_bounds__(64) void k_p2p_allreduce(Peers P, int rank, int wor
   }
 }
 
+// The exchange of a product in ONE kernel and ONE block (the payload is the chain's halo rows + one slot per landmark row:
+// about a hundred doubles per rank): push this rank's [ e_max rows | n_long slots ] into every mailbox, hand over, wait, then
+// unpack STRAIGHT FROM THE MAILBOX -- rows to X[recv_idx], and the owner of long row j adds slot j of every rank in rank order
+// into its row of the result (the same operations as k_exchange_unpack in kernels.hip: the same bits as the other transports).
+__global__ __launch_bounds__(256) void k_p2p_exchange_unpack(Peers P, int rank, int world, const double *__restrict__ send, int64_t e_max,
+                                                             int n_long, int ld, const int32_t *__restrict__ recv_idx, double *X,
+                                                             const int32_t *__restrict__ long_rows, const int32_t *__restrict__ long_owner,
+                                                             double *out, double *kappa, unsigned long long seq, unsigned long long timeout) {
+  const int tid = static_cast<int>(threadIdx.x);
+  const int parity = static_cast<int>(seq & 1);
+  const int64_t stride = (e_max + n_long) * ld;
+  char *mine = P.mail[rank];
+  for (int q = 0; q < world; ++q) {
+    double *dst = reinterpret_cast<double *>(ag_data(P.mail[q], parity, rank, world));
+    for (int64_t i = tid; i < stride; i += 256) __hip_atomic_store(dst + i, send[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < world) {
+    __hip_atomic_store(ag_flag(P.mail[tid], parity, rank, 0), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    wait_flag(ag_flag(mine, parity, tid, 0), seq, timeout, mine);
+  }
+  __syncthreads();
+  const int64_t per = e_max * ld, tot = per * world;
+  for (int64_t t = tid; t < tot; t += 256) {
+    const int64_t r = t / per, w = t - r * per, k = t / ld, j = t - k * ld;
+    const double *src = reinterpret_cast<const double *>(ag_data(mine, parity, static_cast<int>(r), world));
+    X[static_cast<int64_t>(recv_idx[k]) * ld + j] = __hip_atomic_load(const_cast<double *>(src) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // long rows: one wavefront per row, lanes < ld (a landmark's own row of X is this rank's: the scatter above does not write it)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int j = wave; j < n_long; j += 4) {
+    double v = 0.0, k = 0.0;
+    if (lane < ld)
+      for (int r = 0; r < world; ++r)
+        v += __hip_atomic_load(reinterpret_cast<double *>(ag_data(mine, parity, r, world)) + (e_max + j) * ld + lane, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    if (long_owner[j] == rank && lane < ld) {
+      const size_t at = static_cast<size_t>(long_rows[j]) * ld + lane;
+      out[at] = v;
+      if (kappa) k = v * X[at];
+    }
+    if (kappa) {
+      for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off, 64);
+      if (lane == 0) kappa[j] = k;
+    }
+  }
+}
+
 struct Blob {  // kP2PBlobBytes
   hipIpcMemHandle_t handle;  // 64 bytes
   int64_t pid;
@@ -253,6 +302,22 @@ int p2p_allgather(P2PState *s, const void *send, void *recv, size_t bytes, hipSt
     if (hip_err(err, hipGetLastError(), "k_p2p_allgather")) return 1;
   }
   return 0;
+}
+
+bool p2p_exchange_unpack_fits(const P2PState *s, int64_t e_max, int n_long, int ld) {
+  return s && static_cast<size_t>((e_max + n_long) * ld) * sizeof(double) <= std::min<size_t>(kP2PSlotBytes, 32 * 1024);
+}
+
+int p2p_exchange_unpack(P2PState *s, const double *send, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, double *X,
+                        const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa, hipStream_t st, std::string *err) {
+  if (!s || !s->connected) return set_err(err, "p2p: not connected");
+  if (!p2p_exchange_unpack_fits(s, e_max, n_long, ld)) return set_err(err, "p2p: the exchange does not fit one block");
+  ++s->collectives;
+  ++s->kernels;
+  const unsigned long long seq = ++s->ag_seq;
+  hipLaunchKernelGGL(k_p2p_exchange_unpack, dim3(1), dim3(256), 0, st, s->peers, s->rank, s->world, send, e_max, n_long, ld, recv_idx, X,
+                     long_rows, long_owner, out, kappa, seq, s->timeout_ticks);
+  return hip_err(err, hipGetLastError(), "k_p2p_exchange_unpack");
 }
 
 int p2p_allreduce(P2PState *s, double *d, int n, hipStream_t st, std::string *err) {

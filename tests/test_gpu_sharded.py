@@ -442,6 +442,13 @@ def test_bench_two_ranks_runs_end_to_end_over_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0
     assert d["parity_max_rel_err_vs_cpu"] < 1e-10
     assert "multi_gpu" in d and d["multi_gpu"]["exchanged_rows_per_product"] > 0
+    # round 6: the transports are timed in turn -- here the device-side one (two processes sharing the GPU: hipIpc) and the
+    # injected torch.distributed callbacks --, every one must give the first one's bits, `value` is the faster one's
+    runs = {e["transport"]: e for e in d["multi_gpu"]["transports_timed"]}
+    assert set(runs) == {"p2p", "torch"} and all(e["ok"] for e in runs.values()), runs
+    assert runs["p2p"]["p2p_status"]["timeouts"] == 0 and runs["p2p"]["library_collectives_so_far"] == [0, 0]
+    assert abs(d["ms_per_step"] * 1e3 - min(e["step_us"] for e in runs.values())) < 1e-6 * d["ms_per_step"] * 1e3 + 1e-9
+    print("\n  2 ranks on one GPU, 20 000 poses: " + ", ".join("%s %.1f us per step" % (k, e["step_us"]) for k, e in runs.items()))
 
 
 @pytest.mark.parametrize("world", [2, 3])
