@@ -346,8 +346,12 @@ constexpr int kWinTrnMaxLD = CORA_WIN_TRN_MAX_LD;      // + the translation wind
 #ifndef CORA_POSE_COOP_MAX_LD
 // cooperative Hvp epilogue up to this row stride: above it the prefetched Y rows and Lambda blocks (d LD + d d doubles per
 // lane) push the kernel into AGPR spills at one wave per SIMD -- without them p = 11 / 12 / 16 / 24: 39.6 / 40.6 / 60.1 /
-// 98.7 -> 38.7 / 38.9 / 57.0 / 89.9 us (two waves per SIMD), while p = 10 loses (32.5 -> 33.7)
-#define CORA_POSE_COOP_MAX_LD 10
+// 98.7 -> 38.7 / 38.9 / 57.0 / 89.9 us (two waves per SIMD), while p = 10 lost in round 3 (32.5 -> 33.7).  Round 6: with the
+// cooperative form k_spmm<10, 3, *> spilled (92-116 B of scratch per lane at two waves per SIMD: the round-5 review's
+// "config 5's kernel spills"); without it 242-248 registers, no scratch, and faster on today's kernel -- certificate operator
+// at 10 columns 26.25 -> 25.73 us, PMC traffic 1.36x -> 1.19x the format's compulsory bytes (writes 1.25x -> 1.00x), Hvp at
+// p = 10 29.4 -> 28.75 us (profiles/r06_kernel_evolution.md): the limit is 9.
+#define CORA_POSE_COOP_MAX_LD 9
 #endif
 #ifndef CORA_POSE_COOP_MAX_DLD
 #define CORA_POSE_COOP_MAX_DLD 18  // d x row stride up to which the Hvp epilogue's operands travel through LDS (above: per lane)
@@ -2587,6 +2591,18 @@ __device__ unsigned long long g_sub_phase[2 * kSubPhases * kSubTimesMax];
 // are issued before the first one is consumed -- a phase costs two dependent latencies (index, value), not two per
 // row.  (A lane per row: 40-byte pieces, 5 x the line requests; with the fused passes written that way the forward
 // sweep took 50 us instead of 33.)
+#ifndef CORA_SUB_PAD_TILE
+#define CORA_SUB_PAD_TILE 1  // odd row strides: rows of the LDS tile padded to an even number of doubles (16-byte aligned rows)
+#endif
+// Row stride of a substitution block's tile in LDS, in doubles.  With an odd row stride (p = 5: the headline) a row of the
+// tile was 8-byte aligned, so every tile read of the level loop was LD ds_read_b64 per entry; with the rows padded to an even
+// stride they are 16-byte aligned and an entry costs LD / 2 ds_read_b128 + one b64 (p = 5: 3 LDS instructions instead of 5,
+// the level loop's largest phase -- "tile reads and products", profiles/r05_kernel_evolution.md step 15).  Memory keeps
+// its stride: only the tile's addressing changes.
+template <int LD>
+struct SubTile {
+  static constexpr int kStride = (CORA_SUB_PAD_TILE && (LD % 2 == 1) && LD >= 3) ? LD + 1 : LD;
+};
 template <int LD, bool BWD, int FD>
 __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(SubOpDev S, const double *src, double *work, double *dst,
                                                               const SubFuse F) {
@@ -2681,7 +2697,8 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
   // width: short rows do not pay for the level's longest); nlev levels + a closing one.
   constexpr int kSubWaves = kSubThreads / 64;
   const int wv = wave_base >> 6;
-  int4 *hl = reinterpret_cast<int4 *>(smem + ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)));
+  constexpr int LT = SubTile<LD>::kStride;  // row stride of the tile (doubles)
+  int4 *hl = reinterpret_cast<int4 *>(smem + ((static_cast<size_t>(S.max_rows) * LT * 8 + 15) & ~static_cast<size_t>(15)));
   for (int i = tid; i < (nlev + 1) * kSubWaves; i += kSubThreads) hl[i] = gh[i];
   auto header = [&](int l) {
     const int4 h = hl[(l < nlev ? l : nlev) * kSubWaves + wv];  // the closing level has no rows
@@ -2777,11 +2794,11 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
       if (io_runs) {
         const int off = k < bd.run_end[0] ? bd.run_off[0] : (k < bd.run_end[1] ? bd.run_off[1] : (k < bd.run_end[2] ? bd.run_off[2] : bd.run_off[3]));
         at.g[u] = (k + off) * LD + col;
-        at.set_t(u, static_cast<int>(tpos[k]) * LD + col);
+        at.set_t(u, static_cast<int>(tpos[k]) * LT + col);
       } else {
         const int2 rp = io[k];
         at.g[u] = rp.x * LD + col;
-        at.set_t(u, rp.y * LD + col);
+        at.set_t(u, rp.y * LT + col);
       }
     }
   };
@@ -2831,7 +2848,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
         double x[LD];
         load_row<LD>(work + static_cast<size_t>(tgt_row) * LD, x);
 #pragma unroll
-        for (int j = 0; j < LD; ++j) T[(nb + t) * LD + j] = x[j];
+        for (int j = 0; j < LD; ++j) T[(nb + t) * LT + j] = x[j];
       }
     }
   }
@@ -2880,7 +2897,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 #pragma unroll
           for (int u = 0; u < NPL; ++u) {
             const uint32_t li = (u & 1) ? R.i[u >> 1] >> 16 : R.i[u >> 1] & 0xffffu;
-            const double *__restrict__ t = reinterpret_cast<const double *>(smem + __umul24(li, LD * 8)) + c0;
+            const double *__restrict__ t = static_cast<const double *>(__builtin_assume_aligned(smem + __umul24(li, LT * 8), LT % 2 == 0 ? 16 : 8)) + c0;
 #pragma unroll
             for (int j = 0; j < CW; ++j)
               if (c0 + j < LD) s[j] = fma(static_cast<double>(R.v[u]), t[j], s[j]);
@@ -2907,7 +2924,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     __syncthreads();  // every row of the level has read the tile ...
     DBG_CYC(4);
     if (active && wl < nlane && (wl & (g - 1)) == 0) {
-      double *__restrict__ o = reinterpret_cast<double *>(smem + __mul24(r0 + (wl >> gs), LD * 8));
+      double *__restrict__ o = static_cast<double *>(__builtin_assume_aligned(smem + __mul24(r0 + (wl >> gs), LT * 8), LT % 2 == 0 ? 16 : 8));
 #pragma unroll
       for (int j = 0; j < LD; ++j) o[j] = res[j];
       if constexpr (kDirect) {
@@ -2953,7 +2970,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
     for (int u = tid; u < bd.nunits; u += kSubThreads) {
       const int2 pr = un[u];  // {tile position, internal row}
       const size_t row = static_cast<size_t>(pr.y);
-      double *__restrict__ tv = T + pr.x * LD;
+      double *__restrict__ tv = T + pr.x * LT;
       if (row < static_cast<size_t>(F.rng_base)) {
         double y[D][LD], v[D][LD];
 #pragma unroll
@@ -2961,12 +2978,12 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
 #pragma unroll
         for (int a = 0; a < D; ++a)
 #pragma unroll
-          for (int j = 0; j < LD; ++j) v[a][j] = tv[a * LD + j];
+          for (int j = 0; j < LD; ++j) v[a][j] = tv[a * LT + j];
         stiefel_project_thread<LD, D>(y, v);
 #pragma unroll
         for (int a = 0; a < D; ++a)
 #pragma unroll
-          for (int j = 0; j < LD; ++j) tv[a * LD + j] = v[a][j];
+          for (int j = 0; j < LD; ++j) tv[a * LT + j] = v[a][j];
       } else if (row < static_cast<size_t>(F.trn_base)) {
         double y[LD], v[LD];
         load_row<LD>(F.Y + row * LD, y);
@@ -3062,7 +3079,7 @@ __global__ __launch_bounds__(kSubThreads, CORA_SUB_MIN_BLOCKS) void k_subblock(S
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const double *__restrict__ t = T + ci[u] * LD;
+          const double *__restrict__ t = T + ci[u] * LT;
 #pragma unroll
           for (int j = 0; j < LD; ++j) sum[j] = fma(cv[u], t[j], sum[j]);
         }
@@ -3487,7 +3504,7 @@ static hipError_t subblock_ld(const SubOpDev &S, bool backward, const double *sr
                               const SubFuse *F = nullptr) {
   const int grid = launch_subblock_blocks(S);
   if (grid <= 0) return hipSuccess;
-  const size_t lds = ((static_cast<size_t>(S.max_rows) * LD * 8 + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(S.max_lev + 2) * 16;
+  const size_t lds = ((static_cast<size_t>(S.max_rows) * SubTile<LD>::kStride * 8 + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(S.max_lev + 2) * 16;
   if (S.max_level_lanes > kSubThreads || S.max_npl > kSubNpl || lds > 160 * 1024) return hipErrorInvalidValue;
   // (wide rows: the tile of a 435-row block is 56 KB at 16 columns, 84 KB at 24 -- above the 64 KB a kernel gets without asking)
   auto allow_lds = [&](const void *fn) {

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -268,20 +270,55 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
         const int p = parent[v];
         if (p >= 0 && p < first_border) { sz[p] += sz[v]; esz[p] += esz[v]; }
       }
+      // Height of every subtree in rows (a block's barrier levels grow with it: a supernode of <= kSnCap rows per level).
+      // A launch of the sweep lasts as long as its DEEPEST block -- on the reference's mid-size data sets a block is alone
+      // on its CU (mrclam6: 17 levels where the mean is 7.8, profiles/r05_kernel_evolution.md step 13) -- so subtrees much
+      // taller than the typical block are not taken whole: their top rows go to the last stage and what hangs below them
+      // becomes blocks of its own.  Two passes: the blocks the size caps alone would give, the median of their heights,
+      // then the same selection with heights capped at CORA_TRI_LEVEL_CAP times that median.  OFF by default (0): measured
+      // in round 6 (profiles/r06_kernel_evolution.md) at 1.25 / 1.5 / 2.0 -- mrclam6 85.7-87.6 -> 88.8-91.6 / 88.0-89.1 /
+      // 85.8-87.5 us per product end to end, tiers 68.1-68.5 -> 70.6 / 68.8-69.2 / 67.8-68.4, mrclam3b 65.8-66.3 -> 65.3-67.2 /
+      // 70.7-74.7 / 66.9-67.1, 10^5 poses unchanged: what the deepest blocks lose the last stage's products gain (the rows cut
+      // off the tall subtrees join the explicit inverse).  Kept as a switch.
+      std::vector<int32_t> hgt(static_cast<size_t>(first_border), 1);
+      for (int v = 0; v < first_border; ++v) {
+        const int p = parent[v];
+        if (p >= 0 && p < first_border) hgt[p] = std::max(hgt[p], hgt[v] + 1);
+      }
       int64_t taken = 0;
       int nblocks = 0;
-      for (int v = first_border - 1; v >= 0; --v) {
-        const int p = parent[v];
-        if (p >= 0 && p < first_border && stage[p] == 0) {
-          stage[v] = 0;
-          blk[v] = blk[p];
-          ++taken;
-        } else if (sz[v] <= kSubRows && esz[v] <= kSubEnt && (sz[v] >= kMinBlock || p < 0 || p >= first_border) &&
-                   !(group && p >= 0 && (*group)[v] >= 0 && (*group)[v] == (*group)[p])) {
-          stage[v] = 0;
-          blk[v] = v;
-          ++nblocks;
-          ++taken;
+      auto select = [&](int32_t max_height, std::vector<int32_t> *heights) {
+        taken = 0;
+        nblocks = 0;
+        for (int v = first_border - 1; v >= 0; --v) {
+          const int p = parent[v];
+          if (p >= 0 && p < first_border && stage[p] == 0) {
+            stage[v] = 0;
+            blk[v] = blk[p];
+            ++taken;
+          } else if (sz[v] <= kSubRows && esz[v] <= kSubEnt && hgt[v] <= max_height &&
+                     (sz[v] >= kMinBlock || p < 0 || p >= first_border) &&
+                     !(group && p >= 0 && (*group)[v] >= 0 && (*group)[v] == (*group)[p])) {
+            stage[v] = 0;
+            blk[v] = v;
+            ++nblocks;
+            ++taken;
+            if (heights) heights->push_back(hgt[v]);
+          }
+        }
+      };
+      const double level_cap = [] { const char *e = std::getenv("CORA_TRI_LEVEL_CAP"); return e ? std::atof(e) : 0.0; }();
+      std::vector<int32_t> heights;
+      select(INT32_MAX, &heights);
+      if (level_cap > 0.0 && heights.size() >= 8) {
+        std::nth_element(heights.begin(), heights.begin() + heights.size() / 2, heights.end());
+        const int32_t median = heights[heights.size() / 2];
+        const int32_t max_height = static_cast<int32_t>(std::ceil(level_cap * median));
+        if (*std::max_element(heights.begin(), heights.end()) > max_height) {
+          if (timing) std::fprintf(stderr, "  [tri plan] block heights: median %d rows, cap %d\n", median, max_height);
+          std::fill(stage.begin(), stage.end(), -1);
+          std::fill(blk.begin(), blk.end(), -1);
+          select(max_height, nullptr);
         }
       }
       // what is left above the blocks is applied as one explicit inverse: worth it while its entries stay a fraction of

@@ -523,7 +523,8 @@ int cora_debug_stpcg_graph(const cora_ctx *ctx, long out[2]);
  *   CORA_TRI_SUB=0|1          force the explicit-stage form | the substitution-block form
  *   CORA_TRI_SN_CAP=n         rows per supernode whose diagonal block is inverted (default: a pose)
  *   CORA_TRI_UNFOLD_MIN=n     aux sums folded into the last stage's first product below n extra entries
- *   CORA_TRI_LEVEL_CAP=x      (round 6) subtrees deeper than x times the median are not taken whole as solve blocks
+ *   CORA_TRI_LEVEL_CAP=x      (round 6; default 0 = off: measured, no gain) subtrees taller than x times the median block are
+ *                             not taken whole as solve blocks
  *   CORA_TRI_THREADS=n, CORA_TRI_CHECK_ETREE=1, CORA_TRI_TIMING=1   builder threads; elimination tree computed both ways
  *                             and compared; phase times of set-up on stderr
  *   CORA_SUB_IO_LISTS=1, CORA_IO_STATS=1   row I/O of the sweeps from index lists instead of run tables; run statistics

@@ -217,6 +217,44 @@ def test_config3_staircase_level_by_level():
     print("  end: f = %.6f |g| = %.3e, %d levels" % (out["f"], out["grad_norm"], len(out["levels"])))
 
 
+def test_config3_rank3_every_outer_iteration_in_lockstep():
+    """Round-5 review: lock-step covered the first 4-5 outer iterations of a 250-iteration level.  Here EVERY outer iteration of
+    BASELINE config 3's first level (rank 3, the reference's 250-iteration limit, odometry start) is one iteration of the oracle's
+    TNT from the device's own point and radius: same inner iteration count, same accept / reject, same radius, cost within
+    what the ORACLE differs from itself by when its start moves in the last digit (measured inside tests/lockstep.py for every
+    solve that disagrees by more than 1e-6).  And where the level ends lies inside the oracle's own spread: six runs of the
+    oracle from starts perturbed by one unit in the last place end this level between 3.3e9 and 7.0e9
+    (profiles/r06_config3_oracle_spread.txt)."""
+    n = 10_000
+    orc.set_threads(min(8, orc.max_threads()))
+    P = host.Problem.synthetic(dim=3, n_poses=n, n_landmarks=10, n_ranges=n // 2, seed=42,
+                               precond=capi.PRECOND_REGULARIZED_CHOLESKY)
+    P.update()
+    Q, dims = _oracle(P)
+    N = dims.N
+    P.set_rank(3)
+    lam = P.precond_info()["lam"]
+    Qs = Q.to_scipy().tocsr()
+    M = (Qs + lam * sp.identity(N)).tocsr()[:N - 1, :N - 1].tocsr()
+    M.sort_indices()
+    perm_full = elimination_order(Q, dims)
+    chol = orc.Cholesky(orc.CSR.from_scipy(M), perm=perm_full[perm_full < N - 1])
+    assert chol.ok
+    x0 = orc.project_manifold(dims, np.asfortranarray(P.op("getOdomInitialization")))
+    noise = lambda xx, ff: cost_tolerance(Q, xx, ff)  # noqa: E731
+    worst, steps, x, Delta = lockstep(P, Q, dims, x0, 250, dict(precond="chol", lam=lam, chol=chol), long_inner_rel=0.15,
+                                      f_noise=noise, short_rel=1e-6, return_state=True)
+    f_end = orc.cost(Q, x)
+    print("\n  rank 3, %d outer iterations in lockstep: %s; level ends at f = %.6e" % (
+        steps, {k: (float("%.2g" % v) if isinstance(v, float) else v) for k, v in worst.items()}, f_end))
+    assert steps == 250
+    assert 1e9 < f_end < 2e10, f_end      # the oracle's own six runs: 3.28e9 .. 7.02e9
+    # the same level as ONE call of the device's TNT (what solveCORA runs) ends where the step-by-step chain ends: same bits
+    res = P.tnt(x0, max_iterations=250)
+    assert res["iterations"] >= 250
+    assert abs(res["f"] - f_end) <= cost_tolerance(Q, x, f_end) + 1e-6 * f_end, (res["f"], f_end)
+
+
 def test_config3_first_failed_certificate_in_the_reference_s_plain_order():
     """Round-5 review: after a failed factorisation of S + eta I this build seeds the eigensolver's block with the failed pivot's
     direction of non-positive curvature; the reference runs LOBPCG from the bootstrap block and then the ILDL-preconditioned

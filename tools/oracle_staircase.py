@@ -20,7 +20,7 @@ import scipy.sparse.linalg as spla
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cora_amd import host
-from oracle import oracle as orc, tnt as otnt
+from oracle import oracle as orc, staircase as ost, tnt as otnt
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10000
 max_rank = int(sys.argv[2]) if len(sys.argv) > 2 else 7
@@ -36,6 +36,17 @@ dims = orc.Dims(dm_["d"], dm_["n"], dm_["r"], dm_["N"])
 Qs = Q.to_scipy().tocsr()
 x = orc.project_manifold(dims, P.op("getOdomInitialization"))
 PERTURB = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+# certify_solution's singular-value shortcut (src/CORA_problem.cpp:1037-1049: extreme singular values of the point more than
+# 1e6 apart count as certified).  Rounds 3-5 ran this tool WITHOUT it (argument 6 = 0 reproduces those runs); with it the tool
+# takes every decision solveCORA takes.
+SHORTCUT = (int(sys.argv[6]) != 0) if len(sys.argv) > 6 else True
+# Which direction of negative curvature the escape takes.  The reference runs LOBPCG (source absent) until x'Sx < -eta/2 and
+# takes whatever its iteration holds at that moment; any such vector is admissible.  "near": shift-invert Lanczos around
+# -eta -- the admissible direction of SMALLEST curvature (theta ~ -0.1: what rounds 3-5 ran);  "min": shift-invert around a
+# strongly negative shift -- the direction of LARGEST negative curvature, which is what an eigensolver for the minimum
+# eigenvalue (the device's LOBPCG, and the reference's) converges towards (theta ~ -1 .. -30 here, alpha_0 = 100 tol / |theta|
+# correspondingly shorter, src/CORA.cpp:287-288).
+DIRECTION = sys.argv[7] if len(sys.argv) > 7 else "near"
 if PERTURB > 0:
     coin = np.random.default_rng(PERTURB).integers(0, 2, size=x.shape).astype(bool)
     x = np.where(coin, np.nextafter(x, np.inf), np.nextafter(x, -np.inf))
@@ -84,16 +95,19 @@ while rank <= max_rank:
     S = (Qs - Lam).tocsr()
     M = (S + eta * sp.identity(dims.N)).tocsr()
     M.sort_indices()
-    ok = orc.Cholesky(orc.CSR.from_scipy(M), perm=perm_full).ok
-    print("rank %d: TNT %s after %d outer iterations, %d Hvps, f=%.6f |g|=%.3e |Pg|=%.3e  (%.0f s) -> eta=%.3g, S + eta I PSD: %s"
+    short = SHORTCUT and ost.rank_deficient(x)
+    ok = short or orc.Cholesky(orc.CSR.from_scipy(M), perm=perm_full).ok
+    sv = np.linalg.svd(x, compute_uv=False)
+    print("rank %d: TNT %s after %d outer iterations, %d Hvps, f=%.6f |g|=%.3e |Pg|=%.3e  (%.0f s) -> eta=%.3g, sigma_max/sigma_min=%.3g, %s: %s"
           % (rank, res["status"], res["iterations"], res["hvps"], res["f"], res["grad_norm"], res["pgrad_norm"],
-             time.time() - t0, eta, ok), flush=True)
+             time.time() - t0, eta, sv[0] / sv[-1] if sv[-1] > 0 else float("inf"),
+             "certified by the singular-value shortcut" if short else "S + eta I PSD", ok), flush=True)
     if ok:
         break
     # direction of negative curvature (the reference: LOBPCG until x'Sx < -eta/2; any such vector serves the escape)
     # shift-invert Lanczos around a few negative shifts; the first Ritz pair below -eta / 2 is taken
     theta, v = None, None
-    for shift in (eta, 10 * eta, 100 * eta, 1e3 * eta, 1e4 * eta, 1e5 * eta):
+    for shift in ((1e3, 1e4, 1e5, 1e2, 10.0) if DIRECTION == "min" else (eta, 10 * eta, 100 * eta, 1e3 * eta, 1e4 * eta, 1e5 * eta)):
         try:
             w, V = spla.eigsh(S.tocsc(), k=3, sigma=-shift, which="LM", tol=1e-6)
         except Exception as ex:  # singular shift: move on

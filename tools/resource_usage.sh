@@ -1,9 +1,9 @@
 #!/bin/bash
 # usage: tools/resource_usage.sh [CORA_TU] [CORA_LDG] [name filter]  -- registers / scratch / LDS / occupancy of the kernels of
-# one translation unit of kernels.hip as the compiler reports them (no GPU needed)
+# one translation unit of kernels.hip as the compiler reports them (no GPU needed); RES_FLAGS="-D..." adds compiler flags
 cd "$(dirname "$0")/.." || exit 1
 TU=${1:-1}; LDG=${2:-1}; FILTER=${3:-.}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Icora_amd/csrc -DCORA_TU=$TU -DCORA_LDG=$LDG -x hip \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Icora_amd/csrc -DCORA_TU=$TU -DCORA_LDG=$LDG $RES_FLAGS -x hip \
   -c cora_amd/csrc/kernels.hip -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
 python3 -c "
 import re, subprocess, sys
