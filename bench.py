@@ -183,12 +183,17 @@ def stpcg_setup(P, dm, p, x_gt):
     info = P.precond_info()
     t_setup = time.perf_counter() - t0
     h = capi.Context.from_handle(P.context_ptr(), dm["d"], dm["n"], dm["r"], dm["n"] + dm["l"])
-    v = [h.dev_alloc(p) for _ in range(6)]
+    v = [h.dev_alloc(p) for _ in range(7)]
     Yh = np.zeros((dm["N"], p))
     Yh[:, :dm["d"]] = x_gt
     h.upload(Yh, v[5])
     h.project_to_manifold_dev(v[5], v[5])
     h.set_point_dev(v[5])
+    # what TNT holds when it starts an inner solve (the accepted point's wait returns them, cora_tnt_accept_dev): P g and
+    # the inner products <g, g>, <g, P g> -- the solve then starts without a preconditioner apply of its own
+    grad = h.point_ptrs()[2]
+    h.precondition_projected_dev(grad, v[6])
+    h.warm = h.dots_dev([(grad, grad), (grad, v[6])])
     return h, v, info, t_handle, t_setup
 
 
@@ -196,11 +201,12 @@ def stpcg_run(h, v, its):
     """`its` iterations of the solver's own inner loop: cora_stpcg_dev from the Riemannian gradient at the current
     point, tolerance out of reach and a huge radius so that it runs exactly `its` iterations (Hvp + update +
     preconditioner + reductions + direction, scalars on the device).  Returns (iterations done, seconds)."""
-    s, r, z, pk, hp, _ = v
+    s, r, z, pk, hp, _, pg = v
     grad = h.point_ptrs()[2]
     h.sync()
     t0 = time.perf_counter()
-    done, _ = h.stpcg_dev(grad, 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
+    # (cora_stpcg_warm_dev: the entry TNT calls -- host/TNT.cpp -- with P g and its inner products from the accepted point)
+    done, _ = h.stpcg_warm_dev(grad, pg, h.warm[0], h.warm[1], 1e30, s, r, z, pk, hp, kappa_fgr=1e-300, theta=0.0, max_iters=its)
     h.sync()
     return done, time.perf_counter() - t0
 
@@ -249,12 +255,14 @@ def solver_loop_timings(P, ctx, dm, p, x, out, kernel_us, x_gt):
     # full STPCG iteration on the C++ host's own handle with the Cholesky preconditioner installed
     h, v, info, ex["problem_handle_s"], ex["preconditioner_setup_s"] = stpcg_setup(P, dm, p, x_gt)
     ex["preconditioner"] = {"kind": "RegularizedCholesky", "nnz_L": info["nnz"], "lambda": info["lam"]}
-    s, r, z, pk, hp, y = v
+    s, r, z, pk, hp, y, _pg = v
     its = 60
     stpcg_run(h, v, 8)
     done, dt = stpcg_run(h, v, its)
     ex["stpcg_iteration_us"] = dt / max(done, 1) * 1e6
     ex["stpcg_iterations_timed"] = done
+    done_l, dt_l = stpcg_run(h, v, 240)   # the same with four times the iterations: what a solve's start and end weigh
+    ex["stpcg_iteration_us_240"] = dt_l / max(done_l, 1) * 1e6
     ex["stpcg_form"] = {0: "one pass per operation", 1: "fused vector passes (5 launches + the solve)",
                         3: "one explicit inverse: product | kappa + residual | W | W^T | projection + step + direction",
                         2: "sweep-fused: product with the kappa partials | [kappa: a launch of its own above 4 096 partials, else "
@@ -790,7 +798,8 @@ def main():
                                          "(src/CORA.cpp:71-92,119-122; src/CORA_preconditioners.cpp:46-83)",
                 "algorithmic_bytes": tot_b, "us": it_us, "achieved": tot_b / it_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": tot_b / it_us / 1e3 / HBM_PEAK_GBS,
-                "us_is": "host clock over %d iterations of cora_stpcg_dev (no events inside)" % extras["stpcg_iterations_timed"],
+                "us_is": "host clock over %d iterations of cora_stpcg_warm_dev, the entry TNT calls (no events inside); over 240 "
+                         "iterations: %.1f us" % (extras["stpcg_iterations_timed"], extras.get("stpcg_iteration_us_240", float("nan"))),
                 "sum_of_launches_us": sum(k["us"] for k in kern.values() if k.get("us")),
                 "event_overhead_us": ov,
                 "launches": sum(1 for k in kern.values() if k.get("us")),
