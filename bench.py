@@ -400,7 +400,13 @@ def main():
         c_ = None
         try:
             if kind == "p2p":
+                # (a peer that never arrives must cost seconds, not the lease: the waiting kernels give up after this long,
+                # and a transport that has raised a timeout while it was set up is dropped for the next one)
+                os.environ.setdefault("CORA_P2P_TIMEOUT_S", "5")
                 c_ = NativeP2PComm(ctx)
+                st_ = c_.status()
+                if st_["timeouts"] != 0:
+                    raise RuntimeError("a waiting kernel timed out during the set-up: %s" % st_)
             elif kind == "rccl":
                 c_ = NativeRcclComm(ctx, device=dev)
                 assert c_.nranks in (world, -1), "ncclCommCount = %d, WORLD_SIZE = %d" % (c_.nranks, world)
@@ -634,8 +640,12 @@ def main():
             torch.cuda.synchronize()
             c1 = comm.counters()
             comm_counts = {"allgathers_per_product": (c1[0] - c0[0]) / 10.0, "allreduces_per_product": (c1[1] - c0[1]) / 10.0,
-                           "launches_per_product": 4,
-                           "launches": "pack (+ zeroed slots) | long-row chunks | unpack (+ long rows summed in rank order) | slices",
+                           "launches_per_product": 3 if hasattr(comm, "status") else 4,
+                           "launches": ("long-row chunks | exchange (one kernel: exported rows read from X, pushed with the slots "
+                                        "into the peers' mailboxes, hand-over, wait, unpack with the long rows summed in rank "
+                                        "order) | slices" if hasattr(comm, "status") else
+                                        "pack (+ zeroed slots) | long-row chunks | [collective] | unpack (+ long rows summed in "
+                                        "rank order) | slices"),
                            "per_stpcg_iteration": "1 all-gather (the product's) + 2 all-reduces (kappa | <r,r> and <r,v>)"}
     # N > 1: one product gathered on every rank (download is collective) for the parity check on rank 0
     gathered = None

@@ -48,8 +48,10 @@ int p2p_allgather(P2PState *s, const void *send, void *recv, size_t bytes, hipSt
 // The exchange of a product, fused: send = this rank's [ e_max rows | n_long slots ] (ld doubles each); one kernel pushes it,
 // waits for the peers' and unpacks from the mailbox -- rows to X[recv_idx[world * e_max]], every long row's slots added in rank
 // order into the owner's row of `out` (kappa: the rows' shares of <X, out>, one per long row, or nullptr).
+// export_rows != nullptr: the e_max rows are read from X itself (X[export_rows[k]]) and `send` holds the n_long slots only --
+// no pack launch in front of the kernel: a product is chunks | exchange | slices.
 bool p2p_exchange_unpack_fits(const P2PState *s, int64_t e_max, int n_long, int ld);
-int p2p_exchange_unpack(P2PState *s, const double *send, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, double *X,
+int p2p_exchange_unpack(P2PState *s, const double *send, const int32_t *export_rows, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, double *X,
                         const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa, hipStream_t st, std::string *err);
 // sum over the ranks of n device doubles, in place, added in rank order
 int p2p_allreduce(P2PState *s, double *d, int n, hipStream_t st, std::string *err);

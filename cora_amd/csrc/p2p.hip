@@ -108,7 +108,10 @@ __global__ __launch_bounds__(64) void k_p2p_allreduce(Peers P, int rank, int wor
 // about a hundred doubles per rank): push this rank's [ e_max rows | n_long slots ] into every mailbox, hand over, wait, then
 // unpack STRAIGHT FROM THE MAILBOX -- rows to X[recv_idx], and the owner of long row j adds slot j of every rank in rank order
 // into its row of the result (the same operations as k_exchange_unpack in kernels.hip: the same bits as the other transports).
-__global__ __launch_bounds__(256) void k_p2p_exchange_unpack(Peers P, int rank, int world, const double *__restrict__ send, int64_t e_max,
+// export_rows != nullptr: the rows are taken from X itself (rows export_rows[0 .. e_max) of this rank's shard) and only the slots from
+// `send` (which then points at the slots): no pack launch in front of this kernel.
+__global__ __launch_bounds__(256) void k_p2p_exchange_unpack(Peers P, int rank, int world, const double *__restrict__ send,
+                                                             const int32_t *__restrict__ export_rows, int64_t e_max,
                                                              int n_long, int ld, const int32_t *__restrict__ recv_idx, double *X,
                                                              const int32_t *__restrict__ long_rows, const int32_t *__restrict__ long_owner,
                                                              double *out, double *kappa, unsigned long long seq, unsigned long long timeout) {
@@ -116,9 +119,21 @@ __global__ __launch_bounds__(256) void k_p2p_exchange_unpack(Peers P, int rank, 
   const int parity = static_cast<int>(seq & 1);
   const int64_t stride = (e_max + n_long) * ld;
   char *mine = P.mail[rank];
-  for (int q = 0; q < world; ++q) {
-    double *dst = reinterpret_cast<double *>(ag_data(P.mail[q], parity, rank, world));
-    for (int64_t i = tid; i < stride; i += 256) __hip_atomic_store(dst + i, send[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int64_t per = e_max * ld;
+  for (int64_t i = tid; i < stride; i += 256) {  // (a payload of a hundred doubles: one trip for most threads)
+    double v;
+    if (export_rows) {
+      if (i < per) {
+        const int64_t k = i / ld;
+        v = X[static_cast<int64_t>(export_rows[k]) * ld + (i - k * ld)];
+      } else {
+        v = send[i - per];
+      }
+    } else {
+      v = send[i];
+    }
+    for (int q = 0; q < world; ++q)
+      __hip_atomic_store(reinterpret_cast<double *>(ag_data(P.mail[q], parity, rank, world)) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence_system();
   __syncthreads();
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange_unpack(Peers P, int rank, 
     wait_flag(ag_flag(mine, parity, tid, 0), seq, timeout, mine);
   }
   __syncthreads();
-  const int64_t per = e_max * ld, tot = per * world;
+  const int64_t tot = per * world;
   for (int64_t t = tid; t < tot; t += 256) {
     const int64_t r = t / per, w = t - r * per, k = t / ld, j = t - k * ld;
     const double *src = reinterpret_cast<const double *>(ag_data(mine, parity, static_cast<int>(r), world));
@@ -308,14 +323,14 @@ bool p2p_exchange_unpack_fits(const P2PState *s, int64_t e_max, int n_long, int 
   return s && static_cast<size_t>((e_max + n_long) * ld) * sizeof(double) <= std::min<size_t>(kP2PSlotBytes, 32 * 1024);
 }
 
-int p2p_exchange_unpack(P2PState *s, const double *send, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, double *X,
+int p2p_exchange_unpack(P2PState *s, const double *send, const int32_t *export_rows, int64_t e_max, int n_long, int ld, const int32_t *recv_idx, double *X,
                         const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa, hipStream_t st, std::string *err) {
   if (!s || !s->connected) return set_err(err, "p2p: not connected");
   if (!p2p_exchange_unpack_fits(s, e_max, n_long, ld)) return set_err(err, "p2p: the exchange does not fit one block");
   ++s->collectives;
   ++s->kernels;
   const unsigned long long seq = ++s->ag_seq;
-  hipLaunchKernelGGL(k_p2p_exchange_unpack, dim3(1), dim3(256), 0, st, s->peers, s->rank, s->world, send, e_max, n_long, ld, recv_idx, X,
+  hipLaunchKernelGGL(k_p2p_exchange_unpack, dim3(1), dim3(256), 0, st, s->peers, s->rank, s->world, send, export_rows, e_max, n_long, ld, recv_idx, X,
                      long_rows, long_owner, out, kappa, seq, s->timeout_ticks);
   return hip_err(err, hipGetLastError(), "k_p2p_exchange_unpack");
 }
