@@ -38,8 +38,8 @@ const int kShortRow = static_cast<int>(env_i64("CORA_TRI_SHORT_ROW", 64, 8, 1 <<
 const int kWaveRow = static_cast<int>(env_i64("CORA_TRI_WAVE_ROW", 1024, 64, 1 << 30));  // entries: <= this -> one wavefront per row, else chunked
 const int kChunk = static_cast<int>(env_i64("CORA_TRI_CHUNK", 512, 64, 1 << 30));
 constexpr int kDenseBlock = 64;      // stage-0 blocks up to this many rows use the dense wavefront kernel
-const int kSubRows = static_cast<int>(env_i64("CORA_TRI_SUB_ROWS", 512, 32, 512));  // workgroup blocks (SubBlockOpHost): rows and entries of L that sit in LDS next to
-constexpr int kSubEnt = 5000;        // the right-hand sides (512 rows x 24 columns = 96 KB + 50 KB of entries)
+const int kSubRows = static_cast<int>(env_i64("CORA_TRI_SUB_ROWS", 512, 32, 2048));  // workgroup blocks (SubBlockOpHost): rows of a block (its tile of right-hand sides sits in LDS:
+const int kSubEnt = static_cast<int>(env_i64("CORA_TRI_SUB_ENT", 5000, 100, 1 << 30));  // 512 rows x 24 columns = 96 KB) and entries of L per block (streamed since round 2: a cap on a block's work, not on LDS)
 constexpr int kSnCapChain = 4;  // rows of a supernode of the substitution blocks (a 3-D pose: 3 rotation rows + translation)
 const int kLaneEntries = static_cast<int>(env_i64("CORA_TRI_LANE_ENTRIES", 8, 1, 8));  // entries one lane of a row walks through (<= kSubNpl of the kernel: they sit in registers)
 const int kLevelLanes = static_cast<int>(env_i64("CORA_TRI_LEVEL_LANES", 256, 64, 256));  // rows x lanes per row of one level (<= 256 = kSubThreads of the kernel)
