@@ -44,7 +44,7 @@ def units():
 
 def _deps():
     return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "host", "*.h")) + \
-        glob.glob(os.path.join(CSRC, "capi", "*.inc")) + \
+        glob.glob(os.path.join(CSRC, "capi", "*.inc")) + glob.glob(os.path.join(CSRC, "kernels", "*.inc")) + \
         [os.path.join(os.path.dirname(HERE), "include", "cora_hip.h")]
 
 
@@ -88,7 +88,7 @@ def build(force=False, verbose=False):
             continue
         objs.append(o)
         newest = max(os.path.getmtime(p) for p in _deps() if p.endswith(".h") or p == s or
-                     (p.endswith(".inc") and os.path.basename(s) == "capi.hip"))
+                     (p.endswith(".inc") and os.path.basename(os.path.dirname(p)) + ".hip" == os.path.basename(s)))
         forced = force or any(oname.startswith(u) for u in only)
         if not forced and os.path.exists(o) and os.path.getmtime(o) > newest:
             continue
