@@ -94,6 +94,33 @@ def test_p2p_processes_return_the_local_transport_s_bits(world, case, tmp_path):
           % (world, case, got[0]["status"][4], got[0]["status"][5], got[0]["status"][1], got[0]["status"][3], int(got[0]["path"])))
 
 
+@pytest.mark.parametrize("world,case", [(2, "implicit"), (4, "implicit"), (2, "staircase")])
+def test_p2p_processes_on_the_implicit_formulation_and_the_staircase(world, case, tmp_path):
+    """The transport's generic collectives under load: the implicit formulation's packed gather of the translation rows (tens of
+    kilobytes per rank: several blocks of one all-gather kernel, each handing its own slice over) and the in-place gather of whole
+    shards behind every download; solveCORA with certification on a partition (LOBPCG's Gram matrices all-reduced, the sharded
+    certificate operator).  The local transport's bits again, and no library collective."""
+    import p2p_worker as w
+    got = _launch(world, "p2p", case, str(tmp_path / "p2p"))
+
+    def body(r, group):
+        _, out = (w.implicit_case if case == "implicit" else w.staircase_case)(lambda ctx: NativeLocalComm(ctx, group), r, world)
+        return out
+
+    ref = _run_ranks(world, body, "native")
+    for r in range(world):
+        g = got[r]
+        for k, v in ref[r].items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(g[k], v), (case, r, k)
+            else:
+                assert float(g[k]) == float(v), (case, r, k, float(g[k]), v)
+        assert list(g["counters"]) == [0, 0] and g["status"][2] == 0
+        assert g["status"][4] > 0 and g["status"][5] > 0
+    print("\n  %d processes, %s: %d all-gathers + %d all-reduces in %d kernels through the mailboxes; rows gathered %d"
+          % (world, case, got[0]["status"][4], got[0]["status"][5], got[0]["status"][1], int(got[0]["gathered"])))
+
+
 def test_a_dead_peer_raises_a_timeout_instead_of_hanging(tmp_path):
     """One rank of two never shows up for the first collective after the set-up: the other's waiting kernel gives up after
     CORA_P2P_TIMEOUT_S and the status reports it (the GPU is not hung)."""
