@@ -426,9 +426,17 @@ void releaseWork(std::unique_ptr<Work> W) {
   }
 }
 
+// A reservation under way (choleskyReserveStorage: buffers being touched on a thread beside the ordering) has not handed its
+// buffers to the pool yet: whoever asks the pool meanwhile waits for it instead of allocating a second full-size pair that would
+// stay pooled beside the first (round-5 advice; 10^6 poses: hundreds of MB).  The reserving threads themselves do not wait.
+std::atomic<int> g_reserving{0};
+thread_local bool t_reserving = false;
+
 template <class T>
 std::vector<T> takeStorage(std::vector<std::vector<T>> &pool, size_t count) {
   std::vector<T> v;
+  if (!t_reserving)
+    while (g_reserving.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (size_t e = 0; e < pool.size(); ++e)
@@ -484,8 +492,14 @@ CholeskyFactor::~CholeskyFactor() {
 
 void choleskyReserveStorage(size_t entries) {
   if (entries < (1u << 20)) return;  // (small factors are not pooled)
+  g_reserving.fetch_add(1, std::memory_order_acq_rel);
+  struct Done {  // (released when the buffers are in the pool: after F's destructor, declared below, has run)
+    ~Done() { g_reserving.fetch_sub(1, std::memory_order_acq_rel); }
+  } done;
   CholeskyFactor F;  // (its destructor hands the storage to the pool, where choleskyAnalyze / choleskyFactor find it)
+  t_reserving = true;
   std::thread idx([&] {
+    t_reserving = true;
     try {
       F.Li = takeStorage(g_pool_i, entries);
     } catch (...) {  // (a reservation that fails is no reservation)
@@ -496,6 +510,7 @@ void choleskyReserveStorage(size_t entries) {
   } catch (...) {
   }
   idx.join();
+  t_reserving = false;
 }
 
 void choleskyAnalyze(const SparseMatrix &A, int m, const std::vector<int32_t> &perm, SymbolicCache *cache) {
