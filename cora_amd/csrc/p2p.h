@@ -10,7 +10,8 @@
 //             (release, system scope) -- a 1-to-1 hand-off per (receiver, sender) pair at distinct addresses, not one
 //             hot word;
 //     wait    the same kernel spins on the flags of its OWN mailbox (local memory) until every sender's sequence number
-//             has arrived (acquire), with a wall-clock timeout that raises an error word instead of hanging the GPU;
+//             has arrived (acquire), with a wall-clock timeout that raises an error word instead of hanging the GPU (the
+//             word is also counted in pinned host memory: the rank's next collective call fails loudly);
 //     deliver it copies the gathered payloads out of the mailbox (all-gather), or adds them IN RANK ORDER (all-reduce:
 //             the same bits on every rank, like the other transports).
 // No host involvement, no stream synchronisation, no RCCL call on the data path.  Slots are double-buffered by the

@@ -17,7 +17,8 @@ constexpr size_t kAgFlagOff = 0;                                                
 constexpr size_t kArFlagOff = kAgFlagOff + 8ull * 2 * kP2PMaxWorld * kP2PMaxBlocks;          // uint64 [2][world max]
 constexpr size_t kArDataOff = kArFlagOff + 8ull * 2 * kP2PMaxWorld;                          // double [2][world max][reduce max]
 constexpr size_t kErrorOff = kArDataOff + 8ull * 2 * kP2PMaxWorld * kP2PReduceMax;           // uint64: timeouts raised here
-constexpr size_t kAgDataOff = (kErrorOff + 8 + 4095) & ~static_cast<size_t>(4095);           // bytes [2][world][slot]
+constexpr size_t kHostErrOff = kErrorOff + 8;                                                // pointer to a pinned host word (this process's)
+constexpr size_t kAgDataOff = (kHostErrOff + 8 + 4095) & ~static_cast<size_t>(4095);         // bytes [2][world][slot]
 
 struct Peers {
   char *mail[kP2PMaxWorld];
@@ -44,6 +45,9 @@ __device__ __forceinline__ void wait_flag(unsigned long long *flag, unsigned lon
     __builtin_amdgcn_s_sleep(4);
     if (wall_clock64() - t0 > timeout) {
       __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(mine + kErrorOff), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (and in pinned host memory, where the host sees it without a synchronisation: the next collective call fails loudly)
+      unsigned long long *h = *reinterpret_cast<unsigned long long **>(mine + kHostErrOff);
+      if (h) __hip_atomic_fetch_add(h, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
@@ -192,6 +196,7 @@ struct P2PState {
   unsigned long long timeout_ticks = 0;
   long collectives = 0, kernels = 0;
   bool connected = false;
+  unsigned long long *h_err = nullptr;  // pinned: timeouts raised by this rank's waiting kernels (read without a synchronisation)
 };
 
 static int set_err(std::string *err, const std::string &m) {
@@ -240,10 +245,23 @@ int p2p_create(int device, int rank, int world, P2PState **out, void *blob_out, 
     return set_err(err, "p2p: no exportable device memory for the mailbox (hipExtMallocWithFlags / hipMalloc + hipIpcGetMemHandle)");
   }
   s->mine = static_cast<char *>(p);
-  if (hip_err(err, hipMemset(p, 0, s->bytes), "hipMemset") || hip_err(err, hipDeviceSynchronize(), "hipDeviceSynchronize")) {
+  if (hip_err(err, hipMemset(p, 0, s->bytes), "hipMemset") ||
+      hip_err(err, hipHostMalloc(reinterpret_cast<void **>(&s->h_err), sizeof(unsigned long long), hipHostMallocMapped), "hipHostMalloc")) {
     (void)hipFree(p);
     delete s;
     return 1;
+  }
+  *s->h_err = 0;
+  {
+    unsigned long long *dev_view = nullptr;  // the device's address of the pinned word, kept in the mailbox for the kernels
+    if (hip_err(err, hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), s->h_err, 0), "hipHostGetDevicePointer") ||
+        hip_err(err, hipMemcpy(s->mine + kHostErrOff, &dev_view, sizeof(dev_view), hipMemcpyHostToDevice), "hipMemcpy") ||
+        hip_err(err, hipDeviceSynchronize(), "hipDeviceSynchronize")) {
+      (void)hipHostFree(s->h_err);
+      (void)hipFree(p);
+      delete s;
+      return 1;
+    }
   }
   b.pid = static_cast<int64_t>(getpid());
   b.ptr = reinterpret_cast<uint64_t>(p);
@@ -292,11 +310,21 @@ void p2p_destroy(P2PState *s) {
   (void)hipDeviceSynchronize();
   for (void *p : s->opened) (void)hipIpcCloseMemHandle(p);
   if (s->mine) (void)hipFree(s->mine);
+  if (s->h_err) (void)hipHostFree(s->h_err);
   delete s;
+}
+
+// A timeout raised by an earlier collective of this rank (a peer did not arrive): whatever that collective delivered is garbage, so
+// every later call fails instead of computing on (the pinned word is read without a synchronisation).
+static int timed_out(const P2PState *s, std::string *err) {
+  if (!s->h_err || *reinterpret_cast<volatile unsigned long long *>(s->h_err) == 0) return 0;
+  return set_err(err, "p2p: a peer did not arrive within CORA_P2P_TIMEOUT_S (" + std::to_string(*s->h_err) +
+                          " waits gave up): the results of that collective are invalid");
 }
 
 int p2p_allgather(P2PState *s, const void *send, void *recv, size_t bytes, hipStream_t st, std::string *err) {
   if (!s || !s->connected) return set_err(err, "p2p: not connected");
+  if (timed_out(s, err)) return 1;
   if (bytes % 4 != 0) return set_err(err, "p2p all-gather: the payload must be a multiple of 4 bytes");
   ++s->collectives;
   const bool wide = bytes % 8 == 0 && reinterpret_cast<uintptr_t>(send) % 8 == 0 && reinterpret_cast<uintptr_t>(recv) % 8 == 0;
@@ -327,6 +355,7 @@ int p2p_exchange_unpack(P2PState *s, const double *send, const int32_t *export_r
                         const int32_t *long_rows, const int32_t *long_owner, double *out, double *kappa, hipStream_t st, std::string *err) {
   if (!s || !s->connected) return set_err(err, "p2p: not connected");
   if (!p2p_exchange_unpack_fits(s, e_max, n_long, ld)) return set_err(err, "p2p: the exchange does not fit one block");
+  if (timed_out(s, err)) return 1;
   ++s->collectives;
   ++s->kernels;
   const unsigned long long seq = ++s->ag_seq;
@@ -337,6 +366,7 @@ int p2p_exchange_unpack(P2PState *s, const double *send, const int32_t *export_r
 
 int p2p_allreduce(P2PState *s, double *d, int n, hipStream_t st, std::string *err) {
   if (!s || !s->connected) return set_err(err, "p2p: not connected");
+  if (timed_out(s, err)) return 1;
   ++s->collectives;
   for (int at = 0; at < n; at += kP2PReduceMax) {
     const unsigned long long seq = ++s->ar_seq;

@@ -411,7 +411,8 @@ int cora_comm_create_local(cora_ctx *ctx, cora_local_group *group);
  * writes its payload into every peer's mailbox (stores over xGMI; the mailbox is exported with hipIpcGetMemHandle and mapped
  * by the peers, or shared by pointer between threads of one process), sets a per-(receiver, sender) sequence flag with
  * release at system scope, spins on the flags of its OWN mailbox (with a wall-clock timeout, CORA_P2P_TIMEOUT_S, default 60:
- * a dead peer raises an error count instead of hanging the GPU) and delivers -- all-reduces add in rank order, the same bits
+ * a dead peer raises an error count instead of hanging the GPU, and every later collective call of that rank fails with
+ * CORA_ERR_HIP instead of computing on what the timed-out one delivered) and delivers -- all-reduces add in rank order, the same bits
  * as the other transports.  Ranks: one process per GPU, several processes sharing a GPU (tests), or threads.
  *   cora_comm_p2p_handle(ctx, blob)   -> creates this rank's mailbox, blob = CORA_P2P_HANDLE_BYTES to hand to the peers
  *   (launcher: all-gather of the blobs in rank order -- torch.distributed, MPI, a file; like the RCCL id)

@@ -123,7 +123,9 @@ def test_p2p_processes_on_the_implicit_formulation_and_the_staircase(world, case
 
 def test_a_dead_peer_raises_a_timeout_instead_of_hanging(tmp_path):
     """One rank of two never shows up for the first collective after the set-up: the other's waiting kernel gives up after
-    CORA_P2P_TIMEOUT_S and the status reports it (the GPU is not hung)."""
+    CORA_P2P_TIMEOUT_S, the status reports it (the GPU is not hung), and the NEXT collective call of that rank fails with an error
+    instead of computing on what the timed-out collective delivered (the kernels count their timeouts in pinned host memory too,
+    which the library reads without a synchronisation)."""
     code = r'''
 import os, sys, time
 sys.path.insert(0, %r)
@@ -144,8 +146,12 @@ else:
     dm = P.dims()
     Y = P.op("projectToManifold", np.random.default_rng(1).uniform(-1, 1, (dm["N"], 4)))
     t0 = time.time()
-    f = P.op("evaluateObjective", Y)     # exchange + all-reduce: the peer never pushes
-    print("STATUS timeouts=%%d seconds=%%.1f" %% (comm.status()["timeouts"], time.time() - t0))
+    raised = ""
+    try:
+        f = P.op("evaluateObjective", Y)     # exchange + all-reduce: the peer never pushes
+    except Exception as e:                   # the collective AFTER the one that timed out refuses to compute on
+        raised = str(e)
+    print("STATUS timeouts=%%d seconds=%%.1f raised=%%r" %% (comm.status()["timeouts"], time.time() - t0, raised))
 dist.barrier()
 ''' % (ROOT, ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
@@ -163,5 +169,6 @@ dist.barrier()
     line = [l for l in outs[0].splitlines() if l.startswith("STATUS")]
     assert line, outs[0][-3000:]
     assert "timeouts=0" not in line[0], line[0]
-    secs = float(line[0].split("seconds=")[1])
+    assert "did not arrive" in line[0], line[0]      # ... and the next collective call failed loudly
+    secs = float(line[0].split("seconds=")[1].split()[0])
     assert secs < 40, line[0]
