@@ -404,6 +404,18 @@ def main():
                 # and a transport that has raised a timeout while it was set up is dropped for the next one)
                 os.environ.setdefault("CORA_P2P_TIMEOUT_S", "5")
                 c_ = NativeP2PComm(ctx)
+                # pre-flight, before anything else depends on it: three products (exchange of the operand) and an inner
+                # product (all-reduce) on scratch vectors; a transport that times out or fails here is dropped for the next
+                # one while every rank is still at the same point of the script (no torch collective in between)
+                a_, b_ = ctx.dev_alloc(p), ctx.dev_alloc(p)
+                try:
+                    for _ in range(3):
+                        ctx.spmm_dev(a_, p, b_)
+                    ctx.dot_dev(a_, b_, p)
+                    ctx.sync()
+                finally:
+                    ctx.dev_free(a_)
+                    ctx.dev_free(b_)
                 st_ = c_.status()
                 if st_["timeouts"] != 0:
                     raise RuntimeError("a waiting kernel timed out during the set-up: %s" % st_)
