@@ -1061,6 +1061,21 @@ void build_tri_plan(int m, const int32_t *Lp, const int32_t *Li, const double *L
       F.begin_row(row_of[i]);
       for (int32_t q = cnt[i]; q < cnt[i + 1]; ++q) {
         F.add(row_of[cc[q]], vv[q]);
+#ifdef CORA_LAB_BUILD
+        // LAB (wrong results): upper bounds of two forms of the folded product that were priced before building --
+        //   CORA_LAB_DROP_PAIR_AUX : columns with at most two aux rows (the separators) gather none of them: what a grouped gather
+        //                            of [b | aux | aux] could gain at best (round 6, step 8: 13.0 -> 9.7 us);
+        //   CORA_LAB_AUX_CAP=n     : columns with more than n aux rows (the landmarks: one per solve block) gather n of them: what a
+        //                            hierarchical reduction of the landmark slots inside the forward sweep (the round-5 review's
+        //                            item 1a: "the last stage sees 8 partials per row") could gain at best.
+        static const bool lab_drop = std::getenv("CORA_LAB_DROP_PAIR_AUX") != nullptr;
+        static const int lab_cap = std::getenv("CORA_LAB_AUX_CAP") ? std::atoi(std::getenv("CORA_LAB_AUX_CAP")) : 0;
+        if (lab_drop && aux_of[cc[q]].size() <= 2) continue;
+        if (lab_cap > 0 && sub0 && fold && static_cast<int>(aux_of[cc[q]].size()) > lab_cap) {
+          for (int a = 0; a < lab_cap; ++a) F.add(aux_base + aux_of[cc[q]][a], vv[q]);
+          continue;
+        }
+#endif
         if (sub0 && fold)
           for (int32_t a : aux_of[cc[q]]) F.add(aux_base + a, vv[q]);
       }
