@@ -764,7 +764,7 @@ def main():
                        "kernels of the loop costs the stream 2-5 us -- more than the boundary it sits on -- so an interval "
                        "between two events overstates the kernel (round 4's 21 us) and subtracting two events in a row "
                        "understates it: kernel_us is the kernel's own duration from a rocprofv3 kernel trace of the same loop "
-                       "(profiles/r05_bench_kernel_stats.csv holds the same population), the event figures stay in "
+                       "(profiles/r06_bench_kernel_stats.csv holds the same population), the event figures stay in "
                        "kernel_us_events",
             }
             if rl["traffic"]:
